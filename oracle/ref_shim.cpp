@@ -1,0 +1,163 @@
+// oracle/ref_shim.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Host-compiles the reference's own __device__ function bodies (sliced at build time from the files under
+// /root/reference by oracle/build_ref.py into a scratch include dir; nothing is copied into this repo) and
+// exports them through a small extern "C" surface so tests can (1) pin oracle/orp_oracle.c against the REAL
+// reference arithmetic and (2) generate tests/golden/*.npz.
+//
+// The only code in this file is glue: stubs for the CUDA keywords/builtins, a one-thread-per-block launch
+// emulation for the element-wise kernels, and the reference's host-side greedy sweep re-expressed over the
+// reference's own IoU function (rnms_kernel.cu:239-264).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <math.h>
+#include <stdio.h>
+#include <vector>
+
+// ---- CUDA keyword / builtin stubs -------------------------------------------------------------------------
+#define __device__
+#define __global__
+#define __host__
+#define __shared__ static
+#define __syncthreads() ((void)0)
+struct orp_dim3 { int x, y, z; };
+static orp_dim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, blockDim = {1, 1, 1}, gridDim = {1, 1, 1};
+struct float2 { float x, y; };
+static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
+template <typename T> static inline T atomicAdd(T* p, T v) { T old = *p; *p = old + v; return old; }
+#define CUDA_1D_KERNEL_LOOP(i, n) \
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x)
+#define CUDA_KERNEL_LOOP(i, n) \
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += blockDim.x * gridDim.x)
+
+// ---- the reference slices, one namespace each (they all define sig/Point/cross/...) -------------------------
+namespace nsref_rnms_kernel { using std::min; using std::max;
+#include "rnms_kernel.inc"
+}
+namespace nsref_rnms_cpu { using std::min; using std::max;
+#include "rnms_cpu.inc"
+}
+namespace nsref_poly_nms { using namespace std;
+#include "poly_nms.inc"
+}
+namespace nsref_poly_overlaps { using namespace std;
+#include "poly_overlaps.inc"
+}
+namespace nsref_minarearect { using std::min; using std::max;
+#include "minarearect.inc"
+}
+namespace nsref_convex_iou { using std::min; using std::max;
+#include "convex_iou.inc"
+}
+namespace nsref_convex_giou { using std::min; using std::max;
+#include "convex_giou.inc"
+}
+namespace nsref_points_justify { using std::min; using std::max;
+#include "points_justify.inc"
+}
+namespace nsref_focal { using std::min; using std::max;
+#include "focal.inc"
+}
+namespace nsref_chamfer { using std::min; using std::max;
+#include "chamfer.inc"
+}
+// polyiou.cpp is plain C++: include it whole (its std headers are already guarded above).
+namespace nsref_polyiou {
+#include "DOTA_devkit/polyiou.cpp"
+}
+
+extern "C" {
+
+// ---- pairwise IoU scalars -------------------------------------------------------------------------------
+float ref_rnms_iou(const float* p, const float* q) { return nsref_rnms_kernel::devrIoU(p, q); }
+float ref_rnms_cpu_iou(const float* p, const float* q) {
+  return nsref_rnms_cpu::rotate_iou(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7],
+                                  q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]);
+}
+float ref_poly_nms_iou(const float* p, const float* q) { return nsref_poly_nms::devPolyIoU(p, q); }
+float ref_poly_overlaps_iou(const float* b1, const float* b2) { return nsref_poly_overlaps::devPolyIoU(b1, b2); }
+double ref_polyiou_iou(const double* p, const double* q) {
+  std::vector<double> P(p, p + 8), Q(q, q + 8);
+  return nsref_polyiou::iou_poly(P, Q);
+}
+float ref_convex_iou(const float* pts18, const float* gt8) { return nsref_convex_iou::devrIoU(pts18, gt8); }
+// out19 = 18 grads + giou, exactly the row layout of convex_giou_kernel (convex_giou_kernel.cu:817-823)
+void ref_convex_giou(const float* pts18, const float* gt8, float* out19) {
+  float g = nsref_convex_giou::devrIoU(pts18, gt8, out19, 0);
+  out19[18] = g;
+}
+void ref_minarearect(const float* pts18, float* out8) { nsref_minarearect::Findminbox(pts18, out8); }
+
+// ---- batched helpers ------------------------------------------------------------------------------------
+void ref_rnms_iou_matrix(const float* a, int n, const float* b, int k, int stride, float* out) {
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < k; j++) out[(size_t)i * k + j] = nsref_rnms_kernel::devrIoU(a + i * stride, b + j * stride);
+}
+void ref_poly_overlaps(const float* boxes, int n, const float* query, int k, float* out) {
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < k; j++) out[(size_t)i * k + j] = nsref_poly_overlaps::devPolyIoU(boxes + i * 5, query + j * 5);
+}
+void ref_convex_iou_matrix(const float* pts, int n, const float* gts, int k, float* out) {
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < k; j++) out[(size_t)i * k + j] = nsref_convex_iou::devrIoU(pts + i * 18, gts + j * 8);
+}
+void ref_convex_giou_batch(const float* pts, const float* gts, int n, float* out19) {
+  for (int i = 0; i < n; i++) ref_convex_giou(pts + i * 18, gts + i * 8, out19 + (size_t)i * 19);
+}
+void ref_minarearect_batch(const float* pts, int n, float* out) {
+  for (int i = 0; i < n; i++) nsref_minarearect::Findminbox(pts + i * 18, out + i * 8);
+}
+
+// Greedy sweep of rnms_cuda / _poly_nms over ALREADY SORTED dets[n,9] (rnms_kernel.cu:149-201 tile rule:
+// row box i suppresses column box j>i iff IoU(row=i, col=j) > thr; host sweep :239-257).
+// which: 0 = rnms_kernel devrIoU, 1 = poly_nms devPolyIoU.  keep_out gets sorted-order positions.
+int ref_nms_sorted(const float* dets, int n, float thr, int which, int* keep_out) {
+  std::vector<unsigned char> removed(n, 0);
+  int nk = 0;
+  for (int i = 0; i < n; i++) {
+    if (removed[i]) continue;
+    keep_out[nk++] = i;
+    for (int j = i + 1; j < n; j++) {
+      if (removed[j]) continue;  // a bit already set stays set: skipping is equivalent to OR-ing
+      float v = which == 0 ? nsref_rnms_kernel::devrIoU(dets + i * 9, dets + j * 9)
+                           : nsref_poly_nms::devPolyIoU(dets + i * 9, dets + j * 9);
+      if (v > thr) removed[j] = 1;
+    }
+  }
+  return nk;
+}
+
+// ---- element-wise kernels: emulate <<<n blocks, 1 thread>>> ------------------------------------------------
+void ref_points_justify(const float* points, int rows, const float* polys, int cols, float* out) {
+  int n = rows * cols;
+  blockDim.x = 1; threadIdx.x = 0; gridDim.x = n;
+  for (int b = 0; b < n; b++) { blockIdx.x = b; nsref_points_justify::PointsJF<float>(n, points, polys, rows, cols, out); }
+  blockIdx.x = 0; gridDim.x = 1;
+}
+void ref_focal_forward(const float* logits, const int64_t* targets, int num, int classes, float gamma, float alpha,
+                       float* losses) {
+  int n = num * classes;
+  blockDim.x = 1; threadIdx.x = 0; gridDim.x = n;
+  for (int b = 0; b < n; b++) { blockIdx.x = b; nsref_focal::SigmoidFocalLossForward<float>(n, logits, targets, classes, gamma, alpha, num, losses); }
+  blockIdx.x = 0; gridDim.x = 1;
+}
+void ref_focal_backward(const float* logits, const int64_t* targets, const float* d_losses, int num, int classes,
+                        float gamma, float alpha, float* d_logits) {
+  int n = num * classes;
+  blockDim.x = 1; threadIdx.x = 0; gridDim.x = n;
+  for (int b = 0; b < n; b++) { blockIdx.x = b; nsref_focal::SigmoidFocalLossBackward<float>(n, logits, targets, d_losses, classes, gamma, alpha, num, d_logits); }
+  blockIdx.x = 0; gridDim.x = 1;
+}
+// chamfer: one block of one thread walks everything (the kernel is correct for any launch shape).
+void ref_chamfer_nn(int b, int n, const float* xyz, int m, const float* xyz2, float* result, int* result_i) {
+  blockDim.x = 1; threadIdx.x = 0; gridDim.x = 1; blockIdx.x = 0; gridDim.y = 1; blockIdx.y = 0;
+  nsref_chamfer::NmDistanceKernel(b, n, xyz, m, xyz2, result, result_i);
+}
+
+}  // extern "C"
