@@ -1,0 +1,119 @@
+/* include/orp_hip.h -- C ABI of liborp_hip.so: the MI355X (gfx950) drop-in for the native operators on the
+ * Oriented RepPoints dense-head hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); device-pointer entry points only
+ *     enqueue work on it and never synchronise, allocate or free: scratch comes in through `workspace`
+ *     (size it with the matching *_workspace_bytes), so every call is hipGraph-capturable;
+ *   - return value: 0 on success, a negative ORP_E* code for argument errors, or a positive hipError_t;
+ *   - row layouts are those of the reference: oriented boxes / gts [.,8] = x1,y1,...,x4,y4; dets [.,9] = box + score;
+ *     point sets [.,18] = nine (x,y) pairs; rotated boxes [.,5] = cx,cy,w,h,theta(radians).
+ *
+ * Each entry point cites the reference interface (file:line under LiWentomng/OrientedRepPoints) it replaces.
+ */
+#ifndef ORP_HIP_H_
+#define ORP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORP_OK 0
+#define ORP_EINVAL (-1)      /* bad argument (NULL pointer, negative size, unsupported option) */
+#define ORP_EWORKSPACE (-2)  /* workspace too small */
+#define ORP_ETOOBIG (-3)     /* problem exceeds a documented limit */
+
+/* library / build identification: "orp_hip gfx950 <abi>" */
+const char* orp_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Rotated NMS.
+ * Replaces rnms_cuda.rnms(Tensor[M,9] f32 cuda, float) -> LongTensor   (mmdet/ops/nms/src/rnms_cuda.cpp:8-13,
+ * rnms_kernel.cu:204-265) and the device half of _poly_nms (DOTA_devkit/poly_nms_gpu/poly_nms_kernel.cu:277-329).
+ *   dets      [n,9] f32 (8 corner coords + score), any order
+ *   flavor    0 = rnms (devrIoU, rnms_kernel.cu:131-147); 1 = poly_nms (devPolyIoU with the union==0 guard,
+ *             poly_nms_kernel.cu:192-212)
+ *   presorted 0: sort here by (score desc, index asc) -- stable; 1: rows are already in visiting order
+ *   keep_out  [n] int64: ORIGINAL row indices of the kept boxes; ascending when order_out==0 (rnms_cuda's
+ *             contract, rnms_kernel.cu:261-264), in visiting (score) order when order_out==1 (_poly_nms' contract)
+ *   num_keep  [1] int32 (device): number of valid entries in keep_out
+ * Limits: n <= ORP_NMS_MAX_BOXES.  The suppression mask (n * ceil(n/64) u64) lives in the workspace.
+ * ------------------------------------------------------------------------------------------------------- */
+#define ORP_NMS_MAX_BOXES 131072
+size_t orp_rnms_workspace_bytes(int n);
+int orp_rnms(const float* dets, int n, float iou_thr, int flavor, int presorted, int order_out,
+             int64_t* keep_out, int32_t* num_keep, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Batched form: `nseg` independent segments (image x class) laid back to back in dets; seg_offsets [nseg+1] int32
+ * (device).  keep_out holds, segment after segment at offset seg_offsets[s], the kept ORIGINAL (global) row indices
+ * ascending; num_keep [nseg].  One launch sequence for all segments (the (image x class) batching of BASELINE.md
+ * section 3).  max_seg = host-known upper bound on a segment's size (sizes the mask tiles). */
+size_t orp_rnms_batched_workspace_bytes(int n_total, int nseg, int max_seg);
+int orp_rnms_batched(const float* dets, int n_total, const int32_t* seg_offsets, int nseg, int max_seg,
+                     float iou_thr, int flavor, int64_t* keep_out, int32_t* num_keep,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Host-pointer API of DOTA_devkit/poly_nms_gpu (exact signatures of poly_nms.hpp:9-10 and poly_overlaps.hpp:1):
+ * host buffers in, host buffers out, own device allocation and a blocking copy, errors printed to stderr. */
+void _poly_nms(int* keep_out_host, int* num_out_host, const float* polys_host, int polys_num, int polys_dim,
+               float nms_overlap_thresh, int device_id);
+void _overlaps(float* overlaps_host, const float* boxes_host, const float* query_boxes_host, int n, int k,
+               int device_id);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Pairwise IoU matrices.
+ * orp_quad_iou_matrix: fp32 quad-quad IoU of every (a_i, b_j) with the arithmetic of devrIoU (guard=0) or
+ *   devPolyIoU (guard=1); rows of a/b are `stride` floats apart (8 or 9).  out [n,k] f32.
+ * orp_poly_overlaps: device half of _overlaps (poly_overlaps_kernel.cu:330-353): boxes [n,5], query [k,5] -> [n,k].
+ * ------------------------------------------------------------------------------------------------------- */
+int orp_quad_iou_matrix(const float* a, int n, const float* b, int k, int stride, int guard, float* out, void* stream);
+int orp_poly_overlaps(const float* boxes, int n, const float* query, int k, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * minaerarect: convex hull of 9 points -> minimum-area enclosing rectangle -> 4 corners.
+ * Replaces minareabbox(Tensor[M,18]) -> Tensor[M,8]  (mmdet/ops/minarearect/src/minarearect_cuda.cpp:5-9,
+ * minarearect_kernel.cu:455-505).  Optional fused decode of get_bboxes_single
+ * (orientedreppoints_head.py:746-749): out = rect * scale + (cx,cy) per row when `centers` != NULL
+ * (centers [m,2], scales [m]).
+ * ------------------------------------------------------------------------------------------------------- */
+int orp_minarearect(const float* pts, int m, float* out, void* stream);
+int orp_minarearect_decode(const float* pts, int m, const float* centers, const float* scales, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * convex_iou: IoU(hull(9 points), gt quad) for all pairs, fp64 internals.
+ * Replaces convex_iou_cuda(ex[N,18], gt[K,8]) -> flat [N*K]   (mmdet/ops/iou/src/convex_iou_kernel.cu:298-360).
+ * out [n,k] f32 row-major (point set major), exactly the reference's flat layout.
+ * ------------------------------------------------------------------------------------------------------- */
+int orp_convex_iou(const float* pts, int n, const float* gts, int k, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * pointsJf: ray-casting point-in-quad flags for all M x K pairs (mmdet/ops/point_justify/src/
+ * points_justify_kernel.cu:25-119) and the aligned form the SpatialBorderLoss actually needs (row i of 9 points
+ * against quad i; replaces 9 x (M x M) + torch.diag, spatial_border_loss.py:24-67).
+ * ------------------------------------------------------------------------------------------------------- */
+int orp_points_justify(const float* points, int m, const float* polygons, int k, float* out, void* stream);
+int orp_points_in_quad_aligned(const float* pts18, const float* quads, int m, float* out9, void* stream);
+
+/* ChamferDistance2D forward (mmdet/ops/chamfer_2d/src/chamfer_2d.cu:12-141): per batch nearest-neighbour
+ * squared distance + index, both directions.  xyz1 [b,n,2], xyz2 [b,m,2]; dist1/idx1 [b,n], dist2/idx2 [b,m]. */
+int orp_chamfer2d_forward(const float* xyz1, const float* xyz2, int b, int n, int m,
+                          float* dist1, float* dist2, int32_t* idx1, int32_t* idx2, void* stream);
+int orp_chamfer2d_backward(const float* xyz1, const float* xyz2, int b, int n, int m,
+                           const float* grad_dist1, const float* grad_dist2, const int32_t* idx1, const int32_t* idx2,
+                           float* grad_xyz1, float* grad_xyz2, void* stream);
+
+/* sigmoid focal loss forward/backward (mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_cuda.cu:23-167).
+ * logits [num,classes] f32, targets [num] int64 (0 = background, 1..classes), losses / d_logits [num,classes]. */
+int orp_sigmoid_focal_loss_forward(const float* logits, const int64_t* targets, int num, int classes,
+                                   float gamma, float alpha, float* losses, void* stream);
+int orp_sigmoid_focal_loss_backward(const float* logits, const int64_t* targets, const float* d_losses, int num,
+                                    int classes, float gamma, float alpha, float* d_logits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORP_HIP_H_ */

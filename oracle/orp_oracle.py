@@ -1,0 +1,299 @@
+"""ctypes front-end for the CPU oracle (oracle/orp_oracle.c) and, when present, oracle/_ref/libref_orp.so.
+
+TEST INFRASTRUCTURE ONLY: may be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (orientedreppoints_amd/) must never import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = [os.path.join(HERE, f) for f in ("orp_oracle.c", "orp_oracle2.c", "orp_polyclip.inc", "orp_hull.inc")]
+LIB = os.path.join(HERE, "liborp_oracle.so")
+REF_LIB = os.path.join(HERE, "_ref", "libref_orp.so")
+
+_c_f32p = ctypes.c_void_p
+_lib = None
+_ref = None
+
+
+def build(force=False):
+    """gcc -O2 -ffp-contract=off the restatement into oracle/liborp_oracle.so (a few seconds)."""
+    srcs = [s for s in SRC if os.path.exists(s)]
+    if (not force and os.path.exists(LIB)
+            and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs)):
+        return LIB
+    cfiles = [s for s in srcs if s.endswith(".c")]
+    cmd = ["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+           "-Wno-unused-function"] + cfiles + ["-o", LIB, "-lm"]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(LIB)
+        L.orc_quad_iou_f32.restype = ctypes.c_float
+        L.orc_poly_nms_iou_f32.restype = ctypes.c_float
+        L.orc_polyiou_f64.restype = ctypes.c_double
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The reference's own functions (None when oracle/_ref was never built, e.g. no /root/reference)."""
+    global _ref
+    if _ref is None and os.path.exists(REF_LIB):
+        L = ctypes.CDLL(REF_LIB)
+        for n in ("ref_rnms_iou", "ref_rnms_cpu_iou", "ref_poly_nms_iou", "ref_poly_overlaps_iou", "ref_convex_iou"):
+            getattr(L, n).restype = ctypes.c_float
+        L.ref_polyiou_iou.restype = ctypes.c_double
+        _ref = L
+    return _ref
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# oracle (restatement)
+# ---------------------------------------------------------------------------------------------------------
+def quad_iou_matrix(a, b, guard=False):
+    """fp32 quad IoU, all pairs; rows may carry extra columns (e.g. [x1..y4, score])."""
+    a, b = _f32(a), _f32(b)
+    assert a.shape[1] == b.shape[1]
+    out = np.empty((a.shape[0], b.shape[0]), np.float32)
+    lib().orc_quad_iou_matrix_f32(_p(a), a.shape[0], _p(b), b.shape[0], a.shape[1], int(guard), _p(out))
+    return out
+
+
+def polyiou(p, q):
+    p, q = _f64(p), _f64(q)
+    return lib().orc_polyiou_f64(_p(p), _p(q))
+
+
+def sort_order(scores):
+    s = _f32(scores)
+    order = np.empty(s.shape[0], np.int32)
+    lib().orc_sort_order(_p(s), s.shape[0], 1, _p(order))
+    return order
+
+
+def nms_sorted(dets, thr, guard=False):
+    d = _f32(dets)
+    keep = np.empty(d.shape[0], np.int32)
+    n = lib().orc_nms_sorted_f32(_p(d), d.shape[0], d.shape[1], ctypes.c_float(thr), int(guard), _p(keep))
+    return keep[:n].copy()
+
+
+def rnms(dets, thr):
+    """rnms_cuda semantics: original indices of kept boxes, ascending."""
+    d = _f32(dets)
+    keep = np.empty(d.shape[0], np.int64)
+    n = lib().orc_rnms(_p(d), d.shape[0], ctypes.c_float(thr), _p(keep))
+    return keep[:n].copy()
+
+
+def poly_gpu_nms(dets, thr):
+    """poly_nms.pyx:9-24 semantics: numpy argsort()[::-1] order, fp32 devPolyIoU, returns kept ORIGINAL indices
+    in score order."""
+    d = _f32(dets)
+    order = d[:, 8].argsort()[::-1]
+    keep = nms_sorted(d[order], thr, guard=True)
+    return [int(x) for x in order[keep]]
+
+
+def py_cpu_nms_poly(dets, thr):
+    """DOTA_devkit/ResultMerge.py:18-41 (fp64), same visiting order as the reference (numpy argsort()[::-1])."""
+    d = _f64(dets)
+    order = np.ascontiguousarray(d[:, 8].argsort()[::-1], dtype=np.int64)
+    keep = np.empty(d.shape[0], np.int64)
+    n = lib().orc_py_cpu_nms_poly(_p(d), d.shape[0], _p(order), ctypes.c_double(thr), _p(keep))
+    return [int(x) for x in keep[:n]]
+
+
+def poly_overlaps(boxes, query):
+    b, q = _f32(boxes), _f32(query)
+    out = np.empty((b.shape[0], q.shape[0]), np.float32)
+    lib().orc_poly_overlaps(_p(b), b.shape[0], _p(q), q.shape[0], _p(out))
+    return out
+
+
+def rotbox2poly(boxes):
+    b = _f32(boxes)
+    out = np.empty((b.shape[0], 8), np.float32)
+    lib().orc_rotbox2poly(_p(b), b.shape[0], _p(out))
+    return out
+
+
+def minarearect(pts):
+    p = _f32(pts)
+    out = np.empty((p.shape[0], 8), np.float32)
+    lib().orc_minarearect(_p(p), p.shape[0], _p(out))
+    return out
+
+
+def convex_iou(pts, gts):
+    p, g = _f32(pts), _f32(gts)
+    out = np.empty((p.shape[0], g.shape[0]), np.float32)
+    lib().orc_convex_iou(_p(p), p.shape[0], _p(g), g.shape[0], _p(out))
+    return out
+
+
+def stats():
+    L = lib()
+    return dict(max_clip_n=L.orc_stat_max_clip_n(), clip_overflow=L.orc_stat_clip_overflow())
+
+
+def stats_reset():
+    lib().orc_stat_reset()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# reference (_ref) -- same call shapes, for pinning the restatement
+# ---------------------------------------------------------------------------------------------------------
+def ref_quad_iou_matrix(a, b):
+    a, b = _f32(a), _f32(b)
+    out = np.empty((a.shape[0], b.shape[0]), np.float32)
+    ref().ref_rnms_iou_matrix(_p(a), a.shape[0], _p(b), b.shape[0], a.shape[1], _p(out))
+    return out
+
+
+def ref_pair_iou(fn, p, q):
+    p, q = _f32(p), _f32(q)
+    return getattr(ref(), fn)(_p(p), _p(q))
+
+
+def ref_polyiou(p, q):
+    p, q = _f64(p), _f64(q)
+    return ref().ref_polyiou_iou(_p(p), _p(q))
+
+
+def ref_nms_sorted(dets, thr, which=0):
+    d = _f32(dets)
+    assert d.shape[1] == 9
+    keep = np.empty(d.shape[0], np.int32)
+    n = ref().ref_nms_sorted(_p(d), d.shape[0], ctypes.c_float(thr), which, _p(keep))
+    return keep[:n].copy()
+
+
+def ref_poly_overlaps(boxes, query):
+    b, q = _f32(boxes), _f32(query)
+    out = np.empty((b.shape[0], q.shape[0]), np.float32)
+    ref().ref_poly_overlaps(_p(b), b.shape[0], _p(q), q.shape[0], _p(out))
+    return out
+
+
+def ref_minarearect(pts):
+    p = _f32(pts)
+    out = np.empty((p.shape[0], 8), np.float32)
+    ref().ref_minarearect_batch(_p(p), p.shape[0], _p(out))
+    return out
+
+
+def ref_convex_iou(pts, gts):
+    p, g = _f32(pts), _f32(gts)
+    out = np.empty((p.shape[0], g.shape[0]), np.float32)
+    ref().ref_convex_iou_matrix(_p(p), p.shape[0], _p(g), g.shape[0], _p(out))
+    return out
+
+
+def ref_convex_giou(pts, gts):
+    p, g = _f32(pts), _f32(gts)
+    out = np.empty((p.shape[0], 19), np.float32)
+    ref().ref_convex_giou_batch(_p(p), _p(g), p.shape[0], _p(out))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# part 2: pointsJf / chamfer / focal
+# ---------------------------------------------------------------------------------------------------------
+def points_justify(points, polys):
+    p, q = _f32(points), _f32(polys)
+    out = np.empty((p.shape[0], q.shape[0]), np.float32)
+    lib().orc_points_justify(_p(p), p.shape[0], _p(q), q.shape[0], _p(out))
+    return out
+
+
+def points_in_quad_aligned(pts18, quads):
+    p, q = _f32(pts18), _f32(quads)
+    out = np.empty((p.shape[0], 9), np.float32)
+    lib().orc_points_in_quad_aligned(_p(p), _p(q), p.shape[0], _p(out))
+    return out
+
+
+def chamfer_forward(xyz1, xyz2):
+    a, b = _f32(xyz1), _f32(xyz2)
+    B, n, m = a.shape[0], a.shape[1], b.shape[1]
+    d1 = np.empty((B, n), np.float32); i1 = np.empty((B, n), np.int32)
+    d2 = np.empty((B, m), np.float32); i2 = np.empty((B, m), np.int32)
+    lib().orc_chamfer_nn(_p(a), _p(b), B, n, m, _p(d1), _p(i1))
+    lib().orc_chamfer_nn(_p(b), _p(a), B, m, n, _p(d2), _p(i2))
+    return d1, d2, i1, i2
+
+
+def chamfer_backward(xyz1, xyz2, g1, g2, i1, i2):
+    a, b = _f32(xyz1), _f32(xyz2)
+    B, n, m = a.shape[0], a.shape[1], b.shape[1]
+    ga = np.zeros_like(a); gb = np.zeros_like(b)
+    g1, g2 = _f32(g1), _f32(g2)
+    i1 = np.ascontiguousarray(i1, np.int32); i2 = np.ascontiguousarray(i2, np.int32)
+    lib().orc_chamfer_grad(_p(a), _p(b), B, n, m, _p(g1), _p(i1), _p(ga), _p(gb))
+    lib().orc_chamfer_grad(_p(b), _p(a), B, m, n, _p(g2), _p(i2), _p(gb), _p(ga))
+    return ga, gb
+
+
+def focal_forward(logits, targets, gamma, alpha):
+    x = _f32(logits); t = np.ascontiguousarray(targets, np.int64)
+    out = np.empty_like(x)
+    lib().orc_focal_forward(_p(x), _p(t), x.shape[0], x.shape[1], ctypes.c_float(gamma), ctypes.c_float(alpha), _p(out))
+    return out
+
+
+def focal_backward(logits, targets, d_losses, gamma, alpha):
+    x = _f32(logits); t = np.ascontiguousarray(targets, np.int64); g = _f32(d_losses)
+    out = np.empty_like(x)
+    lib().orc_focal_backward(_p(x), _p(t), _p(g), x.shape[0], x.shape[1], ctypes.c_float(gamma), ctypes.c_float(alpha), _p(out))
+    return out
+
+
+def ref_points_justify(points, polys):
+    p, q = _f32(points), _f32(polys)
+    out = np.full((p.shape[0], q.shape[0]), -1, np.float32)
+    ref().ref_points_justify(_p(p), p.shape[0], _p(q), q.shape[0], _p(out))
+    return out
+
+
+def ref_chamfer_nn(xyz, xyz2):
+    a, b = _f32(xyz), _f32(xyz2)
+    B, n, m = a.shape[0], a.shape[1], b.shape[1]
+    d = np.empty((B, n), np.float32); i = np.empty((B, n), np.int32)
+    ref().ref_chamfer_nn(B, n, _p(a), m, _p(b), _p(d), _p(i))
+    return d, i
+
+
+def ref_focal_forward(logits, targets, gamma, alpha):
+    x = _f32(logits); t = np.ascontiguousarray(targets, np.int64)
+    out = np.empty_like(x)
+    ref().ref_focal_forward(_p(x), _p(t), x.shape[0], x.shape[1], ctypes.c_float(gamma), ctypes.c_float(alpha), _p(out))
+    return out
+
+
+def ref_focal_backward(logits, targets, d_losses, gamma, alpha):
+    x = _f32(logits); t = np.ascontiguousarray(targets, np.int64); g = _f32(d_losses)
+    out = np.empty_like(x)
+    ref().ref_focal_backward(_p(x), _p(t), _p(g), x.shape[0], x.shape[1], ctypes.c_float(gamma), ctypes.c_float(alpha), _p(out))
+    return out

@@ -1,0 +1,110 @@
+/* oracle/orp_oracle2.c -- CPU ORACLE part 2 (TEST INFRASTRUCTURE ONLY): the small per-element ops.
+ *   pointsJf          mmdet/ops/point_justify/src/points_justify_kernel.cu:25-102
+ *   ChamferDistance2D mmdet/ops/chamfer_2d/src/chamfer_2d.cu:12-124 (forward), :145-158 (backward)
+ *   sigmoid focal     mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_cuda.cu:23-97
+ * Pinned against oracle/_ref (the reference kernels run under a 1-thread launch emulation) in
+ * tests/test_oracle_vs_ref.py.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+/* ray casting with the reference's early-`break` semantics (points_justify_kernel.cu:51-99) */
+static float point_in_quad(float px, float py, const float* q) {
+  int ncross = 0;
+  int i, j;
+  for (i = 0, j = 3; i < 4; j = i, i++) {
+    float sx = q[2 * i], sy = q[2 * i + 1], tx = q[2 * j], ty = q[2 * j + 1];
+    if (py < (sy < ty ? sy : ty)) continue;
+    if (py > (sy > ty ? sy : ty)) continue;
+    if ((sx == px && sy == py) || (tx == px && ty == py)) break;
+    if ((sy < py && ty >= py) || (sy >= py && ty < py)) {
+      float x = sx + (py - sy) * (tx - sx) / (ty - sy);
+      if (x == px) break;
+      if (x > px) ncross++;
+    }
+  }
+  return (ncross % 2 == 1) ? 1.0f : 0.0f;
+}
+void orc_points_justify(const float* points, int m, const float* polys, int k, float* out) {
+  for (int r = 0; r < m; r++)
+    for (int c = 0; c < k; c++) out[(size_t)r * k + c] = point_in_quad(points[2 * r], points[2 * r + 1], polys + 8 * c);
+}
+/* aligned form = the diagonal the SpatialBorderLoss reads (spatial_border_loss.py:24-67) */
+void orc_points_in_quad_aligned(const float* pts18, const float* quads, int m, float* out9) {
+  for (int r = 0; r < m; r++)
+    for (int t = 0; t < 9; t++)
+      out9[(size_t)r * 9 + t] = point_in_quad(pts18[(size_t)r * 18 + 2 * t], pts18[(size_t)r * 18 + 2 * t + 1], quads + 8 * (size_t)r);
+}
+
+/* nearest neighbour, first minimum wins (strict <); chamfer_2d.cu:21-121 for the sizes the head uses.
+ * NB the reference's `end_ka = end_k - (end_k & 2)` reads one stale LDS slot when m % 4 == 3 -- undefined there,
+ * the mathematically defined nearest neighbour here. */
+void orc_chamfer_nn(const float* xyz, const float* xyz2, int b, int n, int m, float* result, int32_t* result_i) {
+  for (int bi = 0; bi < b; bi++)
+    for (int j = 0; j < n; j++) {
+      float x1 = xyz[((size_t)bi * n + j) * 2], y1 = xyz[((size_t)bi * n + j) * 2 + 1];
+      float best = 0; int best_i = 0;
+      for (int kk = 0; kk < m; kk++) {
+        float x2 = xyz2[((size_t)bi * m + kk) * 2] - x1, y2 = xyz2[((size_t)bi * m + kk) * 2 + 1] - y1;
+        float d = x2 * x2 + y2 * y2;
+        if (kk == 0 || d < best) { best = d; best_i = kk; }
+      }
+      result[(size_t)bi * n + j] = best; result_i[(size_t)bi * n + j] = best_i;
+    }
+}
+/* chamfer_2d.cu:145-158; accumulates into grad_xyz1 / grad_xyz2 (caller zeroes them) */
+void orc_chamfer_grad(const float* xyz1, const float* xyz2, int b, int n, int m, const float* grad_dist1,
+                      const int32_t* idx1, float* grad_xyz1, float* grad_xyz2) {
+  for (int bi = 0; bi < b; bi++)
+    for (int j = 0; j < n; j++) {
+      size_t o1 = ((size_t)bi * n + j) * 2;
+      int j2 = idx1[(size_t)bi * n + j];
+      size_t o2 = ((size_t)bi * m + j2) * 2;
+      float g = grad_dist1[(size_t)bi * n + j] * 2;
+      grad_xyz1[o1] += g * (xyz1[o1] - xyz2[o2]);
+      grad_xyz1[o1 + 1] += g * (xyz1[o1 + 1] - xyz2[o2 + 1]);
+      grad_xyz2[o2] += -(g * (xyz1[o1] - xyz2[o2]));
+      grad_xyz2[o2 + 1] += -(g * (xyz1[o1 + 1] - xyz2[o2 + 1]));
+    }
+}
+
+/* sigmoid focal loss, expression structure (float/double mix) as written in the reference */
+void orc_focal_forward(const float* logits, const int64_t* targets, int num, int classes, float gamma, float alpha,
+                       float* losses) {
+  for (long i = 0; i < (long)num * classes; i++) {
+    int n = (int)(i / classes), d = (int)(i % classes);
+    int t = (int)targets[n];
+    float c1 = (t == (d + 1));
+    float c2 = (t >= 0 & t != (d + 1));
+    float zn = (float)(1.0 - alpha), zp = alpha;
+    float x = logits[i];
+    float p = (float)(1. / (1. + expf(-x)));
+    float term1 = powf((float)(1. - p), gamma) * logf(p > FLT_MIN ? p : FLT_MIN);
+    float term2 = (float)(powf(p, gamma) * (-1. * x * (x >= 0) - logf((float)(1. + expf((float)(x - 2. * x * (x >= 0)))))));
+    float l = 0.0f;
+    l += -c1 * term1 * zp;
+    l += -c2 * term2 * zn;
+    losses[i] = l;
+  }
+}
+void orc_focal_backward(const float* logits, const int64_t* targets, const float* d_losses, int num, int classes,
+                        float gamma, float alpha, float* d_logits) {
+  for (long i = 0; i < (long)num * classes; i++) {
+    int n = (int)(i / classes), d = (int)(i % classes);
+    int t = (int)targets[n];
+    float c1 = (t == (d + 1));
+    float c2 = (t >= 0 & t != (d + 1));
+    float zn = (float)(1.0 - alpha), zp = alpha;
+    float x = logits[i];
+    float p = (float)(1. / (1. + expf(-x)));
+    float term1 = (float)(powf((float)(1. - p), gamma) * (1. - p - (p * gamma * logf(p > FLT_MIN ? p : FLT_MIN))));
+    float term2 = (float)(powf(p, gamma) *
+                          ((-1. * x * (x >= 0) - logf((float)(1. + expf((float)(x - 2. * x * (x >= 0)))))) * (1. - p) * gamma - p));
+    float g = 0.0f;
+    g += -c1 * term1 * zp;
+    g += -c2 * term2 * zn;
+    d_logits[i] = g * d_losses[i];
+  }
+}

@@ -1,0 +1,103 @@
+"""ctypes binding of liborp_hip.so (the C ABI declared in include/orp_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing the import of any operator fails loudly.
+PyTorch is used for device memory, the current stream and (elsewhere) torch.distributed only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liborp_hip.so")
+
+ORP_OK, ORP_EINVAL, ORP_EWORKSPACE, ORP_ETOOBIG = 0, -1, -2, -3
+ORP_NMS_MAX_BOXES = 131072
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/orp_hip.h one to one
+_SIGNATURES = {
+    "orp_version": (ctypes.c_char_p, []),
+    "orp_rnms_workspace_bytes": (_sz, [_i]),
+    "orp_rnms": (_i, [_vp, _i, _f, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "orp_rnms_batched_workspace_bytes": (_sz, [_i, _i, _i]),
+    "orp_rnms_batched": (_i, [_vp, _i, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _sz, _vp]),
+    "_poly_nms": (None, [_vp, _vp, _vp, _i, _i, _f, _i]),
+    "_overlaps": (None, [_vp, _vp, _vp, _i, _i, _i]),
+    "orp_quad_iou_matrix": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "orp_poly_overlaps": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "orp_minarearect": (_i, [_vp, _i, _vp, _vp]),
+    "orp_minarearect_decode": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "orp_convex_iou": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "orp_points_justify": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "orp_points_in_quad_aligned": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "orp_chamfer2d_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "orp_chamfer2d_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "orp_sigmoid_focal_loss_forward": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    "orp_sigmoid_focal_loss_backward": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+}
+
+_lib = None
+
+
+class OrpHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load liborp_hip.so (once).  Raises if it has not been built: there is deliberately no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OrpHipError(
+                "orientedreppoints_amd: HIP library %s is missing. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the hot path." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError = the .so is stale vs the header: also loud
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != ORP_OK:
+        names = {ORP_EINVAL: "ORP_EINVAL", ORP_EWORKSPACE: "ORP_EWORKSPACE", ORP_ETOOBIG: "ORP_ETOOBIG"}
+        raise OrpHipError("%s failed: %s" % (what, names.get(rc, "hipError %d" % rc)))
+
+
+def ptr(t):
+    """Device (or host) address of a contiguous tensor, or NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "orientedreppoints_amd: tensor must be contiguous"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    """hipStream_t of PyTorch's current stream on the tensor's device (ops are stream-ordered, never blocking)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_cuda(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA tensor" % name)
+
+
+_workspaces = {}
+
+
+def workspace(device, nbytes):
+    """A cached, growing byte buffer per device (PyTorch's caching allocator is the memory plumbing)."""
+    key = (device.type, device.index)
+    w = _workspaces.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = w
+    return w

@@ -1,0 +1,66 @@
+"""Compile the HIP kernels + C ABI into orientedreppoints_amd/csrc/liborp_hip.so (gfx950 only, in-tree).
+
+hipcc cross-compiles without a GPU.  The geometry kernels are built with -ffp-contract=off because the fp32
+operation order of the rotated-IoU core is part of the parity contract (bit-exact NMS decisions); the DeformConv
+contraction is built with contraction on (MFMA / FMA is what it is for).
+"""
+import concurrent.futures
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "liborp_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-result", "-Wno-unused-value"]
+# (source, extra flags)
+SOURCES = [
+    ("orp_nms.hip", ["-ffp-contract=off"]),
+    ("orp_overlaps.hip", ["-ffp-contract=off"]),
+    ("orp_minarearect.hip", ["-ffp-contract=off"]),
+    ("orp_convex.hip", ["-ffp-contract=off"]),
+    ("orp_pointwise.hip", ["-ffp-contract=off"]),
+]
+HEADERS = ["orp_geom.hpp", "orp_hull.hpp", os.path.join("..", "..", "include", "orp_hip.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _compile(src, extra):
+    obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if _stale(obj, deps):
+        cmd = [HIPCC] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        subprocess.check_call(cmd, cwd=CSRC)
+    return obj
+
+
+def build_hip(force=False, verbose=False):
+    if not os.path.exists(HIPCC):
+        raise RuntimeError("hipcc not found at %s: cannot build liborp_hip.so" % HIPCC)
+    present = [(s, f) for s, f in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if force:
+        for s, _ in present:
+            o = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
+            if os.path.exists(o):
+                os.remove(o)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(present))) as ex:
+        objs = list(ex.map(lambda sf: _compile(*sf), present))
+    if _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(verbose=True))

@@ -1,0 +1,123 @@
+// orp_convex.hip -- convex_iou: IoU(hull(9 points), gt quad) for all (point set, gt) pairs on gfx950.
+//
+// Replaces convex_iou_kernel + convex_iou_cuda (mmdet/ops/iou/src/convex_iou_kernel.cu:268-360), the op behind
+// MaxIoUAssigner.assign (mmdet/core/bbox/assigners/max_iou_assigner.py:66).  Reference shape: one thread per point
+// set looping over all K gts, the Jarvis hull recomputed K times, Point[100] private arrays, and a D2H -> host
+// loop -> H2D round trip of N*K floats.  Here:
+//   * lane = point set; the hull is built ONCE per lane and parked in an LDS column as float (hull vertices are
+//     copies of the fp32 inputs, so the float -> double widening on load is exact);
+//   * the gt quad is wave-uniform (scalar loads), grid.y splits the gt range so small N still fills the chip;
+//   * fp64 clipping scratch is a per-lane LDS column of 8 + 8 vertices instead of ~3 KB of private stack;
+//   * results are written straight to the [N, K] matrix on the caller's stream -- no host round trip.
+// Arithmetic (fp64 internals, eps 1e-8, signed triangle fan WITHOUT fabs on each term, convex_iou_kernel.cu:137)
+// follows the reference operation for operation: assignment decisions downstream compare these floats.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orp_hip.h"
+#include "orp_hull.hpp"
+
+namespace {
+using orp::Pt;
+
+constexpr int kThreads = 64;                  // one wave per workgroup: LDS per lane is what limits occupancy
+constexpr int kHullKeep = 12;                 // stored hull vertices (a 9-point hull has <= 9)
+
+// float-backed store that widens to double on access (exact)
+struct HullStoreF {
+  Pt<float>* base; int stride;
+  __device__ __forceinline__ Pt<double> get(int i) const { Pt<float> v = base[i * stride]; Pt<double> r; r.x = (double)v.x; r.y = (double)v.y; return r; }
+  __device__ __forceinline__ void set(int i, Pt<double> v) const { Pt<float> f; f.x = (float)v.x; f.y = (float)v.y; base[i * stride] = f; }
+};
+// same, but silently drops writes past its capacity (degenerate / NaN inputs only)
+template <int CAPACITY> struct HullStoreFCap {
+  Pt<float>* base; int stride;
+  __device__ __forceinline__ Pt<double> get(int i) const { Pt<float> v = base[(i < CAPACITY ? i : CAPACITY - 1) * stride]; Pt<double> r; r.x = (double)v.x; r.y = (double)v.y; return r; }
+  __device__ __forceinline__ void set(int i, Pt<double> v) const { if (i < CAPACITY) { Pt<float> f; f.x = (float)v.x; f.y = (float)v.y; base[i * stride] = f; } }
+};
+
+__global__ void __launch_bounds__(kThreads)
+convex_iou_kernel(const float* __restrict__ pts, int n, const float* __restrict__ gts, int k, int gts_per_block,
+                  float* __restrict__ out) {
+  // region A: first the hull builder's input (9) + left chain (10) as float points, later the fp64 clip scratch
+  __shared__ __attribute__((aligned(16))) unsigned char s_a[2 * orp::ORP_CLIP_CAP * sizeof(Pt<double>) * kThreads];
+  __shared__ Pt<float> s_hull[kHullKeep][kThreads];
+  const int lane = threadIdx.x;
+  const int idx = blockIdx.x * kThreads + lane;
+  const bool active = idx < n;
+  const int j0 = blockIdx.y * gts_per_block;
+  const int j1 = min(k, j0 + gts_per_block);
+
+  int n1 = 0;
+  double s_pred = 0.0;
+  HullStoreFCap<kHullKeep> H{&s_hull[0][lane], kThreads};
+  if (active) {
+    Pt<float>* fa = reinterpret_cast<Pt<float>*>(s_a);
+    HullStoreF IN{fa + lane, kThreads};
+    HullStoreF L{fa + 9 * kThreads + lane, kThreads};
+    const float2* src = reinterpret_cast<const float2*>(pts + (size_t)idx * 18);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { float2 v = src[i]; Pt<double> p; p.x = (double)v.x; p.y = (double)v.y; IN.set(i, p); }
+    n1 = orp::jarvis_hull<double>(IN, 9, H, L);
+    if (n1 > kHullKeep) n1 = kHullKeep;
+    // orient CCW once (intersectAreaO: area(ps1) < 0 -> reverse1), then S_pred = area of the oriented ring
+    s_pred = orp::poly_area<double>(H, n1);
+    if (s_pred < 0) {
+      for (int a = 0, b = n1 - 1; a < b; a++, b--) { Pt<double> t = H.get(a); H.set(a, H.get(b)); H.set(b, t); }
+      s_pred = orp::poly_area<double>(H, n1);
+    }
+  }
+  __syncthreads();   // region A changes role (single wave, but keep the LDS ordering explicit)
+  Pt<double>* da = reinterpret_cast<Pt<double>*>(s_a);
+  orp::PolyLds<double> P{da + lane, kThreads};
+  orp::PolyLds<double> Q{da + orp::ORP_CLIP_CAP * kThreads + lane, kThreads};
+
+  for (int j = j0; j < j1; j++) {
+    const float* g = gts + (size_t)j * 8;          // wave-uniform
+    Pt<double> q[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { q[t].x = (double)g[2 * t]; q[t].y = (double)g[2 * t + 1]; }
+    auto area4 = [](const Pt<double>* v) {
+      double res = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) res += v[i].x * v[(i + 1) & 3].y - v[i].y * v[(i + 1) & 3].x;
+      return res / 2.0;
+    };
+    if (area4(q) < 0) { Pt<double> t = q[0]; q[0] = q[3]; q[3] = t; t = q[1]; q[1] = q[2]; q[2] = t; }
+    const double s_gt = area4(q);
+    if (!active) continue;
+    double inter = 0;
+    Pt<double> a = H.get(0);
+    const Pt<double> h0 = a;
+    for (int i = 0; i < n1; i++) {
+      const Pt<double> b = (i + 1 < n1) ? H.get(i + 1) : h0;
+#pragma unroll 1
+      for (int t = 0; t < 4; t++) {
+        Pt<double> c = q[0], d = q[1];
+        if (t == 1) { c = q[1]; d = q[2]; } else if (t == 2) { c = q[2]; d = q[3]; } else if (t == 3) { c = q[3]; d = q[0]; }
+        inter += orp::tri_term<double, false>(P, Q, a, b, c, d);
+      }
+      a = b;
+    }
+    const double uni = fabs(s_pred) + fabs(s_gt) - inter;
+    out[(size_t)idx * k + j] = (float)(inter / uni);
+  }
+}
+}  // namespace
+
+extern "C" {
+int orp_convex_iou(const float* pts, int n, const float* gts, int k, float* out, void* stream) {
+  if (n < 0 || k < 0 || ((n > 0 && k > 0) && (!pts || !gts || !out))) return ORP_EINVAL;
+  if (n == 0 || k == 0) return ORP_OK;
+  const int nb = (n + kThreads - 1) / kThreads;
+  // split the gt range until there are ~8 waves per SIMD worth of workgroups (or one gt per block)
+  int ysplit = 1;
+  while (nb * ysplit < 8192 && ysplit < k) ysplit *= 2;
+  int gpb = (k + ysplit - 1) / ysplit;
+  ysplit = (k + gpb - 1) / gpb;
+  hipLaunchKernelGGL(convex_iou_kernel, dim3(nb, ysplit), dim3(kThreads), 0, (hipStream_t)stream, pts, n, gts, k, gpb,
+                     out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+}

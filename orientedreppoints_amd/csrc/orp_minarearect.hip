@@ -1,0 +1,119 @@
+// orp_minarearect.hip -- minaerarect (9 points -> convex hull -> minimum-area rectangle -> 4 corners) for gfx950.
+//
+// Replaces minareabbox_cuda + minareabbox_kernel (mmdet/ops/minarearect/src/minarearect_kernel.cu:52-505):
+// the reference launches 512-thread blocks, copies the result device->host, loops over it on the host and copies
+// it back (:489-504) -- a blocking round trip per FPN level.  Here the result never leaves HBM, the launch is
+// stream-ordered, and the decode of get_bboxes_single (orientedreppoints_head.py:746-749, rect*stride + centre)
+// can be fused into the store.
+//
+// Numerics mirror the reference: float pi = 3.1415926f, rotation built from cos(theta -/+ pi/2), angles folded
+// into [0, pi/2) in mixed float/double exactly as written, exact `==` de-duplication of edge angles, +-1e12
+// sentinels, first strictly-smallest area wins.  cos() is evaluated as (float)cos((double)x): correctly rounded
+// for practically every input, which is what glibc's cosf gives the CPU oracle (device cosf can be 1 ulp off and a
+// 1-ulp change can flip the first-minimum tie between two edge directions of a rectangle-like hull).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orp_hip.h"
+#include "orp_hull.hpp"
+
+namespace {
+using orp::Pt;
+
+constexpr int kThreads = 128;
+constexpr int kInSlots = 9, kHullSlots = orp::ORP_HULL_MAX + 2, kLeftSlots = orp::ORP_HULL_CAP + 1;
+
+__device__ __forceinline__ float cos_cr(float x) { return (float)cos((double)x); }
+
+__global__ void __launch_bounds__(kThreads)
+minarearect_kernel(const float* __restrict__ pts, int m, const float* __restrict__ centers,
+                   const float* __restrict__ scales, float* __restrict__ out) {
+  __shared__ Pt<float> s_in[kInSlots][kThreads];
+  __shared__ Pt<float> s_hull[kHullSlots][kThreads];
+  __shared__ Pt<float> s_left[kLeftSlots][kThreads];   // reused for the edge angles after the hull is merged
+  const int idx = blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= m) return;
+  orp::PolyLds<float> IN{&s_in[0][threadIdx.x], kThreads};
+  orp::PolyLds<float> H{&s_hull[0][threadIdx.x], kThreads};
+  orp::PolyLds<float> L{&s_left[0][threadIdx.x], kThreads};
+
+  const float2* src = reinterpret_cast<const float2*>(pts + (size_t)idx * 18);
+#pragma unroll
+  for (int i = 0; i < 9; i++) { float2 v = src[i]; Pt<float> p; p.x = v.x; p.y = v.y; IN.set(i, p); }
+  const int n1 = orp::jarvis_hull<float>(IN, 9, H, L);
+  H.set(n1, H.get(0));                       // closed ring: n1 + 1 points, n1 edges
+  const int n_points = n1 + 1, n_edges = n1;
+  const float pi = 3.1415926f;
+
+  // edge angles folded into [0, pi/2)  (minarearect_kernel.cu:74-88); kept in the x field of the L column
+  float* ang = reinterpret_cast<float*>(&s_left[0][threadIdx.x]);
+  const int astride = kThreads * 2;          // floats between consecutive L slots
+  {
+    Pt<float> a = H.get(0);
+    for (int i = 0; i < n_edges; i++) {
+      Pt<float> b = H.get(i + 1);
+      float ex = b.x - a.x, ey = b.y - a.y;
+      float t = (float)atan2((double)ey, (double)ex);
+      if (t >= 0) t = (float)fmod((double)t, (double)pi / 2);
+      else t = t - (int)(t / (pi / 2) - 1) * (pi / 2);
+      if (i < kLeftSlots) ang[i * astride] = t;
+      a = b;
+    }
+  }
+  const int n_ang = n_edges < kLeftSlots ? n_edges : kLeftSlots;
+  float minarea = 1e12f;
+  float b_ang = 0.f, b_xmin = 0.f, b_ymin = 0.f, b_xmax = 0.f, b_ymax = 0.f;
+  for (int i = 0; i < n_ang; i++) {
+    const float t = ang[i * astride];
+    bool dup = false;                        // "unique" = first occurrence of this exact value
+    for (int j = 0; j < i; j++) dup = dup || (ang[j * astride] == t);
+    if (dup) continue;
+    const float R00 = cos_cr(t), R01 = cos_cr(t - pi / 2), R10 = cos_cr(t + pi / 2), R11 = R00;
+    float xmin = 1e12f, ymin = 1e12f, xmax = -1e12f, ymax = -1e12f;
+    for (int j = 0; j < n_points; j++) {
+      Pt<float> p = H.get(j);
+      float rx = 0.0f, ry = 0.0f;
+      rx = rx + R00 * p.x; rx = rx + R01 * p.y;
+      ry = ry + R10 * p.x; ry = ry + R11 * p.y;
+      if (!(isinf(rx) || isnan(rx))) { if (rx < xmin) xmin = rx; if (rx > xmax) xmax = rx; }
+      if (!(isinf(ry) || isnan(ry))) { if (ry < ymin) ymin = ry; if (ry > ymax) ymax = ry; }
+    }
+    const float area = (xmax - xmin) * (ymax - ymin);
+    if (area < minarea) { minarea = area; b_ang = t; b_xmin = xmin; b_ymin = ymin; b_xmax = xmax; b_ymax = ymax; }
+  }
+  // corners (xmax,ymin),(xmin,ymin),(xmin,ymax),(xmax,ymax) as row vectors times R  (:343-452)
+  const float R00 = cos_cr(b_ang), R01 = cos_cr(b_ang - pi / 2), R10 = cos_cr(b_ang + pi / 2), R11 = R00;
+  const float cx[4] = {b_xmax, b_xmin, b_xmin, b_xmax}, cy[4] = {b_ymin, b_ymin, b_ymax, b_ymax};
+  float o[8];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    float s0 = 0.0f, s1 = 0.0f;
+    s0 = s0 + cx[c] * R00; s0 = s0 + cy[c] * R10;
+    s1 = s1 + cx[c] * R01; s1 = s1 + cy[c] * R11;
+    o[2 * c] = s0; o[2 * c + 1] = s1;
+  }
+  if (centers != nullptr) {                  // fused decode: rect * stride + (cx, cy) repeated 4x (head :748-749)
+    const float sc = scales[idx], ccx = centers[2 * idx], ccy = centers[2 * idx + 1];
+#pragma unroll
+    for (int c = 0; c < 4; c++) { o[2 * c] = o[2 * c] * sc + ccx; o[2 * c + 1] = o[2 * c + 1] * sc + ccy; }
+  }
+  float4* dst = reinterpret_cast<float4*>(out + (size_t)idx * 8);
+  dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+  dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+}  // namespace
+
+extern "C" {
+int orp_minarearect_decode(const float* pts, int m, const float* centers, const float* scales, float* out,
+                           void* stream) {
+  if (m < 0 || (m > 0 && (!pts || !out)) || ((centers == nullptr) != (scales == nullptr))) return ORP_EINVAL;
+  if (m == 0) return ORP_OK;
+  hipLaunchKernelGGL(minarearect_kernel, dim3((m + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream,
+                     pts, m, centers, scales, out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+int orp_minarearect(const float* pts, int m, float* out, void* stream) {
+  return orp_minarearect_decode(pts, m, nullptr, nullptr, out, stream);
+}
+}

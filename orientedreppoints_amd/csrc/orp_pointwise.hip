@@ -1,0 +1,212 @@
+// orp_pointwise.hip -- the small per-element ops of the APAA / loss path on gfx950:
+//   pointsJf          mmdet/ops/point_justify/src/points_justify_kernel.cu:25-119
+//   ChamferDistance2D mmdet/ops/chamfer_2d/src/chamfer_2d.cu:12-182
+//   sigmoid focal     mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_cuda.cu:23-167
+// All are HBM-bound element-wise / tiny-reduction kernels: grid-stride, coalesced, no host synchronisation.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "../../include/orp_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+inline int grid_for(long n) { long b = (n + kThreads - 1) / kThreads; if (b > 256L * 32) b = 256L * 32; if (b < 1) b = 1; return (int)b; }
+
+// ---- point in quad (ray casting with the reference's early `break` semantics) -------------------------------------
+// Returns 1.0f when the crossing count accumulated so far is odd.  A vertex hit or a point exactly on an edge stops
+// the edge scan (points_justify_kernel.cu:70-84), so the parity of the crossings counted BEFORE it decides.
+__device__ __forceinline__ float point_in_quad(float px, float py, const float* q) {
+  int ncross = 0;
+  // edge order of the reference loop: (i, j) = (0,3), (1,0), (2,1), (3,2)
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int j = (i + 3) & 3;
+    const float sx = q[2 * i], sy = q[2 * i + 1], tx = q[2 * j], ty = q[2 * j + 1];
+    if (py < fminf(sy, ty)) continue;
+    if (py > fmaxf(sy, ty)) continue;
+    if ((sx == px && sy == py) || (tx == px && ty == py)) break;
+    if ((sy < py && ty >= py) || (sy >= py && ty < py)) {
+      const float x = sx + (py - sy) * (tx - sx) / (ty - sy);
+      if (x == px) break;
+      if (x > px) ncross++;
+    }
+  }
+  return (ncross & 1) ? 1.0f : 0.0f;
+}
+
+__global__ void points_justify_kernel(const float* __restrict__ points, int m, const float* __restrict__ polys, int k,
+                                      float* __restrict__ out) {
+  const long total = (long)m * k;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / k), col = (int)(idx % k);
+    float q[8];
+    const float4* qp = reinterpret_cast<const float4*>(polys + (size_t)col * 8);
+    float4 a = qp[0], b = qp[1];
+    q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    out[idx] = point_in_quad(points[2 * (size_t)row], points[2 * (size_t)row + 1], q);
+  }
+}
+
+// aligned: the 9 points of row i against quad i -> out[i, 0..9)
+__global__ void points_in_quad_aligned_kernel(const float* __restrict__ pts18, const float* __restrict__ quads, int m,
+                                              float* __restrict__ out9) {
+  const long total = (long)m * 9;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / 9), t = (int)(idx % 9);
+    float q[8];
+    const float4* qp = reinterpret_cast<const float4*>(quads + (size_t)row * 8);
+    float4 a = qp[0], b = qp[1];
+    q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    out9[idx] = point_in_quad(pts18[(size_t)row * 18 + 2 * t], pts18[(size_t)row * 18 + 2 * t + 1], q);
+  }
+}
+
+// ---- chamfer 2d -----------------------------------------------------------------------------------------------
+// one thread per (batch, query point): exact nearest neighbour, FIRST minimum wins (strict <), squared distance.
+__global__ void chamfer_nn_kernel(const float* __restrict__ xyz, const float* __restrict__ xyz2, int b, int n, int m,
+                                  float* __restrict__ result, int32_t* __restrict__ result_i) {
+  const long total = (long)b * n;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int bi = (int)(idx / n);
+    const float x1 = xyz[2 * idx], y1 = xyz[2 * idx + 1];
+    const float2* o = reinterpret_cast<const float2*>(xyz2 + (size_t)bi * m * 2);
+    float best = 0.f; int best_i = 0;
+    for (int kk = 0; kk < m; kk++) {
+      const float2 p = o[kk];
+      const float x2 = p.x - x1, y2 = p.y - y1;
+      const float d = x2 * x2 + y2 * y2;
+      if (kk == 0 || d < best) { best = d; best_i = kk; }
+    }
+    result[idx] = best; result_i[idx] = best_i;
+  }
+}
+
+__global__ void chamfer_grad_kernel(const float* __restrict__ xyz1, const float* __restrict__ xyz2, int b, int n, int m,
+                                    const float* __restrict__ grad_dist1, const int32_t* __restrict__ idx1,
+                                    float* __restrict__ grad_xyz1, float* __restrict__ grad_xyz2) {
+  const long total = (long)b * n;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int bi = (int)(idx / n);
+    const float x1 = xyz1[2 * idx], y1 = xyz1[2 * idx + 1];
+    const int j2 = idx1[idx];
+    const size_t o2 = ((size_t)bi * m + j2) * 2;
+    const float x2 = xyz2[o2], y2 = xyz2[o2 + 1];
+    const float g = grad_dist1[idx] * 2;
+    atomicAdd(&grad_xyz1[2 * idx], g * (x1 - x2));
+    atomicAdd(&grad_xyz1[2 * idx + 1], g * (y1 - y2));
+    atomicAdd(&grad_xyz2[o2], -(g * (x1 - x2)));
+    atomicAdd(&grad_xyz2[o2 + 1], -(g * (y1 - y2)));
+  }
+}
+
+// ---- sigmoid focal loss -----------------------------------------------------------------------------------------
+// mixed float/double expression structure kept as written in the reference (sigmoid_focal_loss_cuda.cu:36-57,73-96)
+__global__ void focal_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets, long total,
+                                 int classes, float gamma, float alpha, float* __restrict__ losses) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / classes), d = (int)(i % classes);
+    const int t = (int)targets[n];
+    const float c1 = (t == (d + 1));
+    const float c2 = (t >= 0 & t != (d + 1));
+    const float zn = (float)(1.0 - alpha);
+    const float zp = alpha;
+    const float x = logits[i];
+    const float p = (float)(1. / (1. + expf(-x)));
+    const float term1 = powf((float)(1. - p), gamma) * logf(fmaxf(p, FLT_MIN));
+    const float term2 = (float)(powf(p, gamma) *
+                                (-1. * x * (x >= 0) - logf((float)(1. + expf((float)(x - 2. * x * (x >= 0)))))));
+    float l = 0.0f;
+    l += -c1 * term1 * zp;
+    l += -c2 * term2 * zn;
+    losses[i] = l;
+  }
+}
+
+__global__ void focal_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
+                                 const float* __restrict__ d_losses, long total, int classes, float gamma, float alpha,
+                                 float* __restrict__ d_logits) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / classes), d = (int)(i % classes);
+    const int t = (int)targets[n];
+    const float c1 = (t == (d + 1));
+    const float c2 = (t >= 0 & t != (d + 1));
+    const float zn = (float)(1.0 - alpha);
+    const float zp = alpha;
+    const float x = logits[i];
+    const float p = (float)(1. / (1. + expf(-x)));
+    const float term1 = (float)(powf((float)(1. - p), gamma) * (1. - p - (p * gamma * logf(fmaxf(p, FLT_MIN)))));
+    const float term2 = (float)(powf(p, gamma) *
+                                ((-1. * x * (x >= 0) - logf((float)(1. + expf((float)(x - 2. * x * (x >= 0)))))) *
+                                     (1. - p) * gamma -
+                                 p));
+    float g = 0.0f;
+    g += -c1 * term1 * zp;
+    g += -c2 * term2 * zn;
+    d_logits[i] = g * d_losses[i];
+  }
+}
+
+inline int done() { hipError_t e = hipGetLastError(); return e == hipSuccess ? ORP_OK : (int)e; }
+}  // namespace
+
+extern "C" {
+int orp_points_justify(const float* points, int m, const float* polygons, int k, float* out, void* stream) {
+  if (m < 0 || k < 0 || ((m > 0 && k > 0) && (!points || !polygons || !out))) return ORP_EINVAL;
+  if (m == 0 || k == 0) return ORP_OK;
+  hipLaunchKernelGGL(points_justify_kernel, dim3(grid_for((long)m * k)), dim3(kThreads), 0, (hipStream_t)stream, points,
+                     m, polygons, k, out);
+  return done();
+}
+int orp_points_in_quad_aligned(const float* pts18, const float* quads, int m, float* out9, void* stream) {
+  if (m < 0 || (m > 0 && (!pts18 || !quads || !out9))) return ORP_EINVAL;
+  if (m == 0) return ORP_OK;
+  hipLaunchKernelGGL(points_in_quad_aligned_kernel, dim3(grid_for((long)m * 9)), dim3(kThreads), 0, (hipStream_t)stream,
+                     pts18, quads, m, out9);
+  return done();
+}
+int orp_chamfer2d_forward(const float* xyz1, const float* xyz2, int b, int n, int m, float* dist1, float* dist2,
+                          int32_t* idx1, int32_t* idx2, void* stream) {
+  if (b < 0 || n < 0 || m < 0) return ORP_EINVAL;
+  if (b == 0 || n == 0 || m == 0) return ORP_OK;
+  if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2) return ORP_EINVAL;
+  hipLaunchKernelGGL(chamfer_nn_kernel, dim3(grid_for((long)b * n)), dim3(kThreads), 0, (hipStream_t)stream, xyz1, xyz2,
+                     b, n, m, dist1, idx1);
+  hipLaunchKernelGGL(chamfer_nn_kernel, dim3(grid_for((long)b * m)), dim3(kThreads), 0, (hipStream_t)stream, xyz2, xyz1,
+                     b, m, n, dist2, idx2);
+  return done();
+}
+int orp_chamfer2d_backward(const float* xyz1, const float* xyz2, int b, int n, int m, const float* grad_dist1,
+                           const float* grad_dist2, const int32_t* idx1, const int32_t* idx2, float* grad_xyz1,
+                           float* grad_xyz2, void* stream) {
+  if (b < 0 || n < 0 || m < 0) return ORP_EINVAL;
+  if (b == 0 || n == 0 || m == 0) return ORP_OK;
+  if (!xyz1 || !xyz2 || !grad_dist1 || !grad_dist2 || !idx1 || !idx2 || !grad_xyz1 || !grad_xyz2) return ORP_EINVAL;
+  hipLaunchKernelGGL(chamfer_grad_kernel, dim3(grid_for((long)b * n)), dim3(kThreads), 0, (hipStream_t)stream, xyz1,
+                     xyz2, b, n, m, grad_dist1, idx1, grad_xyz1, grad_xyz2);
+  hipLaunchKernelGGL(chamfer_grad_kernel, dim3(grid_for((long)b * m)), dim3(kThreads), 0, (hipStream_t)stream, xyz2,
+                     xyz1, b, m, n, grad_dist2, idx2, grad_xyz2, grad_xyz1);
+  return done();
+}
+int orp_sigmoid_focal_loss_forward(const float* logits, const int64_t* targets, int num, int classes, float gamma,
+                                   float alpha, float* losses, void* stream) {
+  if (num < 0 || classes < 0) return ORP_EINVAL;
+  if (num == 0 || classes == 0) return ORP_OK;
+  if (!logits || !targets || !losses) return ORP_EINVAL;
+  const long total = (long)num * classes;
+  hipLaunchKernelGGL(focal_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, logits, targets,
+                     total, classes, gamma, alpha, losses);
+  return done();
+}
+int orp_sigmoid_focal_loss_backward(const float* logits, const int64_t* targets, const float* d_losses, int num,
+                                    int classes, float gamma, float alpha, float* d_logits, void* stream) {
+  if (num < 0 || classes < 0) return ORP_EINVAL;
+  if (num == 0 || classes == 0) return ORP_OK;
+  if (!logits || !targets || !d_losses || !d_logits) return ORP_EINVAL;
+  const long total = (long)num * classes;
+  hipLaunchKernelGGL(focal_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, logits, targets,
+                     d_losses, total, classes, gamma, alpha, d_logits);
+  return done();
+}
+}

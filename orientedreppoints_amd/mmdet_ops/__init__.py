@@ -1,0 +1,12 @@
+"""Host-side mirror of the reference's operator API for the dense-head hot path (mmdet/ops/* in
+LiWentomng/OrientedRepPoints), bound to the MI355X HIP library through include/orp_hip.h.
+
+Same names, argument meaning and error behaviour as the reference wrappers, so `from mmdet.ops import X` call sites
+can be re-pointed here unchanged.
+"""
+from .nms_wrapper import rnms, rnms_cuda, poly_nms_gpu  # noqa: F401
+from .minarea_rect import minaerarect  # noqa: F401
+from .iou_wrapper import convex_iou, convex_overlaps  # noqa: F401
+from .chamfer_distance import ChamferDistance2D, Chamfer2D  # noqa: F401
+from .point_justify import pointsJf, points_in_quad_aligned  # noqa: F401
+from .sigmoid_focal_loss import SigmoidFocalLoss, sigmoid_focal_loss  # noqa: F401

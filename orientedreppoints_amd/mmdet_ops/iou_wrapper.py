@@ -1,0 +1,40 @@
+"""Mirror of mmdet/ops/iou/iou_wrapper.py:12-27 (convex_iou / convex_overlaps; convex_giou is added with its kernel)
+and the `convex_iou_cuda.convex_iou` extension function (mmdet/ops/iou/src/convex_iou_cuda.cpp:8-16)."""
+import torch
+
+from .. import _lib
+
+
+class _ConvexIouCuda(object):
+    @staticmethod
+    def convex_iou(pred, target):
+        """pred [N,18], target [K,8] CUDA f32 -> flat [N*K]; empty -> empty CPU float tensor."""
+        _lib.require_cuda(pred, "pred")
+        _lib.require_cuda(target, "target")
+        if pred.numel() == 0 or target.numel() == 0:
+            return torch.empty((0,), dtype=torch.float32, device="cpu")
+        L = _lib.lib()
+        p = pred.detach().float().reshape(-1, 18).contiguous()
+        g = target.detach().float().reshape(-1, 8).contiguous()
+        n, k = p.size(0), g.size(0)
+        out = torch.empty((n * k,), dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            rc = L.orp_convex_iou(_lib.ptr(p), n, _lib.ptr(g), k, _lib.ptr(out), _lib.stream_of(p))
+        _lib.check(rc, "orp_convex_iou")
+        return out
+
+
+convex_iou_cuda = _ConvexIouCuda()
+
+
+def convex_iou(pred, target):
+    ex_num, gt_num = pred.size(0), target.size(0)
+    convex_ious = convex_iou_cuda.convex_iou(pred, target)
+    convex_ious = convex_ious.reshape(ex_num, gt_num)
+    return convex_ious
+
+
+def convex_overlaps(gt_rbboxes, points):
+    overlaps = convex_iou(points, gt_rbboxes)
+    overlaps = overlaps.transpose(1, 0)
+    return overlaps

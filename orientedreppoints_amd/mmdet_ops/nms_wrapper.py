@@ -1,0 +1,97 @@
+"""Mirror of mmdet/ops/nms/nms_wrapper.py:177-199 (`rnms`) and of the extension module it calls
+(mmdet/ops/nms/src/rnms_cuda.cpp:8-13 `rnms_cuda.rnms`), on the MI355X HIP library."""
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class _RnmsCuda(object):
+    """Stands in for the pybind module `mmdet.ops.nms.rnms_cuda` (one function: rnms)."""
+
+    @staticmethod
+    def rnms(dets, threshold):
+        """dets [M,9] f32 CUDA -> LongTensor of kept ORIGINAL indices, ascending (rnms_kernel.cu:261-264).
+        Empty input -> empty CPU long tensor (rnms_cuda.cpp:10-11)."""
+        _lib.require_cuda(dets, "dets")
+        if dets.numel() == 0:
+            return torch.empty((0,), dtype=torch.long, device="cpu")
+        if dets.dim() != 2 or dets.size(1) != 9:
+            raise ValueError("dets must be [M, 9] (8 corner coordinates + score)")
+        keep, num = rnms_device(dets, threshold)
+        return keep[:int(num.item())]
+
+
+rnms_cuda = _RnmsCuda()
+
+
+def rnms_device(dets, iou_thr, flavor=0, presorted=False, order_out=0):
+    """Stream-ordered rotated NMS without any host synchronisation.
+
+    Returns (keep int64 [M] on device, num_keep int32 [1] on device); only keep[:num_keep] is meaningful."""
+    L = _lib.lib()
+    d = dets.detach()
+    if d.dtype != torch.float32:
+        d = d.float()
+    d = d.contiguous()
+    n = d.size(0)
+    if n > _lib.ORP_NMS_MAX_BOXES:
+        raise _lib.OrpHipError("rnms: %d boxes exceeds ORP_NMS_MAX_BOXES" % n)
+    keep = torch.empty((n,), dtype=torch.long, device=d.device)
+    num = torch.empty((1,), dtype=torch.int32, device=d.device)
+    nbytes = L.orp_rnms_workspace_bytes(n)
+    ws = _lib.workspace(d.device, nbytes)
+    with torch.cuda.device(d.device):
+        rc = L.orp_rnms(_lib.ptr(d), n, float(iou_thr), int(flavor), int(bool(presorted)), int(order_out),
+                        _lib.ptr(keep), _lib.ptr(num), _lib.ptr(ws), ws.numel(), _lib.stream_of(d))
+    _lib.check(rc, "orp_rnms")
+    return keep, num
+
+
+def rnms_batched_device(dets, seg_offsets, max_seg, iou_thr, flavor=0):
+    """(image x class) segments in one launch sequence.  dets [N,9]; seg_offsets int32 [S+1] on device;
+    returns (keep int64 [N] -- per segment at its own offset, ascending global indices --, num_keep int32 [S])."""
+    L = _lib.lib()
+    d = dets.detach().float().contiguous()
+    so = seg_offsets.to(device=d.device, dtype=torch.int32).contiguous()
+    n, nseg = d.size(0), so.numel() - 1
+    keep = torch.empty((n,), dtype=torch.long, device=d.device)
+    num = torch.zeros((max(nseg, 1),), dtype=torch.int32, device=d.device)
+    nbytes = L.orp_rnms_batched_workspace_bytes(n, nseg, int(max_seg))
+    ws = _lib.workspace(d.device, nbytes)
+    with torch.cuda.device(d.device):
+        rc = L.orp_rnms_batched(_lib.ptr(d), n, _lib.ptr(so), nseg, int(max_seg), float(iou_thr), int(flavor),
+                                _lib.ptr(keep), _lib.ptr(num), _lib.ptr(ws), ws.numel(), _lib.stream_of(d))
+    _lib.check(rc, "orp_rnms_batched")
+    return keep, num[:nseg]
+
+
+def rnms(dets, iou_thr, device_id=None):
+    """Signature and behaviour of mmdet/ops/nms/nms_wrapper.py:177-199."""
+    # convert dets (tensor or numpy array) to tensor
+    if isinstance(dets, torch.Tensor):
+        dets_th = dets
+    elif isinstance(dets, np.ndarray):
+        device = 'cpu' if device_id is None else 'cuda:{}'.format(device_id)
+        dets_th = torch.from_numpy(dets).to(device)
+    else:
+        raise TypeError(
+            'dets must be either a Tensor or numpy array, but got {}'.format(
+                type(dets)))
+    # execute cpu or cuda nms
+    if dets_th.shape[0] == 0:
+        inds = dets_th.new_zeros(0, dtype=torch.long)
+    else:
+        if dets_th.is_cuda:
+            inds = rnms_cuda.rnms(dets_th, iou_thr)
+        else:
+            raise TypeError('dets must be cuda tensor')
+    if isinstance(dets, np.ndarray):
+        return dets[inds.cpu().numpy(), :], inds
+    return dets[inds, :], inds
+
+
+def poly_nms_gpu(dets, thresh, force_cpu=False):
+    """mmdet/ops/nms/nms_wrapper.py:11-17 re-export of DOTA_devkit's poly_nms_gpu."""
+    from ..dota_devkit.poly_nms_gpu import poly_nms_gpu as _impl
+    return _impl(dets, thresh, force_cpu)

@@ -1,0 +1,250 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against the CPU oracle and the committed golden vectors.
+
+Bars (BASELINE.json north_star): bit-exact for NMS indices / IoU decisions; |delta| <= 1e-4 on IoU / loss floats.
+The fp32 quad IoU core uses only + - * / and comparisons, so it is checked BIT-EXACT as well.
+"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from orientedreppoints_amd import synthetic as S  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from orientedreppoints_amd import _lib
+    _lib.lib()            # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _t(a, dev, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype)
+
+
+def _quad_iou_matrix(a, b, dev, guard=0):
+    from orientedreppoints_amd import _lib
+    ta, tb = _t(a, dev), _t(b, dev)
+    out = torch.empty((ta.size(0), tb.size(0)), dtype=torch.float32, device=dev)
+    rc = _lib.lib().orp_quad_iou_matrix(_lib.ptr(ta), ta.size(0), _lib.ptr(tb), tb.size(0), ta.size(1), guard,
+                                        _lib.ptr(out), _lib.stream_of(ta))
+    _lib.check(rc, "orp_quad_iou_matrix")
+    return out.cpu().numpy()
+
+
+# ---- rotated IoU ------------------------------------------------------------------------------------------------
+def test_quad_iou_bit_exact_golden(dev, golden_dir):
+    g = _g(golden_dir, "quad_iou_nms.npz")
+    for name in ("uniform", "clustered", "offset"):
+        d = g["dets_" + name]
+        got = _quad_iou_matrix(d, d, dev)
+        assert np.array_equal(got.view(np.uint32), g["iou_" + name].view(np.uint32)), name
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_quad_iou_bit_exact_oracle(dev, oracle, seed):
+    d = S.gen_polys(300, 500 + seed, clustered=True).astype(np.float32)
+    dd, _ = S.gen_dense_scene(300, 600 + seed)
+    for x in (d, dd.astype(np.float32)):
+        got = _quad_iou_matrix(x, x, dev)
+        want = oracle.quad_iou_matrix(x, x)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        gotg = _quad_iou_matrix(x, x, dev, guard=1)
+        wantg = oracle.quad_iou_matrix(x, x, guard=True)
+        assert np.array_equal(gotg.view(np.uint32), wantg.view(np.uint32))
+
+
+def test_quad_iou_degenerate(dev, oracle):
+    d = S.gen_polys(64, 9).astype(np.float32)
+    d[:16, 2:8] = np.tile(d[:16, 0:2], 3)          # zero-area boxes (all corners equal)
+    d[16:32] = d[32:48]                             # exact duplicates
+    got = _quad_iou_matrix(d, d, dev)
+    want = oracle.quad_iou_matrix(d, d)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))   # NaNs included, bit for bit
+
+
+# ---- rnms ---------------------------------------------------------------------------------------------------
+def test_rnms_golden_keep_sets(dev, golden_dir):
+    from orientedreppoints_amd.mmdet_ops import rnms
+    g = _g(golden_dir, "quad_iou_nms.npz")
+    for name in ("uniform", "clustered"):
+        d = g["nms_dets_" + name]
+        for thr in (0.1, 0.3, 0.4):
+            dets, inds = rnms(_t(d, dev), thr)
+            want = np.sort(g["nms_keep_%s_%02d_rnms" % (name, int(thr * 10))])
+            assert inds.dtype == torch.long and inds.is_cuda
+            assert np.array_equal(inds.cpu().numpy(), want), (name, thr)
+            assert np.array_equal(dets.cpu().numpy(), d[want])
+    d = g["nms_dets_dense"]
+    _, inds = rnms(_t(d, dev), 0.4)
+    assert np.array_equal(inds.cpu().numpy(), np.sort(g["nms_keep_dense_04_rnms"]))
+
+
+@pytest.mark.parametrize("n,seed,clustered", [(1, 0, False), (63, 1, True), (64, 2, True), (65, 3, True),
+                                              (500, 0, False), (1000, 4, True), (2000, 5, True)])
+def test_rnms_vs_oracle(dev, oracle, n, seed, clustered):
+    from orientedreppoints_amd.mmdet_ops import rnms
+    d = S.gen_polys(n, seed, clustered=clustered).astype(np.float32)
+    for thr in (0.1, 0.4):
+        _, inds = rnms(_t(d, dev), thr)
+        assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, thr)), (n, thr)
+
+
+def test_rnms_class_offset_dense_scene(dev, oracle):
+    """config-4 stress: 2000 dets, 15 classes folded in by the class-offset trick -- fp32 cancellation included."""
+    from orientedreppoints_amd.mmdet_ops import rnms
+    d, _ = S.gen_dense_scene(2000, 31)
+    d = d.astype(np.float32)
+    _, inds = rnms(_t(d, dev), 0.4)
+    assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, 0.4))
+
+
+def test_rnms_ties_and_api_edges(dev, oracle):
+    from orientedreppoints_amd.mmdet_ops import rnms, rnms_cuda
+    d = S.gen_polys(300, 8, clustered=True).astype(np.float32)
+    d[:, 8] = np.round(d[:, 8] * 4) / 4                 # heavy score ties -> (score desc, index asc) order matters
+    _, inds = rnms(_t(d, dev), 0.3)
+    assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, 0.3))
+    # empty input -> empty long tensor; CPU tensor -> TypeError  (nms_wrapper.py:190-197)
+    e = torch.zeros((0, 9), device=dev)
+    dets, inds = rnms(e, 0.4)
+    assert inds.numel() == 0 and inds.dtype == torch.long and dets.shape == (0, 9)
+    with pytest.raises(TypeError):
+        rnms(torch.zeros((3, 9)), 0.4)
+    with pytest.raises(TypeError):
+        rnms([1, 2, 3], 0.4)
+    assert rnms_cuda.rnms(e, 0.4).device.type == "cpu"
+    # numpy input with device_id
+    dn, inds = rnms(d, 0.3, device_id=0)
+    assert isinstance(dn, np.ndarray) and np.array_equal(inds.cpu().numpy(), oracle.rnms(d, 0.3))
+
+
+def test_rnms_batched_segments(dev, oracle):
+    from orientedreppoints_amd.mmdet_ops.nms_wrapper import rnms_batched_device
+    sizes = [0, 1, 130, 64, 500, 0, 333]
+    parts = [S.gen_polys(n, 70 + i, clustered=True).astype(np.float32) for i, n in enumerate(sizes)]
+    d = np.concatenate(parts, 0)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    keep, num = rnms_batched_device(_t(d, dev), torch.from_numpy(off), max(sizes), 0.3)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    for s, n in enumerate(sizes):
+        want = oracle.rnms(parts[s], 0.3) + off[s]
+        assert num[s] == len(want)
+        assert np.array_equal(keep[off[s]:off[s] + num[s]], want), s
+
+
+# ---- DOTA_devkit host-pointer API -----------------------------------------------------------------------------
+def test_poly_gpu_nms_and_overlaps_host_api(dev, oracle, golden_dir):
+    from orientedreppoints_amd.dota_devkit.poly_nms_gpu import poly_gpu_nms, poly_overlaps, poly_nms_gpu
+    d = S.gen_polys(500, 0).astype(np.float32)            # config 0 of BASELINE.json
+    for thr in (0.3, 0.1, 0.4):
+        got = poly_gpu_nms(d, thr)
+        assert [int(x) for x in got] == oracle.poly_gpu_nms(d, thr)
+    assert poly_nms_gpu(np.zeros((0, 9), np.float32), 0.3) == []
+    g = _g(golden_dir, "poly_overlaps.npz")
+    got = poly_overlaps(g["boxes"], g["query"])
+    assert got.shape == g["iou"].shape
+    assert np.nanmax(np.abs(got - g["iou"])) <= 1e-4       # cos/sin come from different libms: tolerance, not bits
+
+
+def test_poly_nms_matches_fp64_cpu_reference_on_config0(dev, oracle):
+    """fp32 GPU poly NMS vs the fp64 CPU path (polyiou + py_cpu_nms_poly) on config 0: same keep set."""
+    from orientedreppoints_amd.dota_devkit.poly_nms_gpu import poly_gpu_nms
+    d64 = S.gen_polys(500, 0)
+    for thr in (0.3, 0.1, 0.4):
+        assert sorted(int(x) for x in poly_gpu_nms(d64.astype(np.float32), thr)) == sorted(oracle.py_cpu_nms_poly(d64, thr))
+
+
+# ---- minaerarect ------------------------------------------------------------------------------------------------
+def test_minarearect(dev, oracle, golden_dir):
+    from orientedreppoints_amd.mmdet_ops import minaerarect
+    g = _g(golden_dir, "minarearect.npz")
+    got = minaerarect(_t(g["pts"], dev)).cpu().numpy()
+    assert got.shape == g["rect"].shape
+    scale = np.maximum(1.0, np.abs(g["rect"]))
+    assert np.max(np.abs(got - g["rect"]) / scale) <= 1e-4
+    sp = minaerarect(_t(g["special"], dev)).cpu().numpy()
+    assert np.allclose(sp, g["special_rect"], atol=1e-4, equal_nan=True)
+    pts = S.gen_pointsets(5344, 77).astype(np.float32)       # max candidates per image at test time
+    got = minaerarect(_t(pts, dev)).cpu().numpy()
+    want = oracle.minarearect(pts)
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) <= 1e-4
+    # empty -> empty CPU tensor reshaped [0,8]; fused decode = rect*scale + centre
+    assert minaerarect(torch.zeros((0, 18), device=dev)).shape == (0, 8)
+    from orientedreppoints_amd.mmdet_ops.minarea_rect import minaerarect_decode
+    c = np.random.RandomState(0).uniform(0, 1024, (pts.shape[0], 2)).astype(np.float32)
+    s = np.random.RandomState(1).choice([8, 16, 32, 64, 128], pts.shape[0]).astype(np.float32)
+    dec = minaerarect_decode(_t(pts, dev), _t(c, dev), _t(s, dev)).cpu().numpy()
+    assert np.allclose(dec, got * s[:, None] + np.tile(c, 4), rtol=1e-6, atol=1e-3)
+
+
+# ---- convex_iou ---------------------------------------------------------------------------------------------------
+def test_convex_iou(dev, oracle, golden_dir):
+    from orientedreppoints_amd.mmdet_ops import convex_iou, convex_overlaps
+    g = _g(golden_dir, "convex_iou.npz")
+    got = convex_iou(_t(g["pts"], dev), _t(g["gts"], dev)).cpu().numpy()
+    assert got.shape == g["iou"].shape
+    assert np.array_equal(np.isnan(got), np.isnan(g["iou"]))
+    assert np.nanmax(np.abs(got - g["iou"])) <= 1e-4
+    assert np.array_equal(got, g["iou"], equal_nan=True), "fp64 + - * / only: expected bit-exact"
+    ov = convex_overlaps(_t(g["gts"], dev), _t(g["pts"], dev)).cpu().numpy()
+    assert np.array_equal(ov, got.T, equal_nan=True)
+    # k = 1 and k = 256 against the oracle at N = one 1024^2 image's coarse levels
+    for k, seed in ((1, 1), (37, 2)):
+        gts = S.gen_gts(k, 900 + seed).astype(np.float32)
+        pts = S.gen_pointsets(1364, 901 + seed).astype(np.float32)
+        got = convex_iou(_t(pts, dev), _t(gts, dev)).cpu().numpy()
+        assert np.array_equal(got, oracle.convex_iou(pts, gts), equal_nan=True)
+
+
+# ---- pointwise ops -----------------------------------------------------------------------------------------------
+def test_points_justify(dev, oracle, golden_dir):
+    from orientedreppoints_amd.mmdet_ops import pointsJf, points_in_quad_aligned
+    g = _g(golden_dir, "points_justify.npz")
+    for p, q, want in ((g["demo_p"], g["demo_q"], g["demo_out"]), (g["P"], g["Q"], g["out"])):
+        out = torch.full((p.shape[0], q.shape[0]), -1.0, device=dev)
+        assert pointsJf(_t(p, dev), _t(q, dev), out) == 1
+        assert np.array_equal(out.cpu().numpy(), want)
+    quads = S.gen_gts(700, 5).astype(np.float32)
+    pts = S.gen_pointsets(700, 6, around=quads.reshape(-1, 4, 2).mean(1)).astype(np.float32)
+    got = points_in_quad_aligned(_t(pts, dev), _t(quads, dev)).cpu().numpy()
+    assert np.array_equal(got, oracle.points_in_quad_aligned(pts, quads))
+    assert 0 < got.sum() < got.size
+
+
+def test_chamfer_and_focal(dev, oracle, golden_dir):
+    from orientedreppoints_amd.mmdet_ops import ChamferDistance2D, Chamfer2D, sigmoid_focal_loss
+    c = _g(golden_dir, "chamfer_focal.npz")
+    a, b = _t(c["a"], dev), _t(c["b"], dev)
+    d1, d2, i1, i2 = Chamfer2D()(a, b)
+    assert np.array_equal(i1.cpu().numpy(), c["idx1"]) and np.array_equal(i2.cpu().numpy(), c["idx2"])
+    assert np.array_equal(d1.cpu().numpy(), c["dist1"]) and np.array_equal(d2.cpu().numpy(), c["dist2"])
+    cd = ChamferDistance2D(a, b).cpu().numpy()
+    want = 0.05 * (np.sqrt(np.maximum(c["dist1"], 1e-12)).mean(-1) + np.sqrt(np.maximum(c["dist2"], 1e-12)).mean(-1)) / 2
+    assert np.allclose(cd, want, rtol=1e-5, atol=1e-6)
+    # backward of the chamfer op against the oracle's scatter
+    a2 = a.clone().requires_grad_(True); b2 = b.clone().requires_grad_(True)
+    o1, o2, _, _ = Chamfer2D()(a2, b2)
+    w1 = torch.linspace(0.5, 1.5, o1.numel(), device=dev).reshape(o1.shape)
+    w2 = torch.linspace(1.5, 0.5, o2.numel(), device=dev).reshape(o2.shape)
+    ((o1 * w1).sum() + (o2 * w2).sum()).backward()
+    ga, gb = oracle.chamfer_backward(c["a"], c["b"], w1.cpu().numpy(), w2.cpu().numpy(), c["idx1"], c["idx2"])
+    assert np.allclose(a2.grad.cpu().numpy(), ga, rtol=1e-4, atol=1e-4)
+    assert np.allclose(b2.grad.cpu().numpy(), gb, rtol=1e-4, atol=1e-4)
+    # focal: tolerance 1e-4 (exp/log/pow come from different libms)
+    x = _t(c["logits"], dev).requires_grad_(True)
+    t = torch.from_numpy(c["targets"]).to(dev)
+    loss = sigmoid_focal_loss(x, t, 2.0, 0.25)
+    assert np.max(np.abs(loss.detach().cpu().numpy() - c["focal_fwd"])) <= 1e-4
+    loss.backward(_t(c["d_losses"], dev))
+    assert np.max(np.abs(x.grad.cpu().numpy() - c["focal_bwd"])) <= 1e-4
+    with pytest.raises(RuntimeError):
+        sigmoid_focal_loss(torch.zeros(2, 15), torch.zeros(2, dtype=torch.long), 2.0, 0.25)
