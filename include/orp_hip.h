@@ -113,6 +113,33 @@ int orp_sigmoid_focal_loss_forward(const float* logits, const int64_t* targets, 
 int orp_sigmoid_focal_loss_backward(const float* logits, const int64_t* targets, const float* d_losses, int num,
                                     int classes, float gamma, float alpha, float* d_logits, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Deformable convolution forward (DCNv1 / DCNv2).
+ * Replaces deform_conv_forward_cuda / modulated_deform_conv_cuda_forward (mmdet/ops/dcn/src/deform_conv_cuda.cpp:
+ * 152-260, 490-590) and their im2col kernels (deform_conv_cuda_kernel.cu:190-277, 570-700).
+ *
+ * orp_dcn_forward_multi: the MFMA implicit-GEMM path.  ALL FPN levels of one DeformConv layer in one launch (the
+ *   head applies the same layer to 5 levels, orientedreppoints_head.py:148-174): levels_host[i] = {input, offset,
+ *   output, height, width}.  input [B,Cin,H,W] (in_layout 0 = NCHW, converted through the workspace; 1 = NHWC),
+ *   offset [B,2*kh*kw,Ho,Wo] NCHW, output [B,Cout,Ho,Wo] (out_layout 0 = NCHW, 1 = NHWC).  weight_packed comes from
+ *   orp_dcn_pack_weight ([Cout,Cin,kh,kw] -> [kh*kw,Cin,Cout]).  Requires orp_dcn_fast_path_ok(...) == 1
+ *   (groups = deformable_groups = 1, kh*kw <= 9, Cin % 32 == 0, Cout % 64 == 0); fp32, fp32-exact MFMA.
+ * orp_dcn_forward_direct: every other configuration (groups, deformable groups; mask != NULL = DCNv2 modulation,
+ *   optional bias), NCHW in/out, original [Cout,Cin/groups,kh,kw] weight.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct { const float* input; const float* offset; float* output; int height; int width; } orp_dcn_level;
+int orp_dcn_fast_path_ok(int c_in, int c_out, int kh, int kw, int groups, int deformable_groups);
+int orp_dcn_pack_weight(const float* weight, int c_out, int c_in, int kh, int kw, float* packed, void* stream);
+size_t orp_dcn_forward_workspace_bytes(const orp_dcn_level* levels_host, int nlevels, int batch, int c_in, int in_layout);
+int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int batch, int c_in, int c_out,
+                          const float* weight_packed, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                          int dil_h, int dil_w, int in_layout, int out_layout, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int orp_dcn_forward_direct(const float* input, const float* offset, const float* mask, const float* weight,
+                           const float* bias, float* output, int batch, int c_in, int height, int width, int c_out,
+                           int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                           int groups, int deformable_groups, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

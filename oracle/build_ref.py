@@ -42,6 +42,7 @@ SLICES = [
     ("points_justify",   "mmdet/ops/point_justify/src/points_justify_kernel.cu", 19, 102),
     ("focal",            "mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_cuda.cu", 23, 97),
     ("chamfer",          "mmdet/ops/chamfer_2d/src/chamfer_2d.cu",              12, 124),
+    ("dcn_im2col",       "mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu",        84, 243),
 ]
 
 

@@ -27,7 +27,7 @@ def build(force=False):
         return LIB
     cfiles = [s for s in srcs if s.endswith(".c")]
     cmd = ["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function"] + cfiles + ["-o", LIB, "-lm"]
+           "-Wno-unused-function", "-Wno-parentheses"] + cfiles + ["-o", LIB, "-lm"]
     subprocess.check_call(cmd)
     return LIB
 
@@ -296,4 +296,35 @@ def ref_focal_backward(logits, targets, d_losses, gamma, alpha):
     x = _f32(logits); t = np.ascontiguousarray(targets, np.int64); g = _f32(d_losses)
     out = np.empty_like(x)
     ref().ref_focal_backward(_p(x), _p(t), _p(g), x.shape[0], x.shape[1], ctypes.c_float(gamma), ctypes.c_float(alpha), _p(out))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# deformable convolution
+# ---------------------------------------------------------------------------------------------------------
+def _odim(n, pad, dil, k, stride):
+    return (n + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+
+
+def dcn_im2col(x, offset, kh, kw, pad, stride, dil, dg=1, use_ref=False):
+    x, offset = _f32(x), _f32(offset)
+    B, C, H, W = x.shape
+    Ho, Wo = _odim(H, pad, dil, kh, stride), _odim(W, pad, dil, kw, stride)
+    col = np.zeros((C * kh * kw, B, Ho, Wo), np.float32)
+    fn = ref().ref_dcn_im2col if use_ref else lib().orc_dcn_im2col
+    fn(_p(x), _p(offset), B, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil, dg, _p(col))
+    return col
+
+
+def dcn_forward(x, offset, weight, stride=1, pad=1, dil=1, groups=1, dg=1, mask=None, bias=None):
+    x, offset, weight = _f32(x), _f32(offset), _f32(weight)
+    B, C, H, W = x.shape
+    Cout, _, kh, kw = weight.shape
+    Ho, Wo = _odim(H, pad, dil, kh, stride), _odim(W, pad, dil, kw, stride)
+    out = np.empty((B, Cout, Ho, Wo), np.float32)
+    m = _f32(mask) if mask is not None else None
+    bb = _f32(bias) if bias is not None else None
+    lib().orc_dcn_forward(_p(x), _p(offset), _p(m) if m is not None else None, _p(weight),
+                          _p(bb) if bb is not None else None, _p(out), B, C, H, W, Cout, kh, kw, stride, stride, pad,
+                          pad, dil, dil, groups, dg)
     return out

@@ -108,3 +108,92 @@ void orc_focal_backward(const float* logits, const int64_t* targets, const float
     d_logits[i] = g * d_losses[i];
   }
 }
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* a2: deformable convolution forward                                                                        */
+/*   bilinear sampling = deformable_im2col_bilinear (deform_conv_cuda_kernel.cu:84-115) in float, zero unless  */
+/*   -1 < h < H and -1 < w < W (:229); contraction out = W . im2col (deform_conv_cuda.cpp:222-237) accumulated  */
+/*   here in DOUBLE so that the oracle is the mathematically tight value for any GEMM summation order.         */
+/*   mask != NULL -> DCNv2 modulation (:620-640), bias != NULL -> + bias (deform_conv_cuda.cpp:560-566).        */
+/* ------------------------------------------------------------------------------------------------------- */
+static float dcn_bilinear(const float* bottom, int data_width, int height, int width, float h, float w) {
+  int h_low = (int)floorf(h), w_low = (int)floorf(w);
+  int h_high = h_low + 1, w_high = w_low + 1;
+  float lh = h - h_low, lw = w - w_low;
+  float hh = 1 - lh, hw = 1 - lw;
+  float v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+  if (h_low >= 0 && w_low >= 0) v1 = bottom[h_low * data_width + w_low];
+  if (h_low >= 0 && w_high <= width - 1) v2 = bottom[h_low * data_width + w_high];
+  if (h_high <= height - 1 && w_low >= 0) v3 = bottom[h_high * data_width + w_low];
+  if (h_high <= height - 1 && w_high <= width - 1) v4 = bottom[h_high * data_width + w_high];
+  float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+  return (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+}
+
+/* col [C*kh*kw][B][Ho][Wo]  (deformable_im2col_gpu_kernel :190-243) */
+void orc_dcn_im2col(const float* im, const float* offset, int B, int C, int H, int W, int kh, int kw, int pad_h,
+                    int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg, float* col) {
+  int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  int cpdg = C / dg;
+  for (int c = 0; c < C; c++)
+    for (int b = 0; b < B; b++)
+      for (int ho = 0; ho < Ho; ho++)
+        for (int wo = 0; wo < Wo; wo++) {
+          const float* imp = im + ((size_t)b * C + c) * H * W;
+          const float* op = offset + ((size_t)b * dg + c / cpdg) * 2 * kh * kw * Ho * Wo;
+          for (int i = 0; i < kh; i++)
+            for (int j = 0; j < kw; j++) {
+              float oh = op[((size_t)(2 * (i * kw + j)) * Ho + ho) * Wo + wo];
+              float ow = op[((size_t)(2 * (i * kw + j) + 1) * Ho + ho) * Wo + wo];
+              float h_im = (ho * stride_h - pad_h) + i * dil_h + oh;
+              float w_im = (wo * stride_w - pad_w) + j * dil_w + ow;
+              float val = 0;
+              if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) val = dcn_bilinear(imp, W, H, W, h_im, w_im);
+              col[((((size_t)c * kh * kw + i * kw + j) * B + b) * Ho + ho) * Wo + wo] = val;
+            }
+        }
+}
+
+void orc_dcn_forward(const float* x, const float* offset, const float* mask, const float* weight, const float* bias,
+                     float* out, int B, int C, int H, int W, int Cout, int kh, int kw, int stride_h, int stride_w,
+                     int pad_h, int pad_w, int dil_h, int dil_w, int groups, int dg) {
+  int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  int taps = kh * kw, cpg = C / groups, opg = Cout / groups, cpdg = C / dg;
+  /* sampled values once per (b, c, tap, ho, wo) */
+  float* samp = (float*)malloc(sizeof(float) * (size_t)C * taps * Ho * Wo);
+  for (int b = 0; b < B; b++) {
+    for (int c = 0; c < C; c++) {
+      const float* imp = x + ((size_t)b * C + c) * H * W;
+      const float* op = offset + ((size_t)b * dg + c / cpdg) * 2 * taps * Ho * Wo;
+      const float* mp = mask ? mask + ((size_t)b * dg + c / cpdg) * taps * Ho * Wo : 0;
+      for (int t = 0; t < taps; t++)
+        for (int ho = 0; ho < Ho; ho++)
+          for (int wo = 0; wo < Wo; wo++) {
+            int i = t / kw, j = t % kw;
+            float oh = op[((size_t)(2 * t) * Ho + ho) * Wo + wo], ow = op[((size_t)(2 * t + 1) * Ho + ho) * Wo + wo];
+            float h_im = (ho * stride_h - pad_h) + i * dil_h + oh;
+            float w_im = (wo * stride_w - pad_w) + j * dil_w + ow;
+            float val = 0;
+            if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) val = dcn_bilinear(imp, W, H, W, h_im, w_im);
+            if (mp) val = val * mp[((size_t)t * Ho + ho) * Wo + wo];
+            samp[(((size_t)c * taps + t) * Ho + ho) * Wo + wo] = val;
+          }
+    }
+    for (int o = 0; o < Cout; o++) {
+      int g = o / opg;
+      for (int ho = 0; ho < Ho; ho++)
+        for (int wo = 0; wo < Wo; wo++) {
+          double acc = 0;
+          for (int cc = 0; cc < cpg; cc++)
+            for (int t = 0; t < taps; t++)
+              acc += (double)weight[((size_t)o * cpg + cc) * taps + t] *
+                     (double)samp[(((size_t)(g * cpg + cc)) * taps + t) * Ho * Wo + (size_t)ho * Wo + wo];
+          if (bias) acc += bias[o];
+          out[(((size_t)b * Cout + o) * Ho + ho) * Wo + wo] = (float)acc;
+        }
+    }
+  }
+  free(samp);
+}

@@ -67,6 +67,9 @@ namespace nsref_focal { using std::min; using std::max;
 namespace nsref_chamfer { using std::min; using std::max;
 #include "chamfer.inc"
 }
+namespace nsref_dcn { using std::min; using std::max;
+#include "dcn_im2col.inc"
+}
 // polyiou.cpp is plain C++: include it whole (its std headers are already guarded above).
 namespace nsref_polyiou {
 #include "DOTA_devkit/polyiou.cpp"
@@ -158,6 +161,22 @@ void ref_focal_backward(const float* logits, const int64_t* targets, const float
 void ref_chamfer_nn(int b, int n, const float* xyz, int m, const float* xyz2, float* result, int* result_i) {
   blockDim.x = 1; threadIdx.x = 0; gridDim.x = 1; blockIdx.x = 0; gridDim.y = 1; blockIdx.y = 0;
   nsref_chamfer::NmDistanceKernel(b, n, xyz, m, xyz2, result, result_i);
+}
+
+// deformable_im2col_gpu_kernel (deform_conv_cuda_kernel.cu:190-243) under the 1-thread-per-block emulation.
+// data_col [C*kh*kw][B][Ho][Wo]
+void ref_dcn_im2col(const float* im, const float* offset, int B, int C, int H, int W, int kh, int kw, int pad_h,
+                    int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg, float* col) {
+  int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  int n = C * Ho * Wo * B;
+  blockDim.x = 1; threadIdx.x = 0; gridDim.x = n;
+  for (int b = 0; b < n; b++) {
+    blockIdx.x = b;
+    nsref_dcn::deformable_im2col_gpu_kernel<float>(n, im, offset, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h,
+                                                   dil_w, C / dg, B, C, dg, Ho, Wo, col);
+  }
+  blockIdx.x = 0; gridDim.x = 1;
 }
 
 }  // extern "C"

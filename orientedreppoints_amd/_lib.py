@@ -39,6 +39,11 @@ _SIGNATURES = {
     "orp_chamfer2d_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "orp_sigmoid_focal_loss_forward": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     "orp_sigmoid_focal_loss_backward": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    "orp_dcn_fast_path_ok": (_i, [_i, _i, _i, _i, _i, _i]),
+    "orp_dcn_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "orp_dcn_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "orp_dcn_forward_multi": (_i, [_vp, _i, _i, _i, _i, _vp] + [_i] * 10 + [_vp, _sz, _vp]),
+    "orp_dcn_forward_direct": (_i, [_vp] * 6 + [_i] * 15 + [_vp]),
 }
 
 _lib = None

@@ -23,6 +23,7 @@ SOURCES = [
     ("orp_minarearect.hip", ["-ffp-contract=off"]),
     ("orp_convex.hip", ["-ffp-contract=off"]),
     ("orp_pointwise.hip", ["-ffp-contract=off"]),
+    ("orp_dcn.hip", []),
 ]
 HEADERS = ["orp_geom.hpp", "orp_hull.hpp", os.path.join("..", "..", "include", "orp_hip.h")]
 

@@ -1,0 +1,447 @@
+// orp_dcn.hip -- deformable convolution (DCNv1 / DCNv2) forward for gfx950 (MI355X).
+//
+// Replaces deform_conv_forward_cuda / modulated_deform_conv_cuda_forward
+//   (mmdet/ops/dcn/src/deform_conv_cuda.cpp:152-260, 490-590; deform_conv_cuda_kernel.cu:84-277, 570-700).
+// The reference materialises the im2col "columns" buffer in HBM ([C*9, B*H*W] fp32 = 151 MB at the 128x128 level)
+// and then calls a library GEMM per im2col_step.  Here the contraction is an IMPLICIT GEMM on the matrix cores:
+//
+//   out[p, o] = sum_{tap, c}  A[p, (tap, c)] * W2[(tap, c), o],      A[p, (tap, c)] = bilinear(x[b, :, :, c], p + tap + d)
+//
+//   * A is never written to HBM: each workgroup (4 waves) owns BM = 32 output positions x up to 256 output
+//     channels and produces the A rows of one kernel tap at a time straight into LDS.  The input is read in NHWC
+//     so that one wave fetches ONE bilinear neighbour of ONE position as a fully coalesced 1 KB row (64 lanes x
+//     float4 = 256 channels); the four bilinear weights of a (position, tap) are wave-uniform and are computed
+//     once per tile, not once per channel as in the reference kernel.
+//   * weights are pre-packed to W2[tap][c][o] (o contiguous), streamed L2 -> LDS in 32-row chunks, double buffered.
+//   * MFMA: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain = the reference's fp32 precision class), wave tile
+//     32 positions x 64 channels.  K order inside a 32-channel chunk is permuted (step (t,i), half kh -> channel
+//     8t + 4kh + i) so that the A fragment is one conflict-free ds_read_b128 per four MFMA steps (row stride padded
+//     to 260 floats).
+//   * all FPN levels go in ONE launch (tile table in the kernel arguments): 21 824 positions -> 682 tiles, instead
+//     of five launches whose small levels cannot fill 256 CUs.
+//   * output is written NCHW (operands swapped so lanes run along positions) or NHWC.
+// A straightforward direct kernel covers every configuration the fast path does not (groups > 1,
+// deformable_groups > 1, odd channel counts, DCNv2 modulation + bias).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orp_hip.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 32;          // output positions per workgroup
+constexpr int BN = 256;         // output channels per workgroup (4 waves x 64)
+constexpr int CB = 256;         // input channels per K phase (one tap)
+constexpr int KC = 32;          // input channels per weight chunk
+constexpr int ASTR = CB + 4;    // padded A row stride (floats): conflict-free ds_read_b128 / ds_write_b128
+constexpr int MAX_TAPS = 9;
+constexpr int MAX_LEVELS = 8;
+constexpr int kThreads = 256;
+
+struct LevelDesc {
+  const float* x;      // NHWC [B, H, W, Cin]
+  const float* off;    // NCHW [B, 2*taps, Ho, Wo]
+  float* out;          // NCHW [B, Cout, Ho, Wo] or NHWC [B, Ho, Wo, Cout]
+  int H, W, Ho, Wo;
+  int tile0;           // first tile of this level
+};
+struct FwdParams {
+  LevelDesc lv[MAX_LEVELS];
+  int nlev, B, Cin, Cout;
+  int kh, kw, sh, sw, ph, pw, dh, dw;
+  const float* w2;     // packed [taps][Cin][Cout]
+};
+
+// ---- helpers -------------------------------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int cin, int taps, float* __restrict__ w2) {
+  // w [o][c][tap] -> w2 [tap][c][o]
+  const long total = (long)cout * cin * taps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int o = (int)(i % cout);
+    const long r = i / cout;
+    const int c = (int)(r % cin), tap = (int)(r / cin);
+    w2[i] = w[((long)o * cin + c) * taps + tap];
+  }
+}
+
+// [B][C][HW] -> [B][HW][C] through a 32x33 LDS tile
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int C, int HW, float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+  const float* src = in + (size_t)b * C * HW;
+  float* dst = out + (size_t)b * C * HW;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    tile[r][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    if (p < HW && c < C) dst[(size_t)p * C + c] = tile[tx][r];
+  }
+}
+
+// ---- the MFMA implicit-GEMM kernel -------------------------------------------------------------------------------
+template <bool OUT_NCHW>
+__global__ void __launch_bounds__(kThreads)
+dcn_fwd_mfma_kernel(const FwdParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sA = reinterpret_cast<float*>(smem);                                // [2][BM][ASTR]
+  float* sB = sA + 2 * BM * ASTR;                                            // [2][KC][BN]
+  float4* sCw = reinterpret_cast<float4*>(sB + 2 * KC * BN);                 // [BM * taps] bilinear weights
+  int4* sCi = reinterpret_cast<int4*>(sCw + BM * MAX_TAPS);                  // [BM * taps] pixel indices
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int taps = P.kh * P.kw;
+  // which level does this tile belong to?
+  int lvl = 0;
+#pragma unroll 1
+  for (int i = 1; i < P.nlev; i++) if ((int)blockIdx.x >= P.lv[i].tile0) lvl = i;
+  const LevelDesc L = P.lv[lvl];
+  const int HoWo = L.Ho * L.Wo;
+  const long npos = (long)P.B * HoWo;
+  const long p0 = (long)(blockIdx.x - L.tile0) * BM;
+  const int nb = blockIdx.y;                                                  // 256-channel output block
+
+  // ---- bilinear coefficient table: one entry per (position, tap), shared by all channels ---------------------
+  for (int e = tid; e < BM * taps; e += kThreads) {
+    const int m = e / taps, tap = e - m * taps;
+    const long p = p0 + m;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 ix = make_int4(0, 0, 0, 0);
+    if (p < npos) {
+      const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+      const int ho = hw / L.Wo, wo = hw - ho * L.Wo;
+      const int ki = tap / P.kw, kj = tap - ki * P.kw;
+      const float* ob = L.off + ((size_t)b * 2 * taps + 2 * tap) * HoWo + hw;
+      const float off_h = ob[0], off_w = ob[HoWo];
+      const float h_im = (float)(ho * P.sh - P.ph + ki * P.dh) + off_h;
+      const float w_im = (float)(wo * P.sw - P.pw + kj * P.dw) + off_w;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)L.H && w_im < (float)L.W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+        const float hh = 1.f - lh, hw_ = 1.f - lw;
+        const bool t_ok = h_low >= 0, b_ok = h_high <= L.H - 1, l_ok = w_low >= 0, r_ok = w_high <= L.W - 1;
+        const int hl = t_ok ? h_low : 0, hhg = b_ok ? h_high : L.H - 1, wl = l_ok ? w_low : 0, whg = r_ok ? w_high : L.W - 1;
+        w.x = (t_ok && l_ok) ? hh * hw_ : 0.f;
+        w.y = (t_ok && r_ok) ? hh * lw : 0.f;
+        w.z = (b_ok && l_ok) ? lh * hw_ : 0.f;
+        w.w = (b_ok && r_ok) ? lh * lw : 0.f;
+        const int base = b * L.H;
+        ix.x = (base + hl) * L.W + wl;
+        ix.y = (base + hl) * L.W + whg;
+        ix.z = (base + hhg) * L.W + wl;
+        ix.w = (base + hhg) * L.W + whg;
+      }
+    }
+    sCw[e] = w; sCi[e] = ix;
+  }
+  __syncthreads();
+
+  const int ncb = (P.Cin + CB - 1) / CB;            // channel blocks per tap
+  const int nphase = taps * ncb;
+
+  // A-row producer: this wave builds rows m = wave, wave+4, ... (8 rows per phase) of the phase's A tile
+  auto gather_row = [&](int phase, int m, float4 (&g)[4], float4& wgt, bool& live) {
+    const int tap = phase / ncb, cb = phase - tap * ncb;
+    const int c = cb * CB + lane * 4;
+    live = (c < P.Cin);
+    wgt = sCw[m * taps + tap];
+    const int4 ix = sCi[m * taps + tap];
+    if (live) {
+      g[0] = *reinterpret_cast<const float4*>(L.x + (size_t)ix.x * P.Cin + c);
+      g[1] = *reinterpret_cast<const float4*>(L.x + (size_t)ix.y * P.Cin + c);
+      g[2] = *reinterpret_cast<const float4*>(L.x + (size_t)ix.z * P.Cin + c);
+      g[3] = *reinterpret_cast<const float4*>(L.x + (size_t)ix.w * P.Cin + c);
+    }
+  };
+  auto store_row = [&](int buf, int m, const float4 (&g)[4], const float4 wgt, bool live) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+      v.x = wgt.x * g[0].x + wgt.y * g[1].x + wgt.z * g[2].x + wgt.w * g[3].x;
+      v.y = wgt.x * g[0].y + wgt.y * g[1].y + wgt.z * g[2].y + wgt.w * g[3].y;
+      v.z = wgt.x * g[0].z + wgt.y * g[1].z + wgt.z * g[2].z + wgt.w * g[3].z;
+      v.w = wgt.x * g[0].w + wgt.y * g[1].w + wgt.z * g[2].w + wgt.w * g[3].w;
+    }
+    *reinterpret_cast<float4*>(sA + ((size_t)buf * BM + m) * ASTR + lane * 4) = v;
+  };
+  // weight chunk loader: 32 rows x 256 cols, 8 float4 per thread
+  auto load_b = [&](int phase, int j, float4 (&r)[8]) {
+    const int tap = phase / ncb, cb = phase - tap * ncb;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int f = tid + kThreads * q;
+      const int row = f >> 6, col = (f & 63) * 4;
+      const int c = cb * CB + j * KC + row, n = nb * BN + col;
+      r[q] = (c < P.Cin && n < P.Cout)
+                 ? *reinterpret_cast<const float4*>(P.w2 + ((size_t)tap * P.Cin + c) * P.Cout + n)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_b = [&](int buf, const float4 (&r)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int f = tid + kThreads * q;
+      const int row = f >> 6, col = (f & 63) * 4;
+      *reinterpret_cast<float4*>(sB + ((size_t)buf * KC + row) * BN + col) = r[q];
+    }
+  };
+
+  // ---- prologue: A tile of phase 0, weight chunk 0 -------------------------------------------------------------
+  {
+    for (int rr = 0; rr < BM / 4; rr++) {
+      const int m = rr * 4 + wave;
+      float4 g[4], wgt; bool live;
+      gather_row(0, m, g, wgt, live);
+      store_row(0, m, g, wgt, live);
+    }
+    float4 r[8];
+    load_b(0, 0, r);
+    store_b(0, r);
+  }
+  __syncthreads();
+
+  floatx16 acc0 = {0}, acc1 = {0};
+  const int n_wave = nb * BN + wave * 64;                 // first output channel of this wave
+  const bool wave_live = n_wave < P.Cout;
+  const int mrow = lane & 31, kh = lane >> 5;
+  int bbuf = 0;
+
+  for (int phase = 0; phase < nphase; phase++) {
+    const int cb = phase % ncb;
+    const int cbeff = min(CB, P.Cin - cb * CB);
+    const int nchunk = (cbeff + KC - 1) / KC;
+    const int rows_per_chunk = (BM / 4 + nchunk - 1) / nchunk;      // A rows of the NEXT phase built per chunk
+    const float* a_cur = sA + (size_t)(phase & 1) * BM * ASTR;
+    for (int j = 0; j < nchunk; j++) {
+      // (1) issue the global loads of the next weight chunk and of the next phase's A rows
+      const bool last_chunk = (j + 1 == nchunk);
+      const bool have_next_b = !(last_chunk && phase + 1 == nphase);
+      float4 rb[8];
+      if (have_next_b) load_b(last_chunk ? phase + 1 : phase, last_chunk ? 0 : j + 1, rb);
+      float4 g[4], wgt = make_float4(0.f, 0.f, 0.f, 0.f); bool live = false; int m_next = -1;
+      // (rows_per_chunk is 1 for 256-channel phases; the loop below handles the general case one row at a time)
+      // (2) MFMA over the current chunk
+      for (int rr = 0; rr < rows_per_chunk; rr++) {
+        const int ridx = j * rows_per_chunk + rr;
+        const bool do_row = (phase + 1 < nphase) && ridx < BM / 4;
+        if (do_row) { m_next = ridx * 4 + wave; gather_row(phase + 1, m_next, g, wgt, live); }
+        if (rr == 0 && wave_live) {
+          const float* bcur = sB + (size_t)bbuf * KC * BN + wave * 64 + mrow;
+          const float* arow = a_cur + (size_t)mrow * ASTR + j * KC + 4 * kh;
+#pragma unroll
+          for (int t = 0; t < KC / 8; t++) {
+            const float4 a4 = *reinterpret_cast<const float4*>(arow + 8 * t);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const int kk = 8 * t + 4 * kh + i;
+              const float b0 = bcur[(size_t)kk * BN];
+              const float b1 = bcur[(size_t)kk * BN + 32];
+              if (OUT_NCHW) {   // D[channel][position]
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, av[i], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, av[i], acc1, 0, 0, 0);
+              } else {          // D[position][channel]
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1, acc1, 0, 0, 0);
+              }
+            }
+          }
+        }
+        if (do_row) store_row((phase + 1) & 1, m_next, g, wgt, live);
+      }
+      // (3) park the prefetched weight chunk in the other buffer
+      if (have_next_b) store_b(bbuf ^ 1, rb);
+      __syncthreads();
+      bbuf ^= 1;
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------
+  if (!wave_live) return;
+  if (OUT_NCHW) {
+    // D rows = channels, cols = positions: lane&31 -> position, reg -> channel
+    const long p = p0 + (lane & 31);
+    if (p < npos) {
+      const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+      float* ob = L.out + (size_t)b * P.Cout * HoWo + hw;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int ch = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n_wave + ch < P.Cout) ob[(size_t)(n_wave + ch) * HoWo] = acc0[r];
+        if (n_wave + 32 + ch < P.Cout) ob[(size_t)(n_wave + 32 + ch) * HoWo] = acc1[r];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const long p = p0 + m;
+      if (p < npos) {
+        float* ob = L.out + (size_t)p * P.Cout + n_wave + (lane & 31);
+        if (n_wave + (lane & 31) < P.Cout) ob[0] = acc0[r];
+        if (n_wave + 32 + (lane & 31) < P.Cout) ob[32] = acc1[r];
+      }
+    }
+  }
+}
+
+// ---- direct kernel: every configuration (groups, deformable groups, DCNv2 mask + bias), NCHW in / out -----------
+__global__ void dcn_fwd_direct_kernel(const float* __restrict__ x, const float* __restrict__ off,
+                                      const float* __restrict__ mask, const float* __restrict__ w,
+                                      const float* __restrict__ bias, float* __restrict__ out, int B, int Cin, int H,
+                                      int W, int Cout, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw,
+                                      int dh, int dw, int groups, int dg) {
+  const long total = (long)B * Cout * Ho * Wo;
+  const int taps = kh * kw, cpg = Cin / groups, opg = Cout / groups, cpdg = Cin / dg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int wo = (int)(idx % Wo);
+    const int ho = (int)((idx / Wo) % Ho);
+    const int o = (int)((idx / ((long)Wo * Ho)) % Cout);
+    const int b = (int)(idx / ((long)Wo * Ho * Cout));
+    const int g = o / opg;
+    float acc = 0.f;
+    for (int cc = 0; cc < cpg; cc++) {
+      const int c = g * cpg + cc;
+      const int dgi = c / cpdg;
+      const float* xp = x + ((size_t)b * Cin + c) * H * W;
+      const float* op = off + ((size_t)b * dg + dgi) * 2 * taps * Ho * Wo;
+      const float* mp = mask ? mask + ((size_t)b * dg + dgi) * taps * Ho * Wo : nullptr;
+      for (int tap = 0; tap < taps; tap++) {
+        const int ki = tap / kw, kj = tap - ki * kw;
+        const float off_h = op[((size_t)(2 * tap) * Ho + ho) * Wo + wo];
+        const float off_w = op[((size_t)(2 * tap + 1) * Ho + ho) * Wo + wo];
+        const float h_im = (float)(ho * sh - ph + ki * dh) + off_h;
+        const float w_im = (float)(wo * sw - pw + kj * dw) + off_w;
+        float val = 0.f;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+          const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+          const int h_high = h_low + 1, w_high = w_low + 1;
+          const float lh = h_im - h_low, lw = w_im - w_low, hh = 1.f - lh, hw_ = 1.f - lw;
+          const float v1 = (h_low >= 0 && w_low >= 0) ? xp[h_low * W + w_low] : 0.f;
+          const float v2 = (h_low >= 0 && w_high <= W - 1) ? xp[h_low * W + w_high] : 0.f;
+          const float v3 = (h_high <= H - 1 && w_low >= 0) ? xp[h_high * W + w_low] : 0.f;
+          const float v4 = (h_high <= H - 1 && w_high <= W - 1) ? xp[h_high * W + w_high] : 0.f;
+          val = hh * hw_ * v1 + hh * lw * v2 + lh * hw_ * v3 + lh * lw * v4;
+        }
+        if (mp) val *= mp[((size_t)tap * Ho + ho) * Wo + wo];
+        acc += w[((size_t)o * cpg + cc) * taps + tap] * val;
+      }
+    }
+    if (bias) acc += bias[o];
+    out[idx] = acc;
+  }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int out_dim(int in, int pad, int dil, int k, int stride) { return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1; }
+
+}  // namespace
+
+extern "C" {
+
+int orp_dcn_pack_weight(const float* weight, int c_out, int c_in, int kh, int kw, float* packed, void* stream) {
+  if (!weight || !packed || c_out <= 0 || c_in <= 0 || kh <= 0 || kw <= 0) return ORP_EINVAL;
+  const long total = (long)c_out * c_in * kh * kw;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, c_out, c_in, kh * kw,
+                     packed);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_dcn_fast_path_ok(int c_in, int c_out, int kh, int kw, int groups, int deformable_groups) {
+  return (groups == 1 && deformable_groups == 1 && kh * kw <= MAX_TAPS && c_in % 32 == 0 && c_in >= 32 &&
+          c_out % 64 == 0 && c_out >= 64) ? 1 : 0;
+}
+
+size_t orp_dcn_forward_workspace_bytes(const orp_dcn_level* levels_host, int nlevels, int batch, int c_in,
+                                       int in_layout) {
+  if (in_layout == 1 || !levels_host) return 256;
+  size_t tot = 0;
+  for (int i = 0; i < nlevels; i++) tot += align256(sizeof(float) * (size_t)batch * c_in * levels_host[i].height * levels_host[i].width);
+  return tot + 256;
+}
+
+int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int batch, int c_in, int c_out,
+                          const float* weight_packed, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                          int dil_h, int dil_w, int in_layout, int out_layout, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  if (!levels_host || nlevels <= 0 || nlevels > MAX_LEVELS || batch <= 0 || !weight_packed) return ORP_EINVAL;
+  if (!orp_dcn_fast_path_ok(c_in, c_out, kh, kw, 1, 1)) return ORP_EINVAL;
+  if ((in_layout != 0 && in_layout != 1) || (out_layout != 0 && out_layout != 1)) return ORP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  FwdParams P;
+  P.nlev = nlevels; P.B = batch; P.Cin = c_in; P.Cout = c_out;
+  P.kh = kh; P.kw = kw; P.sh = stride_h; P.sw = stride_w; P.ph = pad_h; P.pw = pad_w; P.dh = dil_h; P.dw = dil_w;
+  P.w2 = weight_packed;
+  if (in_layout == 0 && workspace_bytes < orp_dcn_forward_workspace_bytes(levels_host, nlevels, batch, c_in, 0))
+    return ORP_EWORKSPACE;
+  char* wsp = reinterpret_cast<char*>(workspace);
+  int tiles = 0;
+  for (int i = 0; i < nlevels; i++) {
+    const orp_dcn_level& lv = levels_host[i];
+    if (!lv.input || !lv.offset || !lv.output || lv.height <= 0 || lv.width <= 0) return ORP_EINVAL;
+    LevelDesc& D = P.lv[i];
+    D.H = lv.height; D.W = lv.width;
+    D.Ho = out_dim(lv.height, pad_h, dil_h, kh, stride_h);
+    D.Wo = out_dim(lv.width, pad_w, dil_w, kw, stride_w);
+    if (D.Ho <= 0 || D.Wo <= 0) return ORP_EINVAL;
+    if ((long)batch * lv.height * lv.width >= (1L << 31)) return ORP_ETOOBIG;
+    D.off = lv.offset; D.out = lv.output;
+    if (in_layout == 0) {
+      float* nhwc = reinterpret_cast<float*>(wsp);
+      const int HW = lv.height * lv.width;
+      wsp += align256(sizeof(float) * (size_t)batch * c_in * HW);
+      hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 31) / 32, (c_in + 31) / 32, batch), dim3(256), 0, st, lv.input,
+                         c_in, HW, nhwc);
+      D.x = nhwc;
+    } else {
+      D.x = lv.input;
+    }
+    D.tile0 = tiles;
+    tiles += (int)(((long)batch * D.Ho * D.Wo + BM - 1) / BM);
+  }
+  for (int i = nlevels; i < MAX_LEVELS; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; }
+  const size_t smem = sizeof(float) * (2 * BM * ASTR + 2 * KC * BN) + (sizeof(float4) + sizeof(int4)) * BM * MAX_TAPS;
+  dim3 grid(tiles, (c_out + BN - 1) / BN);
+  hipError_t e;
+  if (out_layout == 0) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dcn_fwd_mfma_kernel<true>, grid, dim3(kThreads), smem, st, P);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dcn_fwd_mfma_kernel<false>, grid, dim3(kThreads), smem, st, P);
+  }
+  e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_dcn_forward_direct(const float* input, const float* offset, const float* mask, const float* weight,
+                           const float* bias, float* output, int batch, int c_in, int height, int width, int c_out,
+                           int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                           int groups, int deformable_groups, void* stream) {
+  if (!input || !offset || !weight || !output || batch <= 0 || c_in <= 0 || c_out <= 0 || groups <= 0 ||
+      deformable_groups <= 0 || c_in % groups || c_out % groups || c_in % deformable_groups)
+    return ORP_EINVAL;
+  const int Ho = out_dim(height, pad_h, dil_h, kh, stride_h), Wo = out_dim(width, pad_w, dil_w, kw, stride_w);
+  if (Ho <= 0 || Wo <= 0) return ORP_EINVAL;
+  const long total = (long)batch * c_out * Ho * Wo;
+  long blocks = (total + 255) / 256; if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(dcn_fwd_direct_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, input, offset, mask,
+                     weight, bias, output, batch, c_in, height, width, c_out, Ho, Wo, kh, kw, stride_h, stride_w, pad_h,
+                     pad_w, dil_h, dil_w, groups, deformable_groups);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+}  // extern "C"

@@ -10,3 +10,5 @@ from .iou_wrapper import convex_iou, convex_overlaps  # noqa: F401
 from .chamfer_distance import ChamferDistance2D, Chamfer2D  # noqa: F401
 from .point_justify import pointsJf, points_in_quad_aligned  # noqa: F401
 from .sigmoid_focal_loss import SigmoidFocalLoss, sigmoid_focal_loss  # noqa: F401
+from .deform_conv import (DeformConv, DeformConvPack, ModulatedDeformConv, ModulatedDeformConvPack,  # noqa: F401
+                          deform_conv, modulated_deform_conv, deform_conv_forward_multi)

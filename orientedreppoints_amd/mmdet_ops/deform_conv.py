@@ -1,0 +1,361 @@
+"""Mirror of mmdet/ops/dcn/deform_conv.py (DeformConvFunction :14-112, ModulatedDeformConvFunction :115-190,
+DeformConv :197-255, DeformConvPack :258-330, ModulatedDeformConv :333-380, ModulatedDeformConvPack :383-440) on the
+MI355X HIP library.
+
+What changes under the same API: the forward is an MFMA implicit GEMM with no HBM `columns` buffer
+(csrc/orp_dcn.hip); `deform_conv_multi` applies one layer to ALL FPN levels in a single launch (the head calls the
+same DeformConv on 5 levels).  Channels-last (NHWC) inputs are consumed in place and produce channels-last outputs;
+NCHW inputs are converted through a workspace and produce NCHW outputs.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair, _single
+
+from .. import _lib
+
+
+class _DcnLevel(ctypes.Structure):
+    _fields_ = [("input", ctypes.c_void_p), ("offset", ctypes.c_void_p), ("output", ctypes.c_void_p),
+                ("height", ctypes.c_int), ("width", ctypes.c_int)]
+
+
+_packed_cache = {}
+
+
+def _packed_weight(weight):
+    """[Cout,Cin,kh,kw] -> [kh*kw,Cin,Cout], cached per (storage, version)."""
+    w = weight.detach()
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index)
+    hit = _packed_cache.get(id(weight))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = w.float().contiguous()
+    cout, cin, kh, kw = w.shape
+    packed = torch.empty((kh * kw, cin, cout), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.lib().orp_dcn_pack_weight(_lib.ptr(w), cout, cin, kh, kw, _lib.ptr(packed), _lib.stream_of(w))
+    _lib.check(rc, "orp_dcn_pack_weight")
+    if len(_packed_cache) > 64:
+        _packed_cache.clear()
+    _packed_cache[id(weight)] = (key, packed)
+    return packed
+
+
+def _out_hw(h, w, weight, stride, padding, dilation):
+    ho = (h + 2 * padding[0] - (dilation[0] * (weight.size(2) - 1) + 1)) // stride[0] + 1
+    wo = (w + 2 * padding[1] - (dilation[1] * (weight.size(3) - 1) + 1)) // stride[1] + 1
+    return ho, wo
+
+
+def fast_path_ok(weight, groups, deformable_groups):
+    cout, cin_g, kh, kw = weight.shape
+    return bool(_lib.lib().orp_dcn_fast_path_ok(cin_g * groups, cout, kh, kw, groups, deformable_groups))
+
+
+def deform_conv_forward_multi(inputs, offsets, weight, stride, padding, dilation):
+    """One DeformConv layer over a list of feature maps (same batch / channels) in ONE launch.  fp32, no autograd."""
+    L = _lib.lib()
+    stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    x0 = inputs[0]
+    B, cin = x0.size(0), x0.size(1)
+    cout, _, kh, kw = weight.shape
+    nhwc = all(x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+               for x in inputs)
+    packed = _packed_weight(weight)
+    xs, offs, outs = [], [], []
+    levels = (_DcnLevel * len(inputs))()
+    for i, (x, off) in enumerate(zip(inputs, offsets)):
+        assert x.size(0) == B and x.size(1) == cin
+        x = x.detach().float()
+        x = x if nhwc else x.contiguous()
+        off = off.detach().float().contiguous()
+        ho, wo = _out_hw(x.size(2), x.size(3), weight, stride, padding, dilation)
+        if off.size(1) != 2 * kh * kw or off.size(2) != ho or off.size(3) != wo:
+            raise ValueError("offset must be [B, 2*kh*kw, Ho, Wo]")
+        out = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=x.device,
+                          memory_format=torch.channels_last if nhwc else torch.contiguous_format)
+        xs.append(x); offs.append(off); outs.append(out)
+        levels[i] = _DcnLevel(x.data_ptr(), off.data_ptr(), out.data_ptr(), x.size(2), x.size(3))
+    layout = 1 if nhwc else 0
+    nbytes = L.orp_dcn_forward_workspace_bytes(levels, len(inputs), B, cin, layout)
+    ws = _lib.workspace(x0.device, nbytes)
+    with torch.cuda.device(x0.device):
+        rc = L.orp_dcn_forward_multi(levels, len(inputs), B, cin, cout, _lib.ptr(packed), kh, kw, stride[0], stride[1],
+                                     padding[0], padding[1], dilation[0], dilation[1], layout, layout, _lib.ptr(ws),
+                                     ws.numel(), _lib.stream_of(x0))
+    _lib.check(rc, "orp_dcn_forward_multi")
+    return outs
+
+
+def _forward_direct(input, offset, mask, weight, bias, stride, padding, dilation, groups, deformable_groups):
+    x = input.detach().float().contiguous()
+    off = offset.detach().float().contiguous()
+    w = weight.detach().float().contiguous()
+    m = mask.detach().float().contiguous() if mask is not None else None
+    b = bias.detach().float().contiguous() if bias is not None else None
+    B, cin, H, W = x.shape
+    cout, _, kh, kw = w.shape
+    ho, wo = _out_hw(H, W, w, stride, padding, dilation)
+    out = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().orp_dcn_forward_direct(_lib.ptr(x), _lib.ptr(off), _lib.ptr(m), _lib.ptr(w), _lib.ptr(b),
+                                               _lib.ptr(out), B, cin, H, W, cout, kh, kw, stride[0], stride[1],
+                                               padding[0], padding[1], dilation[0], dilation[1], groups,
+                                               deformable_groups, _lib.stream_of(x))
+    _lib.check(rc, "orp_dcn_forward_direct")
+    return out
+
+
+class DeformConvFunction(Function):
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                im2col_step=64):
+        if input is not None and input.dim() != 4:
+            raise ValueError('Expected 4D tensor as input, got {}D tensor instead.'.format(input.dim()))
+        ctx.stride = _pair(stride)
+        ctx.padding = _pair(padding)
+        ctx.dilation = _pair(dilation)
+        ctx.groups = groups
+        ctx.deformable_groups = deformable_groups
+        ctx.im2col_step = im2col_step
+        ctx.save_for_backward(input, offset, weight)
+        DeformConvFunction._output_size(input, weight, ctx.padding, ctx.dilation, ctx.stride)
+        if not input.is_cuda:
+            raise NotImplementedError
+        cur_im2col_step = min(ctx.im2col_step, input.shape[0])
+        assert (input.shape[0] % cur_im2col_step) == 0, 'im2col step must divide batchsize'
+        if fast_path_ok(weight, groups, deformable_groups):
+            out = deform_conv_forward_multi([input], [offset], weight, ctx.stride, ctx.padding, ctx.dilation)[0]
+        else:
+            out = _forward_direct(input, offset, None, weight, None, ctx.stride, ctx.padding, ctx.dilation, groups,
+                                  deformable_groups)
+        return out.to(input.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        from . import deform_conv_backward as bw
+        input, offset, weight = ctx.saved_tensors
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        grad_input = grad_offset = grad_weight = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            grad_input, grad_offset = bw.backward_input(input, offset, weight, grad_output, ctx.stride, ctx.padding,
+                                                        ctx.dilation, ctx.groups, ctx.deformable_groups)
+        if ctx.needs_input_grad[2]:
+            grad_weight = bw.backward_parameters(input, offset, weight, grad_output, ctx.stride, ctx.padding,
+                                                 ctx.dilation, ctx.groups, ctx.deformable_groups)
+        return (grad_input, grad_offset, grad_weight, None, None, None, None, None, None)
+
+    @staticmethod
+    def _output_size(input, weight, padding, dilation, stride):
+        channels = weight.size(0)
+        output_size = (input.size(0), channels)
+        for d in range(input.dim() - 2):
+            in_size = input.size(d + 2)
+            pad = padding[d]
+            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
+            stride_ = stride[d]
+            output_size += ((in_size + (2 * pad) - kernel) // stride_ + 1, )
+        if not all(map(lambda s: s > 0, output_size)):
+            raise ValueError('convolution input is too small (output would be {})'.format(
+                'x'.join(map(str, output_size))))
+        return output_size
+
+
+class ModulatedDeformConvFunction(Function):
+
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+                deformable_groups=1):
+        ctx.stride = stride
+        ctx.padding = padding
+        ctx.dilation = dilation
+        ctx.groups = groups
+        ctx.deformable_groups = deformable_groups
+        ctx.with_bias = bias is not None
+        if not input.is_cuda:
+            raise NotImplementedError
+        if weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad:
+            ctx.save_for_backward(input, offset, mask, weight, bias if bias is not None else input.new_empty(1))
+        out = _forward_direct(input, offset, mask, weight, bias, _pair(stride), _pair(padding), _pair(dilation),
+                              groups, deformable_groups)
+        return out.to(input.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        from . import deform_conv_backward as bw
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, mask, weight, bias = ctx.saved_tensors
+        gi, go, gm, gw, gb = bw.modulated_backward(input, offset, mask, weight, grad_output, _pair(ctx.stride),
+                                                   _pair(ctx.padding), _pair(ctx.dilation), ctx.groups,
+                                                   ctx.deformable_groups, ctx.with_bias)
+        return (gi, go, gm, gw, gb, None, None, None, None, None)
+
+
+deform_conv = DeformConvFunction.apply
+modulated_deform_conv = ModulatedDeformConvFunction.apply
+
+
+class DeformConv(nn.Module):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super(DeformConv, self).__init__()
+        assert not bias
+        assert in_channels % groups == 0, \
+            'in_channels {} cannot be divisible by groups {}'.format(in_channels, groups)
+        assert out_channels % groups == 0, \
+            'out_channels {} cannot be divisible by groups {}'.format(out_channels, groups)
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = _pair(stride)
+        self.padding = _pair(padding)
+        self.dilation = _pair(dilation)
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+        # enable compatibility with nn.Conv2d
+        self.transposed = False
+        self.output_padding = _single(0)
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        # inputs smaller than the kernel are padded, as the reference does (deform_conv.py:239-255)
+        input_pad = (x.size(2) < self.kernel_size[0] or x.size(3) < self.kernel_size[1])
+        if input_pad:
+            pad_h = max(self.kernel_size[0] - x.size(2), 0)
+            pad_w = max(self.kernel_size[1] - x.size(3), 0)
+            x = F.pad(x, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+            offset = F.pad(offset, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+        out = deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                          self.deformable_groups)
+        if input_pad:
+            out = out[:, :, :out.size(2) - pad_h, :out.size(3) - pad_w].contiguous()
+        return out
+
+    def forward_multi(self, xs, offsets):
+        """All FPN levels in one launch (inference / no-grad fast path)."""
+        if fast_path_ok(self.weight, self.groups, self.deformable_groups) and not torch.is_grad_enabled():
+            return deform_conv_forward_multi(xs, offsets, self.weight, self.stride, self.padding, self.dilation)
+        return [self.forward(x, o) for x, o in zip(xs, offsets)]
+
+
+class DeformConvPack(DeformConv):
+    _version = 2
+
+    def __init__(self, *args, **kwargs):
+        super(DeformConvPack, self).__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(
+            self.in_channels, self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
+            kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        offset = self.conv_offset(x)
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                           self.deformable_groups)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        version = local_metadata.get('version', None)
+        if version is None or version < 2:
+            # early checkpoints name the offset conv `<name>_offset`
+            if (prefix + 'conv_offset.weight' not in state_dict and prefix[:-1] + '_offset.weight' in state_dict):
+                state_dict[prefix + 'conv_offset.weight'] = state_dict.pop(prefix[:-1] + '_offset.weight')
+            if (prefix + 'conv_offset.bias' not in state_dict and prefix[:-1] + '_offset.bias' in state_dict):
+                state_dict[prefix + 'conv_offset.bias'] = state_dict.pop(prefix[:-1] + '_offset.bias')
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+
+class ModulatedDeformConv(nn.Module):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=True):
+        super(ModulatedDeformConv, self).__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+        self.with_bias = bias
+        self.transposed = False
+        self.output_padding = _single(0)
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, offset, mask):
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                     self.dilation, self.groups, self.deformable_groups)
+
+
+class ModulatedDeformConvPack(ModulatedDeformConv):
+    _version = 2
+
+    def __init__(self, *args, **kwargs):
+        super(ModulatedDeformConvPack, self).__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(
+            self.in_channels, self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
+            kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        out = self.conv_offset(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        mask = torch.sigmoid(mask)
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                     self.dilation, self.groups, self.deformable_groups)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        version = local_metadata.get('version', None)
+        if version is None or version < 2:
+            if (prefix + 'conv_offset.weight' not in state_dict and prefix[:-1] + '_offset.weight' in state_dict):
+                state_dict[prefix + 'conv_offset.weight'] = state_dict.pop(prefix[:-1] + '_offset.weight')
+            if (prefix + 'conv_offset.bias' not in state_dict and prefix[:-1] + '_offset.bias' in state_dict):
+                state_dict[prefix + 'conv_offset.bias'] = state_dict.pop(prefix[:-1] + '_offset.bias')
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)

@@ -248,3 +248,66 @@ def test_chamfer_and_focal(dev, oracle, golden_dir):
     assert np.max(np.abs(x.grad.cpu().numpy() - c["focal_bwd"])) <= 1e-4
     with pytest.raises(RuntimeError):
         sigmoid_focal_loss(torch.zeros(2, 15), torch.zeros(2, dtype=torch.long), 2.0, 0.25)
+
+
+# ---- deformable convolution -----------------------------------------------------------------------------------------
+def _dcn_case(seed, B, C, H, W, Cout, std_off=2.0):
+    rng = np.random.RandomState(seed)
+    x = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    off = rng.normal(0, std_off, size=(B, 18, H, W)).astype(np.float32)
+    w = rng.normal(0, 0.05, size=(Cout, C, 3, 3)).astype(np.float32)
+    return x, off, w
+
+
+def _rel_err(got, want):
+    return np.max(np.abs(got - want)) / max(1e-6, np.max(np.abs(want)))
+
+
+@pytest.mark.parametrize("B,C,H,W,Cout", [(1, 64, 9, 11, 64), (2, 256, 16, 16, 256), (1, 32, 5, 40, 128),
+                                          (1, 96, 7, 7, 192)])
+def test_dcn_forward_mfma_vs_oracle(dev, oracle, B, C, H, W, Cout):
+    """MFMA implicit GEMM (fp32-exact MFMA) against the oracle's double-accumulated contraction: <= 1e-4 relative."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv
+    x, off, w = _dcn_case(0, B, C, H, W, Cout)
+    want = oracle.dcn_forward(x, off, w, stride=1, pad=1, dil=1)
+    got = deform_conv(_t(x, dev), _t(off, dev), _t(w, dev), 1, 1, 1, 1, 1, 64)
+    assert got.shape == want.shape and got.is_contiguous()
+    assert _rel_err(got.cpu().numpy(), want) <= 1e-4
+    # channels-last in -> channels-last out, same numbers
+    xcl = _t(x, dev).contiguous(memory_format=torch.channels_last)
+    got2 = deform_conv(xcl, _t(off, dev), _t(w, dev), 1, 1, 1, 1, 1, 64)
+    assert got2.is_contiguous(memory_format=torch.channels_last)
+    assert _rel_err(got2.cpu().numpy(), want) <= 1e-4
+
+
+def test_dcn_forward_multi_level_and_offsets_out_of_range(dev, oracle):
+    from orientedreppoints_amd.mmdet_ops import deform_conv_forward_multi
+    cases = [_dcn_case(10 + i, 1, 64, h, h, 64, std_off=4.0) for i, h in enumerate((16, 8, 4, 2, 1))]
+    w = cases[0][2]
+    outs = deform_conv_forward_multi([_t(c[0], dev) for c in cases], [_t(c[1], dev) for c in cases], _t(w, dev), 1, 1, 1)
+    for (x, off, _), o in zip(cases, outs):
+        assert _rel_err(o.cpu().numpy(), oracle.dcn_forward(x, off, w)) <= 1e-4
+
+
+def test_dcn_direct_paths(dev, oracle):
+    """groups / deformable groups / stride / DCNv2 mask + bias go through the direct kernel."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv, modulated_deform_conv, DeformConv
+    rng = np.random.RandomState(3)
+    x = rng.normal(size=(2, 8, 9, 10)).astype(np.float32)
+    w = rng.normal(0, 0.2, size=(6, 4, 3, 3)).astype(np.float32)          # groups = 2
+    off = rng.normal(0, 1.5, size=(2, 2 * 18, 5, 5)).astype(np.float32)   # dg = 2, stride 2
+    got = deform_conv(_t(x, dev), _t(off, dev), _t(w, dev), 2, 1, 1, 2, 2, 64).cpu().numpy()
+    want = oracle.dcn_forward(x, off, w, stride=2, pad=1, dil=1, groups=2, dg=2)
+    assert _rel_err(got, want) <= 1e-4
+    w2 = rng.normal(0, 0.2, size=(6, 8, 3, 3)).astype(np.float32)
+    off2 = rng.normal(0, 1.5, size=(2, 18, 9, 10)).astype(np.float32)
+    mask = rng.uniform(0, 1, size=(2, 9, 9, 10)).astype(np.float32)
+    bias = rng.normal(size=6).astype(np.float32)
+    got = modulated_deform_conv(_t(x, dev), _t(off2, dev), _t(mask, dev), _t(w2, dev), _t(bias, dev), 1, 1, 1, 1, 1)
+    want = oracle.dcn_forward(x, off2, w2, mask=mask, bias=bias)
+    assert _rel_err(got.cpu().numpy(), want) <= 1e-4
+    with pytest.raises(NotImplementedError):
+        deform_conv(torch.zeros(1, 8, 4, 4), torch.zeros(1, 18, 4, 4), torch.zeros(8, 8, 3, 3), 1, 1, 1, 1, 1, 64)
+    m = DeformConv(64, 64, 3, padding=1).to(dev)
+    y = m(torch.randn(1, 64, 2, 2, device=dev), torch.zeros(1, 18, 2, 2, device=dev))   # smaller than the kernel
+    assert y.shape == (1, 64, 2, 2)
