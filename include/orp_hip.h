@@ -140,6 +140,15 @@ int orp_dcn_forward_direct(const float* input, const float* offset, const float*
                            int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                            int groups, int deformable_groups, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Built-in kernel timing (measurement aid for bench.py): when enabled every instrumented launch is bracketed by
+ * a HIP event pair recorded on the launch stream.  Slots: 0 nms mask, 1 nms sweep, 2 nms sort, 3 dcn forward,
+ * 4 minaerarect, 5 convex_iou, 6 convex_giou, 7 iou matrix, 8 dcn backward.
+ * orp_profile_read synchronises on the recorded events and returns their summed duration and count.
+ * ------------------------------------------------------------------------------------------------------- */
+int orp_profile_enable(int on);
+int orp_profile_read(int slot, double* total_ms, int* count, int reset);
+
 #ifdef __cplusplus
 }
 #endif

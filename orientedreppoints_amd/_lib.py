@@ -39,6 +39,8 @@ _SIGNATURES = {
     "orp_chamfer2d_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "orp_sigmoid_focal_loss_forward": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     "orp_sigmoid_focal_loss_backward": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    "orp_profile_enable": (_i, [_i]),
+    "orp_profile_read": (_i, [_i, _vp, _vp, _i]),
     "orp_dcn_fast_path_ok": (_i, [_i, _i, _i, _i, _i, _i]),
     "orp_dcn_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "orp_dcn_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),

@@ -24,8 +24,9 @@ SOURCES = [
     ("orp_convex.hip", ["-ffp-contract=off"]),
     ("orp_pointwise.hip", ["-ffp-contract=off"]),
     ("orp_dcn.hip", []),
+    ("orp_prof.hip", []),
 ]
-HEADERS = ["orp_geom.hpp", "orp_hull.hpp", os.path.join("..", "..", "include", "orp_hip.h")]
+HEADERS = ["orp_geom.hpp", "orp_hull.hpp", "orp_prof.hpp", os.path.join("..", "..", "include", "orp_hip.h")]
 
 
 def _stale(target, deps):

@@ -16,6 +16,7 @@
 
 #include "../../include/orp_hip.h"
 #include "orp_hull.hpp"
+#include "orp_prof.hpp"
 
 namespace {
 using orp::Pt;
@@ -115,6 +116,7 @@ int orp_convex_iou(const float* pts, int n, const float* gts, int k, float* out,
   while (nb * ysplit < 8192 && ysplit < k) ysplit *= 2;
   int gpb = (k + ysplit - 1) / ysplit;
   ysplit = (k + gpb - 1) / gpb;
+  OrpProfScope prof(ORP_PROF_CONVEX_IOU, (hipStream_t)stream);
   hipLaunchKernelGGL(convex_iou_kernel, dim3(nb, ysplit), dim3(kThreads), 0, (hipStream_t)stream, pts, n, gts, k, gpb,
                      out);
   hipError_t e = hipGetLastError();

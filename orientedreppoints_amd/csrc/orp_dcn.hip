@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "../../include/orp_hip.h"
+#include "orp_prof.hpp"
 
 namespace {
 
@@ -411,6 +412,7 @@ int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int bat
   const size_t smem = sizeof(float) * (2 * BM * ASTR + 2 * KC * BN) + (sizeof(float4) + sizeof(int4)) * BM * MAX_TAPS;
   dim3 grid(tiles, (c_out + BN - 1) / BN);
   hipError_t e;
+  OrpProfScope prof(ORP_PROF_DCN_FWD, st);
   if (out_layout == 0) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -16,6 +16,7 @@
 
 #include "../../include/orp_hip.h"
 #include "orp_hull.hpp"
+#include "orp_prof.hpp"
 
 namespace {
 using orp::Pt;
@@ -108,6 +109,7 @@ int orp_minarearect_decode(const float* pts, int m, const float* centers, const 
                            void* stream) {
   if (m < 0 || (m > 0 && (!pts || !out)) || ((centers == nullptr) != (scales == nullptr))) return ORP_EINVAL;
   if (m == 0) return ORP_OK;
+  OrpProfScope prof(ORP_PROF_MINAREARECT, (hipStream_t)stream);
   hipLaunchKernelGGL(minarearect_kernel, dim3((m + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream,
                      pts, m, centers, scales, out);
   hipError_t e = hipGetLastError();

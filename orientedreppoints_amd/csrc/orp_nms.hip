@@ -22,6 +22,7 @@
 
 #include "../../include/orp_hip.h"
 #include "orp_geom.hpp"
+#include "orp_prof.hpp"
 
 namespace {
 
@@ -305,14 +306,20 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
   const int R = pick_rows_per_wave(max_seg, nseg);
   const int rpb = R * (kMaskThreads / 64);
   dim3 grid(max_cb, (max_seg + rpb - 1) / rpb, nseg);
-  if (flavor == 0)
-    hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask);
-  else
-    hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask);
+  {
+    OrpProfScope prof(ORP_PROF_NMS_MASK, st);
+    if (flavor == 0)
+      hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask);
+    else
+      hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask);
+  }
 
   const size_t smem = kSweepHdr + (size_t)max_cb * 3 * sizeof(u64);
-  hipLaunchKernelGGL(nms_sweep_kernel, dim3(nseg), dim3(kSweepThreads), smem, st, mask, order, seg, max_cb, order_out,
-                     keep_out, num_keep);
+  {
+    OrpProfScope prof(ORP_PROF_NMS_SWEEP, st);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(nseg), dim3(kSweepThreads), smem, st, mask, order, seg, max_cb, order_out,
+                       keep_out, num_keep);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }

@@ -1,0 +1,73 @@
+"""FPN neck on stock PyTorch-ROCm (mmdet/models/necks/fpn.py:11-178: start_level, add_extra_convs, num_outs, GN)."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .layers import ConvModule, xavier_init
+from .registry import NECKS
+
+
+@NECKS.register_module
+class FPN(nn.Module):
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 extra_convs_on_inputs=True, relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None,
+                 norm_cfg=None, act_cfg=None):
+        super(FPN, self).__init__()
+        assert isinstance(in_channels, list)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_ins, self.num_outs = len(in_channels), num_outs
+        self.relu_before_extra_convs = relu_before_extra_convs
+        if end_level == -1:
+            self.backbone_end_level = self.num_ins
+            assert num_outs >= self.num_ins - start_level
+        else:
+            self.backbone_end_level = end_level
+            assert end_level <= len(in_channels) and num_outs == end_level - start_level
+        self.start_level, self.end_level = start_level, end_level
+        self.add_extra_convs, self.extra_convs_on_inputs = add_extra_convs, extra_convs_on_inputs
+        self.lateral_convs = nn.ModuleList()
+        self.fpn_convs = nn.ModuleList()
+        for i in range(self.start_level, self.backbone_end_level):
+            self.lateral_convs.append(ConvModule(in_channels[i], out_channels, 1, conv_cfg=conv_cfg,
+                                                 norm_cfg=norm_cfg if not no_norm_on_lateral else None,
+                                                 act_cfg=act_cfg, inplace=False))
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1, conv_cfg=conv_cfg,
+                                             norm_cfg=norm_cfg, act_cfg=act_cfg, inplace=False))
+        extra_levels = num_outs - self.backbone_end_level + self.start_level
+        if add_extra_convs and extra_levels >= 1:
+            for i in range(extra_levels):
+                if i == 0 and self.extra_convs_on_inputs:
+                    ic = self.in_channels[self.backbone_end_level - 1]
+                else:
+                    ic = out_channels
+                self.fpn_convs.append(ConvModule(ic, out_channels, 3, stride=2, padding=1, conv_cfg=conv_cfg,
+                                                 norm_cfg=norm_cfg, act_cfg=act_cfg, inplace=False))
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                xavier_init(m, distribution='uniform')
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        laterals = [lc(inputs[i + self.start_level]) for i, lc in enumerate(self.lateral_convs)]
+        used = len(laterals)
+        for i in range(used - 1, 0, -1):
+            laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
+                                                              mode='nearest')
+        outs = [self.fpn_convs[i](laterals[i]) for i in range(used)]
+        if self.num_outs > len(outs):
+            if not self.add_extra_convs:
+                for i in range(self.num_outs - used):
+                    outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+            else:
+                if self.extra_convs_on_inputs:
+                    outs.append(self.fpn_convs[used](inputs[self.backbone_end_level - 1]))
+                else:
+                    outs.append(self.fpn_convs[used](outs[-1]))
+                for i in range(used + 1, self.num_outs):
+                    if self.relu_before_extra_convs:
+                        outs.append(self.fpn_convs[i](F.relu(outs[-1])))
+                    else:
+                        outs.append(self.fpn_convs[i](outs[-1]))
+        return tuple(outs)

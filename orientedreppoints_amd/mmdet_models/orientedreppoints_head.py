@@ -1,0 +1,209 @@
+"""OrientedRepPointsHead -- host-side mirror of mmdet/models/anchor_heads/orientedreppoints_head.py:20-781 with the
+same constructor arguments, parameter names (cls_convs.{i}.conv/gn, reg_convs, reppoints_cls_conv, reppoints_cls_out,
+reppoints_pts_init_conv/out, reppoints_pts_refine_conv/out) and method signatures, on the MI355X HIP operators.
+
+What is re-designed rather than translated:
+  * forward(): the towers / 1x1 heads stay stock PyTorch convs (run level by level), but the two DeformConvs are
+    applied to ALL five FPN levels in one launch each (mmdet_ops.deform_conv.forward_multi) when no gradient is
+    needed -- the reference launches im2col + GEMM per level;
+  * get_bboxes_single(): the min-area-rect decode (rect * stride + centre) is one fused stream-ordered kernel call
+    for all levels of an image instead of five blocking minaerarect calls with device->host->device copies;
+  * the training-side methods (loss, APAA) live in orientedreppoints_head_train.py.
+"""
+from __future__ import division
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..mmdet_ops.deform_conv import DeformConv
+from ..mmdet_ops.minarea_rect import minaerarect_decode
+from .core import PointGenerator, multi_apply, multiclass_rnms
+from .layers import ConvModule, bias_init_with_prob, normal_init
+from .registry import HEADS, build_loss
+
+
+@HEADS.register_module
+class OrientedRepPointsHead(nn.Module):
+
+    def __init__(self, num_classes, in_channels, feat_channels=256, point_feat_channels=256, stacked_convs=3,
+                 num_points=9, gradient_mul=0.1, point_strides=[8, 16, 32, 64, 128], point_base_scale=4,
+                 conv_cfg=None, norm_cfg=None,
+                 loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 loss_rbox_init=dict(type='GIoULoss', loss_weight=0.375),
+                 loss_rbox_refine=dict(type='GIoULoss', loss_weight=1.0),
+                 loss_spatial_init=dict(type='SpatialBorderLoss', loss_weight=0.05),
+                 loss_spatial_refine=dict(type='SpatialBorderLoss', loss_weight=0.1),
+                 center_init=True, top_ratio=0.4):
+        super(OrientedRepPointsHead, self).__init__()
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.feat_channels = feat_channels
+        self.point_feat_channels = point_feat_channels
+        self.stacked_convs = stacked_convs
+        self.num_points = num_points
+        self.gradient_mul = gradient_mul
+        self.point_base_scale = point_base_scale
+        self.point_strides = point_strides
+        self.conv_cfg = conv_cfg
+        self.norm_cfg = norm_cfg
+        self.use_sigmoid_cls = loss_cls.get('use_sigmoid', False)
+        self.sampling = loss_cls['type'] not in ['FocalLoss']
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_rbox_init = build_loss(loss_rbox_init)
+        self.loss_rbox_refine = build_loss(loss_rbox_refine)
+        self.loss_spatial_init = build_loss(loss_spatial_init)
+        self.loss_spatial_refine = build_loss(loss_spatial_refine)
+        self.center_init = center_init
+        self.top_ratio = top_ratio
+        self.cls_out_channels = self.num_classes - 1 if self.use_sigmoid_cls else self.num_classes
+        self.point_generators = [PointGenerator() for _ in self.point_strides]
+        # the DCN kernel is the sqrt(num_points) x sqrt(num_points) grid the points are initialised on
+        self.dcn_kernel = int(np.sqrt(num_points))
+        self.dcn_pad = int((self.dcn_kernel - 1) / 2)
+        assert self.dcn_kernel * self.dcn_kernel == num_points, 'The points number should be a square number.'
+        assert self.dcn_kernel % 2 == 1, 'The points number should be an odd square number.'
+        dcn_base = np.arange(-self.dcn_pad, self.dcn_pad + 1).astype(np.float64)
+        dcn_base_y = np.repeat(dcn_base, self.dcn_kernel)
+        dcn_base_x = np.tile(dcn_base, self.dcn_kernel)
+        dcn_base_offset = np.stack([dcn_base_y, dcn_base_x], axis=1).reshape((-1))
+        self.dcn_base_offset = torch.tensor(dcn_base_offset).view(1, -1, 1, 1)
+        self._init_layers()
+
+    def _init_layers(self):
+        self.relu = nn.ReLU(inplace=True)
+        self.cls_convs = nn.ModuleList()
+        self.reg_convs = nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = self.in_channels if i == 0 else self.feat_channels
+            self.cls_convs.append(ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                                             conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+            self.reg_convs.append(ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                                             conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+        pts_out_dim = 2 * self.num_points
+        self.reppoints_cls_conv = DeformConv(self.feat_channels, self.point_feat_channels, self.dcn_kernel, 1,
+                                             self.dcn_pad)
+        self.reppoints_cls_out = nn.Conv2d(self.point_feat_channels, self.cls_out_channels, 1, 1, 0)
+        self.reppoints_pts_init_conv = nn.Conv2d(self.feat_channels, self.point_feat_channels, 3, 1, 1)
+        self.reppoints_pts_init_out = nn.Conv2d(self.point_feat_channels, pts_out_dim, 1, 1, 0)
+        self.reppoints_pts_refine_conv = DeformConv(self.feat_channels, self.point_feat_channels, self.dcn_kernel, 1,
+                                                    self.dcn_pad)
+        self.reppoints_pts_refine_out = nn.Conv2d(self.point_feat_channels, pts_out_dim, 1, 1, 0)
+
+    def init_weights(self):
+        for m in self.cls_convs:
+            normal_init(m.conv, std=0.01)
+        for m in self.reg_convs:
+            normal_init(m.conv, std=0.01)
+        bias_cls = bias_init_with_prob(0.01)
+        normal_init(self.reppoints_cls_conv, std=0.01)
+        normal_init(self.reppoints_cls_out, std=0.01, bias=bias_cls)
+        normal_init(self.reppoints_pts_init_conv, std=0.01)
+        normal_init(self.reppoints_pts_init_out, std=0.01)
+        normal_init(self.reppoints_pts_refine_conv, std=0.01)
+        normal_init(self.reppoints_pts_refine_out, std=0.01)
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    def _towers(self, x):
+        cls_feat, pts_feat = x, x
+        for cls_conv in self.cls_convs:
+            cls_feat = cls_conv(cls_feat)
+        for reg_conv in self.reg_convs:
+            pts_feat = reg_conv(pts_feat)
+        pts_out_init = self.reppoints_pts_init_out(self.relu(self.reppoints_pts_init_conv(pts_feat)))
+        return cls_feat, pts_feat, pts_out_init
+
+    def forward_single(self, x):
+        """One level, autograd-capable (reference forward_single, head :148-171)."""
+        dcn_base_offset = self.dcn_base_offset.type_as(x)
+        cls_feat, pts_feat, pts_out_init = self._towers(x)
+        pts_out_init_grad_mul = (1 - self.gradient_mul) * pts_out_init.detach() + self.gradient_mul * pts_out_init
+        dcn_offset = pts_out_init_grad_mul - dcn_base_offset
+        dcn_cls_feat = self.reppoints_cls_conv(cls_feat, dcn_offset)
+        cls_out = self.reppoints_cls_out(self.relu(dcn_cls_feat))
+        pts_out_refine = self.reppoints_pts_refine_out(self.relu(self.reppoints_pts_refine_conv(pts_feat, dcn_offset)))
+        pts_out_refine = pts_out_refine + pts_out_init.detach()
+        return cls_out, pts_out_init, pts_out_refine, x
+
+    def forward(self, feats):
+        if torch.is_grad_enabled():
+            return multi_apply(self.forward_single, feats)
+        # inference: same arithmetic, but each DeformConv covers all levels in ONE launch
+        dcn_base_offset = self.dcn_base_offset.type_as(feats[0])
+        cls_feats, pts_feats, inits, offsets = [], [], [], []
+        for x in feats:
+            cls_feat, pts_feat, pts_out_init = self._towers(x)
+            cls_feats.append(cls_feat); pts_feats.append(pts_feat); inits.append(pts_out_init)
+            offsets.append(pts_out_init - dcn_base_offset)     # (1-g)*p + g*p == p without autograd
+        dcn_cls = self.reppoints_cls_conv.forward_multi(cls_feats, offsets)
+        dcn_pts = self.reppoints_pts_refine_conv.forward_multi(pts_feats, offsets)
+        cls_outs, refines = [], []
+        for c, p, init in zip(dcn_cls, dcn_pts, inits):
+            cls_outs.append(self.reppoints_cls_out(self.relu(c)))
+            refines.append(self.reppoints_pts_refine_out(self.relu(p)) + init)
+        return cls_outs, inits, refines, list(feats)
+
+    # ---- test-time decode + NMS ------------------------------------------------------------------------------------
+    def get_bboxes(self, cls_scores, pts_preds_init, pts_preds_refine, base_feats, img_metas, cfg, rescale=False,
+                   nms=True):
+        assert len(cls_scores) == len(pts_preds_refine)
+        num_levels = len(cls_scores)
+        device = cls_scores[0].device
+        mlvl_points = [self.point_generators[i].grid_points(cls_scores[i].size()[-2:], self.point_strides[i], device)
+                       for i in range(num_levels)]
+        result_list = []
+        for img_id in range(len(img_metas)):
+            cls_score_list = [cls_scores[i][img_id].detach() for i in range(num_levels)]
+            points_pred_list = [pts_preds_refine[i][img_id].detach() for i in range(num_levels)]
+            img_shape = img_metas[img_id]['img_shape']
+            scale_factor = img_metas[img_id]['scale_factor']
+            result_list.append(self.get_bboxes_single(cls_score_list, points_pred_list, mlvl_points, img_shape,
+                                                      scale_factor, cfg, rescale, nms))
+        return result_list
+
+    def get_bboxes_single(self, cls_scores, points_preds, mlvl_points, img_shape, scale_factor, cfg, rescale=False,
+                          nms=True):
+        assert len(cls_scores) == len(points_preds) == len(mlvl_points)
+        lvl_pts, lvl_scores, lvl_centers, lvl_strides = [], [], [], []
+        for i_lvl, (cls_score, points_pred, points) in enumerate(zip(cls_scores, points_preds, mlvl_points)):
+            assert cls_score.size()[-2:] == points_pred.size()[-2:]
+            cls_score = cls_score.permute(1, 2, 0).reshape(-1, self.cls_out_channels)
+            scores = cls_score.sigmoid() if self.use_sigmoid_cls else cls_score.softmax(-1)
+            points_pred = points_pred.permute(1, 2, 0).reshape(-1, 2 * self.num_points)
+            nms_pre = cfg.get('nms_pre', -1)
+            if nms_pre > 0 and scores.shape[0] > nms_pre:
+                if self.use_sigmoid_cls:
+                    max_scores, _ = scores.max(dim=1)
+                else:
+                    max_scores, _ = scores[:, 1:].max(dim=1)
+                _, topk_inds = max_scores.topk(nms_pre)
+                points = points[topk_inds, :]
+                points_pred = points_pred[topk_inds, :]
+                scores = scores[topk_inds, :]
+            # (y, x) -> (x, y) pairs, grid units
+            pts_xy = points_pred.reshape(-1, self.num_points, 2).flip(-1).reshape(-1, 2 * self.num_points)
+            lvl_pts.append(pts_xy)
+            lvl_scores.append(scores)
+            lvl_centers.append(points[:, :2])
+            lvl_strides.append(points[:, 2])
+        pts_all = torch.cat(lvl_pts)
+        centers = torch.cat(lvl_centers).contiguous()
+        strides = torch.cat(lvl_strides).contiguous()
+        # one fused kernel for all levels: hull -> min-area rect -> corners * stride + centre  (head :746-749)
+        mlvl_bboxes = minaerarect_decode(pts_all, centers, strides)
+        mlvl_reppoints = pts_all * strides[:, None] + centers.repeat(1, self.num_points)
+        if rescale:
+            mlvl_bboxes /= mlvl_bboxes.new_tensor(scale_factor)
+            mlvl_reppoints /= mlvl_reppoints.new_tensor(scale_factor)
+        mlvl_scores = torch.cat(lvl_scores)
+        if self.use_sigmoid_cls:
+            padding = mlvl_scores.new_zeros(mlvl_scores.shape[0], 1)
+            mlvl_scores = torch.cat([padding, mlvl_scores], dim=1)
+        if nms:
+            return multiclass_rnms(mlvl_bboxes, mlvl_scores, cfg.score_thr, cfg.nms, cfg.max_per_img,
+                                   multi_reppoints=mlvl_reppoints)
+        return mlvl_bboxes, mlvl_scores
+
+    def loss(self, *args, **kwargs):
+        from .orientedreppoints_head_train import head_loss
+        return head_loss(self, *args, **kwargs)

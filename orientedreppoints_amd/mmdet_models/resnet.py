@@ -1,0 +1,128 @@
+"""ResNet backbone on stock PyTorch-ROCm (mmdet/models/backbones/resnet.py:306-520 interface: depth, num_stages,
+out_indices, frozen_stages, norm_cfg, style, norm_eval).  Parameter names follow torchvision / the released
+checkpoints (conv1, bn1, layer{1..4}.{i}.conv{1,2,3}, bn{1,2,3}, downsample.{0,1}).  Out of the HIP hot path: this
+is the part BASELINE.json says stays stock."""
+import torch.nn as nn
+
+from .layers import build_norm_layer, constant_init, kaiming_init
+from .registry import BACKBONES
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch',
+                 norm_cfg=dict(type='BN')):
+        super(Bottleneck, self).__init__()
+        assert style in ['pytorch', 'caffe']
+        if style == 'pytorch':
+            conv1_stride, conv2_stride = 1, stride
+        else:
+            conv1_stride, conv2_stride = stride, 1
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=conv1_stride, bias=False)
+        self.add_module('bn1', build_norm_layer(norm_cfg, planes)[1])
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=conv2_stride, padding=dilation,
+                               dilation=dilation, bias=False)
+        self.add_module('bn2', build_norm_layer(norm_cfg, planes)[1])
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, kernel_size=1, bias=False)
+        self.add_module('bn3', build_norm_layer(norm_cfg, planes * self.expansion)[1])
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        return self.relu(out)
+
+
+@BACKBONES.register_module
+class ResNet(nn.Module):
+    arch_settings = {50: (Bottleneck, (3, 4, 6, 3)), 101: (Bottleneck, (3, 4, 23, 3)), 152: (Bottleneck, (3, 8, 36, 3))}
+
+    def __init__(self, depth, in_channels=3, num_stages=4, strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1),
+                 out_indices=(0, 1, 2, 3), style='pytorch', frozen_stages=-1, conv_cfg=None,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None, stage_with_dcn=None,
+                 gcb=None, stage_with_gcb=None, gen_attention=None, stage_with_gen_attention=None,
+                 with_cp=False, zero_init_residual=True):
+        super(ResNet, self).__init__()
+        if depth not in self.arch_settings:
+            raise KeyError('invalid depth {} for resnet'.format(depth))
+        assert dcn is None and gcb is None and gen_attention is None, 'plain ResNet only (as the DOTA configs use)'
+        self.depth, self.num_stages, self.out_indices = depth, num_stages, out_indices
+        self.frozen_stages, self.norm_eval = frozen_stages, norm_eval
+        self.zero_init_residual = zero_init_residual
+        block, stage_blocks = self.arch_settings[depth]
+        self.conv1 = nn.Conv2d(in_channels, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.add_module('bn1', build_norm_layer(norm_cfg, 64)[1])
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        inplanes = 64
+        self.res_layers = []
+        for i, num_blocks in enumerate(stage_blocks[:num_stages]):
+            planes = 64 * 2 ** i
+            stride, dilation = strides[i], dilations[i]
+            downsample = None
+            if stride != 1 or inplanes != planes * block.expansion:
+                downsample = nn.Sequential(
+                    nn.Conv2d(inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                    build_norm_layer(norm_cfg, planes * block.expansion)[1])
+            layers = [block(inplanes, planes, stride, dilation, downsample, style, norm_cfg)]
+            inplanes = planes * block.expansion
+            for _ in range(1, num_blocks):
+                layers.append(block(inplanes, planes, 1, dilation, None, style, norm_cfg))
+            name = 'layer{}'.format(i + 1)
+            self.add_module(name, nn.Sequential(*layers))
+            self.res_layers.append(name)
+        self._freeze_stages()
+        self.feat_dim = inplanes
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in [self.conv1, self.bn1]:
+                for param in m.parameters():
+                    param.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, 'layer{}'.format(i))
+            m.eval()
+            for param in m.parameters():
+                param.requires_grad = False
+
+    def init_weights(self, pretrained=None):
+        # no network here: `pretrained` (e.g. 'torchvision://resnet50') is accepted and ignored unless it is a file
+        if isinstance(pretrained, str) and pretrained.endswith(('.pth', '.pt')):
+            import torch
+            sd = torch.load(pretrained, map_location='cpu')
+            self.load_state_dict(sd.get('state_dict', sd), strict=False)
+            return
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                kaiming_init(m)
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                constant_init(m, 1)
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    constant_init(m.bn3, 0)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name)(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def train(self, mode=True):
+        super(ResNet, self).train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()

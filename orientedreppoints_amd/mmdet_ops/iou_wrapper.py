@@ -27,6 +27,36 @@ class _ConvexIouCuda(object):
 convex_iou_cuda = _ConvexIouCuda()
 
 
+class _ConvexGiouCuda(object):
+    @staticmethod
+    def convex_giou(pred, target):
+        """pred [P,18], target [P,8] CUDA f32 (aligned pairs) -> flat [P*19] = 18 grads + giou per row
+        (mmdet/ops/iou/src/convex_giou_cuda.cpp, convex_giou_kernel.cu:806-868)."""
+        _lib.require_cuda(pred, "pred")
+        _lib.require_cuda(target, "target")
+        if pred.numel() == 0 or target.numel() == 0:
+            return torch.empty((0,), dtype=torch.float32, device="cpu")
+        p = pred.detach().float().reshape(-1, 18).contiguous()
+        g = target.detach().float().reshape(-1, 8).contiguous()
+        assert p.size(0) == g.size(0), "ex_boxes must equal to gt_boxes"
+        out = torch.empty((p.size(0) * 19,), dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            rc = _lib.lib().orp_convex_giou(_lib.ptr(p), _lib.ptr(g), p.size(0), _lib.ptr(out), _lib.stream_of(p))
+        _lib.check(rc, "orp_convex_giou")
+        return out
+
+
+convex_giou_cuda = _ConvexGiouCuda()
+
+
+def convex_giou(pred, target):
+    convex_giou_grad = convex_giou_cuda.convex_giou(pred, target)
+    convex_giou_grad = convex_giou_grad.reshape(-1, 19)
+    convex_giou = convex_giou_grad[:, -1]
+    points_grad = convex_giou_grad[:, 0:-1]
+    return convex_giou, points_grad
+
+
 def convex_iou(pred, target):
     ex_num, gt_num = pred.size(0), target.size(0)
     convex_ious = convex_iou_cuda.convex_iou(pred, target)
