@@ -89,6 +89,9 @@ int orp_minarearect_decode(const float* pts, int m, const float* centers, const 
  * out [n,k] f32 row-major (point set major), exactly the reference's flat layout.
  * ------------------------------------------------------------------------------------------------------- */
 int orp_convex_iou(const float* pts, int n, const float* gts, int k, float* out, void* stream);
+/* convex_giou: aligned pairs, GIoU(hull(9 points), gt) and its gradient w.r.t. the 18 coordinates;
+ * out19 [n,19] = 18 grads + giou, the row layout of convex_giou_kernel (convex_giou_kernel.cu:806-868). */
+int orp_convex_giou(const float* pts, const float* gts, int n, float* out19, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * pointsJf: ray-casting point-in-quad flags for all M x K pairs (mmdet/ops/point_justify/src/

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, f) for f in ("orp_oracle.c", "orp_oracle2.c", "orp_polyclip.inc", "orp_hull.inc")]
+SRC = [os.path.join(HERE, f) for f in ("orp_oracle.c", "orp_oracle2.c", "orp_oracle3.c", "orp_polyclip.inc", "orp_hull.inc")]
 LIB = os.path.join(HERE, "liborp_oracle.so")
 REF_LIB = os.path.join(HERE, "_ref", "libref_orp.so")
 
@@ -328,3 +328,12 @@ def dcn_forward(x, offset, weight, stride=1, pad=1, dil=1, groups=1, dg=1, mask=
                           _p(bb) if bb is not None else None, _p(out), B, C, H, W, Cout, kh, kw, stride, stride, pad,
                           pad, dil, dil, groups, dg)
     return out
+
+
+def convex_giou(pts, gts, return_flags=False):
+    """[P,19] = 18 grads + giou per aligned pair; flags[P] = 1 where the reference itself is undefined (scratch overflow)."""
+    p, g = _f32(pts), _f32(gts)
+    out = np.empty((p.shape[0], 19), np.float32)
+    fl = np.zeros(p.shape[0], np.int32)
+    lib().orc_convex_giou(_p(p), _p(g), p.shape[0], _p(out), _p(fl))
+    return (out, fl) if return_flags else out

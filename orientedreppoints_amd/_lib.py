@@ -33,6 +33,7 @@ _SIGNATURES = {
     "orp_minarearect": (_i, [_vp, _i, _vp, _vp]),
     "orp_minarearect_decode": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "orp_convex_iou": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "orp_convex_giou": (_i, [_vp, _vp, _i, _vp, _vp]),
     "orp_points_justify": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "orp_points_in_quad_aligned": (_i, [_vp, _vp, _i, _vp, _vp]),
     "orp_chamfer2d_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -22,6 +22,7 @@ SOURCES = [
     ("orp_overlaps.hip", ["-ffp-contract=off"]),
     ("orp_minarearect.hip", ["-ffp-contract=off"]),
     ("orp_convex.hip", ["-ffp-contract=off"]),
+    ("orp_convex_giou.hip", ["-ffp-contract=off"]),
     ("orp_pointwise.hip", ["-ffp-contract=off"]),
     ("orp_dcn.hip", []),
     ("orp_prof.hip", []),

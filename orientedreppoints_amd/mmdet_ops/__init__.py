@@ -6,7 +6,7 @@ can be re-pointed here unchanged.
 """
 from .nms_wrapper import rnms, rnms_cuda, poly_nms_gpu  # noqa: F401
 from .minarea_rect import minaerarect  # noqa: F401
-from .iou_wrapper import convex_iou, convex_overlaps  # noqa: F401
+from .iou_wrapper import convex_iou, convex_overlaps, convex_giou  # noqa: F401
 from .chamfer_distance import ChamferDistance2D, Chamfer2D  # noqa: F401
 from .point_justify import pointsJf, points_in_quad_aligned  # noqa: F401
 from .sigmoid_focal_loss import SigmoidFocalLoss, sigmoid_focal_loss  # noqa: F401
