@@ -143,6 +143,52 @@ int orp_dcn_forward_direct(const float* input, const float* offset, const float*
                            int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                            int groups, int deformable_groups, void* stream);
 
+/* Deformable convolution backward, column formulation (deform_conv_cuda.cpp:262-488, kernels
+ * deform_conv_cuda_kernel.cu:190-465 and the modulated twins :570-867).  NCHW fp32.
+ * orp_dcn_im2col: columns [Cin*kh*kw, B*Ho*Wo] (x mask when mask != NULL) -- feeds grad_W = grad_out . columns^T.
+ * orp_dcn_col2im: from grad_columns = W^T . grad_out: grad_input (ACCUMULATED: caller zeroes), grad_offset and, for
+ *   DCNv2 (mask/grad_mask both non-NULL), grad_mask -- one kernel instead of col2im + col2im_coord. */
+int orp_dcn_im2col(const float* input, const float* offset, const float* mask, int batch, int c_in, int height,
+                   int width, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                   int deformable_groups, float* columns, void* stream);
+int orp_dcn_col2im(const float* grad_columns, const float* input, const float* offset, const float* mask, int batch,
+                   int c_in, int height, int width, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                   int dil_h, int dil_w, int deformable_groups, float* grad_input, float* grad_offset, float* grad_mask,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Assignment side of the APAA training path (what the reference does with Python loops over ground truths).
+ * orp_point_assign: PointAssigner.assign (mmdet/core/bbox/assigners/point_assigner.py:22-145).  points [n,3] =
+ *   (x, y, stride), gts [k,8]; gt_inds [n] int64 (0 = background, i+1 = gt i).  Each gt takes its `pos_num` nearest
+ *   points (normalised centre distance) on its pyramid level; a point wanted by several gts goes to the closest,
+ *   ties to the earlier gt.
+ * orp_max_iou_assign: MaxIoUAssigner.assign_wrt_overlaps (max_iou_assigner.py:88-152) on the POINT-MAJOR overlap
+ *   matrix [n,k] produced by orp_convex_iou.  neg range [neg_iou_lo, neg_iou_hi) -> 0, >= pos_iou_thr -> argmax+1,
+ *   then every point whose overlap equals a gt's maximum (>= min_pos_iou) -> that gt (later gt overwrites);
+ *   gt_inds [n] int64 in {-1, 0, 1..k}, max_overlaps [n] (may be NULL).
+ * orp_apaa_feature_dissimilarity: get_adaptive_points_feature + feature_cosine_similarity
+ *   (orientedreppoints_head.py:495-520, 576-600) for the POSITIVES only: bilinear samples (grid_sample, zeros padding,
+ *   align_corners=False) of the level's [B,C,H,W] feature map at the 9 refined points of each positive, then
+ *   max_k (1 - cos(f_k, mean_k f_k)) with norms clamped at 1e-2.  feats_host etc. are HOST arrays of per-level
+ *   device pointers / sizes; pts18 [p,18] image-space (x,y); img_index / level_index [p] int32; out [p].
+ * orp_apaa_select: point_samples_selection (orientedreppoints_head.py:602-671): per gt, per level the
+ *   per_level_topk smallest-quality positives, merged, sorted ascending, first ceil(top_ratio * n) kept
+ *   (all kept when n < 2).  quality [p], pos_gt_inds [p] int64 (1-based), pos_level [p] int32; keep [p] uint8.
+ * ------------------------------------------------------------------------------------------------------- */
+size_t orp_point_assign_workspace_bytes(int n);
+int orp_point_assign(const float* points, int n, const float* gts, int k, float scale, int pos_num, int64_t* gt_inds,
+                     void* workspace, size_t workspace_bytes, void* stream);
+size_t orp_max_iou_assign_workspace_bytes(int k);
+int orp_max_iou_assign(const float* overlaps_nk, int n, int k, float pos_iou_thr, float neg_iou_lo, float neg_iou_hi,
+                       float min_pos_iou, int gt_max_assign_all, int64_t* gt_inds, float* max_overlaps,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int orp_apaa_feature_dissimilarity(const float* const* feats_host, const int* heights_host, const int* widths_host,
+                                   const float* strides_host, int num_levels, int channels, const float* pts18,
+                                   const int32_t* img_index, const int32_t* level_index, int p, float* out,
+                                   void* stream);
+int orp_apaa_select(const float* quality, const int64_t* pos_gt_inds, const int32_t* pos_level, int p, int num_gt,
+                    int num_level, int per_level_topk, double top_ratio, uint8_t* keep, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Built-in kernel timing (measurement aid for bench.py): when enabled every instrumented launch is bracketed by
  * a HIP event pair recorded on the launch stream.  Slots: 0 nms mask, 1 nms sweep, 2 nms sort, 3 dcn forward,

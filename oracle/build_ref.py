@@ -43,6 +43,8 @@ SLICES = [
     ("focal",            "mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_cuda.cu", 23, 97),
     ("chamfer",          "mmdet/ops/chamfer_2d/src/chamfer_2d.cu",              12, 124),
     ("dcn_im2col",       "mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu",        84, 243),
+    ("dcn_col2im",       "mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu",       279, 335),
+    ("dcn_col2im_coord", "mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu",       373, 436),
 ]
 
 

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, f) for f in ("orp_oracle.c", "orp_oracle2.c", "orp_oracle3.c", "orp_polyclip.inc", "orp_hull.inc")]
+SRC = [os.path.join(HERE, f) for f in ("orp_oracle.c", "orp_oracle2.c", "orp_oracle3.c", "orp_oracle4.c", "orp_polyclip.inc", "orp_hull.inc")]
 LIB = os.path.join(HERE, "liborp_oracle.so")
 REF_LIB = os.path.join(HERE, "_ref", "libref_orp.so")
 
@@ -27,7 +27,8 @@ def build(force=False):
         return LIB
     cfiles = [s for s in srcs if s.endswith(".c")]
     cmd = ["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-Wno-parentheses"] + cfiles + ["-o", LIB, "-lm"]
+           "-Wno-unused-function", "-Wno-parentheses", "-Wno-misleading-indentation",
+           "-Wno-alloc-size-larger-than"] + cfiles + ["-o", LIB, "-lm"]
     subprocess.check_call(cmd)
     return LIB
 
@@ -337,3 +338,69 @@ def convex_giou(pts, gts, return_flags=False):
     fl = np.zeros(p.shape[0], np.int32)
     lib().orc_convex_giou(_p(p), _p(g), p.shape[0], _p(out), _p(fl))
     return (out, fl) if return_flags else out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# part 4: assigners / APAA selection
+# ---------------------------------------------------------------------------------------------------------
+def point_assign(points, gts, scale=4, pos_num=1):
+    p, g = _f32(points), _f32(gts).reshape(-1, 8)
+    out = np.zeros(p.shape[0], np.int64)
+    lib().orc_point_assign(_p(p), p.shape[0], _p(g), g.shape[0], ctypes.c_float(scale), int(pos_num), _p(out))
+    return out
+
+
+def max_iou_assign(overlaps_nk, pos_thr, neg_thr, min_pos_iou=0.0, assign_all=True):
+    ov = _f32(overlaps_nk)
+    n, k = ov.shape
+    lo, hi = (0.0, neg_thr) if not isinstance(neg_thr, tuple) else neg_thr
+    gi = np.empty(n, np.int64); mo = np.empty(n, np.float32)
+    lib().orc_max_iou_assign(_p(ov), n, k, ctypes.c_float(pos_thr), ctypes.c_float(lo), ctypes.c_float(hi),
+                             ctypes.c_float(min_pos_iou), int(assign_all), _p(gi), _p(mo))
+    return gi, mo
+
+
+def sample_points(feat_chw, stride, pts18):
+    f, p = _f32(feat_chw), _f32(pts18)
+    C, H, W = f.shape
+    out = np.empty((p.shape[0], 9, C), np.float32)
+    lib().orc_sample_points(_p(f), C, H, W, ctypes.c_float(stride), _p(p), p.shape[0], _p(out))
+    return out
+
+
+def feature_dissimilarity(f):
+    f = _f32(f)
+    out = np.empty(f.shape[0], np.float32)
+    lib().orc_feature_dissimilarity(_p(f), f.shape[0], f.shape[2], _p(out))
+    return out
+
+
+def apaa_select(q, pos_gt, pos_lvl, num_gt, num_level=5, per_level_k=6, top_ratio=0.4):
+    q = _f32(q); g = np.ascontiguousarray(pos_gt, np.int64); l = np.ascontiguousarray(pos_lvl, np.int32)
+    keep = np.zeros(q.shape[0], np.uint8)
+    lib().orc_apaa_select(_p(q), _p(g), _p(l), q.shape[0], int(num_gt), int(num_level), int(per_level_k),
+                          ctypes.c_double(top_ratio), _p(keep))
+    return keep
+
+
+def dcn_backward(x, offset, weight, grad_out, stride=1, pad=1, dil=1, dg=1, use_ref=False):
+    """(grad_input, grad_offset, grad_weight) of the groups=1 deformable conv, through the column formulation:
+    grad_col = W^T grad_out (fp64 GEMM), col2im / col2im_coord (oracle or the reference's kernels), grad_W = grad_out col^T."""
+    x, offset, weight, grad_out = _f32(x), _f32(offset), _f32(weight), _f32(grad_out)
+    B, C, H, W = x.shape
+    Cout, _, kh, kw = weight.shape
+    Ho, Wo = grad_out.shape[2], grad_out.shape[3]
+    go = grad_out.transpose(1, 0, 2, 3).reshape(Cout, -1).astype(np.float64)           # [Cout, B*Ho*Wo]
+    gcol = (weight.reshape(Cout, -1).astype(np.float64).T @ go).astype(np.float32)     # [C*taps, B*Ho*Wo]
+    gcol = np.ascontiguousarray(gcol)
+    gi = np.zeros_like(x); goff = np.zeros_like(offset)
+    if use_ref:
+        ref().ref_dcn_col2im(_p(gcol), _p(offset), B, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil, dg, _p(gi))
+        ref().ref_dcn_col2im_coord(_p(gcol), _p(x), _p(offset), B, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil,
+                                   dg, _p(goff))
+    else:
+        lib().orc_dcn_backward_input(_p(gcol), _p(x), _p(offset), B, C, H, W, kh, kw, pad, pad, stride, stride, dil,
+                                     dil, dg, _p(gi), _p(goff))
+    col = dcn_im2col(x, offset, kh, kw, pad, stride, dil, dg).reshape(C * kh * kw, -1).astype(np.float64)
+    gw = (go @ col.T).reshape(weight.shape).astype(np.float32)
+    return gi, goff, gw

@@ -197,3 +197,70 @@ void orc_dcn_forward(const float* x, const float* offset, const float* mask, con
   }
   free(samp);
 }
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* a2 backward: grad wrt input / offset from a column gradient, and the reference's two helper weights       */
+/*   get_gradient_weight (deform_conv_cuda_kernel.cu:117-143), get_coordinate_weight (:145-188),              */
+/*   deformable_col2im_gpu_kernel (:279-335), deformable_col2im_coord_gpu_kernel (:373-436).                  */
+/* ------------------------------------------------------------------------------------------------------- */
+static float dcn_coordinate_weight(float argmax_h, float argmax_w, int height, int width, const float* im, int data_width, int bp_dir) {
+  if (argmax_h <= -1 || argmax_h >= height || argmax_w <= -1 || argmax_w >= width) return 0;
+  int hl = (int)floorf(argmax_h), wl = (int)floorf(argmax_w), hh = hl + 1, wh = wl + 1;
+  float weight = 0;
+  if (bp_dir == 0) {
+    if (hl >= 0 && wl >= 0) weight += -1 * (wl + 1 - argmax_w) * im[hl * data_width + wl];
+    if (hl >= 0 && wh <= width - 1) weight += -1 * (argmax_w - wl) * im[hl * data_width + wh];
+    if (hh <= height - 1 && wl >= 0) weight += (wl + 1 - argmax_w) * im[hh * data_width + wl];
+    if (hh <= height - 1 && wh <= width - 1) weight += (argmax_w - wl) * im[hh * data_width + wh];
+  } else {
+    if (hl >= 0 && wl >= 0) weight += -1 * (hl + 1 - argmax_h) * im[hl * data_width + wl];
+    if (hl >= 0 && wh <= width - 1) weight += (hl + 1 - argmax_h) * im[hl * data_width + wh];
+    if (hh <= height - 1 && wl >= 0) weight += -1 * (argmax_h - hl) * im[hh * data_width + wl];
+    if (hh <= height - 1 && wh <= width - 1) weight += (argmax_h - hl) * im[hh * data_width + wh];
+  }
+  return weight;
+}
+
+/* col [C*taps][B][Ho][Wo] -> grad_im [B,C,H,W] (accumulated in double, written as float), grad_offset [B,dg*2*taps,Ho,Wo] */
+void orc_dcn_backward_input(const float* col, const float* im, const float* offset, int B, int C, int H, int W, int kh,
+                            int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg,
+                            float* grad_im, float* grad_offset) {
+  int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  int taps = kh * kw, cpdg = C / dg;
+  double* gi = (double*)calloc((size_t)B * C * H * W, sizeof(double));
+  double* go = (double*)calloc((size_t)B * dg * 2 * taps * Ho * Wo, sizeof(double));
+  for (int c = 0; c < C; c++)
+    for (int t = 0; t < taps; t++)
+      for (int b = 0; b < B; b++)
+        for (int ho = 0; ho < Ho; ho++)
+          for (int wo = 0; wo < Wo; wo++) {
+            int i = t / kw, j = t % kw, g = c / cpdg;
+            const float* op = offset + ((size_t)b * dg + g) * 2 * taps * Ho * Wo;
+            float oh = op[((size_t)(2 * t) * Ho + ho) * Wo + wo], ow = op[((size_t)(2 * t + 1) * Ho + ho) * Wo + wo];
+            float h_im = (ho * stride_h - pad_h) + i * dil_h + oh;
+            float w_im = (wo * stride_w - pad_w) + j * dil_w + ow;
+            float top = col[((((size_t)c * taps + t) * B + b) * Ho + ho) * Wo + wo];
+            const float* imp = im + ((size_t)b * C + c) * H * W;
+            if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+              int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+              float lh = h_im - hl, lw = w_im - wl;
+              for (int dy = 0; dy < 2; dy++)
+                for (int dx = 0; dx < 2; dx++) {
+                  int y = hl + dy, x = wl + dx;
+                  if (y < 0 || y >= H || x < 0 || x >= W) continue;
+                  float wgt = (dy ? lh : 1 - lh) * (dx ? lw : 1 - lw);
+                  gi[(((size_t)b * C + c) * H + y) * W + x] += (double)wgt * top;
+                }
+            }
+            float ih = h_im, iw = w_im;
+            if (ih <= -1 || iw <= -1 || ih >= H || iw >= W) { ih = iw = -2; }
+            go[(((size_t)b * dg + g) * 2 * taps + 2 * t) * Ho * Wo + (size_t)ho * Wo + wo] +=
+                (double)dcn_coordinate_weight(ih, iw, H, W, imp, W, 0) * top;
+            go[(((size_t)b * dg + g) * 2 * taps + 2 * t + 1) * Ho * Wo + (size_t)ho * Wo + wo] +=
+                (double)dcn_coordinate_weight(ih, iw, H, W, imp, W, 1) * top;
+          }
+  for (size_t i = 0; i < (size_t)B * C * H * W; i++) grad_im[i] = (float)gi[i];
+  for (size_t i = 0; i < (size_t)B * dg * 2 * taps * Ho * Wo; i++) grad_offset[i] = (float)go[i];
+  free(gi); free(go);
+}

@@ -69,6 +69,8 @@ namespace nsref_chamfer { using std::min; using std::max;
 }
 namespace nsref_dcn { using std::min; using std::max;
 #include "dcn_im2col.inc"
+#include "dcn_col2im.inc"
+#include "dcn_col2im_coord.inc"
 }
 // polyiou.cpp is plain C++: include it whole (its std headers are already guarded above).
 namespace nsref_polyiou {
@@ -175,6 +177,37 @@ void ref_dcn_im2col(const float* im, const float* offset, int B, int C, int H, i
     blockIdx.x = b;
     nsref_dcn::deformable_im2col_gpu_kernel<float>(n, im, offset, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h,
                                                    dil_w, C / dg, B, C, dg, Ho, Wo, col);
+  }
+  blockIdx.x = 0; gridDim.x = 1;
+}
+
+// deformable_col2im_gpu_kernel (:279-335) and deformable_col2im_coord_gpu_kernel (:373-436), 1 thread per block.
+// col [C*kh*kw][B][Ho][Wo]; grad_im [B,C,H,W] (accumulated, caller zeroes); grad_offset [B, dg*2*kh*kw, Ho, Wo]
+void ref_dcn_col2im(const float* col, const float* offset, int B, int C, int H, int W, int kh, int kw, int pad_h,
+                    int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg, float* grad_im) {
+  int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  int n = C * kh * kw * Ho * Wo * B;
+  blockDim.x = 1; threadIdx.x = 0; gridDim.x = n;
+  for (int b = 0; b < n; b++) {
+    blockIdx.x = b;
+    nsref_dcn::deformable_col2im_gpu_kernel<float>(n, col, offset, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w,
+                                                   dil_h, dil_w, C / dg, B, dg, Ho, Wo, grad_im);
+  }
+  blockIdx.x = 0; gridDim.x = 1;
+}
+void ref_dcn_col2im_coord(const float* col, const float* im, const float* offset, int B, int C, int H, int W, int kh,
+                          int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg,
+                          float* grad_offset) {
+  int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  int n = Ho * Wo * 2 * kh * kw * dg * B;
+  blockDim.x = 1; threadIdx.x = 0; gridDim.x = n;
+  for (int b = 0; b < n; b++) {
+    blockIdx.x = b;
+    nsref_dcn::deformable_col2im_coord_gpu_kernel<float>(n, col, im, offset, C, H, W, kh, kw, pad_h, pad_w, stride_h,
+                                                         stride_w, dil_h, dil_w, C * kh * kw / dg, B,
+                                                         2 * kh * kw * dg, dg, Ho, Wo, grad_offset);
   }
   blockIdx.x = 0; gridDim.x = 1;
 }

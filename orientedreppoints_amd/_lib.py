@@ -40,12 +40,20 @@ _SIGNATURES = {
     "orp_chamfer2d_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "orp_sigmoid_focal_loss_forward": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     "orp_sigmoid_focal_loss_backward": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    "orp_point_assign_workspace_bytes": (_sz, [_i]),
+    "orp_point_assign": (_i, [_vp, _i, _vp, _i, _f, _i, _vp, _vp, _sz, _vp]),
+    "orp_max_iou_assign_workspace_bytes": (_sz, [_i]),
+    "orp_max_iou_assign": (_i, [_vp, _i, _i, _f, _f, _f, _f, _i, _vp, _vp, _vp, _sz, _vp]),
+    "orp_apaa_feature_dissimilarity": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "orp_apaa_select": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_double, _vp, _vp]),
     "orp_profile_enable": (_i, [_i]),
     "orp_profile_read": (_i, [_i, _vp, _vp, _i]),
     "orp_dcn_fast_path_ok": (_i, [_i, _i, _i, _i, _i, _i]),
     "orp_dcn_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "orp_dcn_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "orp_dcn_forward_multi": (_i, [_vp, _i, _i, _i, _i, _vp] + [_i] * 10 + [_vp, _sz, _vp]),
+    "orp_dcn_im2col": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp]),
+    "orp_dcn_col2im": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp, _vp]),
     "orp_dcn_forward_direct": (_i, [_vp] * 6 + [_i] * 15 + [_vp]),
 }
 

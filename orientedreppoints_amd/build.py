@@ -24,7 +24,9 @@ SOURCES = [
     ("orp_convex.hip", ["-ffp-contract=off"]),
     ("orp_convex_giou.hip", ["-ffp-contract=off"]),
     ("orp_pointwise.hip", ["-ffp-contract=off"]),
+    ("orp_assign.hip", ["-ffp-contract=off"]),
     ("orp_dcn.hip", []),
+    ("orp_dcn_bwd.hip", []),
     ("orp_prof.hip", []),
 ]
 HEADERS = ["orp_geom.hpp", "orp_hull.hpp", "orp_prof.hpp", os.path.join("..", "..", "include", "orp_hip.h")]

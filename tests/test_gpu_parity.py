@@ -350,3 +350,175 @@ def test_giou_loss_module(dev, oracle):
     gref[bad] = 1e-6
     gref = -gref / 200 * 0.375
     assert np.max(np.abs(pred.grad.cpu().numpy() - gref)) <= 1e-5
+
+
+# ---- assigners / APAA ------------------------------------------------------------------------------------------------
+def _apaa(golden_dir):
+    return np.load(os.path.join(golden_dir, "apaa_py.npz"))
+
+
+def test_point_assigner_kernel(dev, oracle, golden_dir):
+    from orientedreppoints_amd.mmdet_models.assigners import PointAssigner
+    g = _apaa(golden_dir)
+    for pn in (1, 3):
+        r = PointAssigner(scale=4, pos_num=pn).assign(_t(g["points"], dev), _t(g["gts"], dev), None,
+                                                      torch.from_numpy(g["gt_labels"]).to(dev))
+        assert np.array_equal(r.gt_inds.cpu().numpy(), g["pa_gt_inds_%d" % pn])          # reference python
+        assert np.array_equal(r.labels.cpu().numpy(), g["pa_labels_%d" % pn])
+    # one 1024^2 image, 300 gts, against the oracle
+    pts = []
+    for s in (8, 16, 32, 64, 128):
+        f = 1024 // s
+        ys, xs = np.meshgrid(np.arange(f) * s, np.arange(f) * s, indexing="ij")
+        pts.append(np.stack([xs.ravel(), ys.ravel(), np.full(f * f, s)], 1))
+    pts = np.concatenate(pts, 0).astype(np.float32)
+    gts = S.gen_gts(300, 4).astype(np.float32)
+    r = PointAssigner(scale=4, pos_num=1).assign(_t(pts, dev), _t(gts, dev))
+    assert np.array_equal(r.gt_inds.cpu().numpy(), oracle.point_assign(pts, gts, 4, 1))
+    r0 = PointAssigner().assign(_t(pts, dev), torch.zeros((0, 8), device=dev))
+    assert int(r0.gt_inds.abs().sum()) == 0
+
+
+def test_max_iou_assigner_kernel(dev, oracle, golden_dir):
+    from orientedreppoints_amd.mmdet_models.assigners import MaxIoUAssigner
+    g = _apaa(golden_dir)
+    a = MaxIoUAssigner(pos_iou_thr=0.1, neg_iou_thr=0.1, min_pos_iou=0, ignore_iof_thr=-1)
+    r = a.assign_wrt_overlaps(_t(g["overlaps"], dev), torch.from_numpy(g["gt_labels"]).to(dev))
+    assert np.array_equal(r.gt_inds.cpu().numpy(), g["mia_gt_inds"])
+    assert np.array_equal(r.max_overlaps.cpu().numpy(), g["mia_max_overlaps"])
+    assert np.array_equal(r.labels.cpu().numpy(), g["mia_labels"])
+    a2 = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.3, min_pos_iou=0.2, ignore_iof_thr=-1)
+    assert np.array_equal(a2.assign_wrt_overlaps(_t(g["overlaps"], dev)).gt_inds.cpu().numpy(), g["mia2_gt_inds"])
+    # full assign(): convex_iou + assignment on the device, against oracle(convex_iou) + oracle(assign)
+    r = a.assign(_t(g["psets"], dev), _t(g["gts"], dev))
+    ov = oracle.convex_iou(g["psets"], g["gts"])
+    gi, mo = oracle.max_iou_assign(ov, 0.1, 0.1, 0.0, True)
+    assert np.array_equal(r.gt_inds.cpu().numpy(), gi)
+    # NaN overlaps behave as torch.max does (NaN wins): row stays -1
+    ovn = g["overlaps"].copy(); ovn[3, 7] = np.nan
+    rn = a.assign_wrt_overlaps(_t(ovn, dev)).gt_inds.cpu().numpy()
+    gin, _ = oracle.max_iou_assign(np.ascontiguousarray(ovn.T), 0.1, 0.1, 0.0, True)
+    assert np.array_equal(rn, gin) and rn[7] == -1
+
+
+def test_apaa_feature_dissimilarity_and_selection(dev, oracle, golden_dir):
+    from orientedreppoints_amd.mmdet_ops import apaa
+    g = _apaa(golden_dir)
+    # sampling + cosine in one kernel vs (oracle sample_points -> oracle dissimilarity) and vs torch grid_sample
+    rng = np.random.RandomState(3)
+    feats = [rng.normal(size=(2, 64, h, h)).astype(np.float32) for h in (32, 16, 8)]
+    strides = [8, 16, 32]
+    P = 500
+    lvl = rng.randint(0, 3, P).astype(np.int32); img = rng.randint(0, 2, P).astype(np.int32)
+    pts = rng.uniform(-20, 276, (P, 18)).astype(np.float32)
+    got = apaa.apaa_feature_dissimilarity([_t(f, dev) for f in feats], strides, _t(pts, dev),
+                                          torch.from_numpy(img).to(dev), torch.from_numpy(lvl).to(dev)).cpu().numpy()
+    want = np.empty(P, np.float32)
+    for i in range(P):
+        s = oracle.sample_points(feats[lvl[i]][img[i]], strides[lvl[i]], pts[i:i + 1])
+        want[i] = oracle.feature_dissimilarity(s)[0]
+    assert np.max(np.abs(got - want)) <= 1e-4
+    # selection: reference python golden + a larger random case against the oracle
+    pos = g["qa_pos_inds"]
+    bounds = np.cumsum([0, 1024, 256, 64, 16, 4])
+    plvl = (np.searchsorted(bounds, pos, side="right") - 1).astype(np.int32)
+    keep = apaa.apaa_select(_t(g["qa_out"], dev), torch.from_numpy(g["sel_pos_gt_inds"]).to(dev),
+                            torch.from_numpy(plvl).to(dev), int(g["sel_pos_gt_inds"].max()), 5).cpu().numpy()
+    assert np.array_equal(keep, g["sel_label"][pos] > 0) and keep.sum() == int(g["sel_num_pos"])
+    q = rng.uniform(0, 5, 6000).astype(np.float32)
+    gt = rng.randint(1, 200, 6000).astype(np.int64); lv = rng.randint(0, 5, 6000).astype(np.int32)
+    keep = apaa.apaa_select(_t(q, dev), torch.from_numpy(gt).to(dev), torch.from_numpy(lv).to(dev), 199, 5).cpu().numpy()
+    assert np.array_equal(keep, oracle.apaa_select(q, gt, lv, 199).astype(bool))
+
+
+def test_points_quality_assessment_vs_reference_python(dev, golden_dir):
+    """Q of every positive (focal + GIoU x2 + chamfer x2 + feature term) against the reference's own
+    points_quality_assessment run on CPU through the oracle ops."""
+    import types
+    from orientedreppoints_amd.mmdet_models import orientedreppoints_head_train as T
+    from orientedreppoints_amd.mmdet_models.losses import FocalLoss, GIoULoss
+    g = _apaa(golden_dir)
+    head = types.SimpleNamespace(num_points=9, point_strides=[8, 16, 32, 64, 128],
+                                 loss_cls=FocalLoss(), loss_rbox_refine=GIoULoss())
+    pos = torch.from_numpy(g["qa_pos_inds"]).to(dev)
+    N = g["psets"].shape[0]
+    label = torch.from_numpy(g["mia_labels"]).to(dev)
+    rbox_w = torch.zeros(N, device=dev); rbox_w[pos] = 1.0
+    # the golden used a [N,9,32] feature tensor directly: take that term from the oracle-equivalent torch formula
+    f = _t(g["qa_pfeat"], dev)[pos]
+    mean = f.mean(1, keepdim=True)
+    u = f / f.norm(dim=2, keepdim=True).clamp(min=1e-2); v = mean / mean.norm(dim=2, keepdim=True).clamp(min=1e-2)
+    feat_term = (1 - torch.nn.functional.cosine_similarity(u, v, dim=2, eps=1e-6)).max(1)[0]
+    import orientedreppoints_amd.mmdet_ops.apaa as apaa_mod
+    orig = apaa_mod.apaa_feature_dissimilarity
+    apaa_mod.apaa_feature_dissimilarity = lambda *a, **k: feat_term
+    try:
+        q = T.points_quality_assessment(head, None, 0, torch.zeros(N, dtype=torch.int32, device=dev),
+                                        _t(g["qa_cls_score"], dev), _t(g["psets"], dev), _t(g["qa_pts_refine"], dev),
+                                        label, _t(g["qa_rbbox_gt"], dev), torch.ones(N, device=dev), rbox_w, pos)
+    finally:
+        apaa_mod.apaa_feature_dissimilarity = orig
+    assert np.max(np.abs(q.cpu().numpy() - g["qa_out"])) <= 1e-4
+    sp = T.sampling_points(_t(g["gts"], dev), 10).cpu().numpy()
+    assert np.max(np.abs(sp - g["sampling_points"])) <= 1e-5
+
+
+# ---- deformable convolution backward ------------------------------------------------------------------------------------
+def test_dcn_backward(dev, oracle):
+    from orientedreppoints_amd.mmdet_ops import deform_conv, modulated_deform_conv
+    x, off, w = _dcn_case(5, 2, 64, 10, 12, 64)
+    go = np.random.RandomState(6).normal(size=(2, 64, 10, 12)).astype(np.float32)
+    tx, toff, tw = (_t(a, dev).requires_grad_(True) for a in (x, off, w))
+    out = deform_conv(tx, toff, tw, 1, 1, 1, 1, 1, 64)
+    out.backward(_t(go, dev))
+    gi, goff, gw = oracle.dcn_backward(x, off, w, go)
+    for got, want in ((tx.grad, gi), (toff.grad, goff), (tw.grad, gw)):
+        assert _rel_err(got.cpu().numpy(), want) <= 1e-4
+    # DCNv2: autograd gradcheck-style finite difference on the mask / bias path in fp32 is too noisy -> compare with
+    # an explicit torch formulation: out = sum_c,t W * (mask * sample); here only shapes + finiteness + mask grad sign
+    rng = np.random.RandomState(7)
+    x2 = _t(rng.normal(size=(1, 8, 6, 6)).astype(np.float32), dev).requires_grad_(True)
+    off2 = _t(rng.normal(0, 1, size=(1, 18, 6, 6)).astype(np.float32), dev).requires_grad_(True)
+    m2 = _t(rng.uniform(0.2, 1, size=(1, 9, 6, 6)).astype(np.float32), dev).requires_grad_(True)
+    w2 = _t(rng.normal(0, 0.2, size=(4, 8, 3, 3)).astype(np.float32), dev).requires_grad_(True)
+    b2 = torch.zeros(4, device=dev, requires_grad=True)
+    y = modulated_deform_conv(x2, off2, m2, w2, b2, 1, 1, 1, 1, 1)
+    y.sum().backward()
+    # d(sum y)/d mask[t,p] = sum_c (sum_o W[o,c,t]) * sample[c,t,p]  -> rebuild from the oracle's im2col
+    col = oracle.dcn_im2col(x2.detach().cpu().numpy(), off2.detach().cpu().numpy(), 3, 3, 1, 1, 1).reshape(8, 9, 36)
+    ws = w2.detach().cpu().numpy().sum(0).reshape(8, 9)
+    want_m = (col * ws[:, :, None]).sum(0).reshape(1, 9, 6, 6)
+    assert np.max(np.abs(m2.grad.cpu().numpy() - want_m)) <= 1e-4
+    assert np.allclose(b2.grad.cpu().numpy(), 36.0)
+    assert torch.isfinite(x2.grad).all() and torch.isfinite(off2.grad).all() and torch.isfinite(w2.grad).all()
+
+
+# ---- end to end: one training step of the detector ---------------------------------------------------------------------
+def test_detector_train_step_and_inference(dev):
+    from orientedreppoints_amd.dota_configs import r50_model, train_cfg, test_cfg
+    from orientedreppoints_amd.mmdet_models import ConfigDict, build_detector
+    torch.manual_seed(0)
+    model = build_detector(ConfigDict(r50_model), train_cfg=ConfigDict(train_cfg), test_cfg=ConfigDict(test_cfg)).to(dev)
+    model.train()
+    B, size = 2, 256
+    img = torch.randn(B, 3, size, size, device=dev)
+    metas = [dict(img_shape=(size, size, 3), pad_shape=(size, size, 3), scale_factor=1.0, flip=False)] * B
+    gts = [_t(S.gen_polys(6, 40 + i, wh=(16, 120))[:, :8] / 4.0, dev) for i in range(B)]
+    labels = [torch.randint(1, 16, (6,), device=dev) for _ in range(B)]
+    losses = model(img, metas, return_loss=True, gt_bboxes=gts, gt_labels=labels)
+    assert set(losses) == {'loss_cls', 'loss_rbox_init', 'loss_rbox_refine', 'loss_spatial_init', 'loss_spatial_refine'}
+    total = 0
+    for k, v in losses.items():
+        vs = v if isinstance(v, (list, tuple)) else [v]
+        for t in vs:
+            assert torch.isfinite(t).all(), k
+            total = total + t.sum()
+    assert float(total) > 0
+    total.backward()
+    g = model.bbox_head.reppoints_cls_conv.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    assert model.bbox_head.reppoints_pts_init_out.weight.grad is not None
+    model.eval()
+    with torch.no_grad():
+        res = model(img[:1], metas[:1], return_loss=False)
+    assert len(res) == 15 and all(r.shape[1] == 27 for r in res)
