@@ -4,6 +4,15 @@ import os
 
 
 class ConfigDict(dict):
+    """dict with attribute access; nested dicts are wrapped on construction."""
+
+    def __init__(self, *args, **kwargs):
+        super(ConfigDict, self).__init__(*args, **kwargs)
+        for k, v in list(self.items()):
+            if isinstance(v, dict) and not isinstance(v, ConfigDict):
+                dict.__setitem__(self, k, ConfigDict(v))
+            elif isinstance(v, (list, tuple)) and any(isinstance(x, dict) for x in v):
+                dict.__setitem__(self, k, type(v)(ConfigDict(x) if isinstance(x, dict) else x for x in v))
 
     def __getattr__(self, name):
         try:
