@@ -72,6 +72,9 @@ void _overlaps(float* overlaps_host, const float* boxes_host, const float* query
  * ------------------------------------------------------------------------------------------------------- */
 int orp_quad_iou_matrix(const float* a, int n, const float* b, int k, int stride, int guard, float* out, void* stream);
 int orp_poly_overlaps(const float* boxes, int n, const float* query, int k, float* out, void* stream);
+/* orp_box_iou_rotated: box_iou_rotated (mmdet/ops/box_iou_rotated/src/box_iou_rotated_cuda.cu:14-94,
+ *   box_iou_rotated_utils.h:314-341): boxes1 [n,5], boxes2 [k,5] (cx,cy,w,h,theta radians) -> [n,k]. */
+int orp_box_iou_rotated(const float* boxes1, int n, const float* boxes2, int k, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * minaerarect: convex hull of 9 points -> minimum-area enclosing rectangle -> 4 corners.

@@ -404,3 +404,11 @@ def dcn_backward(x, offset, weight, grad_out, stride=1, pad=1, dil=1, dg=1, use_
     col = dcn_im2col(x, offset, kh, kw, pad, stride, dil, dg).reshape(C * kh * kw, -1).astype(np.float64)
     gw = (go @ col.T).reshape(weight.shape).astype(np.float32)
     return gi, goff, gw
+
+
+def box_iou_rotated(b1, b2, use_ref=False):
+    a, b = _f32(b1), _f32(b2)
+    out = np.empty((a.shape[0], b.shape[0]), np.float32)
+    fn = ref().ref_box_iou_rotated if use_ref else lib().orc_box_iou_rotated
+    fn(_p(a), a.shape[0], _p(b), b.shape[0], _p(out))
+    return out

@@ -264,3 +264,89 @@ void orc_dcn_backward_input(const float* col, const float* im, const float* offs
   for (size_t i = 0; i < (size_t)B * dg * 2 * taps * Ho * Wo; i++) grad_offset[i] = (float)go[i];
   free(gi); free(go);
 }
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* a9: box_iou_rotated (cx,cy,w,h,theta[rad])                                                                */
+/*   mmdet/ops/box_iou_rotated/src/box_iou_rotated_utils.h:50-341: vertices (:57-76), edge intersections +      */
+/*   contained vertices (:78-156), Graham scan with the CUDA branch's exchange sort (:159-271), fan area          */
+/*   (:273-288), IoU on centre-shifted boxes (:314-341).                                                         */
+/* ------------------------------------------------------------------------------------------------------- */
+typedef struct { float x, y; } bpt;
+static float b_dot(bpt a, bpt b) { return a.x * b.x + a.y * b.y; }
+static float b_cross(bpt a, bpt b) { return a.x * b.y - b.x * a.y; }
+static bpt b_sub(bpt a, bpt b) { bpt r = {a.x - b.x, a.y - b.y}; return r; }
+
+static void b_vertices(const float* box, bpt* pts) {
+  double theta = box[4];
+  float c2 = (float)cos(theta) * 0.5f, s2 = (float)sin(theta) * 0.5f;
+  pts[0].x = box[0] - s2 * box[3] - c2 * box[2];
+  pts[0].y = box[1] + c2 * box[3] - s2 * box[2];
+  pts[1].x = box[0] + s2 * box[3] - c2 * box[2];
+  pts[1].y = box[1] - c2 * box[3] - s2 * box[2];
+  pts[2].x = 2 * box[0] - pts[0].x; pts[2].y = 2 * box[1] - pts[0].y;
+  pts[3].x = 2 * box[0] - pts[1].x; pts[3].y = 2 * box[1] - pts[1].y;
+}
+
+static float b_intersection(const float* box1, const float* box2) {
+  bpt p1[4], p2[4], v1[4], v2[4], in[24], q[24];
+  float dist[24];
+  b_vertices(box1, p1); b_vertices(box2, p2);
+  for (int i = 0; i < 4; i++) { v1[i] = b_sub(p1[(i + 1) % 4], p1[i]); v2[i] = b_sub(p2[(i + 1) % 4], p2[i]); }
+  int num = 0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      float det = b_cross(v2[j], v1[i]);
+      if (fabs(det) <= 1e-14) continue;
+      bpt v12 = b_sub(p2[j], p1[i]);
+      float t1 = b_cross(v2[j], v12) / det, t2 = b_cross(v1[i], v12) / det;
+      if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) { in[num].x = p1[i].x + v1[i].x * t1; in[num].y = p1[i].y + v1[i].y * t1; num++; }
+    }
+  { bpt AB = v2[0], DA = v2[3]; float abab = b_dot(AB, AB), adad = b_dot(DA, DA);
+    for (int i = 0; i < 4; i++) { bpt AP = b_sub(p1[i], p2[0]); float apab = b_dot(AP, AB), apad = -b_dot(AP, DA);
+      if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) in[num++] = p1[i]; } }
+  { bpt AB = v1[0], DA = v1[3]; float abab = b_dot(AB, AB), adad = b_dot(DA, DA);
+    for (int i = 0; i < 4; i++) { bpt AP = b_sub(p2[i], p1[0]); float apab = b_dot(AP, AB), apad = -b_dot(AP, DA);
+      if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) in[num++] = p2[i]; } }
+  if (num <= 2) return 0.0f;
+  /* Graham scan, shift_to_zero = true */
+  int t = 0;
+  for (int i = 1; i < num; i++) if (in[i].y < in[t].y || (in[i].y == in[t].y && in[i].x < in[t].x)) t = i;
+  bpt start = in[t];
+  for (int i = 0; i < num; i++) q[i] = b_sub(in[i], start);
+  { bpt tmp = q[0]; q[0] = q[t]; q[t] = tmp; }
+  for (int i = 0; i < num; i++) dist[i] = b_dot(q[i], q[i]);
+  for (int i = 1; i < num - 1; i++)
+    for (int j = i + 1; j < num; j++) {
+      float cp = b_cross(q[i], q[j]);
+      if ((cp < -1e-6) || (fabs(cp) < 1e-6 && dist[i] > dist[j])) {
+        bpt qt = q[i]; q[i] = q[j]; q[j] = qt; float dt = dist[i]; dist[i] = dist[j]; dist[j] = dt;
+      }
+    }
+  int k;
+  for (k = 1; k < num; k++) if (dist[k] > 1e-8) break;
+  if (k == num) return 0.0f;
+  q[1] = q[k];
+  int m = 2;
+  for (int i = k + 1; i < num; i++) {
+    while (m > 1 && b_cross(b_sub(q[i], q[m - 2]), b_sub(q[m - 1], q[m - 2])) >= 0) m--;
+    q[m++] = q[i];
+  }
+  if (m <= 2) return 0.0f;
+  float area = 0;
+  for (int i = 1; i < m - 1; i++) area += (float)fabs(b_cross(b_sub(q[i], q[0]), b_sub(q[i + 1], q[0])));
+  return (float)(area / 2.0);
+}
+
+void orc_box_iou_rotated(const float* b1, int n, const float* b2, int k, float* out) {
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < k; j++) {
+      const float* r1 = b1 + 5 * (size_t)i; const float* r2 = b2 + 5 * (size_t)j;
+      double sx = (r1[0] + r2[0]) / 2.0, sy = (r1[1] + r2[1]) / 2.0;
+      float a[5] = {(float)(r1[0] - sx), (float)(r1[1] - sy), r1[2], r1[3], r1[4]};
+      float b[5] = {(float)(r2[0] - sx), (float)(r2[1] - sy), r2[2], r2[3], r2[4]};
+      float area1 = a[2] * a[3], area2 = b[2] * b[3];
+      if (area1 < 1e-14 || area2 < 1e-14) { out[(size_t)i * k + j] = 0.f; continue; }
+      float inter = b_intersection(a, b);
+      out[(size_t)i * k + j] = inter / (area1 + area2 - inter);
+    }
+}

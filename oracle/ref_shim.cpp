@@ -77,7 +77,15 @@ namespace nsref_polyiou {
 #include "DOTA_devkit/polyiou.cpp"
 }
 
+// box_iou_rotated_utils.h is a plain header (HOST_DEVICE macros): include it where it lies (CPU branch, std::sort)
+#include "mmdet/ops/box_iou_rotated/src/box_iou_rotated_utils.h"
+
 extern "C" {
+
+void ref_box_iou_rotated(const float* b1, int n, const float* b2, int k, float* out) {
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < k; j++) out[(size_t)i * k + j] = single_box_iou_rotated<float>(b1 + i * 5, b2 + j * 5);
+}
 
 // ---- pairwise IoU scalars -------------------------------------------------------------------------------
 float ref_rnms_iou(const float* p, const float* q) { return nsref_rnms_kernel::devrIoU(p, q); }

@@ -30,6 +30,7 @@ _SIGNATURES = {
     "_overlaps": (None, [_vp, _vp, _vp, _i, _i, _i]),
     "orp_quad_iou_matrix": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "orp_poly_overlaps": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "orp_box_iou_rotated": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "orp_minarearect": (_i, [_vp, _i, _vp, _vp]),
     "orp_minarearect_decode": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "orp_convex_iou": (_i, [_vp, _i, _vp, _i, _vp, _vp]),

@@ -21,6 +21,7 @@ SOURCES = [
     ("orp_nms.hip", ["-ffp-contract=off"]),
     ("orp_overlaps.hip", ["-ffp-contract=off"]),
     ("orp_minarearect.hip", ["-ffp-contract=off"]),
+    ("orp_box_iou_rotated.hip", ["-ffp-contract=off"]),
     ("orp_convex.hip", ["-ffp-contract=off"]),
     ("orp_convex_giou.hip", ["-ffp-contract=off"]),
     ("orp_pointwise.hip", ["-ffp-contract=off"]),

@@ -12,3 +12,4 @@ from .point_justify import pointsJf, points_in_quad_aligned  # noqa: F401
 from .sigmoid_focal_loss import SigmoidFocalLoss, sigmoid_focal_loss  # noqa: F401
 from .deform_conv import (DeformConv, DeformConvPack, ModulatedDeformConv, ModulatedDeformConvPack,  # noqa: F401
                           deform_conv, modulated_deform_conv, deform_conv_forward_multi)
+from .box_iou_rotated import box_iou_rotated  # noqa: F401

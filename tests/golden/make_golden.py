@@ -60,6 +60,14 @@ def main():
     rq = S.gen_rboxes(90, 6).astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "poly_overlaps.npz"), boxes=rb, query=rq, iou=O.ref_poly_overlaps(rb, rq))
 
+    # ---- box_iou_rotated (reference header, CPU branch) + the check value of SURVEY 8c ------------------------
+    ba = S.gen_rboxes(100, 15).astype(np.float32)
+    bb = S.gen_rboxes(80, 16).astype(np.float32)
+    bb[:30, :2] = ba[:30, :2] + np.random.RandomState(17).normal(0, 10, (30, 2)).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "box_iou_rotated.npz"), a=ba, b=bb, iou=O.box_iou_rotated(ba, bb, use_ref=True),
+                        unit=O.box_iou_rotated(np.array([[0, 0, 10, 10, 0]], np.float32),
+                                               np.array([[0.5, 0.5, 10, 10, 0]], np.float32), use_ref=True))
+
     # ---- minaerarect ----------------------------------------------------------------------------------------
     pts = S.gen_pointsets(1500, 7).astype(np.float32)
     grid = np.array([[x, y] for y in range(3) for x in range(0, 5, 2)], np.float32).reshape(1, 18)

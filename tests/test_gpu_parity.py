@@ -525,3 +525,15 @@ def test_detector_train_step_and_inference(dev):
     with torch.no_grad():
         res = model(img[:1], metas[:1], return_loss=False)
     assert len(res) == 15 and all(r.shape[1] in (9, 27) for r in res)   # empty results are [0,9] as in rbbox2result
+
+
+def test_box_iou_rotated(dev, oracle, golden_dir):
+    from orientedreppoints_amd.mmdet_ops import box_iou_rotated
+    g = _g(golden_dir, "box_iou_rotated.npz")
+    got = box_iou_rotated(_t(g["a"], dev), _t(g["b"], dev)).cpu().numpy()
+    assert got.shape == g["iou"].shape and np.max(np.abs(got - g["iou"])) <= 1e-4
+    a = S.gen_rboxes(700, 31).astype(np.float32); b = S.gen_rboxes(300, 32).astype(np.float32)
+    b[:200, :2] = a[:200, :2] + 5
+    got = box_iou_rotated(_t(a, dev), _t(b, dev)).cpu().numpy()
+    assert np.max(np.abs(got - oracle.box_iou_rotated(a, b))) <= 1e-4
+    assert box_iou_rotated(torch.zeros((0, 5), device=dev), _t(b, dev)).shape == (0, 300)

@@ -97,3 +97,11 @@ def test_clip_scratch_bound(oracle):
     oracle.quad_iou_matrix(z, z)
     st = oracle.stats()
     assert st["clip_overflow"] == 0 and st["max_clip_n"] <= 6, st
+
+
+def test_box_iou_rotated(oracle, golden_dir):
+    g = _load(golden_dir, "box_iou_rotated.npz")
+    got = oracle.box_iou_rotated(g["a"], g["b"])
+    assert np.max(np.abs(got - g["iou"])) <= 1e-6
+    assert abs(float(g["unit"][0, 0]) - 0.8223) < 1e-4       # SURVEY 8c check value for 10x10 boxes offset by 0.5
+    assert (got > 0.1).sum() > 20
