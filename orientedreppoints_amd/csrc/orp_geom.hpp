@@ -11,19 +11,30 @@
 // vertices and lives in a per-lane LDS column (stride = workgroup size, so a wave's accesses to one slot are
 // bank-conflict free whatever slot each lane is at) or, for the PolyRegs variant, in registers.
 #pragma once
+// The header is plain C++: under hipcc every function is a __device__ inline; under a host compiler (g++) the very
+// same source builds as ordinary inline functions, which is how tests/ check the fp32 operation order on the CPU
+// against the oracle before a GPU is involved (tests/host_harness).
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#define ORP_HD __device__ __forceinline__
+#else
+#define ORP_HD inline
+#endif
 
 namespace orp {
 
 template <typename T> struct Pt { T x, y; };
 
-template <typename T> __device__ __forceinline__ int sig(T d) {
+ORP_HD float orp_abs(float x) { return __builtin_fabsf(x); }
+ORP_HD double orp_abs(double x) { return __builtin_fabs(x); }
+
+template <typename T> ORP_HD int sig(T d) {
   return (int)(d > (T)1E-8) - (int)(d < -(T)1E-8);
 }
-template <typename T> __device__ __forceinline__ bool same_pt(Pt<T> a, Pt<T> b) {
+template <typename T> ORP_HD bool same_pt(Pt<T> a, Pt<T> b) {
   return sig(a.x - b.x) == 0 && sig(a.y - b.y) == 0;
 }
-template <typename T> __device__ __forceinline__ T cross3(Pt<T> o, Pt<T> a, Pt<T> b) {
+template <typename T> ORP_HD T cross3(Pt<T> o, Pt<T> a, Pt<T> b) {
   return (a.x - o.x) * (b.y - o.y) - (b.x - o.x) * (a.y - o.y);
 }
 
@@ -31,14 +42,14 @@ template <typename T> __device__ __forceinline__ T cross3(Pt<T> o, Pt<T> a, Pt<T
 // (a) per-lane column in LDS: element i of this lane's polygon lives at base[i * stride]
 template <typename T> struct PolyLds {
   Pt<T>* base; int stride;
-  __device__ __forceinline__ Pt<T> get(int i) const { return base[i * stride]; }
-  __device__ __forceinline__ void set(int i, Pt<T> v) const { base[i * stride] = v; }
+  ORP_HD Pt<T> get(int i) const { return base[i * stride]; }
+  ORP_HD void set(int i, Pt<T> v) const { base[i * stride] = v; }
 };
 // (b) private array (the compiler decides between registers and scratch); used by low-volume kernels
 template <typename T, int CAP> struct PolyPriv {
   Pt<T> v[CAP];
-  __device__ __forceinline__ Pt<T> get(int i) const { return v[i]; }
-  __device__ __forceinline__ void set(int i, Pt<T> p) { v[i] = p; }
+  ORP_HD Pt<T> get(int i) const { return v[i]; }
+  ORP_HD void set(int i, Pt<T> p) { v[i] = p; }
 };
 
 constexpr int ORP_CLIP_CAP = 8;   // clipped triangle: 3 -> <=4 -> <=5 -> <=6 vertices (+ eps-sign duplicates)
@@ -46,7 +57,7 @@ constexpr int ORP_CLIP_CAP = 8;   // clipped triangle: 3 -> <=4 -> <=5 -> <=6 ve
 // Keep the part of polygon P (n vertices) left of a->b; result back in P (reference polygon_cut).
 // S1 = working polygon store, S2 = scratch store.  Returns the new vertex count.
 template <typename T, typename S1, typename S2>
-__device__ __forceinline__ int polygon_cut(S1& P, S2& Q, int n, Pt<T> a, Pt<T> b) {
+ORP_HD int polygon_cut(S1& P, S2& Q, int n, Pt<T> a, Pt<T> b) {
   if (n == 0) return 0;
   int m = 0;
   const T bax = b.x - a.x, bay = b.y - a.y;     // loop-invariant sub-expressions of cross3(a, b, .)
@@ -89,7 +100,7 @@ __device__ __forceinline__ int polygon_cut(S1& P, S2& Q, int n, Pt<T> a, Pt<T> b
 
 // signed shoelace / 2 of the polygon in P (n vertices)
 template <typename T, typename S1>
-__device__ __forceinline__ T poly_area(const S1& P, int n) {
+ORP_HD T poly_area(const S1& P, int n) {
   T res = 0;
   if (n == 0) return res / (T)2;
   Pt<T> p0 = P.get(0), cur = p0;
@@ -103,7 +114,7 @@ __device__ __forceinline__ T poly_area(const S1& P, int n) {
 
 // signed area of triangle(O,a,b) ∩ triangle(O,c,d)   (reference intersectArea(a,b,c,d))
 template <typename T, bool ABS_TERM, typename S1, typename S2>
-__device__ __forceinline__ T tri_term(S1& P, S2& Q, Pt<T> a, Pt<T> b, Pt<T> c, Pt<T> d) {
+ORP_HD T tri_term(S1& P, S2& Q, Pt<T> a, Pt<T> b, Pt<T> c, Pt<T> d) {
   Pt<T> o; o.x = (T)0; o.y = (T)0;
   int s1 = sig(cross3(o, a, b));
   int s2 = sig(cross3(o, c, d));
@@ -116,7 +127,7 @@ __device__ __forceinline__ T tri_term(S1& P, S2& Q, Pt<T> a, Pt<T> b, Pt<T> c, P
   n = polygon_cut<T>(P, Q, n, c, d);
   n = polygon_cut<T>(P, Q, n, d, o);
   T res = poly_area<T>(P, n);
-  if (ABS_TERM) res = fabs(res);
+  if (ABS_TERM) res = orp_abs(res);
   if (s1 * s2 == -1) res = -res;
   return res;
 }
@@ -128,7 +139,7 @@ template <typename T, int N> struct SmallPoly {
 };
 
 template <typename T, int N>
-__device__ __forceinline__ T small_area(const SmallPoly<T, N>& s) {
+ORP_HD T small_area(const SmallPoly<T, N>& s) {
   T res = 0;
   for (int i = 0; i < N; i++) {
     if (i < s.n) {
@@ -141,7 +152,7 @@ __device__ __forceinline__ T small_area(const SmallPoly<T, N>& s) {
 }
 
 template <typename T, int N>
-__device__ __forceinline__ void small_reverse(SmallPoly<T, N>& s) {
+ORP_HD void small_reverse(SmallPoly<T, N>& s) {
   for (int i = 0; i < N / 2; i++) {
     int j = s.n - 1 - i;
     if (i < j) { Pt<T> t = s.v[i]; s.v[i] = s.v[j]; s.v[j] = t; }
@@ -151,7 +162,7 @@ __device__ __forceinline__ void small_reverse(SmallPoly<T, N>& s) {
 // quad-quad specialisation: everything unrolled, vertices in registers (reference devrIoU / devPolyIoU /
 // iou_poly).  GUARD adds poly_nms' `union == 0 -> (i+1)/(u+1)` rule (poly_nms_kernel.cu:205-207).
 template <typename T, bool GUARD, typename S1, typename S2>
-__device__ __forceinline__ T quad_iou(S1& P, S2& Q, const T* p8, const T* q8) {
+ORP_HD T quad_iou(S1& P, S2& Q, const T* p8, const T* q8) {
   Pt<T> a[4], b[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) { a[i].x = p8[2 * i]; a[i].y = p8[2 * i + 1]; b[i].x = q8[2 * i]; b[i].y = q8[2 * i + 1]; }
@@ -176,7 +187,7 @@ __device__ __forceinline__ T quad_iou(S1& P, S2& Q, const T* p8, const T* q8) {
       inter += tri_term<T, true>(P, Q, ai, aj, bi, bj);
     }
   }
-  T uni = fabs(area4(a)) + fabs(area4(b)) - inter;
+  T uni = orp_abs(area4(a)) + orp_abs(area4(b)) - inter;
   if (GUARD) { if (uni == (T)0) return (inter + (T)1) / (uni + (T)1); }
   return inter / uni;
 }

@@ -19,9 +19,11 @@
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/orp_hip.h"
 #include "orp_geom.hpp"
+#include "orp_quadfast.hpp"
 #include "orp_prof.hpp"
 
 namespace {
@@ -58,61 +60,197 @@ __global__ void iota_kernel(int32_t* v, int n) {
 
 __global__ void set_single_segment_kernel(int32_t* seg_off, int n) { seg_off[0] = 0; seg_off[1] = n; }
 
-// sorted[i][0..7] = dets[order[i]][0..7]
-__global__ void gather_boxes_kernel(const float* __restrict__ dets, const int32_t* __restrict__ order, int n,
-                                    float4* __restrict__ sorted) {
+// prep[i] = quad_prepare(dets[order[i]][0..7]): orientation, oriented fan triangles, signs, |area| -- once per box
+__global__ void prep_boxes_kernel(const float* __restrict__ dets, const int32_t* __restrict__ order, int n,
+                                  orp::QuadPrep* __restrict__ prep) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* s = dets + (size_t)order[i] * 9;
-  sorted[2 * i] = make_float4(s[0], s[1], s[2], s[3]);
-  sorted[2 * i + 1] = make_float4(s[4], s[5], s[6], s[7]);
+  float q8[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) q8[k] = s[k];
+  orp::QuadPrep p;
+  orp::quad_prepare(q8, p);
+  prep[i] = p;
 }
 
 // ---- mask kernel -------------------------------------------------------------------------------------------
-// grid = (max_cb, row_groups, nseg); block = 256.  Wave w of block (c, g, s) owns rows
-// [g*4R + w*R, +R) of segment s against columns [64c, 64c+64).
+// grid = (max_cb, row_groups, nseg); block = 256.  Block (c, g, s) owns the tile rows [g*RB, +RB) x columns
+// [64c, 64c+64) of segment s (RB = 4 * rows_per_wave <= 64), in two phases:
+//   A  lane = column, the wave's row is uniform (scalar loads of its QuadPrep): orp::pair_is_far decides -- without a
+//      division -- that every fan term of the pair is exactly 0 (84 % of the pairs of a dense DOTA scene).  Resolved
+//      pairs set their bit by one wavefront ballot; the others go to a workgroup queue in LDS;
+//   B  the queue is drained by all 256 lanes, one unresolved pair per lane (row and column records come from the
+//      tile's LDS copy), through the register decision tree of orp_quadfast.hpp (generic polygon loop only for the
+//      ~1e-5 of pairs the tree does not cover).  Heavy pairs are thus packed densely into wavefronts instead of
+//      leaving 5 of 6 lanes idle next to them.
+constexpr int kMaxTileRows = 64;
+
+struct TileLds {
+  float4 rowE[4][kMaxTileRows];      // oriented fan edges (ax, ay, bx, by) per edge, per tile row
+  float4 colE[4][64];
+  int rowS[kMaxTileRows];            // 4 signs packed 2 bits each (0 -> 0, +1 -> 1, -1 -> 2) | force_slow << 8
+  int colS[64];
+  float rowArea[kMaxTileRows];
+  float colArea[64];
+  u64 words[kMaxTileRows];
+  unsigned short queue[kMaxTileRows * 64];
+  int qcount;
+};
+
+__device__ __forceinline__ int pack_signs(const orp::QuadPrep& p) {
+  int v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) v |= (p.s[k] == 0 ? 0 : (p.s[k] > 0 ? 1 : 2)) << (2 * k);
+  return v | (p.force_slow << 8);
+}
+__device__ __forceinline__ int unpack_sign(int packed, int k) {
+  const int b = (packed >> (2 * k)) & 3;
+  return b == 0 ? 0 : (b == 1 ? 1 : -1);
+}
+
+// full evaluation of one queued pair from the tile's LDS records (phase B)
 template <bool GUARD>
-__global__ void __launch_bounds__(kMaskThreads)
-nms_mask_kernel(const float4* __restrict__ boxes, const int32_t* __restrict__ seg_off, int rows_per_wave,
+__device__ __forceinline__ float tile_pair_iou(const TileLds& T, int rl, int cl) {
+  const int rs = T.rowS[rl], cs = T.colS[cl];
+  bool slow = ((rs | cs) >> 8) != 0;
+  float inter = 0.f;
+#pragma unroll 1
+  for (int i = 0; i < 4; i++) {
+    const int s1 = unpack_sign(rs, i);
+    if (s1 == 0) continue;
+    const float4 e = T.rowE[i][rl];
+#pragma unroll 1
+    for (int j = 0; j < 4; j++) {
+      const int s2 = unpack_sign(cs, j);
+      if (s2 == 0) continue;
+      const float4 g = T.colE[j][cl];
+      const orp::FanCol f = orp::fan_col(g.x, g.y, g.z, g.w);
+      float t = orp::tri_term_fast(e.x, e.y, e.z, e.w, f, slow);
+      if (s1 * s2 == -1) t = -t;
+      inter += t;
+    }
+  }
+  if (slow) {                                            // generic polygon loop, scratch-resident (rare)
+    orp::PolyPriv<float, orp::ORP_CLIP_CAP> P, Q;
+    inter = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+      const int s1 = unpack_sign(rs, i);
+      if (s1 == 0) continue;
+      const float4 e = T.rowE[i][rl];
+      Pt<float> a, b;
+      a.x = e.x; a.y = e.y; b.x = e.z; b.y = e.w;
+#pragma unroll 1
+      for (int j = 0; j < 4; j++) {
+        const int s2 = unpack_sign(cs, j);
+        if (s2 == 0) continue;
+        const float4 g = T.colE[j][cl];
+        Pt<float> cc, d;
+        cc.x = g.x; cc.y = g.y; d.x = g.z; d.y = g.w;
+        float t = orp::tri_term_oriented<float>(P, Q, a, b, cc, d);
+        if (s1 * s2 == -1) t = -t;
+        inter += t;
+      }
+    }
+  }
+  const float uni = T.rowArea[rl] + T.colArea[cl] - inter;
+  if (GUARD) { if (uni == 0.f) return (inter + 1.f) / (uni + 1.f); }
+  return inter / uni;
+}
+
+template <bool GUARD>
+__global__ void __launch_bounds__(kMaskThreads, 4)
+nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restrict__ seg_off, int rows_per_wave,
                 int mask_stride, float thr, u64* __restrict__ mask) {
-  __shared__ Pt<float> scratch[2 * orp::ORP_CLIP_CAP][kMaskThreads];
+  __shared__ TileLds T;
   const int seg = blockIdx.z;
   const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
   const int c = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int rpb = rows_per_wave * (kMaskThreads / 64);
   const int row_base = blockIdx.y * rpb;
   if (row_base >= n || c * 64 >= n) return;
   if ((row_base >> 6) > c) return;                       // lower-triangular tile: never read by the sweep
 
-  orp::PolyLds<float> P{&scratch[0][threadIdx.x], kMaskThreads};
-  orp::PolyLds<float> Q{&scratch[orp::ORP_CLIP_CAP][threadIdx.x], kMaskThreads};
-
+  // ---- stage the tile's row / column records in LDS (phase B reads them with per-lane indices) ----------------
   const int col = c * 64 + lane;
-  float q8[8];
-  if (col < n) {
-    float4 a = boxes[2 * (size_t)(s0 + col)], b = boxes[2 * (size_t)(s0 + col) + 1];
-    q8[0] = a.x; q8[1] = a.y; q8[2] = a.z; q8[3] = a.w; q8[4] = b.x; q8[5] = b.y; q8[6] = b.z; q8[7] = b.w;
-  } else {
+  orp::FarCol fc;
+  {
+    orp::QuadPrep cp;
+    if (col < n) {
+      cp = prep[s0 + col];
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; i++) q8[i] = 0.f;
-  }
-  const int r_first = __builtin_amdgcn_readfirstlane(row_base + wave * rows_per_wave);
-  for (int rr = 0; rr < rows_per_wave; rr++) {
-    const int r = r_first + rr;                          // wave-uniform
-    if (r >= n) break;
-    const float* rp = reinterpret_cast<const float*>(boxes + 2 * (size_t)(s0 + r));
-    float p8[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) p8[i] = rp[i];           // uniform address -> scalar loads
-    bool hit = false;
-    if (col < n && col > r) {
-      float iou = orp::quad_iou<float, GUARD>(P, Q, p8, q8);
-      hit = iou > thr;
+      for (int k = 0; k < 4; k++) { cp.ax[k] = cp.ay[k] = cp.bx[k] = cp.by[k] = cp.vx[k] = cp.vy[k] = 0.f; cp.s[k] = 0; }
+      cp.area_abs = 0.f; cp.force_slow = 0; cp.mabs = 0.f;
     }
-    u64 bits = __ballot(hit);
-    if (lane == 0) mask[(size_t)(s0 + r) * mask_stride + c] = bits;
+    fc = orp::far_col(cp);
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) T.colE[k][lane] = make_float4(cp.ax[k], cp.ay[k], cp.bx[k], cp.by[k]);
+      T.colS[lane] = pack_signs(cp);
+      T.colArea[lane] = cp.area_abs;
+    }
+    if (tid < rpb) {
+      const int r = row_base + tid;
+      if (r < n) {
+        const orp::QuadPrep rp = prep[s0 + r];
+#pragma unroll
+        for (int k = 0; k < 4; k++) T.rowE[k][tid] = make_float4(rp.ax[k], rp.ay[k], rp.bx[k], rp.by[k]);
+        T.rowS[tid] = pack_signs(rp);
+        T.rowArea[tid] = rp.area_abs;
+      }
+      T.words[tid] = 0ull;
+    }
+    if (tid == 0) T.qcount = 0;
   }
+  __syncthreads();
+  const bool cslow = (T.colS[lane] >> 8) != 0;
+  const float carea = T.colArea[lane];
+
+  // ---- phase A ---------------------------------------------------------------------------------------------------
+  const int rl_first = __builtin_amdgcn_readfirstlane(wave * rows_per_wave);
+  for (int rr = 0; rr < rows_per_wave; rr++) {
+    const int rl = rl_first + rr;                        // wave-uniform
+    const int r = row_base + rl;
+    if (r >= n) break;
+    const orp::QuadPrep* rp = prep + (s0 + r);           // uniform address -> scalar loads
+    const bool valid = (col < n) & (col > r);
+    bool resolved = false;
+    if (valid && !(cslow | (rp->force_slow != 0))) {
+      float rvx[4], rvy[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { rvx[k] = rp->vx[k]; rvy[k] = rp->vy[k]; }
+      resolved = orp::pair_is_far(rvx, rvy, rp->mabs, fc);
+    }
+    const bool hit0 = resolved && (orp::iou_of_zero_inter<GUARD>(rp->area_abs, carea) > thr);
+    const u64 bits = __ballot(hit0);
+    const bool pend = valid && !resolved;
+    const u64 pmask = __ballot(pend);
+    if (pmask) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&T.qcount, __popcll(pmask));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (pend) {
+        const int pos = base + __popcll(pmask & ((1ull << lane) - 1ull));
+        T.queue[pos] = (unsigned short)((rl << 6) | lane);
+      }
+    }
+    if (lane == 0 && bits) T.words[rl] = bits;          // this wave owns row rl in phase A
+  }
+  __syncthreads();
+
+  // ---- phase B ---------------------------------------------------------------------------------------------------
+  const int nq = T.qcount;
+  for (int q = tid; q < nq; q += kMaskThreads) {
+    const int item = T.queue[q];
+    const int rl = item >> 6, cl = item & 63;
+    const float iou = tile_pair_iou<GUARD>(T, rl, cl);
+    if (iou > thr) atomicOr(&T.words[rl], 1ull << cl);
+  }
+  __syncthreads();
+  if (tid < rpb && row_base + tid < n) mask[(size_t)(s0 + row_base + tid) * mask_stride + c] = T.words[tid];
 }
 
 // ---- sweep + compaction kernel --------------------------------------------------------------------------------
@@ -239,7 +377,7 @@ NmsLayout nms_layout(int n_total, int nseg, int max_seg) {
   L.off_keys_out = o; o += align256(sizeof(u64) * n);
   L.off_vals_in = o; o += align256(sizeof(int32_t) * n);
   L.off_order = o; o += align256(sizeof(int32_t) * n);
-  L.off_boxes = o; o += align256(sizeof(float) * 8 * n);
+  L.off_boxes = o; o += align256(sizeof(orp::QuadPrep) * n);
   L.off_mask = o; o += align256(sizeof(u64) * n * cb);
   size_t cub = 0;
   hipcub::DeviceRadixSort::SortPairs((void*)nullptr, cub, (const u64*)nullptr, (u64*)nullptr, (const int32_t*)nullptr,
@@ -251,9 +389,11 @@ NmsLayout nms_layout(int n_total, int nseg, int max_seg) {
 }
 
 int pick_rows_per_wave(int max_seg, int nseg) {
+  if (const char* e = getenv("ORP_NMS_ROWS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return v; }
   const long cb = (max_seg + 63) / 64;
   const long tiles = cb * (cb + 1) / 2 * (nseg > 0 ? nseg : 1);
-  long r = tiles * 64 / 8192;          // aim at >= 8192 waves (8 per SIMD) when the problem is big enough
+  // one workgroup per (4R rows x 64 cols) tile; aim at >= 2048 workgroups (8 per CU) when the problem is big enough
+  long r = tiles * 16 / 2048;
   int R = 1;
   while (R * 2 <= r && R < 16) R *= 2;
   return R;
@@ -274,7 +414,7 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
   u64* keys_out = reinterpret_cast<u64*>(base + L.off_keys_out);
   int32_t* vals_in = reinterpret_cast<int32_t*>(base + L.off_vals_in);
   int32_t* order = reinterpret_cast<int32_t*>(base + L.off_order);
-  float4* boxes = reinterpret_cast<float4*>(base + L.off_boxes);
+  orp::QuadPrep* boxes = reinterpret_cast<orp::QuadPrep*>(base + L.off_boxes);
   u64* mask = reinterpret_cast<u64*>(base + L.off_mask);
   void* cub = base + L.off_cub;
 
@@ -300,7 +440,7 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
                                                       end_bit, st);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(gather_boxes_kernel, dim3(nb), dim3(tb), 0, st, dets, order, n_total, boxes);
+  hipLaunchKernelGGL(prep_boxes_kernel, dim3(nb), dim3(tb), 0, st, dets, order, n_total, boxes);
 
   const int max_cb = (max_seg + 63) / 64;
   const int R = pick_rows_per_wave(max_seg, nseg);
