@@ -6,14 +6,17 @@
 //
 // MI355X design (not a translation of the 64-thread CUDA tiling):
 //   1. stable radix sort of (segment, score desc) keys (rocPRIM), gather boxes into an 8-float row layout;
-//   2. mask kernel: one WAVE owns R rows x 64 columns of an upper-triangular tile; the 64 lanes hold the 64
-//      column boxes in registers, the row box is wave-uniform (scalar loads), and the 64-bit suppression word
-//      of a row is ONE wavefront ballot -- no LDS box tile, no atomics, lower-triangle tiles never launched
-//      past an early exit.  Clipping scratch is a per-lane LDS column (orp_geom.hpp), not 8 KB of private stack;
-//   3. sweep kernel: one workgroup per segment walks the 64-row blocks: a scalar (readlane) pass resolves the
-//      diagonal word, then all 1024 lanes OR the kept rows' words into the LDS `removed` bitmap; the same
-//      kernel scatters keep flags back to original indices and compacts them in ascending order (ballot-free
-//      popcount scan), so the host never sees the mask.
+//   2. per-box pre-pass (QuadPrep: orientation, oriented origin-fan triangles, signs, |area|), then the mask
+//      kernel: a workgroup owns a (<=64 rows x 64 columns) upper-triangular tile.  Phase A (lane = column, row
+//      wave-uniform through scalar loads) proves for ~84 % of the pairs of a dense scene, without a division,
+//      that every fan term is exactly 0 (orp_quadfast.hpp pair_is_far) and emits their bits by one wavefront
+//      ballot; the remaining pairs are queued in LDS and drained in phase B by quads of lanes running the
+//      register decision tree (no per-lane polygon storage), with the fp32 sum kept in the reference's order
+//      by DPP quad broadcasts.  Lower-triangle tiles exit immediately;
+//   3. sweep kernel: one workgroup per segment walks the 64-row blocks with the next block-row's mask words
+//      prefetched before the (sparse, readlane-based) diagonal pass, ORs the kept rows' words into the LDS
+//      `removed` bitmap, then scatters keep flags back to original indices and compacts them in ascending
+//      order (popcount scan), so the host never sees the mask.
 // The IoU arithmetic is bit-identical to the reference's fp32 devrIoU / devPolyIoU (see orp_geom.hpp).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -109,38 +112,58 @@ __device__ __forceinline__ int unpack_sign(int packed, int k) {
   return b == 0 ? 0 : (b == 1 ? 1 : -1);
 }
 
-// full evaluation of one queued pair from the tile's LDS records (phase B)
+// value of lane (quad base + k) for every lane of a quad (DPP quad_perm broadcast, one VALU op)
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
+}
+template <int K>
+__device__ __forceinline__ int quad_bcast_i(int v) {
+  return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xf, 0xf, true);
+}
+
+// Phase B: one queued pair per QUAD of lanes -- lane k of the quad evaluates the four fan terms of row edge k, then
+// the 16 values are summed in the reference's order (row edge outer, column edge inner) through quad broadcasts, so
+// the fp32 accumulation is unchanged while the critical path per pair is 4 terms instead of 16.
+// Returns the pair's IoU (valid on every lane of the quad).
 template <bool GUARD>
-__device__ __forceinline__ float tile_pair_iou(const TileLds& T, int rl, int cl) {
+__device__ __forceinline__ float tile_pair_iou_quad(const TileLds& T, int rl, int cl, int k, bool live) {
   const int rs = T.rowS[rl], cs = T.colS[cl];
-  bool slow = ((rs | cs) >> 8) != 0;
-  float inter = 0.f;
+  bool slow = live && (((rs | cs) >> 8) != 0);
+  const int s1 = unpack_sign(rs, k);
+  const float4 e = T.rowE[k][rl];
+  float t[4];
 #pragma unroll 1
-  for (int i = 0; i < 4; i++) {
-    const int s1 = unpack_sign(rs, i);
-    if (s1 == 0) continue;
-    const float4 e = T.rowE[i][rl];
-#pragma unroll 1
-    for (int j = 0; j < 4; j++) {
-      const int s2 = unpack_sign(cs, j);
-      if (s2 == 0) continue;
+  for (int j = 0; j < 4; j++) {
+    const int s2 = unpack_sign(cs, j);
+    float v = 0.f;
+    if (live && s1 != 0 && s2 != 0) {
       const float4 g = T.colE[j][cl];
       const orp::FanCol f = orp::fan_col(g.x, g.y, g.z, g.w);
-      float t = orp::tri_term_fast(e.x, e.y, e.z, e.w, f, slow);
-      if (s1 * s2 == -1) t = -t;
-      inter += t;
+      v = orp::tri_term_fast(e.x, e.y, e.z, e.w, f, slow);
+      if (s1 * s2 == -1) v = -v;
     }
+    // static register slot for a dynamic j without private-memory indexing
+    t[0] = (j == 0) ? v : t[0]; t[1] = (j == 1) ? v : t[1]; t[2] = (j == 2) ? v : t[2]; t[3] = (j == 3) ? v : t[3];
   }
-  if (slow) {                                            // generic polygon loop, scratch-resident (rare)
+  // skipped terms contribute +0: inter never holds -0, so x + (+-0) == x and the sum equals the reference's
+  float inter = 0.f;
+  inter += quad_bcast<0>(t[0]); inter += quad_bcast<0>(t[1]); inter += quad_bcast<0>(t[2]); inter += quad_bcast<0>(t[3]);
+  inter += quad_bcast<1>(t[0]); inter += quad_bcast<1>(t[1]); inter += quad_bcast<1>(t[2]); inter += quad_bcast<1>(t[3]);
+  inter += quad_bcast<2>(t[0]); inter += quad_bcast<2>(t[1]); inter += quad_bcast<2>(t[2]); inter += quad_bcast<2>(t[3]);
+  inter += quad_bcast<3>(t[0]); inter += quad_bcast<3>(t[1]); inter += quad_bcast<3>(t[2]); inter += quad_bcast<3>(t[3]);
+  const int sl = slow ? 1 : 0;
+  const int any_slow = quad_bcast_i<0>(sl) | quad_bcast_i<1>(sl) | quad_bcast_i<2>(sl) | quad_bcast_i<3>(sl);
+  if (any_slow && k == 0) {                              // generic polygon loop, scratch-resident (rare)
     orp::PolyPriv<float, orp::ORP_CLIP_CAP> P, Q;
     inter = 0.f;
 #pragma unroll 1
     for (int i = 0; i < 4; i++) {
-      const int s1 = unpack_sign(rs, i);
-      if (s1 == 0) continue;
-      const float4 e = T.rowE[i][rl];
+      const int si = unpack_sign(rs, i);
+      if (si == 0) continue;
+      const float4 ei = T.rowE[i][rl];
       Pt<float> a, b;
-      a.x = e.x; a.y = e.y; b.x = e.z; b.y = e.w;
+      a.x = ei.x; a.y = ei.y; b.x = ei.z; b.y = ei.w;
 #pragma unroll 1
       for (int j = 0; j < 4; j++) {
         const int s2 = unpack_sign(cs, j);
@@ -148,9 +171,9 @@ __device__ __forceinline__ float tile_pair_iou(const TileLds& T, int rl, int cl)
         const float4 g = T.colE[j][cl];
         Pt<float> cc, d;
         cc.x = g.x; cc.y = g.y; d.x = g.z; d.y = g.w;
-        float t = orp::tri_term_oriented<float>(P, Q, a, b, cc, d);
-        if (s1 * s2 == -1) t = -t;
-        inter += t;
+        float v = orp::tri_term_oriented<float>(P, Q, a, b, cc, d);
+        if (si * s2 == -1) v = -v;
+        inter += v;
       }
     }
   }
@@ -162,7 +185,7 @@ __device__ __forceinline__ float tile_pair_iou(const TileLds& T, int rl, int cl)
 template <bool GUARD>
 __global__ void __launch_bounds__(kMaskThreads, 4)
 nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restrict__ seg_off, int rows_per_wave,
-                int mask_stride, float thr, u64* __restrict__ mask) {
+                int mask_stride, float thr, u64* __restrict__ mask, int dbg) {
   __shared__ TileLds T;
   const int seg = blockIdx.z;
   const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
@@ -222,7 +245,7 @@ nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restric
       float rvx[4], rvy[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) { rvx[k] = rp->vx[k]; rvy[k] = rp->vy[k]; }
-      resolved = orp::pair_is_far(rvx, rvy, rp->mabs, fc);
+      resolved = (dbg & 2) ? true : orp::pair_is_far(rvx, rvy, rp->mabs, fc);
     }
     const bool hit0 = resolved && (orp::iou_of_zero_inter<GUARD>(rp->area_abs, carea) > thr);
     const u64 bits = __ballot(hit0);
@@ -241,13 +264,16 @@ nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restric
   }
   __syncthreads();
 
-  // ---- phase B ---------------------------------------------------------------------------------------------------
-  const int nq = T.qcount;
-  for (int q = tid; q < nq; q += kMaskThreads) {
-    const int item = T.queue[q];
+  // ---- phase B: one queued pair per quad of lanes -------------------------------------------------------------
+  const int nq = (dbg & 1) ? 0 : T.qcount;
+  const int k = lane & 3;
+  for (int q0 = 0; q0 < nq; q0 += kMaskThreads / 4) {    // uniform trip count: DPP needs the whole quad alive
+    const int q = q0 + (tid >> 2);
+    const bool live = q < nq;
+    const int item = live ? T.queue[q] : 0;
     const int rl = item >> 6, cl = item & 63;
-    const float iou = tile_pair_iou<GUARD>(T, rl, cl);
-    if (iou > thr) atomicOr(&T.words[rl], 1ull << cl);
+    const float iou = tile_pair_iou_quad<GUARD>(T, rl, cl, k, live);
+    if (live && k == 0 && iou > thr) atomicOr(&T.words[rl], 1ull << cl);
   }
   __syncthreads();
   if (tid < rpb && row_base + tid < n) mask[(size_t)(s0 + row_base + tid) * mask_stride + c] = T.words[tid];
@@ -300,38 +326,71 @@ nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order
   for (int i = tid; i < cb; i += kSweepThreads) { removed[i] = 0; keepbits[i] = 0; origbits[i] = 0; }
   __syncthreads();
 
+  // Block-row sweep, software-pipelined: at the top of iteration blk every thread ISSUES the loads of its share of
+  // block-row blk (all 64 rows x the column words right of the diagonal, kept or not -- at most kPre words per thread)
+  // and wave 0 the loads of the NEXT diagonal words; the HBM/L2 latency then overlaps the diagonal pass and the
+  // barrier instead of following them.  The diagonal pass only visits rows whose diagonal word is non-zero (rows with
+  // an empty word cannot suppress anything inside the block), which in practice is a handful per block.
+  constexpr int kPre = 8;
+  u64 d_next = 0ull;
+  if (wave == 0) { const int row = lane; d_next = (row < n) ? mask[(size_t)(s0 + row) * mask_stride + 0] : 0ull; }
   for (int blk = 0; blk < cb; blk++) {
+    const int ncols = cb - (blk + 1);
+    int slices = 1, rows_per_slice = 64;
+    if (ncols > 0) {
+      slices = kSweepThreads / ncols; if (slices < 1) slices = 1; if (slices > 64) slices = 64;
+      rows_per_slice = (64 + slices - 1) / slices;
+    }
+    // thread -> (column word, row slice) of its first work item; prefetch up to kPre rows of it
+    u64 pre[kPre];
+    const int w0 = tid;
+    const bool has = (ncols > 0) && (w0 < ncols * slices);
+    const int cidx0 = blk + 1 + (has ? (w0 % ncols) : 0);
+    const int k00 = has ? (w0 / ncols) * rows_per_slice : 0;
+#pragma unroll
+    for (int u = 0; u < kPre; u++) {
+      const int kk = k00 + u;
+      const int row = blk * 64 + kk;
+      pre[u] = (has && u < rows_per_slice && kk < 64 && row < n) ? mask[(size_t)(s0 + row) * mask_stride + cidx0] : 0ull;
+    }
     if (wave == 0) {
-      const int row = blk * 64 + lane;
-      const u64 d = (row < n) ? mask[(size_t)(s0 + row) * mask_stride + blk] : 0ull;
+      const u64 d = d_next;
+      const int nrow = (blk + 1) * 64 + lane;
+      d_next = (blk + 1 < cb && nrow < n) ? mask[(size_t)(s0 + nrow) * mask_stride + blk + 1] : 0ull;
       const u64 cur0 = removed[blk];
       unsigned clo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur0);
       unsigned chi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur0 >> 32));
       u64 cur = ((u64)chi << 32) | clo;
       const int valid = __builtin_amdgcn_readfirstlane(min(64, n - blk * 64));
+      const u64 vmask = (valid >= 64) ? ~0ull : ((1ull << valid) - 1ull);
       const int dlo = (int)(unsigned)d, dhi = (int)(unsigned)(d >> 32);
-      u64 kept = 0;
-      for (int k = 0; k < valid; k++) {          // wave-uniform serial pass: scalar unit + v_readlane
-        if (!((cur >> k) & 1ull)) {
-          kept |= (1ull << k);
-          cur |= ((u64)(unsigned)__builtin_amdgcn_readlane(dhi, k) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane(dlo, k);
-        }
+      u64 todo = __ballot(d != 0ull) & vmask;          // rows that can suppress inside this block
+      while (todo) {                                     // wave-uniform, ascending row order
+        const int kk = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        if (!((cur >> kk) & 1ull))
+          cur |= ((u64)(unsigned)__builtin_amdgcn_readlane(dhi, kk) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane(dlo, kk);
       }
+      const u64 kept = ~cur & vmask;
       if (lane == 0) { *s_kept = kept; keepbits[blk] = kept; }
     }
     __syncthreads();
     const u64 kept = *s_kept;
-    const int ncols = cb - (blk + 1);
     if (ncols > 0 && kept != 0) {
-      // thread -> (column word, row slice): spread the <=64 kept rows over the otherwise idle lanes
-      int slices = kSweepThreads / ncols; if (slices < 1) slices = 1; if (slices > 64) slices = 64;
-      const int rows_per_slice = (64 + slices - 1) / slices;
       for (int w = tid; w < ncols * slices; w += kSweepThreads) {
         const int cidx = blk + 1 + (w % ncols);
         const int k0 = (w / ncols) * rows_per_slice;
         u64 acc = 0;
-        for (int k = k0; k < k0 + rows_per_slice && k < 64; k++)
-          if ((kept >> k) & 1ull) acc |= mask[(size_t)(s0 + blk * 64 + k) * mask_stride + cidx];
+        if (w == w0) {
+#pragma unroll
+          for (int u = 0; u < kPre; u++)
+            if (u < rows_per_slice && k0 + u < 64 && ((kept >> (k0 + u)) & 1ull)) acc |= pre[u];
+          for (int kk = k0 + kPre; kk < k0 + rows_per_slice && kk < 64; kk++)
+            if ((kept >> kk) & 1ull) acc |= mask[(size_t)(s0 + blk * 64 + kk) * mask_stride + cidx];
+        } else {
+          for (int kk = k0; kk < k0 + rows_per_slice && kk < 64; kk++)
+            if ((kept >> kk) & 1ull) acc |= mask[(size_t)(s0 + blk * 64 + kk) * mask_stride + cidx];
+        }
         if (acc) atomicOr(&removed[cidx], acc);
       }
     }
@@ -389,7 +448,8 @@ NmsLayout nms_layout(int n_total, int nseg, int max_seg) {
 }
 
 int pick_rows_per_wave(int max_seg, int nseg) {
-  if (const char* e = getenv("ORP_NMS_ROWS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return v; }
+  static const int forced = getenv("ORP_NMS_ROWS") ? atoi(getenv("ORP_NMS_ROWS")) : 0;   // dev aid
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) return forced;
   const long cb = (max_seg + 63) / 64;
   const long tiles = cb * (cb + 1) / 2 * (nseg > 0 ? nseg : 1);
   // one workgroup per (4R rows x 64 cols) tile; aim at >= 2048 workgroups (8 per CU) when the problem is big enough
@@ -446,12 +506,13 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
   const int R = pick_rows_per_wave(max_seg, nseg);
   const int rpb = R * (kMaskThreads / 64);
   dim3 grid(max_cb, (max_seg + rpb - 1) / rpb, nseg);
+  static const int dbg = getenv("ORP_NMS_DBG") ? atoi(getenv("ORP_NMS_DBG")) : 0;   // dev aid: 1 = skip phase B, 2 = skip classifier
   {
     OrpProfScope prof(ORP_PROF_NMS_MASK, st);
     if (flavor == 0)
-      hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask);
+      hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg);
     else
-      hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask);
+      hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg);
   }
 
   const size_t smem = kSweepHdr + (size_t)max_cb * 3 * sizeof(u64);
