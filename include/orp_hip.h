@@ -135,6 +135,8 @@ int orp_sigmoid_focal_loss_backward(const float* logits, const int64_t* targets,
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct { const float* input; const float* offset; float* output; int height; int width; } orp_dcn_level;
 int orp_dcn_fast_path_ok(int c_in, int c_out, int kh, int kw, int groups, int deformable_groups);
+/* `packed` holds orp_dcn_packed_weight_floats() floats: [kh*kw][Cin][Cout] followed by [kh*kw][Cin/4][Cout][4]. */
+size_t orp_dcn_packed_weight_floats(int c_out, int c_in, int kh, int kw);
 int orp_dcn_pack_weight(const float* weight, int c_out, int c_in, int kh, int kw, float* packed, void* stream);
 size_t orp_dcn_forward_workspace_bytes(const orp_dcn_level* levels_host, int nlevels, int batch, int c_in, int in_layout);
 int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int batch, int c_in, int c_out,

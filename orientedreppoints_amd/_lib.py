@@ -51,6 +51,7 @@ _SIGNATURES = {
     "orp_profile_read": (_i, [_i, _vp, _vp, _i]),
     "orp_dcn_fast_path_ok": (_i, [_i, _i, _i, _i, _i, _i]),
     "orp_dcn_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "orp_dcn_packed_weight_floats": (_sz, [_i, _i, _i, _i]),
     "orp_dcn_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "orp_dcn_forward_multi": (_i, [_vp, _i, _i, _i, _i, _vp] + [_i] * 10 + [_vp, _sz, _vp]),
     "orp_dcn_im2col": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp]),

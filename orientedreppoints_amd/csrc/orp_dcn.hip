@@ -24,6 +24,7 @@
 // deformable_groups > 1, odd channel counts, DCNv2 modulation + bias).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/orp_hip.h"
 #include "orp_prof.hpp"
@@ -53,6 +54,7 @@ struct FwdParams {
   int nlev, B, Cin, Cout;
   int kh, kw, sh, sw, ph, pw, dh, dw;
   const float* w2;     // packed [taps][Cin][Cout]
+  const float* w3;     // packed [taps][Cin/4][Cout][4] (second-generation kernel: B fragments straight from L2)
 };
 
 // ---- helpers -------------------------------------------------------------------------------------------------
@@ -63,7 +65,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
     const int o = (int)(i % cout);
     const long r = i / cout;
     const int c = (int)(r % cin), tap = (int)(r / cin);
-    w2[i] = w[((long)o * cin + c) * taps + tap];
+    const float v = w[((long)o * cin + c) * taps + tap];
+    w2[i] = v;
+    if ((cin & 3) == 0) w2[total + (((long)tap * (cin >> 2) + (c >> 2)) * cout + o) * 4 + (c & 3)] = v;
   }
 }
 
@@ -292,6 +296,240 @@ dcn_fwd_mfma_kernel(const FwdParams P) {
   }
 }
 
+// ---- MFMA implicit GEMM, second generation: MT x 32 positions per workgroup, 8 waves (2 per SIMD) -----------------
+// Same contraction and the same exact-fp32 MFMA as above, re-tiled after the first rocprofv3 PMC pass (round 1:
+// SQ_VALU_MFMA_BUSY 35 %, SQ_WAIT_ANY 37 % of wave cycles, 2.36 MB of packed weights streamed L2 -> LDS per 32-position
+// tile = 16 B/clk/CU):
+//   * a workgroup owns MT*32 positions (MT = 3 -> the 21 824 positions of a 1024x1024 image are 228 tiles, ONE round
+//     on 256 CUs; the weight stream per position drops 3x);
+//   * 8 waves = 2 per SIMD: wave w owns the 32 output channels [32w, 32w+32) for all MT position sub-tiles (MT
+//     accumulators), so while one wave of a SIMD waits on LDS / the barrier the other one feeds the matrix pipe;
+//   * the A tile (one kernel tap, 256 channels) is single-buffered in LDS: the rows of the NEXT tap are gathered
+//     (coalesced 1 KB NHWC rows), bilinearly combined and parked in registers while the current tap is contracted, and
+//     written after its last chunk (two barriers per tap, none per chunk); the weight fragments of a wave go L2 ->
+//     registers directly (packing [tap][c/4][o][4]: one float4 per lane per four k-steps), prefetched one chunk ahead;
+//   * blockIdx -> tile is XCD-aware: the 8 XCDs each take a contiguous slab of tiles, so a feature-map row is pulled
+//     into ONE XCD's L2 instead of all eight.
+constexpr int KC2 = 16;          // input channels per weight chunk
+constexpr int kThreads2 = 512;
+
+template <int MT, bool OUT_NCHW>
+__global__ void __launch_bounds__(kThreads2)
+dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
+  constexpr int BM2 = 32 * MT;
+  constexpr int ROWS = BM2 / 8;                                              // A rows produced per wave per tap
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sA = reinterpret_cast<float*>(smem);                                // [BM2][ASTR]
+  float4* sCw = reinterpret_cast<float4*>(sA + BM2 * ASTR);                  // [BM2 * taps] bilinear weights
+  int4* sCi = reinterpret_cast<int4*>(sCw + BM2 * MAX_TAPS);                 // [BM2 * taps] pixel indices
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int taps = P.kh * P.kw;
+  // XCD-aware remap: hardware places block b on XCD b % 8; give XCD x the contiguous tiles [x*per, (x+1)*per)
+  int tile;
+  {
+    const int b = blockIdx.x, per = (total_tiles + 7) >> 3;
+    tile = (b & 7) * per + (b >> 3);
+    if (tile >= total_tiles) return;                                         // whole workgroup leaves together
+  }
+  int lvl = 0;
+#pragma unroll 1
+  for (int i = 1; i < P.nlev; i++) if (tile >= P.lv[i].tile0) lvl = i;
+  const LevelDesc L = P.lv[lvl];
+  const int HoWo = L.Ho * L.Wo;
+  const long npos = (long)P.B * HoWo;
+  const long p0 = (long)(tile - L.tile0) * BM2;
+  const int nb = blockIdx.y;
+
+  for (int e = tid; e < BM2 * taps; e += kThreads2) {
+    const int m = e / taps, tap = e - m * taps;
+    const long p = p0 + m;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 ix = make_int4(0, 0, 0, 0);
+    if (p < npos) {
+      const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+      const int ho = hw / L.Wo, wo = hw - ho * L.Wo;
+      const int ki = tap / P.kw, kj = tap - ki * P.kw;
+      const float* ob = L.off + ((size_t)b * 2 * taps + 2 * tap) * HoWo + hw;
+      const float off_h = ob[0], off_w = ob[HoWo];
+      const float h_im = (float)(ho * P.sh - P.ph + ki * P.dh) + off_h;
+      const float w_im = (float)(wo * P.sw - P.pw + kj * P.dw) + off_w;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)L.H && w_im < (float)L.W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+        const float hh = 1.f - lh, hw_ = 1.f - lw;
+        const bool t_ok = h_low >= 0, b_ok = h_high <= L.H - 1, l_ok = w_low >= 0, r_ok = w_high <= L.W - 1;
+        const int hl = t_ok ? h_low : 0, hhg = b_ok ? h_high : L.H - 1, wl = l_ok ? w_low : 0, whg = r_ok ? w_high : L.W - 1;
+        w.x = (t_ok && l_ok) ? hh * hw_ : 0.f;
+        w.y = (t_ok && r_ok) ? hh * lw : 0.f;
+        w.z = (b_ok && l_ok) ? lh * hw_ : 0.f;
+        w.w = (b_ok && r_ok) ? lh * lw : 0.f;
+        const int base = b * L.H;
+        ix.x = (base + hl) * L.W + wl;
+        ix.y = (base + hl) * L.W + whg;
+        ix.z = (base + hhg) * L.W + wl;
+        ix.w = (base + hhg) * L.W + whg;
+      }
+    }
+    sCw[e] = w; sCi[e] = ix;
+  }
+  __syncthreads();
+
+  const int ncb = P.Cin / CB;                        // 256-channel blocks per tap (Cin % 256 == 0 on this path)
+  const int nphase = taps * ncb;
+  constexpr int NCHUNK = CB / KC2;                   // 16 chunks per phase
+
+  // one A row = 256 channels = 64 lanes x float4: four coalesced 1 KB neighbour rows, combined with wave-uniform weights
+  auto gather_issue = [&](int phase, int m, float4 (&g)[4]) {
+    const int tap = phase / ncb, cb = phase - tap * ncb;
+    const int4 ix = sCi[m * taps + tap];
+    const float* base = L.x + cb * CB + lane * 4;
+    g[0] = *reinterpret_cast<const float4*>(base + (size_t)ix.x * P.Cin);
+    g[1] = *reinterpret_cast<const float4*>(base + (size_t)ix.y * P.Cin);
+    g[2] = *reinterpret_cast<const float4*>(base + (size_t)ix.z * P.Cin);
+    g[3] = *reinterpret_cast<const float4*>(base + (size_t)ix.w * P.Cin);
+  };
+  auto combine = [&](int phase, int m, const float4 (&g)[4]) {
+    const int tap = phase / ncb;
+    const float4 wgt = sCw[m * taps + tap];
+    float4 v;
+    v.x = wgt.x * g[0].x + wgt.y * g[1].x + wgt.z * g[2].x + wgt.w * g[3].x;
+    v.y = wgt.x * g[0].y + wgt.y * g[1].y + wgt.z * g[2].y + wgt.w * g[3].y;
+    v.z = wgt.x * g[0].z + wgt.y * g[1].z + wgt.z * g[2].z + wgt.w * g[3].z;
+    v.w = wgt.x * g[0].w + wgt.y * g[1].w + wgt.z * g[2].w + wgt.w * g[3].w;
+    return v;
+  };
+  // B fragments never touch LDS: wave w only ever needs its own 32 output channels, and with the [tap][c/4][o][4]
+  // packing the four k-steps (t, i = 0..3) of lane (n, kh) are ONE float4 (channels 8t + 4kh + i of output n):
+  // lanes 0-31 / 32-63 read two contiguous 512 B segments.  No shared weight buffer -> no per-chunk barrier.
+  const int n_wave = nb * BN + wave * 32;                 // first output channel of this wave
+  const int mrow = lane & 31, kh = lane >> 5;
+  const bool n_ok = (n_wave + mrow) < P.Cout;
+  auto load_bq = [&](int phase, int j, float4 (&r)[2]) {
+    const int tap = phase / ncb, cb = phase - tap * ncb;
+    const size_t c4 = (size_t)(tap * P.Cin + cb * CB + j * KC2 + 4 * kh) >> 2;
+    const float* base = P.w3 + (c4 * P.Cout + n_wave + mrow) * 4;
+    if (n_ok) {
+      r[0] = *reinterpret_cast<const float4*>(base);
+      r[1] = *reinterpret_cast<const float4*>(base + (size_t)8 * P.Cout);     // channels + 8 -> c4 + 2
+    } else {
+      r[0] = r[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  // ---- prologue: A tile of phase 0, weight fragments of chunk 0 ------------------------------------------------
+  float4 bq[2];
+  {
+    load_bq(0, 0, bq);
+    // four rows in flight per wave (16 outstanding 1 KB loads) so the first tap's gather latency is paid ROWS/4 times
+#pragma unroll 1
+    for (int r0 = 0; r0 < ROWS; r0 += 4) {
+      float4 g[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) gather_issue(0, (r0 + u) * 8 + wave, g[u]);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int m = (r0 + u) * 8 + wave;
+        *reinterpret_cast<float4*>(sA + (size_t)m * ASTR + lane * 4) = combine(0, m, g[u]);
+      }
+    }
+  }
+  __syncthreads();
+
+  floatx16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) acc[mt] = floatx16{0};
+
+#pragma unroll 1
+  for (int phase = 0; phase < nphase; phase++) {
+    const bool next_phase = phase + 1 < nphase;
+    float4 hold[ROWS];
+#pragma unroll
+    for (int j = 0; j < NCHUNK; j++) {
+      // (1) issue the global loads of the next chunk's weight fragments and of one row of the next phase's A tile
+      const bool last_chunk = (j + 1 == NCHUNK);
+      float4 bn[2];
+      if (!(last_chunk && !next_phase)) load_bq(last_chunk ? phase + 1 : phase, last_chunk ? 0 : j + 1, bn);
+      else { bn[0] = bn[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      float4 g[4];
+      const bool do_row = next_phase && (j < ROWS);
+      if (do_row) gather_issue(phase + 1, j * 8 + wave, g);
+      // (2) MFMA over the current chunk
+      {
+        const float* arow = sA + (size_t)mrow * ASTR + j * KC2 + 4 * kh;
+#pragma unroll
+        for (int t = 0; t < KC2 / 8; t++) {
+          float4 a4[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++) a4[mt] = *reinterpret_cast<const float4*>(arow + (size_t)mt * 32 * ASTR + 8 * t);
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float b0 = (i == 0) ? bq[t].x : (i == 1) ? bq[t].y : (i == 2) ? bq[t].z : bq[t].w;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+              const float av = (i == 0) ? a4[mt].x : (i == 1) ? a4[mt].y : (i == 2) ? a4[mt].z : a4[mt].w;
+              if (OUT_NCHW) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, av, acc[mt], 0, 0, 0);   // D[channel][position]
+              else          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[mt], 0, 0, 0);   // D[position][channel]
+            }
+          }
+        }
+      }
+      if (do_row) hold[j < ROWS ? j : 0] = combine(phase + 1, j * 8 + wave, g);
+      bq[0] = bn[0]; bq[1] = bn[1];
+    }
+    // two barriers per tap: every wave is past its last read of this tap's A tile -> overwrite it with the next tap's rows
+    if (next_phase) {
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < ROWS; rr++)
+        *reinterpret_cast<float4*>(sA + (size_t)(rr * 8 + wave) * ASTR + lane * 4) = hold[rr];
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------
+  if (n_wave >= P.Cout) return;
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) {
+    if (OUT_NCHW) {
+      const long p = p0 + mt * 32 + (lane & 31);
+      if (p < npos) {
+        const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+        float* ob = L.out + (size_t)b * P.Cout * HoWo + hw;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int ch = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (n_wave + ch < P.Cout) ob[(size_t)(n_wave + ch) * HoWo] = acc[mt][r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const long p = p0 + mt * 32 + m;
+        if (p < npos && n_wave + (lane & 31) < P.Cout) L.out[(size_t)p * P.Cout + n_wave + (lane & 31)] = acc[mt][r];
+      }
+    }
+  }
+}
+
+template <int MT>
+size_t mfma2_smem() {
+  return sizeof(float) * ((size_t)32 * MT * ASTR) + (sizeof(float4) + sizeof(int4)) * 32 * MT * MAX_TAPS;
+}
+
+template <int MT, bool OUT_NCHW>
+hipError_t launch_mfma2(const FwdParams& P, int tiles, int nblk_n, hipStream_t st) {
+  const size_t smem = mfma2_smem<MT>();
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma2_kernel<MT, OUT_NCHW>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  const int per = (tiles + 7) >> 3;
+  hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<MT, OUT_NCHW>), dim3(per * 8, nblk_n), dim3(kThreads2), smem, st, P, tiles);
+  return hipGetLastError();
+}
+
 // ---- direct kernel: every configuration (groups, deformable groups, DCNv2 mask + bias), NCHW in / out -----------
 __global__ void dcn_fwd_direct_kernel(const float* __restrict__ x, const float* __restrict__ off,
                                       const float* __restrict__ mask, const float* __restrict__ w,
@@ -356,6 +594,10 @@ int orp_dcn_pack_weight(const float* weight, int c_out, int c_in, int kh, int kw
   return e == hipSuccess ? ORP_OK : (int)e;
 }
 
+size_t orp_dcn_packed_weight_floats(int c_out, int c_in, int kh, int kw) {
+  return (size_t)2 * c_out * c_in * kh * kw;          // [tap][c][o] followed by [tap][c/4][o][4]
+}
+
 int orp_dcn_fast_path_ok(int c_in, int c_out, int kh, int kw, int groups, int deformable_groups) {
   return (groups == 1 && deformable_groups == 1 && kh * kw <= MAX_TAPS && c_in % 32 == 0 && c_in >= 32 &&
           c_out % 64 == 0 && c_out >= 64) ? 1 : 0;
@@ -381,9 +623,28 @@ int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int bat
   P.nlev = nlevels; P.B = batch; P.Cin = c_in; P.Cout = c_out;
   P.kh = kh; P.kw = kw; P.sh = stride_h; P.sw = stride_w; P.ph = pad_h; P.pw = pad_w; P.dh = dil_h; P.dw = dil_w;
   P.w2 = weight_packed;
+  P.w3 = weight_packed + (size_t)kh * kw * c_in * c_out;
   if (in_layout == 0 && workspace_bytes < orp_dcn_forward_workspace_bytes(levels_host, nlevels, batch, c_in, 0))
     return ORP_EWORKSPACE;
   char* wsp = reinterpret_cast<char*>(workspace);
+  // tile height: the second-generation kernel (MT*32 positions per workgroup) when Cin is a multiple of 256; MT is
+  // chosen to minimise rounds x tile height on 256 CUs (B=1, 1024x1024: MT = 3 -> 228 tiles, one round)
+  static const int force_mt = getenv("ORP_DCN_MT") ? atoi(getenv("ORP_DCN_MT")) : -1;   // dev aid: 0 = first-generation kernel
+  int MT = 0;
+  if (c_in % CB == 0) {
+    long npos_all = 0;
+    for (int i = 0; i < nlevels; i++)
+      npos_all += (long)batch * out_dim(levels_host[i].height, pad_h, dil_h, kh, stride_h) *
+                  out_dim(levels_host[i].width, pad_w, dil_w, kw, stride_w);
+    long best = -1;
+    for (int mt = 1; mt <= 3; mt++) {
+      const long t = (npos_all + 32 * mt - 1) / (32 * mt) + nlevels;     // upper bound incl. per-level remainders
+      const long cost = ((t + 255) / 256) * mt * 100 + (mt == 1 ? 40 : mt == 2 ? 10 : 0);   // small bias to taller tiles
+      if (best < 0 || cost < best) { best = cost; MT = mt; }
+    }
+    if (force_mt >= 0 && force_mt <= 3) MT = force_mt;
+  }
+  const int bm = MT > 0 ? 32 * MT : BM;
   int tiles = 0;
   for (int i = 0; i < nlevels; i++) {
     const orp_dcn_level& lv = levels_host[i];
@@ -406,13 +667,21 @@ int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int bat
       D.x = lv.input;
     }
     D.tile0 = tiles;
-    tiles += (int)(((long)batch * D.Ho * D.Wo + BM - 1) / BM);
+    tiles += (int)(((long)batch * D.Ho * D.Wo + bm - 1) / bm);
   }
   for (int i = nlevels; i < MAX_LEVELS; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; }
-  const size_t smem = sizeof(float) * (2 * BM * ASTR + 2 * KC * BN) + (sizeof(float4) + sizeof(int4)) * BM * MAX_TAPS;
-  dim3 grid(tiles, (c_out + BN - 1) / BN);
   hipError_t e;
   OrpProfScope prof(ORP_PROF_DCN_FWD, st);
+  const int nblk_n = (c_out + BN - 1) / BN;
+  if (MT > 0) {
+    const bool nchw = out_layout == 0;
+    if (MT == 1) e = nchw ? launch_mfma2<1, true>(P, tiles, nblk_n, st) : launch_mfma2<1, false>(P, tiles, nblk_n, st);
+    else if (MT == 2) e = nchw ? launch_mfma2<2, true>(P, tiles, nblk_n, st) : launch_mfma2<2, false>(P, tiles, nblk_n, st);
+    else e = nchw ? launch_mfma2<3, true>(P, tiles, nblk_n, st) : launch_mfma2<3, false>(P, tiles, nblk_n, st);
+    return e == hipSuccess ? ORP_OK : (int)e;
+  }
+  const size_t smem = sizeof(float) * (2 * BM * ASTR + 2 * KC * BN) + (sizeof(float4) + sizeof(int4)) * BM * MAX_TAPS;
+  dim3 grid(tiles, nblk_n);
   if (out_layout == 0) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -29,7 +29,7 @@ _packed_cache = {}
 
 
 def _packed_weight(weight):
-    """[Cout,Cin,kh,kw] -> [kh*kw,Cin,Cout], cached per (storage, version)."""
+    """[Cout,Cin,kh,kw] -> [kh*kw,Cin,Cout] ++ [kh*kw,Cin/4,Cout,4] (both kernel generations), cached per (storage, version)."""
     w = weight.detach()
     key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index)
     hit = _packed_cache.get(id(weight))
@@ -37,7 +37,7 @@ def _packed_weight(weight):
         return hit[1]
     w = w.float().contiguous()
     cout, cin, kh, kw = w.shape
-    packed = torch.empty((kh * kw, cin, cout), dtype=torch.float32, device=w.device)
+    packed = torch.empty((_lib.lib().orp_dcn_packed_weight_floats(cout, cin, kh, kw),), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
         rc = _lib.lib().orp_dcn_pack_weight(_lib.ptr(w), cout, cin, kh, kw, _lib.ptr(packed), _lib.stream_of(w))
     _lib.check(rc, "orp_dcn_pack_weight")

@@ -1,0 +1,25 @@
+"""Launch the hot-path kernels a few times on the bench shapes (for rocprofv3 --pmc passes; development aid).
+usage: python tools/run_hot_kernels.py [dcn|nms|all] [iters]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from orientedreppoints_amd import synthetic as S
+which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device('cuda:0')
+if which in ('dcn', 'all'):
+    from orientedreppoints_amd.mmdet_ops import deform_conv_forward_multi
+    torch.manual_seed(0)
+    w = torch.randn(256, 256, 3, 3, device=dev) * 0.01
+    xs = [torch.randn(1, 256, h, h, device=dev).contiguous(memory_format=torch.channels_last) for h in (128, 64, 32, 16, 8)]
+    offs = [torch.randn(1, 18, h, h, device=dev) * 2 for h in (128, 64, 32, 16, 8)]
+    for _ in range(iters):
+        deform_conv_forward_multi(xs, offs, w, 1, 1, 1)
+if which in ('nms', 'all'):
+    from orientedreppoints_amd.mmdet_ops.nms_wrapper import rnms_device
+    d, _ = S.gen_dense_scene(2000, 1)
+    t = torch.from_numpy(d.astype(np.float32)).to(dev)
+    for _ in range(iters):
+        rnms_device(t, 0.4)
+torch.cuda.synchronize()
+print('done')
