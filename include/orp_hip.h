@@ -195,6 +195,24 @@ int orp_apaa_select(const float* quality, const int64_t* pos_gt_inds, const int3
                     int num_level, int per_level_topk, double top_ratio, uint8_t* keep, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Fused normalisation + activation passes (inference), SURVEY 8f rank 3 "head towers fused for MI355X".
+ * orp_groupnorm_act_multi: GroupNorm (+ ReLU) of the dense-head ConvModules (mmdet/ops/conv_module.py:130-140 as used
+ *   by orientedreppoints_head.py:91-113), ALL FPN levels of one layer in one launch pair (statistics, then one
+ *   read-modify-write pass).  levels_host[i] = {input, output, height, width}, tensors NCHW [B,C,H,W] fp32; output may
+ *   alias input.  workspace: orp_groupnorm_workspace_bytes().
+ * orp_affine_act: y = relu?(x*scale[c] + shift[c] (+ residual)) -- eval-mode BatchNorm folded to a per-channel affine
+ *   and fused with the bottleneck's residual add + ReLU (mmdet/models/backbones/resnet.py:133-170); residual may be
+ *   NULL, y may alias x.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct { const float* input; float* output; int height; int width; } orp_norm_level;
+size_t orp_groupnorm_workspace_bytes(const orp_norm_level* levels_host, int nlevels, int batch, int channels, int groups);
+int orp_groupnorm_act_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, int groups,
+                            const float* gamma, const float* beta, float eps, int relu, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int orp_affine_act(const float* x, const float* residual, const float* scale, const float* shift, float* y, int batch,
+                   int channels, int hw, int relu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Built-in kernel timing (measurement aid for bench.py): when enabled every instrumented launch is bracketed by
  * a HIP event pair recorded on the launch stream.  Slots: 0 nms mask, 1 nms sweep, 2 nms sort, 3 dcn forward,
  * 4 minaerarect, 5 convex_iou, 6 convex_giou, 7 iou matrix, 8 dcn backward.

@@ -113,6 +113,23 @@ class OrientedRepPointsHead(nn.Module):
         pts_out_init = self.reppoints_pts_init_out(self.relu(self.reppoints_pts_init_conv(pts_feat)))
         return cls_feat, pts_feat, pts_out_init
 
+    def _fused_towers_ok(self, feats):
+        x = feats[0]
+        if not (x.is_cuda and x.dtype == torch.float32):
+            return False
+        for m in list(self.cls_convs) + list(self.reg_convs):
+            if not (m.with_norm and isinstance(m.norm, nn.GroupNorm) and m.with_activation):
+                return False
+        return True
+
+    @staticmethod
+    def _tower_multi(convs, feats):
+        from ..mmdet_ops.fused_norm import group_norm_act_multi
+        cur = list(feats)
+        for m in convs:
+            cur = group_norm_act_multi([m.conv(x) for x in cur], m.norm, relu=True, inplace=True)
+        return cur
+
     def forward_single(self, x):
         """One level, autograd-capable (reference forward_single, head :148-171)."""
         dcn_base_offset = self.dcn_base_offset.type_as(x)
@@ -128,13 +145,20 @@ class OrientedRepPointsHead(nn.Module):
     def forward(self, feats):
         if torch.is_grad_enabled():
             return multi_apply(self.forward_single, feats)
-        # inference: same arithmetic, but each DeformConv covers all levels in ONE launch
+        # inference: same arithmetic, but every layer covers all levels at once: the tower ConvModules run their
+        # GroupNorm+ReLU as one fused HIP launch pair over the five levels, each DeformConv is ONE launch
         dcn_base_offset = self.dcn_base_offset.type_as(feats[0])
-        cls_feats, pts_feats, inits, offsets = [], [], [], []
-        for x in feats:
-            cls_feat, pts_feat, pts_out_init = self._towers(x)
-            cls_feats.append(cls_feat); pts_feats.append(pts_feat); inits.append(pts_out_init)
-            offsets.append(pts_out_init - dcn_base_offset)     # (1-g)*p + g*p == p without autograd
+        fused = self._fused_towers_ok(feats)
+        if fused:
+            cls_feats = self._tower_multi(self.cls_convs, feats)
+            pts_feats = self._tower_multi(self.reg_convs, feats)
+            inits = [self.reppoints_pts_init_out(self.relu(self.reppoints_pts_init_conv(p))) for p in pts_feats]
+        else:
+            cls_feats, pts_feats, inits = [], [], []
+            for x in feats:
+                cls_feat, pts_feat, pts_out_init = self._towers(x)
+                cls_feats.append(cls_feat); pts_feats.append(pts_feat); inits.append(pts_out_init)
+        offsets = [init - dcn_base_offset for init in inits]    # (1-g)*p + g*p == p without autograd
         dcn_cls = self.reppoints_cls_conv.forward_multi(cls_feats, offsets)
         dcn_pts = self.reppoints_pts_refine_conv.forward_multi(pts_feats, offsets)
         cls_outs, refines = [], []

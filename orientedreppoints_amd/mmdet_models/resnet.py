@@ -2,6 +2,7 @@
 out_indices, frozen_stages, norm_cfg, style, norm_eval).  Parameter names follow torchvision / the released
 checkpoints (conv1, bn1, layer{1..4}.{i}.conv{1,2,3}, bn{1,2,3}, downsample.{0,1}).  Out of the HIP hot path: this
 is the part BASELINE.json says stays stock."""
+import torch
 import torch.nn as nn
 
 from .layers import build_norm_layer, constant_init, kaiming_init
@@ -29,7 +30,25 @@ class Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
+    def _fused_ok(self, x):
+        # inference only: eval-mode BatchNorm is a per-channel affine -> one fused HIP pass with the ReLU / residual add
+        return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32 and \
+            isinstance(self.bn1, nn.BatchNorm2d) and not self.bn1.training and not self.bn3.training
+
+    def _forward_fused(self, x):
+        from ..mmdet_ops.fused_norm import bn_act
+        out = bn_act(self.conv1(x).contiguous(), self.bn1, relu=True)
+        out = bn_act(self.conv2(out).contiguous(), self.bn2, relu=True)
+        out = self.conv3(out).contiguous()
+        if self.downsample is not None:
+            identity = bn_act(self.downsample[0](x).contiguous(), self.downsample[1], relu=False)
+        else:
+            identity = x.contiguous()
+        return bn_act(out, self.bn3, residual=identity, relu=True)
+
     def forward(self, x):
+        if self._fused_ok(x):
+            return self._forward_fused(x)
         identity = x
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
@@ -111,7 +130,12 @@ class ResNet(nn.Module):
                     constant_init(m.bn3, 0)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        if (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32 and \
+                isinstance(self.bn1, nn.BatchNorm2d) and not self.bn1.training:
+            from ..mmdet_ops.fused_norm import bn_act
+            x = self.maxpool(bn_act(self.conv1(x).contiguous(), self.bn1, relu=True))
+        else:
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

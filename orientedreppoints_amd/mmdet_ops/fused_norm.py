@@ -1,0 +1,77 @@
+"""Fused normalisation + activation passes for inference (include/orp_hip.h `orp_groupnorm_act_multi`,
+`orp_affine_act`): the GroupNorm+ReLU of the dense-head ConvModules for all FPN levels in one launch pair, and the
+eval-mode BatchNorm (+ residual) + ReLU of the ResNet bottlenecks as one pass.  No autograd: callers use them only
+under torch.no_grad(); with gradients enabled the stock PyTorch modules run."""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+
+class _NormLevel(ctypes.Structure):
+    _fields_ = [("input", ctypes.c_void_p), ("output", ctypes.c_void_p), ("height", ctypes.c_int),
+                ("width", ctypes.c_int)]
+
+
+def group_norm_act_multi(xs, gn, relu=True, inplace=True):
+    """[GroupNorm(+ReLU)(x) for x in xs] -- xs: list of [B,C,H,W] fp32 CUDA tensors (one per FPN level)."""
+    L = _lib.lib()
+    x0 = xs[0]
+    B, C = x0.size(0), x0.size(1)
+    levels = (_NormLevel * len(xs))()
+    ins, outs = [], []
+    for i, x in enumerate(xs):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.size(0) == B and x.size(1) == C):
+            raise ValueError("group_norm_act_multi expects fp32 CUDA [B,C,H,W] tensors with equal B and C")
+        x = x.detach().contiguous()
+        y = x if inplace else torch.empty_like(x)
+        ins.append(x); outs.append(y)
+        levels[i] = _NormLevel(x.data_ptr(), y.data_ptr(), x.size(2), x.size(3))
+    nbytes = L.orp_groupnorm_workspace_bytes(levels, len(xs), B, C, gn.num_groups)
+    ws = _lib.workspace(x0.device, nbytes)
+    gamma = gn.weight.detach().float().contiguous()
+    beta = gn.bias.detach().float().contiguous()
+    with torch.cuda.device(x0.device):
+        rc = L.orp_groupnorm_act_multi(levels, len(xs), B, C, gn.num_groups, _lib.ptr(gamma), _lib.ptr(beta),
+                                       float(gn.eps), 1 if relu else 0, _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
+    _lib.check(rc, "orp_groupnorm_act_multi")
+    return outs
+
+
+_affine_cache = {}
+
+
+def _bn_affine(bn):
+    """eval-mode BatchNorm as (scale, shift): y = x*scale + shift; cached per parameter versions."""
+    key = (bn.weight._version if bn.weight is not None else -1, bn.bias._version if bn.bias is not None else -1,
+           bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.running_mean.device.index)
+    hit = _affine_cache.get(id(bn))
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+        w = bn.weight.float() if bn.weight is not None else torch.ones_like(rstd)
+        b = bn.bias.float() if bn.bias is not None else torch.zeros_like(rstd)
+        scale = (w * rstd).contiguous()
+        shift = (b - bn.running_mean.float() * scale).contiguous()
+    if len(_affine_cache) > 512:
+        _affine_cache.clear()
+    _affine_cache[id(bn)] = (key, scale, shift)
+    return scale, shift
+
+
+def bn_act(x, bn, residual=None, relu=True):
+    """relu?(BatchNorm_eval(x) (+ residual)) in ONE pass, in place on x ([B,C,H,W] fp32 CUDA, contiguous)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        raise ValueError("bn_act expects a contiguous fp32 CUDA [B,C,H,W] tensor")
+    if residual is not None and not (residual.shape == x.shape and residual.is_contiguous()
+                                     and residual.dtype == torch.float32):
+        raise ValueError("bn_act: residual must match x")
+    scale, shift = _bn_affine(bn)
+    B, C, H, W = x.shape
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().orp_affine_act(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(x),
+                                       B, C, H * W, 1 if relu else 0, _lib.stream_of(x))
+    _lib.check(rc, "orp_affine_act")
+    return x

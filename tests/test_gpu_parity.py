@@ -537,3 +537,59 @@ def test_box_iou_rotated(dev, oracle, golden_dir):
     got = box_iou_rotated(_t(a, dev), _t(b, dev)).cpu().numpy()
     assert np.max(np.abs(got - oracle.box_iou_rotated(a, b))) <= 1e-4
     assert box_iou_rotated(torch.zeros((0, 5), device=dev), _t(b, dev)).shape == (0, 300)
+
+
+# ---- fused normalisation passes (inference): against the stock PyTorch fp32 modules they replace ---------------------
+@pytest.mark.parametrize("B,C,G,sizes", [(1, 256, 32, [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)]),
+                                         (2, 64, 32, [(9, 7), (3, 5)]), (1, 32, 4, [(1, 1), (130, 17)])])
+def test_groupnorm_relu_multi_vs_torch(dev, B, C, G, sizes):
+    from orientedreppoints_amd.mmdet_ops.fused_norm import group_norm_act_multi
+    torch.manual_seed(0)
+    gn = torch.nn.GroupNorm(G, C).to(dev)
+    with torch.no_grad():
+        gn.weight.normal_(1.0, 0.3); gn.bias.normal_(0.0, 0.3)
+    xs = [torch.randn(B, C, h, w, device=dev) * 3.0 + 1.5 for h, w in sizes]
+    for relu in (True, False):
+        with torch.no_grad():
+            want = [torch.relu(gn(x)) if relu else gn(x) for x in xs]
+            got = group_norm_act_multi([x.clone() for x in xs], gn, relu=relu, inplace=True)
+        for g_, w_ in zip(got, want):
+            assert float((g_ - w_).abs().max()) <= 1e-4
+
+
+def test_bn_act_vs_torch(dev):
+    from orientedreppoints_amd.mmdet_ops.fused_norm import bn_act
+    torch.manual_seed(1)
+    for B, C, H, W in [(1, 64, 32, 32), (2, 24, 7, 9)]:
+        bn = torch.nn.BatchNorm2d(C).to(dev).eval()
+        with torch.no_grad():
+            bn.weight.normal_(1.0, 0.3); bn.bias.normal_(0, 0.3)
+            bn.running_mean.normal_(0, 1.0); bn.running_var.uniform_(0.3, 2.0)
+        x = torch.randn(B, C, H, W, device=dev) * 2
+        r = torch.randn(B, C, H, W, device=dev)
+        with torch.no_grad():
+            assert float((bn_act(x.clone(), bn, relu=True) - torch.relu(bn(x))).abs().max()) <= 1e-5
+            assert float((bn_act(x.clone(), bn, residual=r, relu=True) - torch.relu(bn(x) + r)).abs().max()) <= 1e-5
+            assert float((bn_act(x.clone(), bn, relu=False) - bn(x)).abs().max()) <= 1e-5
+
+
+def test_detector_fused_inference_matches_stock_modules(dev):
+    """The fused inference forward (GroupNorm+ReLU launch pairs, folded BatchNorm) against the same model run through
+    the stock PyTorch modules (the autograd-capable per-level forward)."""
+    from orientedreppoints_amd.dota_configs import r50_model, test_cfg
+    from orientedreppoints_amd.mmdet_models import ConfigDict, build_detector
+    torch.manual_seed(0)
+    model = build_detector(ConfigDict(r50_model), train_cfg=None, test_cfg=ConfigDict(test_cfg)).to(dev).eval()
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    img = torch.randn(1, 3, 256, 256, device=dev)
+    with torch.no_grad():
+        fused = model.bbox_head(model.extract_feat(img))
+    with torch.enable_grad():
+        stock = model.bbox_head(model.extract_feat(img))
+    for a_list, b_list in zip(fused[:3], stock[:3]):
+        for a, b in zip(a_list, b_list):
+            scale = max(1.0, float(b.abs().max()))
+            assert float((a - b.detach()).abs().max()) <= 1e-3 * scale
