@@ -4,16 +4,18 @@
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 Workload (BASELINE.json configs[1]): OrientedRepPoints R-50 FPN inference, 1024x1024 DOTA patch, 15 classes,
-bs = 1 per GPU.  A "step" is one full `simple_test`: stock PyTorch-ROCm ResNet-50 + FPN, the dense head (conv
-towers stock, both DeformConvs on the HIP MFMA kernel), decode (fused min-area-rect kernel), multiclass rotated NMS
+bs = 1 per GPU.  A "step" is one full `simple_test`: stock PyTorch-ROCm ResNet-50 + FPN convolutions (eval BatchNorm +
+residual + ReLU as one fused HIP pass), the dense head (tower convs stock, GroupNorm+ReLU fused HIP launch pairs,
+both DeformConvs on the HIP MFMA kernel), decode (fused min-area-rect kernel), multiclass rotated NMS
 (HIP mask + on-device sweep) and rbbox2result (the D2H the reference's test loop also pays).  Inputs are resident in
 HBM before the timed region.  Random-init weights and a synthetic image (no network): because a random-init head
 scores ~0.01 everywhere and predicts zero-size point sets, two biases are calibrated ONCE before timing so that the
 post-processing sees a realistic dense scene (see `calibrate_head`) -- the compute of every layer is unchanged.
 
-One JSON line on rank 0: metric/value = whole-job images/sec; plus `roofline` for the dominant hot-path kernel
-(nms_mask_kernel, timed live with HIP events inside liborp_hip.so over the timed region) and `cpu_baseline` (the CPU
-oracle port of polyiou + py_cpu_nms_poly timed on the host on one image's detections).
+One JSON line on rank 0: metric/value = whole-job images/sec; plus `roofline` for the dominant hot-path kernel (the
+DeformConv implicit GEMM, timed live with HIP events inside liborp_hip.so over the timed region, MFMA-bound), `nms`
+(the rotated-IoU + NMS stage: us/img, mask/sweep kernel times) and `cpu_baseline` (the CPU oracle port of polyiou +
+py_cpu_nms_poly timed on the host on one image's detections).
 """
 import argparse
 import ctypes
@@ -34,6 +36,7 @@ from orientedreppoints_amd.mmdet_models import ConfigDict, build_detector  # noq
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD at 2.4 GHz
 IMG = 1024
 TARGET_DETS = 2000               # (point, class) pairs above score_thr per image: the "dense scene" of BASELINE configs
 
@@ -88,15 +91,19 @@ def nms_inputs_of_one_image(model, img, metas):
     return captured
 
 
-def cpu_baseline(dets_np, thr):
-    """polyiou (fp64) + py_cpu_nms_poly greedy loop, C port of the reference's CPU path, 1 host core."""
+def cpu_baseline(dets_np, thr, budget_s=10.0):
+    """polyiou (fp64) + py_cpu_nms_poly greedy loop, C port of the reference's CPU path, 1 host core.  Repeated on
+    the image's detections until ~budget_s of CPU work is spent; returns (mean seconds per image, kept, repeats)."""
     from oracle import orp_oracle as O
     O.build()
     d64 = dets_np.astype(np.float64)
-    t0 = time.perf_counter()
-    keep = O.py_cpu_nms_poly(d64, thr)
-    dt = time.perf_counter() - t0
-    return dt, len(keep)
+    total, reps, keep = 0.0, 0, []
+    while total < budget_s and reps < 64:
+        t0 = time.perf_counter()
+        keep = O.py_cpu_nms_poly(d64, thr)
+        total += time.perf_counter() - t0
+        reps += 1
+    return total / reps, len(keep), reps
 
 
 def main():
@@ -184,27 +191,55 @@ def main():
         torch.cuda.synchronize()
         nms_us = e0.elapsed_time(e1) / 20 * 1e3
 
-    mask_ms, mask_n = prof['nms_mask']
+    # ---- roofline of the dominant hot-path kernel: the DeformConv implicit GEMM (exact-fp32 MFMA) -------------------
+    # algorithmic flops per launch = 2 * positions * Cout * Cin * taps, all FPN levels in one launch;
+    # algorithmic bytes = 4 * (x + offsets + packed weights + out).  `traffic` = HBM bytes per launch from the
+    # rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE).
+    dcn_ms, dcn_n = prof['dcn_fwd']
     roof = None
+    npos = args.batch * sum((IMG // s_) ** 2 for s_ in (8, 16, 32, 64, 128))
+    cin = cout = 256
+    if dcn_n > 0:
+        avg_s = dcn_ms / dcn_n * 1e-3
+        flops = 2.0 * npos * cout * cin * 9
+        alg_bytes = 4.0 * (npos * cin + npos * 18 + 9 * cin * cout + npos * cout)
+        achieved = flops / avg_s / 1e12
+        traffic = None
+        pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc.json')
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                if args.batch == pmc.get('dcn_fwd', {}).get('batch'):
+                    traffic = pmc['dcn_fwd']['hbm_bytes_per_launch']
+            except Exception:
+                traffic = None
+        roof = dict(kernel='dcn_fwd_mfma2_kernel', bound='mfma', achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS,
+                    unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=traffic, avg_launch_us=avg_s * 1e6,
+                    launches=dcn_n, positions_per_launch=npos, algorithmic_flops_per_launch=flops,
+                    algorithmic_bytes_per_launch=alg_bytes,
+                    note='exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense = the fp32 vector peak); two '
+                         'launches per image (cls + refine DeformConv)')
+    # ---- the rotated-IoU + NMS stage (HBM is the formal bound, the work is fp32 VALU) --------------------------------
+    mask_ms, mask_n = prof['nms_mask']
+    nms = None
     if mask_n > 0 and M > 0:
         avg_s = mask_ms / mask_n * 1e-3
-        # algorithmic bytes of the mask formulation: 36*M read + mask words 8*M*ceil(M/64) written
         cb = (M + 63) // 64
-        alg_bytes = 36.0 * M + 8.0 * M * cb
-        achieved = alg_bytes / avg_s / 1e9
+        alg_bytes = 36.0 * M + 8.0 * M * cb       # SURVEY 8d, mask formulation
         pairs = M * (M - 1) / 2.0
-        roof = dict(kernel='nms_mask_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=achieved / HBM_PEAK_GBS, traffic=None, avg_launch_us=avg_s * 1e6, launches=mask_n,
-                    boxes_per_launch=M, algorithmic_bytes_per_launch=alg_bytes,
-                    alu=dict(pairs_per_launch=pairs, gpairs_per_s=pairs / avg_s / 1e9,
-                             note='rotated IoU is ALU-bound: ~5 kflop fp32 per pair (16 triangle-fan terms)',
-                             est_frac_fp32_vector_peak=pairs * 5e3 / avg_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS))
+        nms = dict(stage_us_per_img=nms_us, boxes=M, mask_kernel_us=avg_s * 1e6,
+                   sweep_kernel_us=(prof['nms_sweep'][0] / prof['nms_sweep'][1] * 1e3) if prof['nms_sweep'][1] else None,
+                   algorithmic_bytes_per_launch=alg_bytes, hbm_gbs=alg_bytes / avg_s / 1e9,
+                   hbm_frac=alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, pairs_per_launch=pairs,
+                   gpairs_per_s=pairs / avg_s / 1e9,
+                   note='bit-exact fp32 triangle-fan IoU: ALU-bound, 0.6 MB of traffic per launch')
     cpu = None
     if not args.no_cpu_baseline and M > 0:
-        dt, kept = cpu_baseline(dets.cpu().numpy(), cap['thr'])
+        dt, kept, reps = cpu_baseline(dets.cpu().numpy(), cap['thr'])
         cpu = dict(value=dt * 1e6, unit='us/img (rotated-IoU + poly NMS stage)', cores=1, kind='port',
-                   sample='1 image, %d class-offset detections, fp64 polyiou + py_cpu_nms_poly greedy loop '
-                          '(C port of DOTA_devkit/polyiou.cpp + ResultMerge.py:18-41), kept %d' % (M, kept))
+                   sample='%d repeats of 1 image, %d class-offset detections, fp64 polyiou + py_cpu_nms_poly greedy '
+                          'loop (C port of DOTA_devkit/polyiou.cpp + ResultMerge.py:18-41), kept %d'
+                          % (reps, M, kept), gpu_stage_us_per_img=nms_us)
 
     out = {
         'metric': 'images/sec (1024x1024 DOTA, R-50 FPN)', 'value': value, 'unit': 'images/s', 'n_gpus': world,
@@ -217,7 +252,7 @@ def main():
         'detections_per_step': ndet,
         'rotated_iou_nms_us_per_img': nms_us, 'nms_boxes': M,
         'kernel_us': {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()},
-        'roofline': roof, 'cpu_baseline': cpu,
+        'roofline': roof, 'nms': nms, 'cpu_baseline': cpu,
     }
     print(json.dumps(out))
     if distributed:

@@ -2,6 +2,7 @@
 mmdet/ops/norm.py:3-55, mmcv.cnn init functions).  Stock PyTorch modules; parameter names match the released
 checkpoints (`<name>.conv.weight`, `<name>.gn.weight`, ...)."""
 import numpy as np
+import torch
 import torch.nn as nn
 
 norm_cfg_table = {'BN': ('bn', nn.BatchNorm2d), 'SyncBN': ('bn', nn.SyncBatchNorm), 'GN': ('gn', nn.GroupNorm)}
@@ -98,6 +99,11 @@ class ConvModule(nn.Module):
 
     def forward(self, x, activate=True, norm=True):
         x = self.conv(x)
+        if norm and self.with_norm and isinstance(self.norm, nn.GroupNorm) and not torch.is_grad_enabled() \
+                and x.is_cuda and x.dtype == torch.float32:
+            # inference: GroupNorm (+ ReLU) as one fused HIP launch pair (mmdet_ops/fused_norm.py)
+            from ..mmdet_ops.fused_norm import group_norm_act_multi
+            return group_norm_act_multi([x], self.norm, relu=bool(activate and self.with_activation), inplace=True)[0]
         if norm and self.with_norm:
             x = self.norm(x)
         if activate and self.with_activation:

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Fold the rocprofv3 --pmc passes (gpurun_out/pmc_*/.../*counter_collection.csv, one pass per counter set, produced by
+tools/pmc_pass.sh on tools/run_hot_kernels.py) into profiles/<name>_pmc.json + a readable summary.
+HBM bytes per launch = 2 * FETCH_SIZE (gfx950: the counter tallies 128-B requests of wide reads at 64 B, see
+/opt/skills/guides/MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KiB, averaged over the launches of the pass.
+usage: tools/make_pmc_json.py profiles/r01 gpurun_out/pmc_a gpurun_out/pmc_b ..."""
+import collections, csv, glob, json, sys
+
+dst, dirs = sys.argv[1], sys.argv[2:]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in dirs:
+    for f in glob.glob(d + '/*/*counter_collection.csv'):
+        for r in csv.DictReader(open(f)):
+            k = r['Kernel_Name']
+            key = ('dcn_fwd' if 'dcn_fwd' in k else 'nms_mask' if 'nms_mask' in k else 'nms_sweep' if 'nms_sweep' in k
+                   else 'gn_apply' if 'gn_apply' in k else 'gn_stats' if 'gn_stats' in k else None)
+            if key:
+                agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
+out = {}
+for k, c in agg.items():
+    m = {n: sum(v) / len(v) for n, v in c.items()}
+    e = dict(counters=m, launches=max(len(v) for v in c.values()))
+    if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
+        e['fetch_bytes_per_launch'] = 2.0 * m['FETCH_SIZE'] * 1024
+        e['write_bytes_per_launch'] = m['WRITE_SIZE'] * 1024
+        e['hbm_bytes_per_launch'] = e['fetch_bytes_per_launch'] + e['write_bytes_per_launch']
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in m and 'GRBM_GUI_ACTIVE' in m and m['GRBM_GUI_ACTIVE'] > 0:
+        # MFMA busy is summed over 1024 SIMDs, GRBM_GUI_ACTIVE over 8 XCDs
+        e['mfma_busy_frac'] = (m['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0) / (m['GRBM_GUI_ACTIVE'] / 8.0)
+    if k == 'dcn_fwd':
+        e['batch'] = 1
+    out[k] = e
+json.dump(out, open(dst + '_pmc.json', 'w'), indent=1, sort_keys=True)
+with open(dst + '_pmc.txt', 'w') as f:
+    for k, e in sorted(out.items()):
+        f.write('%s  launches %d\n' % (k, e['launches']))
+        for n, v in sorted(e['counters'].items()):
+            f.write('    %-28s %.4g\n' % (n, v))
+        for n in ('fetch_bytes_per_launch', 'write_bytes_per_launch', 'hbm_bytes_per_launch', 'mfma_busy_frac'):
+            if n in e:
+                f.write('    %-28s %.4g\n' % (n, e[n]))
+print(open(dst + '_pmc.txt').read())
