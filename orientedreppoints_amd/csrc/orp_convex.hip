@@ -16,6 +16,7 @@
 
 #include "../../include/orp_hip.h"
 #include "orp_hull.hpp"
+#include "orp_quadfast.hpp"
 #include "orp_prof.hpp"
 
 namespace {
@@ -23,6 +24,7 @@ using orp::Pt;
 
 constexpr int kThreads = 64;                  // one wave per workgroup: LDS per lane is what limits occupancy
 constexpr int kHullKeep = 12;                 // stored hull vertices (a 9-point hull has <= 9)
+constexpr int kMaxGtsPerBlock = 64;           // queue capacity = 64 lanes x this many gts
 
 // float-backed store that widens to double on access (exact)
 struct HullStoreF {
@@ -50,7 +52,8 @@ convex_iou_kernel(const float* __restrict__ pts, int n, const float* __restrict_
   const int j1 = min(k, j0 + gts_per_block);
 
   int n1 = 0;
-  double s_pred = 0.0;
+  double s_pred = 0.0, hull_mabs = 0.0;
+  bool finite_ok = true;
   HullStoreFCap<kHullKeep> H{&s_hull[0][lane], kThreads};
   if (active) {
     Pt<float>* fa = reinterpret_cast<Pt<float>*>(s_a);
@@ -67,12 +70,33 @@ convex_iou_kernel(const float* __restrict__ pts, int n, const float* __restrict_
       for (int a = 0, b = n1 - 1; a < b; a++, b--) { Pt<double> t = H.get(a); H.set(a, H.get(b)); H.set(b, t); }
       s_pred = orp::poly_area<double>(H, n1);
     }
+    for (int v = 0; v < n1; v++) {
+      const Pt<double> p = H.get(v);
+      hull_mabs = fmax(hull_mabs, fmax(fabs(p.x), fabs(p.y)));
+      finite_ok = finite_ok && (fabs(p.x) < 1e100) && (fabs(p.y) < 1e100);
+    }
   }
   __syncthreads();   // region A changes role (single wave, but keep the LDS ordering explicit)
   Pt<double>* da = reinterpret_cast<Pt<double>*>(s_a);
   orp::PolyLds<double> P{da + lane, kThreads};
   orp::PolyLds<double> Q{da + orp::ORP_CLIP_CAP * kThreads + lane, kThreads};
 
+  // ---- phase A: lane = point set, gt wave-uniform.  Exact-zero classifier (fp64 twin of orp::pair_is_far,
+  // orp_quadfast.hpp): proves without a division that every fan term of the (hull, gt) pair is exactly 0.
+  //   cw_far : every hull vertex v is not strictly left of every ray O->w: X[v][w] = w.x*v.y - v.x*w.y <= eps is the
+  //            reference's own stage-1 test, so each term dies there;
+  //   ccw_far: every X > E and the stage-2 crossings stay away from the origin (beta * X[v][d] > E): all vertices that
+  //            reach stage 3 are strictly right of d->O and only origin points remain.  E = 48*u*D*(M+D) + 1e-7 with
+  //            u = 2^-53 (derivation in orp_quadfast.hpp; the absolute 1e-8 of sig() dominates in fp64).
+  // Resolved pairs are written at once; the others are queued and evaluated densely in phase B (one pair per lane,
+  // hull and gt fetched by index), instead of one straggler lane holding 63 finished ones.
+  __shared__ unsigned short s_queue[kThreads * kMaxGtsPerBlock];
+  __shared__ int s_n1[kThreads];
+  __shared__ double s_spred[kThreads];
+  __shared__ int s_qcount;
+  s_n1[lane] = n1; s_spred[lane] = s_pred;
+  if (lane == 0) s_qcount = 0;
+  __syncthreads();
   for (int j = j0; j < j1; j++) {
     const float* g = gts + (size_t)j * 8;          // wave-uniform
     Pt<double> q[4];
@@ -86,22 +110,139 @@ convex_iou_kernel(const float* __restrict__ pts, int n, const float* __restrict_
     };
     if (area4(q) < 0) { Pt<double> t = q[0]; q[0] = q[3]; q[3] = t; t = q[1]; q[1] = q[2]; q[2] = t; }
     const double s_gt = area4(q);
-    if (!active) continue;
-    double inter = 0;
-    Pt<double> a = H.get(0);
-    const Pt<double> h0 = a;
-    for (int i = 0; i < n1; i++) {
-      const Pt<double> b = (i + 1 < n1) ? H.get(i + 1) : h0;
+    bool far = false;
+    if (active && finite_ok) {
+      double gD = 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; t++) { gD = fmax(gD, fmax(fabs(q[t].x), fabs(q[t].y))); }
+      if (gD < 1e100) {
+        double mx = -1e300, mn = 1e300;
+        for (int v = 0; v < n1; v++) {
+          const Pt<double> p = H.get(v);
+#pragma unroll
+          for (int w = 0; w < 4; w++) {
+            const double x = q[w].x * p.y - p.x * q[w].y;
+            mx = fmax(mx, x); mn = fmin(mn, x);
+          }
+        }
+        if (!(mx > 1e-8)) {
+          far = true;
+        } else {
+          const double E = 5.33e-15 * gD * (hull_mabs + gD) + 1e-7;     // 48 * 2^-53 = 5.33e-15
+          if (mn > E) {
+            // oriented gt edges (tri_term swaps c,d when cross(O,c,d) < 0), their direction and value at the origin
+            bool ok = true;
 #pragma unroll 1
-      for (int t = 0; t < 4; t++) {
-        Pt<double> c = q[0], d = q[1];
-        if (t == 1) { c = q[1]; d = q[2]; } else if (t == 2) { c = q[2]; d = q[3]; } else if (t == 3) { c = q[3]; d = q[0]; }
-        inter += orp::tri_term<double, false>(P, Q, a, b, c, d);
+            for (int t = 0; t < 4; t++) {
+              Pt<double> c = q[0], d = q[1];
+              if (t == 1) { c = q[1]; d = q[2]; } else if (t == 2) { c = q[2]; d = q[3]; } else if (t == 3) { c = q[3]; d = q[0]; }
+              const int s2 = orp::sig(orp::cross3(Pt<double>{0.0, 0.0}, c, d));
+              if (s2 == 0) continue;                       // the reference skips degenerate gt edges
+              if (s2 == -1) { const Pt<double> tmp = c; c = d; d = tmp; }
+              const double bax = d.x - c.x, bay = d.y - c.y;
+              const double c0 = bax * (0.0 - c.y) - (0.0 - c.x) * bay;
+              bool okt = c0 > 1e-8;
+              for (int v = 0; v < n1; v++) {
+                const Pt<double> p = H.get(v);
+                double mnv = 1e300;
+#pragma unroll
+                for (int w = 0; w < 4; w++) mnv = fmin(mnv, q[w].x * p.y - p.x * q[w].y);
+                const double cv = bax * (p.y - c.y) - (p.x - c.x) * bay;
+                okt = okt & ((cv > 1e-8) | ((cv < -1e-8) & (mnv * c0 > E * (c0 - cv))));
+              }
+              ok = ok & okt;
+            }
+            far = ok;
+          }
+        }
+      }
+    }
+    if (active && far) {
+      const double inter0 = 0;
+      const double uni0 = fabs(s_pred) + fabs(s_gt) - inter0;
+      out[(size_t)idx * k + j] = (float)(inter0 / uni0);
+    }
+    const bool pend = active && !far;
+    const unsigned long long pmask = __ballot(pend);
+    if (pmask) {
+      const int base = s_qcount;                       // single wave: uniform read, then lane 0 bumps it
+      if (pend) s_queue[base + __popcll(pmask & ((1ull << lane) - 1ull))] = (unsigned short)(((j - j0) << 6) | lane);
+      __syncthreads();
+      if (lane == 0) s_qcount = base + __popcll(pmask);
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: one queued pair per lane ---------------------------------------------------------------------------
+  const int nq = s_qcount;
+  for (int q0 = 0; q0 < nq; q0 += kThreads) {
+    const int qi = q0 + lane;
+    if (qi >= nq) continue;
+    const int item = s_queue[qi];
+    const int sl = item & 63, j = j0 + (item >> 6);
+    const int hn = s_n1[sl];
+    const double hs = s_spred[sl];
+    HullStoreFCap<kHullKeep> HS{&s_hull[0][sl], kThreads};
+    const float* g = gts + (size_t)j * 8;
+    Pt<double> q[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { q[t].x = (double)g[2 * t]; q[t].y = (double)g[2 * t + 1]; }
+    auto area4 = [](const Pt<double>* v) {
+      double res = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) res += v[i].x * v[(i + 1) & 3].y - v[i].y * v[(i + 1) & 3].x;
+      return res / 2.0;
+    };
+    if (area4(q) < 0) { Pt<double> t = q[0]; q[0] = q[3]; q[3] = t; t = q[1]; q[1] = q[2]; q[2] = t; }
+    const double s_gt = area4(q);
+    // oriented gt fan triangles (tri_term swaps c,d when cross(O,c,d) < 0) and their stage-2/3 line constants
+    orp::FanColT<double> gf[4];
+    int gs[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      Pt<double> c = q[t], d = q[(t + 1) & 3];
+      gs[t] = orp::sig(orp::cross3(Pt<double>{0.0, 0.0}, c, d));
+      if (gs[t] == -1) { const Pt<double> tmp = c; c = d; d = tmp; }
+      gf[t] = orp::fan_col<double>(c.x, c.y, d.x, d.y);
+    }
+    // register decision tree (orp_quadfast.hpp, fp64 instantiation, signed terms); generic polygon loop on the
+    // per-lane LDS columns only if a term falls outside the tree
+    double inter = 0;
+    bool slow = false;
+    Pt<double> a = HS.get(0);
+    const Pt<double> h0 = a;
+    for (int i = 0; i < hn; i++) {
+      const Pt<double> b = (i + 1 < hn) ? HS.get(i + 1) : h0;
+      const int s1 = orp::sig(orp::cross3(Pt<double>{0.0, 0.0}, a, b));
+      if (s1 != 0) {
+        const Pt<double> ea = (s1 == -1) ? b : a, eb = (s1 == -1) ? a : b;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          if (gs[t] == 0) continue;
+          double v = orp::tri_term_fast_t<double, false>(ea.x, ea.y, eb.x, eb.y, gf[t], slow);
+          if (s1 * gs[t] == -1) v = -v;
+          inter += v;
+        }
       }
       a = b;
     }
-    const double uni = fabs(s_pred) + fabs(s_gt) - inter;
-    out[(size_t)idx * k + j] = (float)(inter / uni);
+    if (slow) {
+      inter = 0;
+      a = h0;
+      for (int i = 0; i < hn; i++) {
+        const Pt<double> b = (i + 1 < hn) ? HS.get(i + 1) : h0;
+#pragma unroll 1
+        for (int t = 0; t < 4; t++) {
+          Pt<double> c = q[0], d = q[1];
+          if (t == 1) { c = q[1]; d = q[2]; } else if (t == 2) { c = q[2]; d = q[3]; } else if (t == 3) { c = q[3]; d = q[0]; }
+          inter += orp::tri_term<double, false>(P, Q, a, b, c, d);
+        }
+        a = b;
+      }
+    }
+    const double uni = fabs(hs) + fabs(s_gt) - inter;
+    out[(size_t)(blockIdx.x * kThreads + sl) * k + j] = (float)(inter / uni);
   }
 }
 }  // namespace
@@ -115,6 +256,7 @@ int orp_convex_iou(const float* pts, int n, const float* gts, int k, float* out,
   int ysplit = 1;
   while (nb * ysplit < 8192 && ysplit < k) ysplit *= 2;
   int gpb = (k + ysplit - 1) / ysplit;
+  if (gpb > kMaxGtsPerBlock) gpb = kMaxGtsPerBlock;
   ysplit = (k + gpb - 1) / gpb;
   OrpProfScope prof(ORP_PROF_CONVEX_IOU, (hipStream_t)stream);
   hipLaunchKernelGGL(convex_iou_kernel, dim3(nb, ysplit), dim3(kThreads), 0, (hipStream_t)stream, pts, n, gts, k, gpb,

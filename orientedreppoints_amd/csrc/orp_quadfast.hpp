@@ -74,79 +74,87 @@ ORP_HD void quad_prepare(const float* q8, QuadPrep& o) {
 
 // |area| of tri(O,a,b) ∩ tri(O,c,d) for triangles that are ALREADY oriented CCW (generic loop; the slow path).
 template <typename T, typename S1, typename S2>
-ORP_HD T tri_term_oriented(S1& P, S2& Q, Pt<T> a, Pt<T> b, Pt<T> c, Pt<T> d) {
+ORP_HD T tri_term_oriented_signed(S1& P, S2& Q, Pt<T> a, Pt<T> b, Pt<T> c, Pt<T> d) {
   Pt<T> o; o.x = (T)0; o.y = (T)0;
   P.set(0, o); P.set(1, a); P.set(2, b);
   int n = 3;
   n = polygon_cut<T>(P, Q, n, o, c);
   n = polygon_cut<T>(P, Q, n, c, d);
   n = polygon_cut<T>(P, Q, n, d, o);
-  return orp_abs(poly_area<T>(P, n));
+  return poly_area<T>(P, n);
+}
+template <typename T, typename S1, typename S2>
+ORP_HD T tri_term_oriented(S1& P, S2& Q, Pt<T> a, Pt<T> b, Pt<T> c, Pt<T> d) {
+  return orp_abs(tri_term_oriented_signed<T>(P, Q, a, b, c, d));
 }
 
-// sign predicates of sig() as single float compares (NaN behaves as sig(NaN) = 0)
+// sign predicates of sig() as single compares (NaN behaves as sig(NaN) = 0); T = float (quad IoU) or double (convex IoU)
 constexpr float kEps = 1e-8f;
-ORP_HD bool pos_(float d) { return d > kEps; }                      // sig(d) > 0
-ORP_HD bool neg_(float d) { return d < -kEps; }                     // sig(d) < 0
-ORP_HD bool zer_(float d) { return !(orp_abs(d) > kEps); }          // sig(d) == 0
-ORP_HD bool near0(float x, float y) { return zer_(x) & zer_(y); }
-ORP_HD bool same2(float ax, float ay, float bx, float by) { return zer_(ax - bx) & zer_(ay - by); }
+template <typename T> ORP_HD bool pos_(T d) { return d > (T)1e-8; }                       // sig(d) > 0
+template <typename T> ORP_HD bool neg_(T d) { return d < -(T)1e-8; }                      // sig(d) < 0
+template <typename T> ORP_HD bool zer_(T d) { return !(orp_abs(d) > (T)1e-8); }           // sig(d) == 0
+template <typename T> ORP_HD bool near0(T x, T y) { return zer_(x) & zer_(y); }
+template <typename T> ORP_HD bool same2(T ax, T ay, T bx, T by) { return zer_(ax - bx) & zer_(ay - by); }
 
 // Column-side constants of one fan triangle (O, c, d), CCW: everything stage 2 / 3 need that does not depend on the
 // other box.
-struct FanCol {
-  float cx, cy, dx, dy;
-  float bax2, bay2, c0;      // line c->d: direction and its value at the origin
+template <typename T> struct FanColT {
+  T cx, cy, dx, dy;
+  T bax2, bay2, c0;          // line c->d: direction and its value at the origin
 };
-ORP_HD FanCol fan_col(float cx, float cy, float dx, float dy) {
-  FanCol f; f.cx = cx; f.cy = cy; f.dx = dx; f.dy = dy;
+typedef FanColT<float> FanCol;
+template <typename T> ORP_HD FanColT<T> fan_col(T cx, T cy, T dx, T dy) {
+  FanColT<T> f; f.cx = cx; f.cy = cy; f.dx = dx; f.dy = dy;
   f.bax2 = dx - cx; f.bay2 = dy - cy;
-  f.c0 = f.bax2 * (0.f - cy) - (0.f - cx) * f.bay2;
+  f.c0 = f.bax2 * ((T)0 - cy) - ((T)0 - cx) * f.bay2;
   return f;
 }
 
 // crossing of segment cur->nxt with the cutting line, from the line values at both ends (reference lineCross):
 // X = (cur*cnxt - nxt*ccur) / (cnxt - ccur).  With cur or nxt = O = (+0,+0) this is the reference's expression up to
 // the sign of an exact zero.
-ORP_HD void cross_pt(float curx, float cury, float ccur, float nxtx, float nxty, float cnxt, float& x, float& y,
-                     bool& bad) {
-  const float den = cnxt - ccur;
+template <typename T>
+ORP_HD void cross_pt(T curx, T cury, T ccur, T nxtx, T nxty, T cnxt, T& x, T& y, bool& bad) {
+  const T den = cnxt - ccur;
   bad = bad | zer_(den);
   x = (curx * cnxt - nxtx * ccur) / den;
   y = (cury * cnxt - nxty * ccur) / den;
 }
 
-// Returns |area(tri(O,a,b) ∩ tri(O,c,d))| exactly as tri_term_oriented would, or sets `slow` when the decision tree
-// does not cover the configuration (the caller then evaluates the generic loop; the value returned with slow set is
-// meaningless).  (ax,ay)->(bx,by) and f are oriented CCW.  Written for a 64-wide wave: predicates are single float
-// compares combined with non-short-circuit logic (scalar mask ops, no branches), one crossing routine per stage with
-// selected operands (a wave whose lanes sit in different sign cases executes each division block once), early
-// returns only where lanes commonly leave together.
-ORP_HD float tri_term_fast(float ax, float ay, float bx, float by, const FanCol& f, bool& slow) {
+// Returns area(tri(O,a,b) ∩ tri(O,c,d)) (its absolute value when ABS_TERM, the fp32 quad kernels; signed, the fp64
+// convex kernels) exactly as the generic polygon loop would, or sets `slow` when the decision tree does not cover the
+// configuration (the caller then evaluates the generic loop; the value returned with slow set is meaningless).
+// (ax,ay)->(bx,by) and f are oriented CCW.  Written for a 64-wide wave: predicates are single compares combined with
+// non-short-circuit logic (scalar mask ops, no branches), one crossing routine per stage with selected operands (a
+// wave whose lanes sit in different sign cases executes each division block once), early returns only where lanes
+// commonly leave together.
+template <typename T, bool ABS_TERM>
+ORP_HD T tri_term_fast_t(T ax, T ay, T bx, T by, const FanColT<T>& f, bool& slow) {
+  const T Z = (T)0;
   // ---- stage 1: keep left of O->c.  value(p) = c.x*p.y - p.x*c.y, value(O) = 0 exactly ------------------------
-  const float ca = f.cx * ay - ax * f.cy;
-  const float cb = f.cx * by - bx * f.cy;
+  const T ca = f.cx * ay - ax * f.cy;
+  const T cb = f.cx * by - bx * f.cy;
   const bool a_pos = pos_(ca), b_pos = pos_(cb);
-  if (!(a_pos | b_pos)) return 0.f;                      // <= 2 distinct vertices survive: area exactly 0
+  if (!(a_pos | b_pos)) return Z;                        // <= 2 distinct vertices survive: area exactly 0
   bool bad = !b_pos | zer_(ca);                          // (+,-), (+,0), (0,+): not a strict CCW fan pattern
-  float p1x = ax, p1y = ay;
-  const float p2x = bx, p2y = by;
-  if (neg_(ca)) cross_pt(ax, ay, ca, bx, by, cb, p1x, p1y, bad);    // [O, X(a->b), b]
+  T p1x = ax, p1y = ay;
+  const T p2x = bx, p2y = by;
+  if (neg_(ca)) cross_pt<T>(ax, ay, ca, bx, by, cb, p1x, p1y, bad);    // [O, X(a->b), b]
   bad = bad | near0(p1x, p1y) | near0(p2x, p2y) | same2(p1x, p1y, p2x, p2y);
 
   // ---- stage 2: keep left of c->d on [O, p1, p2] ------------------------------------------------------------------
-  const float c1 = f.bax2 * (p1y - f.cy) - (p1x - f.cx) * f.bay2;
-  const float c2 = f.bax2 * (p2y - f.cy) - (p2x - f.cx) * f.bay2;
+  const T c1 = f.bax2 * (p1y - f.cy) - (p1x - f.cx) * f.bay2;
+  const T c2 = f.bax2 * (p2y - f.cy) - (p2x - f.cx) * f.bay2;
   const bool n1 = neg_(c1), n2 = neg_(c2);
   bad = bad | !pos_(f.c0) | zer_(c1) | zer_(c2);
   // working polygon [O, w1, w2, (w3)]
-  float w1x = p1x, w1y = p1y, w2x = p2x, w2y = p2y, w3x = p2x, w3y = p2y;
+  T w1x = p1x, w1y = p1y, w2x = p2x, w2y = p2y, w3x = p2x, w3y = p2y;
   bool four = false;
   if (n1 | n2) {
     // crossing A: the first sign change walking O -> p1 -> p2 -> O; crossing B: the second
-    float Ax, Ay, Bx, By;
-    cross_pt(n1 ? 0.f : p1x, n1 ? 0.f : p1y, n1 ? f.c0 : c1, n1 ? p1x : p2x, n1 ? p1y : p2y, n1 ? c1 : c2, Ax, Ay, bad);
-    cross_pt(n2 ? p2x : p1x, n2 ? p2y : p1y, n2 ? c2 : c1, n2 ? 0.f : p2x, n2 ? 0.f : p2y, n2 ? f.c0 : c2, Bx, By, bad);
+    T Ax, Ay, Bx, By;
+    cross_pt<T>(n1 ? Z : p1x, n1 ? Z : p1y, n1 ? f.c0 : c1, n1 ? p1x : p2x, n1 ? p1y : p2y, n1 ? c1 : c2, Ax, Ay, bad);
+    cross_pt<T>(n2 ? p2x : p1x, n2 ? p2y : p1y, n2 ? c2 : c1, n2 ? Z : p2x, n2 ? Z : p2y, n2 ? f.c0 : c2, Bx, By, bad);
     w1x = n1 ? Ax : p1x; w1y = n1 ? Ay : p1y;           // (-,-): [O,A,B]   (-,+): [O,A,B,p2]   (+,-): [O,p1,A,B]
     w2x = n1 ? Bx : Ax;  w2y = n1 ? By : Ay;
     w3x = n1 ? p2x : Bx; w3y = n1 ? p2y : By;
@@ -156,32 +164,36 @@ ORP_HD float tri_term_fast(float ax, float ay, float bx, float by, const FanCol&
   }
 
   // ---- stage 3: keep left of d->O.  value(O) = 0 exactly ---------------------------------------------------------
-  const float bax3 = 0.f - f.dx, bay3 = 0.f - f.dy;
-  const float t1 = bax3 * (w1y - f.dy) - (w1x - f.dx) * bay3;
-  const float t2 = bax3 * (w2y - f.dy) - (w2x - f.dx) * bay3;
-  const float t3 = bax3 * (w3y - f.dy) - (w3x - f.dx) * bay3;
+  const T bax3 = Z - f.dx, bay3 = Z - f.dy;
+  const T t1 = bax3 * (w1y - f.dy) - (w1x - f.dx) * bay3;
+  const T t2 = bax3 * (w2y - f.dy) - (w2x - f.dx) * bay3;
+  const T t3 = bax3 * (w3y - f.dy) - (w3x - f.dx) * bay3;
   const bool u1p = pos_(t1), u2p = pos_(t2), u3p = pos_(t3);
   // exact zero: triangle with no strictly-left fan vertex, or quad with every vertex strictly right
   const bool dead = four ? (neg_(t1) & neg_(t2) & neg_(t3)) : !(u1p | u2p);
-  if (dead) { slow = slow | bad; return 0.f; }
+  if (dead) { slow = slow | bad; return Z; }
   bad = bad | !u1p | zer_(t2) | (four & (zer_(t3) | (!u2p & u3p)));
   // u1 > 0 from here on (or bad).  `two`: w2 kept; `cut`: some vertex is cut off -> one crossing X after the last kept
   const bool two = u2p;
   const bool cut = four ? !(two & u3p) : !two;
-  float Xx = 0.f, Xy = 0.f;
+  T Xx = Z, Xy = Z;
   if (cut) {
-    cross_pt(two ? w2x : w1x, two ? w2y : w1y, two ? t2 : t1, two ? w3x : w2x, two ? w3y : w2y, two ? t3 : t2, Xx, Xy, bad);
+    cross_pt<T>(two ? w2x : w1x, two ? w2y : w1y, two ? t2 : t1, two ? w3x : w2x, two ? w3y : w2y, two ? t3 : t2, Xx, Xy, bad);
     bad = bad | near0(Xx, Xy) | same2(two ? w2x : w1x, two ? w2y : w1y, Xx, Xy);
   }
   // shoelace over [O, w1, (w2), (w3 | X)]: the two terms touching O are exact zeros
-  const float v2x = two ? w2x : Xx, v2y = two ? w2y : Xy;
-  float res = w1x * v2y - w1y * v2x;
+  const T v2x = two ? w2x : Xx, v2y = two ? w2y : Xy;
+  T res = w1x * v2y - w1y * v2x;
   if (two & four) {
-    const float v3x = cut ? Xx : w3x, v3y = cut ? Xy : w3y;
+    const T v3x = cut ? Xx : w3x, v3y = cut ? Xy : w3y;
     res += w2x * v3y - w2y * v3x;
   }
   slow = slow | bad;
-  return orp_abs(res / 2.0f);
+  res = res / (T)2;
+  return ABS_TERM ? orp_abs(res) : res;
+}
+ORP_HD float tri_term_fast(float ax, float ay, float bx, float by, const FanCol& f, bool& slow) {
+  return tri_term_fast_t<float, true>(ax, ay, bx, by, f, slow);
 }
 
 // ---- pair-level exact-zero classifier ("phase A") ---------------------------------------------------------------

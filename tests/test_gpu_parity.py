@@ -205,6 +205,38 @@ def test_convex_iou(dev, oracle, golden_dir):
         assert np.array_equal(got, oracle.convex_iou(pts, gts), equal_nan=True)
 
 
+def test_convex_iou_far_pair_classifier_cases(dev, oracle):
+    """The exact-zero classifier in front of the fp64 fan must never change a bit: point sets on top of, next to, far
+    from and angularly aligned with the gts; sets at / around the coordinate origin; degenerate sets; negative
+    coordinates; the full first FPN level of a 1024^2 image."""
+    from orientedreppoints_amd.mmdet_ops import convex_iou
+    rng = np.random.RandomState(5)
+    gts = S.gen_gts(24, 77).astype(np.float32)
+    ctr = gts.reshape(-1, 4, 2).mean(1)
+    cases = {
+        "on_gts": S.gen_pointsets(600, 1, around=np.repeat(ctr, 25, 0) + rng.normal(0, 6, (600, 2))),
+        "same_ray": S.gen_pointsets(480, 2, around=np.repeat(ctr, 20, 0) * rng.uniform(0.3, 2.5, (480, 1))),
+        "random": S.gen_pointsets(800, 3),
+        "near_origin": S.gen_pointsets(300, 4, around=rng.normal(0, 10, (300, 2))),
+        "negative": S.gen_pointsets(300, 5, around=rng.uniform(-600, 600, (300, 2))),
+        "degenerate": np.concatenate([np.repeat(rng.uniform(0, 1000, (50, 1, 2)), 9, 1).reshape(50, 18),
+                                      np.zeros((5, 18)),
+                                      np.stack([np.linspace(0, 8, 9)] * 2, 1).reshape(1, 18) + rng.uniform(0, 900, (40, 1))]),
+    }
+    for name, pts in cases.items():
+        pts = np.ascontiguousarray(pts, np.float32)
+        for g in (gts, (gts - 512).astype(np.float32), gts[:1] * 0):
+            got = convex_iou(_t(pts, dev), _t(g, dev)).cpu().numpy()
+            want = oracle.convex_iou(pts, g)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+    # level 0 of a 1024^2 image (128 x 128 locations) against 12 gts
+    yy, xx = np.meshgrid(np.arange(128), np.arange(128), indexing="ij")
+    around = np.stack([xx.reshape(-1) * 8.0 + 4, yy.reshape(-1) * 8.0 + 4], 1)
+    pts = np.ascontiguousarray(S.gen_pointsets(128 * 128, 6, around=around), np.float32)
+    got = convex_iou(_t(pts, dev), _t(gts[:12], dev)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), oracle.convex_iou(pts, gts[:12]).view(np.uint32))
+
+
 # ---- pointwise ops -----------------------------------------------------------------------------------------------
 def test_points_justify(dev, oracle, golden_dir):
     from orientedreppoints_amd.mmdet_ops import pointsJf, points_in_quad_aligned
