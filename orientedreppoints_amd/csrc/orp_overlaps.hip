@@ -3,9 +3,9 @@
 // Replaces
 //   DOTA_devkit/poly_nms_gpu/poly_overlaps_kernel.cu:280-427  (RotBox2Poly, devPolyIoU, overlaps_kernel, _overlaps)
 // and provides the all-pairs fp32 quad IoU (devrIoU / devPolyIoU arithmetic) used by tests and by the merge /
-// evaluation tools.  Layout: lane = column (query / b row) so the [N,K] result is written coalesced, the row box
-// is wave-uniform (scalar loads); one wave per row x 64 columns, 4 waves per workgroup; clipping scratch in
-// per-lane LDS columns (orp_geom.hpp).
+// evaluation tools.  Layout: lane = column (query / b row) so the [N,K] result is written coalesced; a workgroup
+// owns 16 rows x 64 columns and runs the two-phase tile of orp_tile.hpp (exact-zero classifier, then the register
+// decision tree on the queued pairs).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -13,6 +13,8 @@
 
 #include "../../include/orp_hip.h"
 #include "orp_geom.hpp"
+#include "orp_quadfast.hpp"
+#include "orp_tile.hpp"
 
 namespace {
 using orp::Pt;
@@ -34,41 +36,125 @@ __device__ __forceinline__ void rotbox2poly(const float* dbox, float* p8) {
   p8[7] = (float)(y_ctr + ss * (-w / 2.0) + cs * (-h / 2.0));
 }
 
-// MODE 0: rows are quads (stride floats apart); MODE 1: rows are 5-param rotated boxes
+// MODE 0: rows are quads (stride floats apart); MODE 1: rows are 5-param rotated boxes.
+// One workgroup = a tile of kRows rows x 64 columns, evaluated like the NMS mask tile (orp_tile.hpp): every box of
+// the tile is prepared once into LDS (orientation, oriented fan triangles, signs, |area|), phase A (lane = column,
+// row wave-uniform) resolves the pairs whose intersection is exactly 0 with the division-free classifier and writes
+// 0/union directly, the rest are queued and evaluated densely by quads of lanes on the register decision tree.
+constexpr int kRows = 16;              // 4 rows per wave
+
+struct RowFar { float vx[4], vy[4]; float mabs; int slow; };
+
 template <int MODE, bool GUARD>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 4)
 iou_matrix_kernel(const float* __restrict__ a, int n, const float* __restrict__ b, int k, int stride,
                   float* __restrict__ out) {
-  __shared__ Pt<float> scratch[2 * orp::ORP_CLIP_CAP][kThreads];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ orp_tile::TileLds T;
+  __shared__ RowFar rowF[kRows];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = blockIdx.x * 64 + lane;
-  const int row = __builtin_amdgcn_readfirstlane(blockIdx.y * (kThreads / 64) + wave);
-  if (row >= n) return;
-  orp::PolyLds<float> P{&scratch[0][threadIdx.x], kThreads};
-  orp::PolyLds<float> Q{&scratch[orp::ORP_CLIP_CAP][threadIdx.x], kThreads};
-  float p8[8], q8[8];
-  if (MODE == 0) {
-    const float* rp = a + (size_t)row * stride;
+  const int row_base = blockIdx.y * kRows;
+
+  // every wave prepares its lane's column box (registers: classifier constants); wave 0 also files the LDS record
+  orp::FarCol fc;
+  {
+    float q8[8];
+    if (col < k) {
+      if (MODE == 0) {
+        const float* cp = b + (size_t)col * stride;
 #pragma unroll
-    for (int i = 0; i < 8; i++) p8[i] = rp[i];
-  } else {
-    rotbox2poly(a + (size_t)row * 5, p8);
-  }
-  if (col >= k) return;
-  if (MODE == 0) {
-    const float* cp = b + (size_t)col * stride;
+        for (int i = 0; i < 8; i++) q8[i] = cp[i];
+      } else {
+        rotbox2poly(b + (size_t)col * 5, q8);
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; i++) q8[i] = cp[i];
-  } else {
-    rotbox2poly(b + (size_t)col * 5, q8);
+      for (int i = 0; i < 8; i++) q8[i] = 0.f;
+    }
+    orp::QuadPrep cp;
+    orp::quad_prepare(q8, cp);
+    fc = orp::far_col(cp);
+    if (wave == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) T.colE[e][lane] = make_float4(cp.ax[e], cp.ay[e], cp.bx[e], cp.by[e]);
+      T.colS[lane] = orp_tile::pack_signs(cp);
+      T.colArea[lane] = cp.area_abs;
+    }
   }
-  out[(size_t)row * k + col] = orp::quad_iou<float, GUARD>(P, Q, p8, q8);
+  if (tid < kRows) {
+    const int r = row_base + tid;
+    float p8[8];
+    if (r < n) {
+      if (MODE == 0) {
+        const float* rp = a + (size_t)r * stride;
+#pragma unroll
+        for (int i = 0; i < 8; i++) p8[i] = rp[i];
+      } else {
+        rotbox2poly(a + (size_t)r * 5, p8);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) p8[i] = 0.f;
+    }
+    orp::QuadPrep rp;
+    orp::quad_prepare(p8, rp);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      T.rowE[e][tid] = make_float4(rp.ax[e], rp.ay[e], rp.bx[e], rp.by[e]);
+      rowF[tid].vx[e] = rp.vx[e]; rowF[tid].vy[e] = rp.vy[e];
+    }
+    rowF[tid].mabs = rp.mabs; rowF[tid].slow = rp.force_slow;
+    T.rowS[tid] = orp_tile::pack_signs(rp);
+    T.rowArea[tid] = rp.area_abs;
+  }
+  if (tid == 0) T.qcount = 0;
+  __syncthreads();
+  const bool cslow = (T.colS[lane] >> 8) != 0;
+  const float carea = T.colArea[lane];
+
+  // ---- phase A ---------------------------------------------------------------------------------------------------
+  const int rl_first = __builtin_amdgcn_readfirstlane(wave * (kRows / 4));
+  for (int rr = 0; rr < kRows / 4; rr++) {
+    const int rl = rl_first + rr;                        // wave-uniform
+    const int r = row_base + rl;
+    if (r >= n) break;
+    const bool valid = col < k;
+    bool resolved = false;
+    if (valid && !(cslow | (rowF[rl].slow != 0))) {
+      float rvx[4], rvy[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { rvx[e] = rowF[rl].vx[e]; rvy[e] = rowF[rl].vy[e]; }   // uniform address: LDS broadcast
+      resolved = orp::pair_is_far(rvx, rvy, rowF[rl].mabs, fc);
+    }
+    if (resolved) out[(size_t)r * k + col] = orp::iou_of_zero_inter<GUARD>(T.rowArea[rl], carea);
+    const bool pend = valid && !resolved;
+    const unsigned long long pmask = __ballot(pend);
+    if (pmask) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&T.qcount, __popcll(pmask));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (pend) T.queue[base + __popcll(pmask & ((1ull << lane) - 1ull))] = (unsigned short)((rl << 6) | lane);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: one queued pair per quad of lanes -------------------------------------------------------------
+  const int nq = T.qcount;
+  const int kq = lane & 3;
+  for (int q0 = 0; q0 < nq; q0 += kThreads / 4) {        // uniform trip count: DPP needs the whole quad alive
+    const int q = q0 + (tid >> 2);
+    const bool live = q < nq;
+    const int item = live ? T.queue[q] : 0;
+    const int rl = item >> 6, cl = item & 63;
+    const float iou = orp_tile::tile_pair_iou_quad<GUARD>(T, rl, cl, kq, live);
+    if (live && kq == 0) out[(size_t)(row_base + rl) * k + blockIdx.x * 64 + cl] = iou;
+  }
 }
 
 int launch(int mode, int guard, const float* a, int n, const float* b, int k, int stride, float* out, hipStream_t st) {
   if (n < 0 || k < 0 || ((n > 0 && k > 0) && (!a || !b || !out))) return ORP_EINVAL;
   if (n == 0 || k == 0) return ORP_OK;
-  dim3 grid((k + 63) / 64, (n + kThreads / 64 - 1) / (kThreads / 64)), block(kThreads);
+  dim3 grid((k + 63) / 64, (n + kRows - 1) / kRows), block(kThreads);
   if (mode == 1) hipLaunchKernelGGL((iou_matrix_kernel<1, true>), grid, block, 0, st, a, n, b, k, 5, out);
   else if (guard) hipLaunchKernelGGL((iou_matrix_kernel<0, true>), grid, block, 0, st, a, n, b, k, stride, out);
   else hipLaunchKernelGGL((iou_matrix_kernel<0, false>), grid, block, 0, st, a, n, b, k, stride, out);

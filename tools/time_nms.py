@@ -36,3 +36,14 @@ for n, clustered in ((500, True), (2000, True), (2000, False), (5344, True), (16
     m, s = prof(0), prof(1)
     _lib.lib().orp_profile_enable(0)
     print("rnms n=%d clustered=%s: total %.1f us  mask %.1f us  sweep %.1f us  kept=%d parity=%s" % (n, clustered, us, m, s, len(got), ok))
+
+# all-pairs IoU matrix (orp_quad_iou_matrix)
+for n in (2000, 5344):
+    d, _ = S.gen_dense_scene(n, 1)
+    t = torch.from_numpy(np.ascontiguousarray(d[:, :8], np.float32)).to(dev)
+    out = torch.empty((n, n), dtype=torch.float32, device=dev)
+    def run():
+        rc = _lib.lib().orp_quad_iou_matrix(_lib.ptr(t), n, _lib.ptr(t), n, 8, 0, _lib.ptr(out), _lib.stream_of(t))
+        assert rc == 0
+    us = timeit(run, iters=10)
+    print("quad_iou_matrix %d x %d: %.1f us (%.3f ns/pair)" % (n, n, us, us * 1e3 / (n * n)))
