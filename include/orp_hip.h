@@ -194,6 +194,13 @@ int orp_apaa_feature_dissimilarity(const float* const* feats_host, const int* he
 int orp_apaa_select(const float* quality, const int64_t* pos_gt_inds, const int32_t* pos_level, int p, int num_gt,
                     int num_level, int per_level_topk, double top_ratio, uint8_t* keep, void* stream);
 
+/* Soft rotated NMS on the HOST -- replaces rnms_cpu.soft_rnms (mmdet/ops/nms/src/rnms_cpu.cpp:165-333), CPU-only in
+ * the reference too.  dets_host [m,9] fp32 (8 corners + score); method 0 = hard, 1 = linear, 2 = gaussian;
+ * out_host [m,10] receives the surviving rows (8 corners, rescored score, original index as float) in selection
+ * order, *num_out their count. */
+int orp_soft_rnms_host(const float* dets_host, int m, float iou_thr, int method, float sigma, float min_score,
+                       float* out_host, int* num_out);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Fused normalisation + activation passes (inference), SURVEY 8f rank 3 "head towers fused for MI355X".
  * orp_groupnorm_act_multi: GroupNorm (+ ReLU) of the dense-head ConvModules (mmdet/ops/conv_module.py:130-140 as used

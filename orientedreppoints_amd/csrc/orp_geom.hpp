@@ -16,7 +16,7 @@
 // against the oracle before a GPU is involved (tests/host_harness).
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
-#define ORP_HD __device__ __forceinline__
+#define ORP_HD __host__ __device__ __forceinline__
 #else
 #define ORP_HD inline
 #endif

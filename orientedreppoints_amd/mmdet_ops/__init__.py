@@ -4,7 +4,7 @@ LiWentomng/OrientedRepPoints), bound to the MI355X HIP library through include/o
 Same names, argument meaning and error behaviour as the reference wrappers, so `from mmdet.ops import X` call sites
 can be re-pointed here unchanged.
 """
-from .nms_wrapper import rnms, rnms_cuda, poly_nms_gpu  # noqa: F401
+from .nms_wrapper import rnms, rnms_cuda, poly_nms_gpu, soft_rnms  # noqa: F401
 from .minarea_rect import minaerarect  # noqa: F401
 from .iou_wrapper import convex_iou, convex_overlaps, convex_giou  # noqa: F401
 from .chamfer_distance import ChamferDistance2D, Chamfer2D  # noqa: F401

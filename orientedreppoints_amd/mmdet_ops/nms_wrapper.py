@@ -95,3 +95,35 @@ def poly_nms_gpu(dets, thresh, force_cpu=False):
     """mmdet/ops/nms/nms_wrapper.py:11-17 re-export of DOTA_devkit's poly_nms_gpu."""
     from ..dota_devkit.poly_nms_gpu import poly_nms_gpu as _impl
     return _impl(dets, thresh, force_cpu)
+
+
+def soft_rnms(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3):
+    """Soft rotated NMS -- CPU only, as in the reference (mmdet/ops/nms/nms_wrapper.py:120-175 over
+    rnms_cpu.soft_rnms).  dets [M,9] torch tensor or numpy array; returns (new_dets [K,9], inds [K]) in the input's
+    type.  The work is done by the host function `orp_soft_rnms_host` of liborp_hip.so."""
+    import ctypes
+    if isinstance(dets, torch.Tensor):
+        is_tensor = True
+        dets_np = dets.detach().cpu().numpy()
+    elif isinstance(dets, np.ndarray):
+        is_tensor = False
+        dets_np = dets
+    else:
+        raise TypeError('dets must be either a Tensor or numpy array, but got {}'.format(type(dets)))
+    method_codes = {'linear': 1, 'gaussian': 2, 'original': 0}
+    if method not in method_codes:
+        raise ValueError('Invalid method for SoftNMS: {}'.format(method))
+    d = np.ascontiguousarray(dets_np, np.float32)
+    m = d.shape[0]
+    out = np.empty((max(m, 1), 10), np.float32)
+    num = ctypes.c_int(0)
+    rc = _lib.lib().orp_soft_rnms_host(d.ctypes.data_as(ctypes.c_void_p), m, float(iou_thr), method_codes[method],
+                                       float(sigma), float(min_score), out.ctypes.data_as(ctypes.c_void_p),
+                                       ctypes.cast(ctypes.byref(num), ctypes.c_void_p))
+    _lib.check(rc, "orp_soft_rnms_host")
+    res = out[:num.value]
+    new_dets, inds = res[:, :9], res[:, 9]
+    if is_tensor:
+        return (torch.from_numpy(new_dets.copy()).to(device=dets.device, dtype=dets.dtype),
+                torch.from_numpy(inds.copy()).to(device=dets.device, dtype=torch.long))
+    return new_dets.astype(dets.dtype), inds.astype(np.int64)
