@@ -160,6 +160,11 @@ int orp_dcn_col2im(const float* grad_columns, const float* input, const float* o
                    int c_in, int height, int width, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
                    int dil_h, int dil_w, int deformable_groups, float* grad_input, float* grad_offset, float* grad_mask,
                    void* stream);
+/* channel-parallel variant for deformable_groups = 1: grad_columns_t [B*Ho*Wo, kh*kw, Cin] (position-major, from
+ * grad_out(NHWC) . W[Cout, kh*kw*Cin]), input / grad_input NHWC (grad_input zeroed by the caller), offsets NCHW. */
+int orp_dcn_col2im_nhwc(const float* grad_columns_t, const float* input_nhwc, const float* offset, int batch, int c_in,
+                        int height, int width, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                        int dil_h, int dil_w, float* grad_input_nhwc, float* grad_offset, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Assignment side of the APAA training path (what the reference does with Python loops over ground truths).

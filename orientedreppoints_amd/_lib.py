@@ -56,6 +56,7 @@ _SIGNATURES = {
     "orp_dcn_forward_multi": (_i, [_vp, _i, _i, _i, _i, _vp] + [_i] * 10 + [_vp, _sz, _vp]),
     "orp_dcn_im2col": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp]),
     "orp_dcn_col2im": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp, _vp]),
+    "orp_dcn_col2im_nhwc": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp, _vp, _vp]),
     "orp_dcn_forward_direct": (_i, [_vp] * 6 + [_i] * 15 + [_vp]),
     "orp_soft_rnms_host": (_i, [_vp, _i, _f, _i, _f, _f, _vp, _vp]),
     "orp_groupnorm_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),

@@ -51,8 +51,29 @@ def _prep(*ts):
     return [t.detach().float().contiguous() if t is not None else None for t in ts]
 
 
+def _backward_input_nhwc(input, offset, weight, grad_output, stride, padding, dilation):
+    """groups = deformable_groups = 1: position-major grad columns (one GEMM on NHWC grad_out) + the channel-parallel
+    col2im kernel (coalesced rows, wave-reduced grad_offset)."""
+    B, C, H, W, kh, kw, Ho, Wo = _geo(input, weight, stride, padding, dilation)
+    Cout = weight.size(0)
+    go = grad_output.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout)                  # NHWC rows (view or one copy)
+    w2 = weight.permute(0, 2, 3, 1).reshape(Cout, kh * kw * C)                       # [o][tap][c]
+    gcol_t = torch.mm(go, w2)                                                        # [B*P, taps*C]
+    x_nhwc = input.permute(0, 2, 3, 1).contiguous()
+    gx_nhwc = torch.zeros_like(x_nhwc)
+    grad_offset = torch.empty_like(offset)
+    with torch.cuda.device(input.device):
+        rc = _lib.lib().orp_dcn_col2im_nhwc(_lib.ptr(gcol_t), _lib.ptr(x_nhwc), _lib.ptr(offset), B, C, H, W, kh, kw,
+                                            stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                                            _lib.ptr(gx_nhwc), _lib.ptr(grad_offset), _lib.stream_of(input))
+    _lib.check(rc, "orp_dcn_col2im_nhwc")
+    return gx_nhwc.permute(0, 3, 1, 2).contiguous(), grad_offset
+
+
 def backward_input(input, offset, weight, grad_output, stride, padding, dilation, groups, deformable_groups):
     input, offset, weight, grad_output = _prep(input, offset, weight, grad_output)
+    if groups == 1 and deformable_groups == 1:
+        return _backward_input_nhwc(input, offset, weight, grad_output, stride, padding, dilation)
     gcol = _grad_columns(weight, grad_output, groups)
     gi, go, _ = _col2im(gcol, input, offset, None, weight, stride, padding, dilation, deformable_groups)
     return gi, go
