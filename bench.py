@@ -113,6 +113,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=1, help='images per GPU per step (config 1: 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cudnn-benchmark', type=int, default=0,
+                    help='torch.backends.cudnn.benchmark (MIOpen find mode), the reference\'s cfg.cudnn_benchmark '
+                         '(tools/test.py:108-110)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -127,6 +130,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', rank=rank, world_size=world)
     _lib.lib()     # fail loudly if the HIP library is missing
+    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
 
     torch.manual_seed(0)
     model = build_detector(ConfigDict(r50_model), train_cfg=None, test_cfg=ConfigDict(TEST_CFG)).to(dev).eval()
