@@ -124,6 +124,77 @@ def multiclass_rnms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, 
     return torch.cat([bboxes, scores[:, None]], 1), labels
 
 
+def multiclass_rnms_static(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num, multi_reppoints, capacity=16384):
+    """`multiclass_rnms` with the reference's exact semantics (bbox_nms.py:93-182: same detections, same order, the
+    class-offset trick on fp32 coordinates) but with STATIC shapes and no host synchronisation: boolean-mask indexing /
+    nonzero (one blocking D2H each) become a cumsum + scatter into a fixed-capacity buffer, the NMS takes its box
+    count from device memory (`orp_rnms_batched`, one segment [0, n)), the `> max_num` re-sort is a top-k selected on
+    device.  Everything between the head's convolutions and the final result copy is stream-ordered and
+    hipGraph-capturable.
+
+    Returns a packed float32 tensor [max_num + 1, W + 2]: rows = [reppoints | 8 corners | score | label]; the last row
+    holds (count, overflow).  overflow = more than `capacity` (point, class) pairs passed score_thr -> the caller must
+    fall back to the dynamic path."""
+    M0 = multi_scores.size(0)
+    C = multi_scores.size(1) - 1
+    dev = multi_scores.device
+    assert multi_bboxes.shape[1] == 8, 'static path: class-agnostic boxes [M0, 8]'
+    flat = multi_scores[:, 1:].reshape(-1)
+    numel = flat.numel()
+    cap = int(min(capacity, numel))
+    valid = flat > score_thr
+    total = valid.sum()
+    pos = torch.cumsum(valid, 0) - 1
+    slot = torch.where(valid & (pos < cap), pos, torch.full_like(pos, cap))
+    idx = torch.zeros(cap + 1, dtype=torch.long, device=dev).scatter_(0, slot, torch.arange(numel, device=dev))[:cap]
+    n = torch.clamp(total, max=cap)
+    ar = torch.arange(cap, device=dev)
+    live = ar < n
+    pt, lab = idx // C, idx % C
+    boxes = multi_bboxes[pt]
+    neg_inf = torch.full((), float('-inf'), device=dev)
+    sc = torch.where(live, flat[idx], neg_inf)
+    max_coordinate = torch.where(live[:, None], boxes, neg_inf).max()
+    offsets = lab.to(boxes) * (max_coordinate + 1)
+    dets = torch.cat([boxes + offsets[:, None], sc[:, None]], 1)
+    nms_cfg_ = dict(nms_cfg)
+    nms_type = nms_cfg_.pop('type', 'rnms')
+    assert nms_type == 'rnms', 'static path implements the rnms configuration of the DOTA configs'
+    seg = torch.stack([torch.zeros_like(n), n]).to(torch.int32)
+    keep, num = nms_wrapper.rnms_batched_device(dets, seg, cap, nms_cfg_.get('iou_thr', 0.4))
+    kn = num[0].to(torch.long)
+    livek = ar < kn
+    sel = torch.where(livek, keep, torch.zeros_like(keep))
+    k_scores = torch.where(livek, sc[sel], neg_inf)
+    m = int(min(max_num, cap)) if max_num > 0 else cap
+    # reference: keep order (ascending index) unless more than max_num survive, then score-descending top max_num
+    _, top_i = k_scores.topk(m)
+    pick = torch.where(kn > m, top_i, ar[:m])
+    rows = sel[pick]
+    count = torch.clamp(kn, max=m)
+    out_live = (ar[:m] < count)
+    body = torch.cat([multi_reppoints[pt[rows]], boxes[rows], sc[rows][:, None], lab[rows].to(boxes)[:, None]], 1)
+    body = torch.where(out_live[:, None], body, torch.zeros_like(body))
+    tail = torch.zeros(1, body.size(1), dtype=body.dtype, device=dev)
+    tail[0, 0] = count.to(body.dtype)
+    tail[0, 1] = (total > cap).to(body.dtype)
+    return torch.cat([body, tail], 0)
+
+
+def rbbox2result_packed(packed, num_classes):
+    """One D2H copy of the packed static result -> the reference's per-class list (rbbox2result).  Returns None when
+    the capacity overflowed (caller falls back to the dynamic path)."""
+    host = packed.cpu().numpy()
+    count, overflow = int(host[-1, 0]), bool(host[-1, 1])
+    if overflow:
+        return None
+    if count == 0:
+        return [np.zeros((0, 9), dtype=np.float32) for _ in range(num_classes - 1)]
+    bboxes = host[:count, :-1]
+    labels = host[:count, -1].astype(np.int64)
+    return [bboxes[labels == i, :] for i in range(num_classes - 1)]
+
+
 def rbbox2result(bboxes, labels, num_classes):
     if bboxes.shape[0] == 0:
         return [np.zeros((0, 9), dtype=np.float32) for _ in range(num_classes - 1)]

@@ -3,7 +3,7 @@ base.py:97-149): backbone + neck on stock PyTorch-ROCm, dense head on the HIP op
 import torch
 import torch.nn as nn
 
-from .core import rbbox2result
+from .core import rbbox2result, rbbox2result_packed
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
 
@@ -53,6 +53,13 @@ class OrientedRepPointsDetector(nn.Module):
         x = self.extract_feat(img)
         outs = self.bbox_head(x)
         bbox_inputs = tuple(outs) + (img_metas, self.test_cfg, rescale)
+        if img.is_cuda and self.test_cfg.get('static_postprocess', True) and \
+                self.test_cfg.nms.get('type', 'rnms') == 'rnms' and not torch.is_grad_enabled():
+            # decode -> multiclass NMS -> packing without a single host synchronisation; ONE D2H per image at the end
+            packed = self.bbox_head.get_bboxes(*bbox_inputs, static=True)
+            results = [rbbox2result_packed(p, self.bbox_head.num_classes) for p in packed]
+            if all(r is not None for r in results):
+                return results
         bbox_list = self.bbox_head.get_bboxes(*bbox_inputs)
         return [rbbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)
                 for det_bboxes, det_labels in bbox_list]

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from ..mmdet_ops.deform_conv import DeformConv
 from ..mmdet_ops.minarea_rect import minaerarect_decode
-from .core import PointGenerator, multi_apply, multiclass_rnms
+from .core import PointGenerator, multi_apply, multiclass_rnms, multiclass_rnms_static
 from .layers import ConvModule, bias_init_with_prob, normal_init
 from .registry import HEADS, build_loss
 
@@ -169,7 +169,7 @@ class OrientedRepPointsHead(nn.Module):
 
     # ---- test-time decode + NMS ------------------------------------------------------------------------------------
     def get_bboxes(self, cls_scores, pts_preds_init, pts_preds_refine, base_feats, img_metas, cfg, rescale=False,
-                   nms=True):
+                   nms=True, static=False):
         assert len(cls_scores) == len(pts_preds_refine)
         num_levels = len(cls_scores)
         device = cls_scores[0].device
@@ -182,11 +182,11 @@ class OrientedRepPointsHead(nn.Module):
             img_shape = img_metas[img_id]['img_shape']
             scale_factor = img_metas[img_id]['scale_factor']
             result_list.append(self.get_bboxes_single(cls_score_list, points_pred_list, mlvl_points, img_shape,
-                                                      scale_factor, cfg, rescale, nms))
+                                                      scale_factor, cfg, rescale, nms, static=static))
         return result_list
 
     def get_bboxes_single(self, cls_scores, points_preds, mlvl_points, img_shape, scale_factor, cfg, rescale=False,
-                          nms=True):
+                          nms=True, static=False):
         assert len(cls_scores) == len(points_preds) == len(mlvl_points)
         lvl_pts, lvl_scores, lvl_centers, lvl_strides = [], [], [], []
         for i_lvl, (cls_score, points_pred, points) in enumerate(zip(cls_scores, points_preds, mlvl_points)):
@@ -223,6 +223,10 @@ class OrientedRepPointsHead(nn.Module):
         if self.use_sigmoid_cls:
             padding = mlvl_scores.new_zeros(mlvl_scores.shape[0], 1)
             mlvl_scores = torch.cat([padding, mlvl_scores], dim=1)
+        if nms and static:
+            # sync-free, fixed-shape variant: one packed device tensor (see core.multiclass_rnms_static)
+            return multiclass_rnms_static(mlvl_bboxes, mlvl_scores, cfg.score_thr, cfg.nms, cfg.max_per_img,
+                                          mlvl_reppoints, capacity=cfg.get('static_capacity', 16384))
         if nms:
             return multiclass_rnms(mlvl_bboxes, mlvl_scores, cfg.score_thr, cfg.nms, cfg.max_per_img,
                                    multi_reppoints=mlvl_reppoints)

@@ -625,3 +625,34 @@ def test_detector_fused_inference_matches_stock_modules(dev):
         for a, b in zip(a_list, b_list):
             scale = max(1.0, float(b.abs().max()))
             assert float((a - b.detach()).abs().max()) <= 1e-3 * scale
+
+
+def test_static_postprocess_equals_reference_path(dev):
+    """decode -> multiclass_rnms -> rbbox2result: the sync-free fixed-shape pipeline must return exactly what the
+    reference-shaped dynamic path returns (same detections, same per-class order), incl. the > max_per_img re-sort,
+    the empty case and the capacity-overflow fallback."""
+    from orientedreppoints_amd.mmdet_models import ConfigDict
+    from orientedreppoints_amd.mmdet_models.core import (multiclass_rnms, multiclass_rnms_static, rbbox2result,
+                                                         rbbox2result_packed)
+    rng = np.random.RandomState(3)
+    for n, thr, max_num, cap in ((1500, 0.05, 2000, 16384), (1500, 0.05, 300, 16384), (400, 0.999, 2000, 16384),
+                                 (1500, 0.05, 2000, 512)):
+        d = S.gen_polys(n, 21, clustered=True)
+        boxes = _t(d[:, :8], dev)
+        scores = np.zeros((n, 16), np.float32)
+        scores[:, 1:] = rng.uniform(0, 1, (n, 15)) * (rng.uniform(0, 1, (n, 15)) < 0.08)
+        scores = _t(scores, dev)
+        rep = _t(rng.uniform(0, 1024, (n, 18)), dev)
+        nms_cfg = ConfigDict(type='rnms', iou_thr=0.4)
+        want_b, want_l = multiclass_rnms(boxes, scores, thr, nms_cfg, max_num, multi_reppoints=rep)
+        want = rbbox2result(want_b, want_l, 16)
+        got = rbbox2result_packed(multiclass_rnms_static(boxes, scores, thr, nms_cfg, max_num, rep, capacity=cap), 16)
+        if cap < int((scores[:, 1:] > thr).sum()):
+            assert got is None
+            continue
+        assert len(got) == len(want) == 15
+        for g_, w_ in zip(got, want):
+            if want_b.size(0) > max_num and w_.shape[0] > 0:      # unstable score sort in the reference: compare as sets
+                assert sorted(map(tuple, g_.tolist())) == sorted(map(tuple, w_.tolist()))
+            else:
+                assert np.array_equal(g_, w_)
