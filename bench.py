@@ -113,6 +113,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=1, help='images per GPU per step (config 1: 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', type=int, default=0,
+                    help='1: additionally time the step as ONE hipGraph replay (device part captured once; reported '
+                         'as graph_replay_ms next to the eager measurement)')
     ap.add_argument('--cudnn-benchmark', type=int, default=0,
                     help='torch.backends.cudnn.benchmark (MIOpen find mode), the reference\'s cfg.cudnn_benchmark '
                          '(tools/test.py:108-110)')
@@ -166,6 +169,39 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    graph_ms = None
+    if args.graph and not distributed:
+        # the whole device part (backbone .. packed detections) as one hipGraph; D2H + per-class split stay outside
+        from orientedreppoints_amd.mmdet_models.core import rbbox2result_packed
+        head = model.bbox_head
+        static_img = img.clone()
+
+        def device_part():
+            outs = head(model.extract_feat(static_img))
+            return head.get_bboxes(*(tuple(outs) + (metas, model.test_cfg, False)), static=True)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(3):
+                    device_part()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g):
+                packed = device_part()
+            for _ in range(args.warmup):
+                g.replay()
+                [rbbox2result_packed(p, head.num_classes) for p in packed]
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for _ in range(args.steps):
+                g.replay()
+                [rbbox2result_packed(p, head.num_classes) for p in packed]
+            torch.cuda.synchronize()
+            graph_ms = (time.perf_counter() - tg) / args.steps * 1e3
+        except Exception as e:   # noqa: BLE001  (report, do not fail the eager measurement)
+            graph_ms = 'failed: %s' % (str(e)[:200],)
 
     prof = {name: read_prof(slot) for name, slot in
             (('nms_mask', 0), ('nms_sweep', 1), ('dcn_fwd', 3), ('minarearect', 4))}
@@ -256,6 +292,7 @@ def main():
         'detections_per_step': ndet,
         'rotated_iou_nms_us_per_img': nms_us, 'nms_boxes': M,
         'kernel_us': {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()},
+        'graph_replay_ms': graph_ms,
         'roofline': roof, 'nms': nms, 'cpu_baseline': cpu,
     }
     print(json.dumps(out))

@@ -522,8 +522,10 @@ size_t mfma2_smem() {
 template <int MT, bool OUT_NCHW>
 hipError_t launch_mfma2(const FwdParams& P, int tiles, int nblk_n, hipStream_t st) {
   const size_t smem = mfma2_smem<MT>();
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma2_kernel<MT, OUT_NCHW>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  // once per kernel instantiation (not per launch: the call is not allowed while a stream is being captured)
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma2_kernel<MT, OUT_NCHW>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipError_t e = attr;
   if (e != hipSuccess) return e;
   const int per = (tiles + 7) >> 3;
   hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<MT, OUT_NCHW>), dim3(per * 8, nblk_n), dim3(kThreads2), smem, st, P, tiles);
@@ -683,14 +685,14 @@ int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int bat
   const size_t smem = sizeof(float) * (2 * BM * ASTR + 2 * KC * BN) + (sizeof(float4) + sizeof(int4)) * BM * MAX_TAPS;
   dim3 grid(tiles, nblk_n);
   if (out_layout == 0) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma_kernel<true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (attr != hipSuccess) return (int)attr;
     hipLaunchKernelGGL(dcn_fwd_mfma_kernel<true>, grid, dim3(kThreads), smem, st, P);
   } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma_kernel<false>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (attr != hipSuccess) return (int)attr;
     hipLaunchKernelGGL(dcn_fwd_mfma_kernel<false>, grid, dim3(kThreads), smem, st, P);
   }
   e = hipGetLastError();

@@ -113,6 +113,17 @@ class OrientedRepPointsHead(nn.Module):
         pts_out_init = self.reppoints_pts_init_out(self.relu(self.reppoints_pts_init_conv(pts_feat)))
         return cls_feat, pts_feat, pts_out_init
 
+    def _base_offset_on(self, x):
+        """dcn_base_offset on x's device / dtype, cached (the reference re-uploads the 18 floats every forward with
+        `.type_as(x)`: a blocking H2D copy per call, and illegal inside a stream capture)."""
+        key = (x.device, x.dtype)
+        cache = self.__dict__.setdefault('_base_offset_cache', {})
+        t = cache.get(key)
+        if t is None:
+            t = self.dcn_base_offset.to(device=x.device, dtype=x.dtype)
+            cache[key] = t
+        return t
+
     def _fused_towers_ok(self, feats):
         x = feats[0]
         if not (x.is_cuda and x.dtype == torch.float32):
@@ -147,7 +158,7 @@ class OrientedRepPointsHead(nn.Module):
             return multi_apply(self.forward_single, feats)
         # inference: same arithmetic, but every layer covers all levels at once: the tower ConvModules run their
         # GroupNorm+ReLU as one fused HIP launch pair over the five levels, each DeformConv is ONE launch
-        dcn_base_offset = self.dcn_base_offset.type_as(feats[0])
+        dcn_base_offset = self._base_offset_on(feats[0])
         fused = self._fused_towers_ok(feats)
         if fused:
             cls_feats = self._tower_multi(self.cls_convs, feats)
