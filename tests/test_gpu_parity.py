@@ -668,7 +668,8 @@ def test_inference_device_part_is_hipgraph_capturable(dev):
     model = build_detector(ConfigDict(r50_model), train_cfg=None, test_cfg=ConfigDict(test_cfg)).to(dev).eval()
     head = model.bbox_head
     with torch.no_grad():
-        head.reppoints_cls_out.bias.fill_(-2.0)          # ~12 % of the (point, class) pairs pass score_thr
+        head.reppoints_cls_out.weight.normal_(0, 0.05)
+        head.reppoints_cls_out.bias.fill_(-3.3)          # logit(0.05) = -2.94: a minority of the pairs pass score_thr
         head.reppoints_pts_init_out.bias.copy_(torch.tensor(
             [[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 0], [0, 1], [1, -1], [1, 0], [1, 1]],
             dtype=torch.float32, device=dev).reshape(-1) * 2.0)
