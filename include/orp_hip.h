@@ -199,6 +199,15 @@ int orp_apaa_feature_dissimilarity(const float* const* feats_host, const int* he
 int orp_apaa_select(const float* quality, const int64_t* pos_gt_inds, const int32_t* pos_level, int p, int num_gt,
                     int num_level, int per_level_topk, double top_ratio, uint8_t* keep, void* stream);
 
+/* fp64 greedy polygon NMS -- the merge step of the DOTA evaluation workflow (DOTA_devkit/ResultMerge.py:18-41
+ * py_cpu_nms_poly over polyiou.cpp:108-128 iou_poly), SURVEY 8f rank 2.  dets_sorted [n,9] DOUBLE on device, already
+ * in visiting order (the caller applies numpy's `scores.argsort()[::-1]` exactly as the reference does); a box
+ * survives a kept predecessor only if iou <= thr (NaN suppresses, ResultMerge.py:38).  keep_out [n] int64 receives the
+ * kept POSITIONS in visiting order, num_keep[0] their count. */
+size_t orp_poly_nms_f64_workspace_bytes(int n);
+int orp_poly_nms_f64(const double* dets_sorted, int n, double iou_thr, int64_t* keep_out, int32_t* num_keep,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* Soft rotated NMS on the HOST -- replaces rnms_cpu.soft_rnms (mmdet/ops/nms/src/rnms_cpu.cpp:165-333), CPU-only in
  * the reference too.  dets_host [m,9] fp32 (8 corners + score); method 0 = hard, 1 = linear, 2 = gaussian;
  * out_host [m,10] receives the surviving rows (8 corners, rescored score, original index as float) in selection

@@ -188,6 +188,55 @@ nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restric
   if (tid < rpb && row_base + tid < n) mask[(size_t)(s0 + row_base + tid) * mask_stride + c] = T.words[tid];
 }
 
+// ---- fp64 mask kernel: the merge NMS of DOTA_devkit/ResultMerge.py (polyiou.cpp arithmetic) -------------------------
+// Same triangle-fan core instantiated in double (orp_quadfast.hpp is templated on the precision): classifier first,
+// register decision tree for what it leaves, generic polygon loop as the fallback -- one pair per lane, no queue
+// (merge sets are a few thousand boxes per (class, image); the CPU reference spends minutes in python here).
+// Suppression follows ResultMerge.py:38 `inds = np.where(ovr <= thresh)`: a box is dropped unless iou <= thr, so a NaN
+// IoU (degenerate boxes) suppresses -- the opposite of the `iou > thr` test of rnms.
+__global__ void prep_boxes_f64_kernel(const double* __restrict__ dets, int n, orp::QuadPrepT<double>* __restrict__ prep) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double q8[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) q8[k] = dets[(size_t)i * 9 + k];
+  orp::QuadPrepT<double> p;
+  orp::quad_prepare<double>(q8, p);
+  prep[i] = p;
+}
+
+__global__ void __launch_bounds__(kMaskThreads)
+nms_mask_f64_kernel(const orp::QuadPrepT<double>* __restrict__ prep, int n, int rows_per_wave, int mask_stride,
+                    double thr, u64* __restrict__ mask) {
+  const int c = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rpb = rows_per_wave * (kMaskThreads / 64);
+  const int row_base = blockIdx.y * rpb;
+  if (row_base >= n || c * 64 >= n) return;
+  if ((row_base >> 6) > c) return;
+  const int col = c * 64 + lane;
+  orp::QuadPrepT<double> cp;
+  if (col < n) {
+    cp = prep[col];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { cp.ax[k] = cp.ay[k] = cp.bx[k] = cp.by[k] = cp.vx[k] = cp.vy[k] = 0.0; cp.s[k] = 0; }
+    cp.area_abs = 0.0; cp.force_slow = 0; cp.mabs = 0.0; cp.pad0 = 0.0;
+  }
+  const int r_first = __builtin_amdgcn_readfirstlane(row_base + wave * rows_per_wave);
+  for (int rr = 0; rr < rows_per_wave; rr++) {
+    const int r = r_first + rr;
+    if (r >= n) break;
+    bool hit = false;
+    if (col < n && col > r) {
+      const double iou = orp::quad_iou_two_phase_t<double, false>(prep + r, &cp);
+      hit = !(iou <= thr);
+    }
+    const u64 bits = __ballot(hit);
+    if (lane == 0) mask[(size_t)r * mask_stride + c] = bits;
+  }
+}
+
 // ---- sweep + compaction kernel --------------------------------------------------------------------------------
 // one workgroup per segment.  All LDS is dynamic (16-B aligned carve, cdna guide G17):
 //   [0,8) kept word | [16, 16+4096) scan scratch | removed[cb] u64 | keepbits[cb] u64 | origbits[cb] u64
@@ -490,6 +539,47 @@ done:
   if (d_num) (void)hipFree(d_num);
   if (d_ws) (void)hipFree(d_ws);
 #undef ORP_CHK
+}
+
+// fp64 greedy polygon NMS over PRE-SORTED dets [n,9] (device, double): ResultMerge.py:18-41 semantics; keep_out receives
+// the kept POSITIONS (ascending = visiting order), num_keep[0] their count.
+size_t orp_poly_nms_f64_workspace_bytes(int n) {
+  const size_t nn = (size_t)(n > 0 ? n : 1), cb = (nn + 63) / 64;
+  return align256(sizeof(int32_t) * 2) + align256(sizeof(int32_t) * nn) + align256(sizeof(orp::QuadPrepT<double>) * nn) +
+         align256(sizeof(u64) * nn * cb);
+}
+
+int orp_poly_nms_f64(const double* dets_sorted, int n, double iou_thr, int64_t* keep_out, int32_t* num_keep,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+  if (n < 0 || (!dets_sorted && n > 0) || !keep_out || !num_keep) return ORP_EINVAL;
+  if (n > ORP_NMS_MAX_BOXES) return ORP_ETOOBIG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    hipError_t e0 = hipMemsetAsync(num_keep, 0, sizeof(int32_t), st);
+    return e0 == hipSuccess ? ORP_OK : (int)e0;
+  }
+  if (!workspace || workspace_bytes < orp_poly_nms_f64_workspace_bytes(n)) return ORP_EWORKSPACE;
+  char* base = reinterpret_cast<char*>(workspace);
+  const size_t nn = (size_t)n, cb = (nn + 63) / 64;
+  int32_t* seg = reinterpret_cast<int32_t*>(base); base += align256(sizeof(int32_t) * 2);
+  int32_t* order = reinterpret_cast<int32_t*>(base); base += align256(sizeof(int32_t) * nn);
+  orp::QuadPrepT<double>* prep = reinterpret_cast<orp::QuadPrepT<double>*>(base); base += align256(sizeof(orp::QuadPrepT<double>) * nn);
+  u64* mask = reinterpret_cast<u64*>(base);
+  const int tb = 256, nb = (n + tb - 1) / tb;
+  hipLaunchKernelGGL(set_single_segment_kernel, dim3(1), dim3(1), 0, st, seg, n);
+  hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(tb), 0, st, order, n);
+  hipLaunchKernelGGL(prep_boxes_f64_kernel, dim3(nb), dim3(tb), 0, st, dets_sorted, n, prep);
+  const int max_cb = (int)cb;
+  int R = 1;
+  { const long tiles = (long)cb * (cb + 1) / 2; long r = tiles * 64 / 8192; while (R * 2 <= r && R < 16) R *= 2; }
+  const int rpb = R * (kMaskThreads / 64);
+  hipLaunchKernelGGL(nms_mask_f64_kernel, dim3(max_cb, (n + rpb - 1) / rpb), dim3(kMaskThreads), 0, st, prep, n, R,
+                     max_cb, iou_thr, mask);
+  const size_t smem = kSweepHdr + (size_t)max_cb * 3 * sizeof(u64);
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(kSweepThreads), smem, st, mask, order, seg, max_cb, 1, keep_out,
+                     num_keep);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
 }
 
 }  // extern "C"

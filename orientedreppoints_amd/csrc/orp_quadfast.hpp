@@ -30,44 +30,49 @@
 
 namespace orp {
 
-struct QuadPrep {            // 32 words = 128 B per box
-  float ax[4], ay[4];        // fan triangle k = (O, a_k, b_k), oriented CCW (endpoints swapped when s[k] == -1)
-  float bx[4], by[4];
-  int s[4];                  // sig(cross(O, v_k, v_{k+1})) of the polygon edge BEFORE the swap; 0 = degenerate
-  float vx[4], vy[4];        // the quad's vertices after the polygon-level re-orientation
-  float area_abs;            // |shoelace/2| of the (re-oriented) quad
-  int force_slow;            // non-finite / huge coordinates: use the generic path for every term of this box
-  float mabs;                // max |coordinate|
-  float pad0;
-};
+// per-precision constants: unit roundoff factor of the classifier bound (48 * u), "infinity", finite-input bound
+template <typename T> struct PrecT;
+template <> struct PrecT<float>  { static ORP_HD float  e48u() { return 2.861e-6f; } static ORP_HD float  big() { return 3.0e38f; } static ORP_HD float  fin() { return 1e9f; } };
+template <> struct PrecT<double> { static ORP_HD double e48u() { return 5.33e-15; }  static ORP_HD double big() { return 1e300; }   static ORP_HD double fin() { return 1e100; } };
 
-ORP_HD bool orp_finite_small(float v) { return orp_abs(v) < 1e9f; }   // false for NaN / inf
+template <typename T> struct QuadPrepT {   // float: 32 words = 128 B per box
+  T ax[4], ay[4];            // fan triangle k = (O, a_k, b_k), oriented CCW (endpoints swapped when s[k] == -1)
+  T bx[4], by[4];
+  int s[4];                  // sig(cross(O, v_k, v_{k+1})) of the polygon edge BEFORE the swap; 0 = degenerate
+  T vx[4], vy[4];            // the quad's vertices after the polygon-level re-orientation
+  T area_abs;                // |shoelace/2| of the (re-oriented) quad
+  int force_slow;            // non-finite / huge coordinates: use the generic path for every term of this box
+  T mabs;                    // max |coordinate|
+  T pad0;
+};
+typedef QuadPrepT<float> QuadPrep;
 
 // quad8 = x1,y1,..,x4,y4 as stored in dets rows.  Mirrors the head of quad_iou(): polygon-level reversal when the
 // signed area is negative, areas recomputed after the reversal, then the per-term orientation of tri_term().
-ORP_HD void quad_prepare(const float* q8, QuadPrep& o) {
-  Pt<float> v[4];
+template <typename T>
+ORP_HD void quad_prepare(const T* q8, QuadPrepT<T>& o) {
+  Pt<T> v[4];
   bool fin = true;
-  float m = 0.f;
+  T m = (T)0;
   for (int i = 0; i < 4; i++) {
     v[i].x = q8[2 * i]; v[i].y = q8[2 * i + 1];
-    fin = fin && orp_finite_small(v[i].x) && orp_finite_small(v[i].y);
-    const float ax_ = orp_abs(v[i].x), ay_ = orp_abs(v[i].y);
+    fin = fin && (orp_abs(v[i].x) < PrecT<T>::fin()) && (orp_abs(v[i].y) < PrecT<T>::fin());   // false for NaN / inf
+    const T ax_ = orp_abs(v[i].x), ay_ = orp_abs(v[i].y);
     m = (ax_ > m) ? ax_ : m; m = (ay_ > m) ? ay_ : m;
   }
-  float res = 0;
+  T res = 0;
   for (int i = 0; i < 4; i++) res += v[i].x * v[(i + 1) & 3].y - v[i].y * v[(i + 1) & 3].x;
-  if (res / 2.0f < 0) { Pt<float> t = v[0]; v[0] = v[3]; v[3] = t; t = v[1]; v[1] = v[2]; v[2] = t; }
+  if (res / (T)2 < 0) { Pt<T> t = v[0]; v[0] = v[3]; v[3] = t; t = v[1]; v[1] = v[2]; v[2] = t; }
   res = 0;
   for (int i = 0; i < 4; i++) res += v[i].x * v[(i + 1) & 3].y - v[i].y * v[(i + 1) & 3].x;
-  o.area_abs = orp_abs(res / 2.0f);
+  o.area_abs = orp_abs(res / (T)2);
   o.force_slow = fin ? 0 : 1;
-  o.mabs = m; o.pad0 = 0.f;
+  o.mabs = m; o.pad0 = (T)0;
   for (int k = 0; k < 4; k++) {
-    Pt<float> a = v[k], b = v[(k + 1) & 3];
+    Pt<T> a = v[k], b = v[(k + 1) & 3];
     o.vx[k] = a.x; o.vy[k] = a.y;
-    int s = sig<float>(a.x * b.y - b.x * a.y);            // cross3(o, a, b) with o = (0,0): (a.x-0)*(b.y-0) - ...
-    if (s == -1) { Pt<float> t = a; a = b; b = t; }
+    int s = sig<T>(a.x * b.y - b.x * a.y);                // cross3(o, a, b) with o = (0,0): (a.x-0)*(b.y-0) - ...
+    if (s == -1) { Pt<T> t = a; a = b; b = t; }
     o.ax[k] = a.x; o.ay[k] = a.y; o.bx[k] = b.x; o.by[k] = b.y; o.s[k] = s;
   }
 }
@@ -212,39 +217,42 @@ ORP_HD float tri_term_fast(float ax, float ay, float bx, float by, const FanCol&
 //            rounding of the test itself.
 // Anything else is "unresolved" and gets the full evaluation.  Degenerate column edges (s == 0) are skipped by the
 // reference, so they impose no condition.
-struct FarCol {                 // per-lane column constants of the classifier
-  float wx[4], wy[4];           // column vertices
-  float cx[4], cy[4], bax2[4], bay2[4], c0[4];   // oriented column edges: start point, direction, value at O
+template <typename T> struct FarColT {      // per-lane column constants of the classifier
+  T wx[4], wy[4];               // column vertices
+  T cx[4], cy[4], bax2[4], bay2[4], c0[4];   // oriented column edges: start point, direction, value at O
   int s[4];
-  float mabs;
+  T mabs;
 };
-ORP_HD FarCol far_col(const QuadPrep& p) {
-  FarCol f;
+typedef FarColT<float> FarCol;
+template <typename T>
+ORP_HD FarColT<T> far_col(const QuadPrepT<T>& p) {
+  FarColT<T> f;
   for (int j = 0; j < 4; j++) {
     f.wx[j] = p.vx[j]; f.wy[j] = p.vy[j];
-    const FanCol t = fan_col(p.ax[j], p.ay[j], p.bx[j], p.by[j]);
+    const FanColT<T> t = fan_col<T>(p.ax[j], p.ay[j], p.bx[j], p.by[j]);
     f.cx[j] = t.cx; f.cy[j] = t.cy; f.bax2[j] = t.bax2; f.bay2[j] = t.bay2; f.c0[j] = t.c0; f.s[j] = p.s[j];
   }
   f.mabs = p.mabs;
   return f;
 }
 // rvx/rvy: the row box's vertices, rm its mabs.  Returns true when inter == +0 exactly.
-ORP_HD bool pair_is_far(const float* rvx, const float* rvy, float rm, const FarCol& c) {
-  float mx = -3.0e38f, mn = 3.0e38f, mnv[4];
+template <typename T>
+ORP_HD bool pair_is_far(const T* rvx, const T* rvy, T rm, const FarColT<T>& c) {
+  T mx = -PrecT<T>::big(), mn = PrecT<T>::big(), mnv[4];
 #pragma unroll
   for (int v = 0; v < 4; v++) {
-    float m = 3.0e38f;
+    T m = PrecT<T>::big();
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-      const float x = c.wx[w] * rvy[v] - rvx[v] * c.wy[w];
+      const T x = c.wx[w] * rvy[v] - rvx[v] * c.wy[w];
       mx = (x > mx) ? x : mx;
       m = (x < m) ? x : m;
     }
     mnv[v] = m;
     mn = (m < mn) ? m : mn;
   }
-  if (!(mx > kEps)) return true;                               // cw_far (NaN-free: callers exclude force_slow boxes)
-  const float E = 2.861e-6f * c.mabs * (rm + c.mabs) + 1e-7f;  // 48 * 2^-24 = 2.861e-6
+  if (!(mx > (T)1e-8)) return true;                            // cw_far (NaN-free: callers exclude force_slow boxes)
+  const T E = PrecT<T>::e48u() * c.mabs * (rm + c.mabs) + (T)1e-7;   // 48 * u * D * (M + D) + 1e-7
   if (!(mn > E)) return false;
   bool ok = true;
 #pragma unroll
@@ -252,7 +260,7 @@ ORP_HD bool pair_is_far(const float* rvx, const float* rvy, float rm, const FarC
     bool okj = pos_(c.c0[j]);
 #pragma unroll
     for (int v = 0; v < 4; v++) {
-      const float cv = c.bax2[j] * (rvy[v] - c.cy[j]) - (rvx[v] - c.cx[j]) * c.bay2[j];
+      const T cv = c.bax2[j] * (rvy[v] - c.cy[j]) - (rvx[v] - c.cx[j]) * c.bay2[j];
       okj = okj & (pos_(cv) | (neg_(cv) & (mnv[v] * c.c0[j] > E * (c.c0[j] - cv))));
     }
     ok = ok & (okj | (c.s[j] == 0));
@@ -261,103 +269,117 @@ ORP_HD bool pair_is_far(const float* rvx, const float* rvy, float rm, const FarC
 }
 
 // Column box held in registers by a lane: the four fan triangles + per-box scalars.
-struct QuadCol {
-  FanCol f[4];
+template <typename T> struct QuadColT {
+  FanColT<T> f[4];
   int s[4];
-  float area_abs;
+  T area_abs;
   int force_slow;
 };
-ORP_HD QuadCol quad_col(const QuadPrep& p) {
-  QuadCol c;
-  for (int j = 0; j < 4; j++) { c.f[j] = fan_col(p.ax[j], p.ay[j], p.bx[j], p.by[j]); c.s[j] = p.s[j]; }
+typedef QuadColT<float> QuadCol;
+template <typename T>
+ORP_HD QuadColT<T> quad_col(const QuadPrepT<T>& p) {
+  QuadColT<T> c;
+  for (int j = 0; j < 4; j++) { c.f[j] = fan_col<T>(p.ax[j], p.ay[j], p.bx[j], p.by[j]); c.s[j] = p.s[j]; }
   c.area_abs = p.area_abs; c.force_slow = p.force_slow;
   return c;
 }
 
 // Generic evaluation of one prepared pair (every term through the polygon loop).  Rare path: scratch-resident
 // private polygons, one code instance.
-template <bool GUARD>
-ORP_HD float quad_iou_prepared_generic(const QuadPrep* r, const QuadCol& c) {
-  PolyPriv<float, ORP_CLIP_CAP> P, Q;
-  float inter = 0.f;
+template <typename T, bool GUARD>
+ORP_HD T quad_iou_prepared_generic_t(const QuadPrepT<T>* r, const QuadColT<T>& c) {
+  PolyPriv<T, ORP_CLIP_CAP> P, Q;
+  T inter = (T)0;
 #pragma unroll 1
   for (int i = 0; i < 4; i++) {
     const int s1 = r->s[i];
     if (s1 == 0) continue;
-    Pt<float> a, b;
+    Pt<T> a, b;
     a.x = r->ax[i]; a.y = r->ay[i]; b.x = r->bx[i]; b.y = r->by[i];
 #pragma unroll 1
     for (int j = 0; j < 4; j++) {
-      FanCol f = c.f[0]; int s2 = c.s[0];
+      FanColT<T> f = c.f[0]; int s2 = c.s[0];
       if (j == 1) { f = c.f[1]; s2 = c.s[1]; } else if (j == 2) { f = c.f[2]; s2 = c.s[2]; } else if (j == 3) { f = c.f[3]; s2 = c.s[3]; }
       if (s2 == 0) continue;
-      Pt<float> cc, d;
+      Pt<T> cc, d;
       cc.x = f.cx; cc.y = f.cy; d.x = f.dx; d.y = f.dy;
-      float t = tri_term_oriented<float>(P, Q, a, b, cc, d);
+      T t = tri_term_oriented<T>(P, Q, a, b, cc, d);
       if (s1 * s2 == -1) t = -t;
       inter += t;
     }
   }
-  const float uni = r->area_abs + c.area_abs - inter;
-  if (GUARD) { if (uni == 0.f) return (inter + 1.f) / (uni + 1.f); }
+  const T uni = r->area_abs + c.area_abs - inter;
+  if (GUARD) { if (uni == (T)0) return (inter + (T)1) / (uni + (T)1); }
   return inter / uni;
 }
 
 // IoU of the prepared row box `r` (wave-uniform: scalar loads on the GPU) with the register-resident column box.
-// Term order (row edge outer, column edge inner) and the fp32 accumulation order are those of quad_iou().
+// Term order (row edge outer, column edge inner) and the accumulation order are those of quad_iou().
 // `nslow` (optional, host statistics) counts pairs that took the generic path.
-template <bool GUARD>
-ORP_HD float quad_iou_prepared(const QuadPrep* r, const QuadCol& c, int* nslow = nullptr) {
-  float inter = 0.f;
+template <typename T, bool GUARD>
+ORP_HD T quad_iou_prepared_t(const QuadPrepT<T>* r, const QuadColT<T>& c, int* nslow = nullptr) {
+  T inter = (T)0;
   bool slow = (r->force_slow | c.force_slow) != 0;
 #pragma unroll 1
   for (int i = 0; i < 4; i++) {
     const int s1 = r->s[i];
     if (s1 == 0) continue;
-    const float ax = r->ax[i], ay = r->ay[i], bx = r->bx[i], by = r->by[i];
+    const T ax = r->ax[i], ay = r->ay[i], bx = r->bx[i], by = r->by[i];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       if (c.s[j] == 0) continue;
-      float t = tri_term_fast(ax, ay, bx, by, c.f[j], slow);
+      T t = tri_term_fast_t<T, true>(ax, ay, bx, by, c.f[j], slow);
       if (s1 * c.s[j] == -1) t = -t;
       inter += t;
     }
   }
   if (slow) {
     if (nslow) (*nslow)++;
-    return quad_iou_prepared_generic<GUARD>(r, c);
+    return quad_iou_prepared_generic_t<T, GUARD>(r, c);
   }
-  const float uni = r->area_abs + c.area_abs - inter;
-  if (GUARD) { if (uni == 0.f) return (inter + 1.f) / (uni + 1.f); }
+  const T uni = r->area_abs + c.area_abs - inter;
+  if (GUARD) { if (uni == (T)0) return (inter + (T)1) / (uni + (T)1); }
   return inter / uni;
+}
+template <bool GUARD>
+ORP_HD float quad_iou_prepared(const QuadPrep* r, const QuadCol& c, int* nslow = nullptr) {
+  return quad_iou_prepared_t<float, GUARD>(r, c, nslow);
 }
 
 // IoU value of a pair whose intersection is exactly +0 (what quad_iou() returns when every term is 0).
+template <typename T, bool GUARD>
+ORP_HD T iou_of_zero_inter_t(T row_area_abs, T col_area_abs) {
+  const T inter = (T)0;
+  const T uni = row_area_abs + col_area_abs - inter;
+  if (GUARD) { if (uni == (T)0) return (inter + (T)1) / (uni + (T)1); }
+  return inter / uni;
+}
 template <bool GUARD>
 ORP_HD float iou_of_zero_inter(float row_area_abs, float col_area_abs) {
-  const float inter = 0.f;
-  const float uni = row_area_abs + col_area_abs - inter;
-  if (GUARD) { if (uni == 0.f) return (inter + 1.f) / (uni + 1.f); }
-  return inter / uni;
+  return iou_of_zero_inter_t<float, GUARD>(row_area_abs, col_area_abs);
 }
 
 // The composition the kernels implement (classifier, then full evaluation of what it leaves), as one function: this
-// is what tests/host_harness runs on the CPU against the oracle.  stats[0] += pairs resolved by the classifier,
-// stats[1] += pairs on the generic path.
-template <bool GUARD>
-ORP_HD float quad_iou_two_phase(const QuadPrep* r, const QuadPrep* c, long long* stats = nullptr) {
+// is what tests/host_harness runs on the CPU against the oracle, and what the fp64 merge-NMS kernel calls per pair.
+// stats[0] += pairs resolved by the classifier, stats[1] += pairs on the generic path.
+template <typename T, bool GUARD>
+ORP_HD T quad_iou_two_phase_t(const QuadPrepT<T>* r, const QuadPrepT<T>* c, long long* stats = nullptr) {
   if ((r->force_slow | c->force_slow) == 0) {
-    const FarCol fc = far_col(*c);
-    if (pair_is_far(r->vx, r->vy, r->mabs, fc)) {
+    const FarColT<T> fc = far_col<T>(*c);
+    if (pair_is_far<T>(r->vx, r->vy, r->mabs, fc)) {
       if (stats) stats[0]++;
-      return iou_of_zero_inter<GUARD>(r->area_abs, c->area_abs);
+      return iou_of_zero_inter_t<T, GUARD>(r->area_abs, c->area_abs);
     }
   }
-  const QuadCol qc = quad_col(*c);
+  const QuadColT<T> qc = quad_col<T>(*c);
   int nslow = 0;
-  const float v = quad_iou_prepared<GUARD>(r, qc, &nslow);
+  const T v = quad_iou_prepared_t<T, GUARD>(r, qc, &nslow);
   if (stats) stats[1] += nslow;
   return v;
+}
+template <bool GUARD>
+ORP_HD float quad_iou_two_phase(const QuadPrep* r, const QuadPrep* c, long long* stats = nullptr) {
+  return quad_iou_two_phase_t<float, GUARD>(r, c, stats);
 }
 
 }  // namespace orp

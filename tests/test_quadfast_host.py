@@ -99,3 +99,26 @@ def test_generic_path_same_header(harness):
     harness.host_quadgeneric_matrix(q.ctypes.data_as(ctypes.c_void_p), 300, q.ctypes.data_as(ctypes.c_void_p), 300, 0,
                                     out.ctypes.data_as(ctypes.c_void_p))
     assert np.array_equal(out.view(np.uint32), O.quad_iou_matrix(q, q).view(np.uint32))
+
+
+def test_fp64_instantiation_matches_polyiou(harness):
+    """The same header instantiated in double = the arithmetic of DOTA_devkit/polyiou.cpp (iou_poly), which the merge
+    NMS kernel uses: bit-exact against the oracle's polyiou restatement (itself pinned on the reference's polyiou)."""
+    rng = np.random.RandomState(0)
+    d = S.gen_polys(140, 3, clustered=True)[:, :8]
+    cases = {
+        "clustered": d,
+        "aabb_int": _aabb(80, 0, 12, 1).astype(np.float64),
+        "near_dup": np.concatenate([d[:40], d[:40] + 1e-9 * rng.randn(40, 8), d[:40, [2, 3, 4, 5, 6, 7, 0, 1]]]),
+        "origin": S.gen_polys(100, 9)[:, :8] - 512,
+        "degenerate": np.concatenate([np.zeros((3, 8)), d[:30]]),
+    }
+    for name, q in cases.items():
+        q = np.ascontiguousarray(q, np.float64)
+        n = len(q)
+        out = np.empty((n, n), np.float64)
+        st = np.zeros(2, np.int64)
+        harness.host_quadfast_matrix_f64(q.ctypes.data_as(ctypes.c_void_p), n, q.ctypes.data_as(ctypes.c_void_p), n,
+                                         out.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p))
+        want = np.array([[O.polyiou(q[i], q[j]) for j in range(n)] for i in range(n)])
+        assert np.array_equal(out.view(np.uint64), want.view(np.uint64)), name
