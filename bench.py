@@ -83,11 +83,14 @@ def nms_inputs_of_one_image(model, img, metas):
         captured['thr'] = iou_thr
         return orig(dets, iou_thr, device_id)
     nms_wrapper.rnms = spy
+    static = model.test_cfg.get('static_postprocess', True)
+    model.test_cfg['static_postprocess'] = False      # the reference-shaped path hands the [M,9] dets to `rnms`
     try:
         with torch.no_grad():
             model.simple_test(img, metas)
     finally:
         nms_wrapper.rnms = orig
+        model.test_cfg['static_postprocess'] = static
     return captured
 
 
@@ -104,6 +107,79 @@ def cpu_baseline(dets_np, thr, budget_s=10.0):
         total += time.perf_counter() - t0
         reps += 1
     return total / reps, len(keep), reps
+
+
+def per_op_table(dev, budget_s=2.0):
+    """Per-op microseconds at the configs[1] shapes next to the CPU reference port (oracle/, 1 host core) of the same op
+    on a bounded sample -- BASELINE.json: "per-op us reported next to the CPU reference".  GPU: HIP-event pairs around
+    >= 10 launches after warm-up; CPU: the oracle timed once on the stated sample, scaled linearly to the full size."""
+    from oracle import orp_oracle as O
+    from orientedreppoints_amd import synthetic as S
+    from orientedreppoints_amd.mmdet_ops import convex_iou, deform_conv_forward_multi, minaerarect
+    from orientedreppoints_amd.mmdet_ops.nms_wrapper import rnms_device
+    O.build()
+
+    def gpu_us(fn, iters=10, warm=2):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+
+    def cpu_us(fn):
+        t0 = time.perf_counter()
+        fn()
+        return (time.perf_counter() - t0) * 1e6
+
+    out = {}
+    # min-area-rect decode of the <= 5344 candidates of one image
+    pts = S.gen_pointsets(5344, 2).astype(np.float32)
+    tp = torch.from_numpy(pts).to(dev)
+    n_s = 1024
+    out['minaerarect_5344_sets'] = dict(gpu_us=gpu_us(lambda: minaerarect(tp)),
+                                        cpu_us=cpu_us(lambda: O.minarearect(pts[:n_s])) * 5344 / n_s,
+                                        cpu_sample='%d sets, scaled x%.2f' % (n_s, 5344 / n_s))
+    # refine-stage assigner IoU: all 21824 point sets of an image x 32 gts (grid-ordered, as the head produces them)
+    ar = []
+    for st in (8, 16, 32, 64, 128):
+        nn = IMG // st
+        yy, xx = np.meshgrid(np.arange(nn), np.arange(nn), indexing='ij')
+        ar.append(np.stack([xx.reshape(-1) * st + st / 2.0, yy.reshape(-1) * st + st / 2.0], 1))
+    around = np.concatenate(ar)
+    pall = np.ascontiguousarray(S.gen_pointsets(len(around), 6, around=around), np.float32)
+    gts = S.gen_gts(32, 3).astype(np.float32)
+    tpa, tg = torch.from_numpy(pall).to(dev), torch.from_numpy(gts).to(dev)
+    n_s = 1024
+    sel = np.linspace(0, len(pall) - 1, n_s).astype(np.int64)
+    out['convex_iou_21824x32'] = dict(gpu_us=gpu_us(lambda: convex_iou(tpa, tg), iters=5),
+                                      cpu_us=cpu_us(lambda: O.convex_iou(pall[sel], gts)) * len(pall) / n_s,
+                                      cpu_sample='%d point sets x 32 gts, scaled x%.2f' % (n_s, len(pall) / n_s))
+    # rotated NMS of a 2000-box class-offset dense scene (fp32 reference arithmetic on both sides)
+    d = S.gen_dense_scene(2000, 1)[0].astype(np.float32)
+    td = torch.from_numpy(d).to(dev)
+    n_s = 1000
+    out['rnms_2000_boxes'] = dict(gpu_us=gpu_us(lambda: rnms_device(td, 0.4)),
+                                  cpu_us=cpu_us(lambda: O.rnms(d[:n_s], 0.4)) * (2000.0 / n_s) ** 2,
+                                  cpu_sample='%d boxes (fp32 devrIoU port), scaled x%.1f (pairs)' % (n_s, (2000.0 / n_s) ** 2))
+    # DeformConv forward: GPU = all five levels of one image in one launch; CPU = the 16x16 level, scaled by positions
+    torch.manual_seed(0)
+    w = torch.randn(256, 256, 3, 3, device=dev) * 0.01
+    xs = [torch.randn(1, 256, IMG // st, IMG // st, device=dev).contiguous(memory_format=torch.channels_last)
+          for st in (8, 16, 32, 64, 128)]
+    offs = [torch.randn(1, 18, IMG // st, IMG // st, device=dev) * 2 for st in (8, 16, 32, 64, 128)]
+    xc = xs[3].contiguous().cpu().numpy()[:, :64]
+    oc = offs[3].cpu().numpy()
+    wc = w.cpu().numpy()[:64, :64]
+    scale = (21824.0 / 256.0) * (256.0 * 256.0) / (64.0 * 64.0)
+    out['deform_conv_21824_positions'] = dict(
+        gpu_us=gpu_us(lambda: deform_conv_forward_multi(xs, offs, w, 1, 1, 1)),
+        cpu_us=cpu_us(lambda: O.dcn_forward(xc, oc, wc, 1, 1, 1)) * scale,
+        cpu_sample='16x16 level, 64 -> 64 channels, scaled x%.0f (positions x channel pairs)' % scale)
+    return out
 
 
 def main():
@@ -273,6 +349,12 @@ def main():
                    hbm_frac=alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, pairs_per_launch=pairs,
                    gpairs_per_s=pairs / avg_s / 1e9,
                    note='bit-exact fp32 triangle-fan IoU: ALU-bound, 0.6 MB of traffic per launch')
+    per_op = None
+    if not args.no_cpu_baseline:
+        try:
+            per_op = per_op_table(dev)
+        except Exception as e:   # noqa: BLE001  (a secondary table must not take the headline line down)
+            per_op = 'failed: %s' % (str(e)[:200],)
     cpu = None
     if not args.no_cpu_baseline and M > 0:
         dt, kept, reps = cpu_baseline(dets.cpu().numpy(), cap['thr'])
@@ -293,7 +375,7 @@ def main():
         'rotated_iou_nms_us_per_img': nms_us, 'nms_boxes': M,
         'kernel_us': {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()},
         'graph_replay_ms': graph_ms,
-        'roofline': roof, 'nms': nms, 'cpu_baseline': cpu,
+        'roofline': roof, 'nms': nms, 'per_op_us': per_op, 'cpu_baseline': cpu,
     }
     print(json.dumps(out))
     if distributed:

@@ -99,6 +99,13 @@ __device__ double tri_term_grad(D2 a, D2 b, D2 c, D2 d, double* grad_AB, int ord
   if (s1 == 0 || s2 == 0) return 0.0;
   if (s1 == -1) { D2 t = a; a = b; b = t; swapped = true; }
   if (s2 == -1) { D2 t = c; c = d; d = t; }
+  // exact zero (argument in orp_quadfast.hpp): if neither fan vertex is strictly left of O->c, at most 2 distinct
+  // vertices survive the first cut -- the shoelace sum AND its gradient (area_grad of a <= 2-gon) are exactly 0, which
+  // is what the full evaluation below would return.  About half of the 36 terms of an overlapping pair end here.
+  {
+    const double ca = c.x * a.y - a.x * c.y, cb = c.x * b.y - b.x * c.y;     // crs(o, c, a), crs(o, c, b)
+    if (!(ca > 1E-8) && !(cb > 1E-8)) return 0.0;
+  }
   D2 p[CAP];
   CutRec r1[CAP], r2[CAP], r3[CAP];
   p[0] = o; p[1] = a; p[2] = b;
