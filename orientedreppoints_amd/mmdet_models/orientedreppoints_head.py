@@ -143,7 +143,7 @@ class OrientedRepPointsHead(nn.Module):
 
     def forward_single(self, x):
         """One level, autograd-capable (reference forward_single, head :148-171)."""
-        dcn_base_offset = self.dcn_base_offset.type_as(x)
+        dcn_base_offset = self._base_offset_on(x)
         cls_feat, pts_feat, pts_out_init = self._towers(x)
         pts_out_init_grad_mul = (1 - self.gradient_mul) * pts_out_init.detach() + self.gradient_mul * pts_out_init
         dcn_offset = pts_out_init_grad_mul - dcn_base_offset
