@@ -91,19 +91,12 @@ __global__ void prep_boxes_kernel(const float* __restrict__ dets, const int32_t*
 //      tile's LDS copy), through the register decision tree of orp_quadfast.hpp (generic polygon loop only for the
 //      ~1e-5 of pairs the tree does not cover).  Heavy pairs are thus packed densely into wavefronts instead of
 //      leaving 5 of 6 lanes idle next to them.
+// one (rpb rows x 64 columns) tile: phase A, queue, phase B, mask words out
 template <bool GUARD>
-__global__ void __launch_bounds__(kMaskThreads, 4)
-nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restrict__ seg_off, int rows_per_wave,
-                int mask_stride, float thr, u64* __restrict__ mask, int dbg) {
-  __shared__ TileLds T;
-  const int seg = blockIdx.z;
-  const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
-  const int c = blockIdx.x;
+__device__ __forceinline__ void mask_tile(TileLds& T, const orp::QuadPrep* __restrict__ prep, int s0, int n, int c,
+                                          int row_base, int rpb, int rows_per_wave, int mask_stride, float thr,
+                                          u64* __restrict__ mask, int dbg) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int rpb = rows_per_wave * (kMaskThreads / 64);
-  const int row_base = blockIdx.y * rpb;
-  if (row_base >= n || c * 64 >= n) return;
-  if ((row_base >> 6) > c) return;                       // lower-triangular tile: never read by the sweep
 
   // ---- stage the tile's row / column records in LDS (phase B reads them with per-lane indices) ----------------
   const int col = c * 64 + lane;
@@ -186,6 +179,44 @@ nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restric
   }
   __syncthreads();
   if (tid < rpb && row_base + tid < n) mask[(size_t)(s0 + row_base + tid) * mask_stride + c] = T.words[tid];
+}
+
+// exact launch: the host knows the box count -> one workgroup per tile (grid = column blocks x row groups x segments)
+template <bool GUARD>
+__global__ void __launch_bounds__(kMaskThreads, 4)
+nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restrict__ seg_off, int rows_per_wave,
+                int mask_stride, float thr, u64* __restrict__ mask, int dbg) {
+  __shared__ TileLds T;
+  const int seg = blockIdx.z;
+  const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
+  const int c = blockIdx.x;
+  const int rpb = rows_per_wave * (kMaskThreads / 64);
+  const int row_base = blockIdx.y * rpb;
+  if (row_base >= n || c * 64 >= n) return;
+  if ((row_base >> 6) > c) return;                       // lower-triangular tile: never read by the sweep
+  mask_tile<GUARD>(T, prep, s0, n, c, row_base, rpb, rows_per_wave, mask_stride, thr, mask, dbg);
+}
+
+// capacity launch: the box count lives in DEVICE memory (seg_off) and the host only knows an upper bound -- a bounded
+// grid whose workgroups loop over the tiles of the actual count (sync-free / hipGraph callers: an 8 K capacity holding
+// 2 K boxes must not pay for 60 K empty workgroups)
+template <bool GUARD>
+__global__ void __launch_bounds__(kMaskThreads, 4)
+nms_mask_loop_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restrict__ seg_off, int rows_per_wave,
+                     int mask_stride, float thr, u64* __restrict__ mask, int dbg) {
+  __shared__ TileLds T;
+  const int seg = blockIdx.z;
+  const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
+  const int rpb = rows_per_wave * (kMaskThreads / 64);
+  const int cbn = (n + 63) >> 6, ngroups = (n + rpb - 1) / rpb;
+  const int total_tiles = cbn * ngroups;
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int c = tile % cbn;
+    const int row_base = (tile / cbn) * rpb;
+    if ((row_base >> 6) > c) continue;
+    mask_tile<GUARD>(T, prep, s0, n, c, row_base, rpb, rows_per_wave, mask_stride, thr, mask, dbg);
+    __syncthreads();                                     // T is reused by the next tile
+  }
 }
 
 // ---- fp64 mask kernel: the merge NMS of DOTA_devkit/ResultMerge.py (polyiou.cpp arithmetic) -------------------------
@@ -461,16 +492,29 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
   hipLaunchKernelGGL(prep_boxes_kernel, dim3(nb), dim3(tb), 0, st, dets, order, n_total, boxes);
 
   const int max_cb = (max_seg + 63) / 64;
-  const int R = pick_rows_per_wave(max_seg, nseg);
+  // exact_n: max_seg IS the box count (orp_rnms) -> one workgroup per tile.  Otherwise max_seg is only a capacity (the
+  // count lives in device memory: batched / sync-free callers): 16-row tiles and a bounded grid whose workgroups loop
+  // over the tiles of the actual count -- an 8 K capacity holding 2 K boxes must not pay for 60 K empty workgroups.
+  const bool exact_n = single_segment;
+  const int R = exact_n ? pick_rows_per_wave(max_seg, nseg) : (max_seg <= 8192 ? (max_seg <= 256 ? 1 : 4) : 16);
   const int rpb = R * (kMaskThreads / 64);
   dim3 grid(max_cb, (max_seg + rpb - 1) / rpb, nseg);
+  if (!exact_n) {
+    long ntile = (long)max_cb * ((max_seg + rpb - 1) / rpb);
+    const long cap_wg = 8192 / (nseg < 8 ? nseg : 8);
+    if (ntile > cap_wg) ntile = cap_wg;
+    grid = dim3((unsigned)ntile, 1, nseg);
+  }
   static const int dbg = getenv("ORP_NMS_DBG") ? atoi(getenv("ORP_NMS_DBG")) : 0;   // dev aid: 1 = skip phase B, 2 = skip classifier
   {
     OrpProfScope prof(ORP_PROF_NMS_MASK, st);
-    if (flavor == 0)
-      hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg);
-    else
-      hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg);
+    if (exact_n) {
+      if (flavor == 0) hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg);
+      else hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg);
+    } else {
+      if (flavor == 0) hipLaunchKernelGGL(nms_mask_loop_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg);
+      else hipLaunchKernelGGL(nms_mask_loop_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg);
+    }
   }
 
   const size_t smem = kSweepHdr + (size_t)max_cb * 3 * sizeof(u64);

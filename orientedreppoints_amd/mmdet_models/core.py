@@ -124,7 +124,7 @@ def multiclass_rnms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, 
     return torch.cat([bboxes, scores[:, None]], 1), labels
 
 
-def multiclass_rnms_static(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num, multi_reppoints, capacity=16384):
+def multiclass_rnms_static(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num, multi_reppoints, capacity=8192):
     """`multiclass_rnms` with the reference's exact semantics (bbox_nms.py:93-182: same detections, same order, the
     class-offset trick on fp32 coordinates) but with STATIC shapes and no host synchronisation: boolean-mask indexing /
     nonzero (one blocking D2H each) become a cumsum + scatter into a fixed-capacity buffer, the NMS takes its box

@@ -237,7 +237,7 @@ class OrientedRepPointsHead(nn.Module):
         if nms and static:
             # sync-free, fixed-shape variant: one packed device tensor (see core.multiclass_rnms_static)
             return multiclass_rnms_static(mlvl_bboxes, mlvl_scores, cfg.score_thr, cfg.nms, cfg.max_per_img,
-                                          mlvl_reppoints, capacity=cfg.get('static_capacity', 16384))
+                                          mlvl_reppoints, capacity=cfg.get('static_capacity', 8192))
         if nms:
             return multiclass_rnms(mlvl_bboxes, mlvl_scores, cfg.score_thr, cfg.nms, cfg.max_per_img,
                                    multi_reppoints=mlvl_reppoints)
