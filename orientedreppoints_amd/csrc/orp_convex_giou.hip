@@ -92,7 +92,10 @@ __device__ void cut_backward(const CutRec* rec, int n_out, int k, const double* 
   }
 }
 
-__device__ double tri_term_grad(D2 a, D2 b, D2 c, D2 d, double* grad_AB, int order, int convex_n) {
+// value of the fan term and its gradient w.r.t. the ORIGINAL (a, b): g4 = d/da.x, d/da.y, d/db.x, d/db.y (zeros on the
+// early exits)
+__device__ double tri_term_grad4(D2 a, D2 b, D2 c, D2 d, double* g4) {
+  g4[0] = g4[1] = g4[2] = g4[3] = 0.0;
   D2 o; o.x = 0; o.y = 0;
   bool swapped = false;
   const int s1 = sg(crs(o, a, b)), s2 = sg(crs(o, c, d));
@@ -122,9 +125,7 @@ __device__ double tri_term_grad(D2 a, D2 b, D2 c, D2 d, double* grad_AB, int ord
   if (s1 * s2 == -1) { sgn = -1.0; res = -res; }
   double gax = sgn * g0[2], gay = sgn * g0[3], gbx = sgn * g0[4], gby = sgn * g0[5];
   if (swapped) { double t = gax; gax = gbx; gbx = t; t = gay; gay = gby; gby = t; }
-  const int nxt = (order != convex_n - 1) ? order + 1 : 0;
-  grad_AB[2 * order] += gax; grad_AB[2 * order + 1] += gay;
-  grad_AB[2 * nxt] += gbx; grad_AB[2 * nxt + 1] += gby;
+  g4[0] = gax; g4[1] = gay; g4[2] = gbx; g4[3] = gby;
   return res;
 }
 
@@ -173,30 +174,67 @@ __device__ int jarvis(D2* in_poly, int n_poly, int* to_input, int cap) {
   return n_poly;
 }
 
+// One WAVE per (point set, gt) pair.  Lane 0 builds the hull and orients both polygons (LDS), then the <= 36 fan terms
+// (hull edge i, gt edge j) run one per lane -- each with its clip records and reverse-mode pull-back -- and park their
+// value + 4 gradient components in LDS; lane 0 accumulates them in the reference's (i outer, j inner) order, so values
+// and gradients are what the serial loop produced, and finishes union / enclosing hull / GIoU.  The previous shape
+// (one THREAD per pair, 36 serial terms on private arrays) left a call with a few thousand positives running on a few
+// dozen waves for 0.6 ms.
 __global__ void __launch_bounds__(kThreads)
 convex_giou_kernel(const float* __restrict__ pts, const float* __restrict__ gts, int n, float* __restrict__ out19) {
-  const int idx = blockIdx.x * kThreads + threadIdx.x;
-  if (idx >= n) return;
+  const int idx = blockIdx.x;
+  const int lane = threadIdx.x;
+  __shared__ D2 s_ps1[HCAP];
+  __shared__ D2 s_ps2[5];
+  __shared__ int s_to_input[HCAP];
+  __shared__ int s_n1;
+  __shared__ double s_val[36];
+  __shared__ double s_g4[36][4];
   const float* p = pts + (size_t)idx * 18;
   const float* q = gts + (size_t)idx * 8;
+  const int n2 = 4;
+  if (lane == 0) {
+    D2 ps1[HCAP], ps2[5];
+    int to_input[HCAP];
+    for (int i = 0; i < HCAP; i++) to_input[i] = -1;
+    for (int i = 0; i < 9; i++) { ps1[i].x = (double)p[2 * i]; ps1[i].y = (double)p[2 * i + 1]; }
+    int n1 = jarvis(ps1, 9, to_input, 9);
+    if (n1 > 9) n1 = 9;
+    for (int i = 0; i < 4; i++) { ps2[i].x = (double)q[2 * i]; ps2[i].y = (double)q[2 * i + 1]; }
+    if (area_of(ps1, n1) < 0) for (int a = 0, b = n1 - 1; a < b; a++, b--) { D2 t = ps1[a]; ps1[a] = ps1[b]; ps1[b] = t; }
+    if (area_of(ps2, n2) < 0) for (int a = 0, b = n2 - 1; a < b; a++, b--) { D2 t = ps2[a]; ps2[a] = ps2[b]; ps2[b] = t; }
+    for (int i = 0; i < HCAP; i++) { s_ps1[i] = ps1[i < n1 ? i : 0]; s_to_input[i] = to_input[i]; }
+    for (int i = 0; i < 4; i++) s_ps2[i] = ps2[i];
+    s_n1 = n1;
+  }
+  __syncthreads();
+  const int n1 = s_n1;
+  if (lane < 4 * n1 && lane < 36) {
+    const int i = lane >> 2, j = lane & 3;
+    double g4[4];
+    const double v = tri_term_grad4(s_ps1[i], s_ps1[(i + 1 < n1) ? i + 1 : 0], s_ps2[j], s_ps2[(j + 1 < n2) ? j + 1 : 0], g4);
+    s_val[lane] = v;
+    s_g4[lane][0] = g4[0]; s_g4[lane][1] = g4[1]; s_g4[lane][2] = g4[2]; s_g4[lane][3] = g4[3];
+  }
+  __syncthreads();
+  if (lane != 0) return;
+
   D2 ps1[HCAP], ps2[5];
-  int to_input[HCAP];
-  for (int i = 0; i < HCAP; i++) to_input[i] = -1;
-  for (int i = 0; i < 9; i++) { ps1[i].x = (double)p[2 * i]; ps1[i].y = (double)p[2 * i + 1]; }
-  int n1 = jarvis(ps1, 9, to_input, 9);
-  if (n1 > 9) n1 = 9;
-  int n2 = 4;
-  for (int i = 0; i < 4; i++) { ps2[i].x = (double)q[2 * i]; ps2[i].y = (double)q[2 * i + 1]; }
+  for (int i = 0; i < n1; i++) ps1[i] = s_ps1[i];
+  for (int i = 0; i < 4; i++) ps2[i] = s_ps2[i];
   double grad_A[18], grad_AB[20], grad_C[18];
   for (int i = 0; i < 18; i++) { grad_A[i] = 0; grad_AB[i] = 0; grad_C[i] = 0; }
   grad_AB[18] = grad_AB[19] = 0;
-
-  if (area_of(ps1, n1) < 0) for (int a = 0, b = n1 - 1; a < b; a++, b--) { D2 t = ps1[a]; ps1[a] = ps1[b]; ps1[b] = t; }
-  if (area_of(ps2, n2) < 0) for (int a = 0, b = n2 - 1; a < b; a++, b--) { D2 t = ps2[a]; ps2[a] = ps2[b]; ps2[b] = t; }
   double inter = 0;
-  for (int i = 0; i < n1; i++)
-    for (int j = 0; j < n2; j++)
-      inter += tri_term_grad(ps1[i], ps1[(i + 1 < n1) ? i + 1 : 0], ps2[j], ps2[(j + 1 < n2) ? j + 1 : 0], grad_AB, i, n1);
+  for (int i = 0; i < n1; i++) {
+    const int nxt = (i != n1 - 1) ? i + 1 : 0;
+    for (int j = 0; j < n2; j++) {
+      const int t = i * 4 + j;
+      inter += s_val[t];
+      grad_AB[2 * i] += s_g4[t][0]; grad_AB[2 * i + 1] += s_g4[t][1];
+      grad_AB[2 * nxt] += s_g4[t][2]; grad_AB[2 * nxt + 1] += s_g4[t][3];
+    }
+  }
 
   const double s_pred = area_of(ps1, n1);
   area_grad(ps1, n1, grad_A);
@@ -231,7 +269,7 @@ convex_giou_kernel(const float* __restrict__ pts, const float* __restrict__ gts,
   float g[18];
   for (int i = 0; i < 18; i++) g[i] = 0.f;
   for (int i = 0; i < n1; i++) {
-    const int gp = to_input[i];
+    const int gp = s_to_input[i];
     if (gp < 0 || gp > 8) continue;
     for (int t = 0; t < 2; t++)
       g[2 * gp + t] = (float)((uni + inter) / (uni * uni) * grad_AB[2 * i + t] - iou / uni * grad_A[2 * i + t] -
@@ -247,8 +285,7 @@ extern "C" int orp_convex_giou(const float* pts, const float* gts, int n, float*
   if (n < 0 || (n > 0 && (!pts || !gts || !out19))) return ORP_EINVAL;
   if (n == 0) return ORP_OK;
   OrpProfScope prof(ORP_PROF_CONVEX_GIOU, (hipStream_t)stream);
-  hipLaunchKernelGGL(convex_giou_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream,
-                     pts, gts, n, out19);
+  hipLaunchKernelGGL(convex_giou_kernel, dim3(n), dim3(kThreads), 0, (hipStream_t)stream, pts, gts, n, out19);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }
