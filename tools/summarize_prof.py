@@ -20,7 +20,9 @@ with open(dst + '_kernel_stats.csv', 'w', newline='') as f:
 trace = glob.glob(os.path.join(src, '*', '*kernel_trace.csv'))[0]
 tr = list(csv.DictReader(open(trace)))
 tr.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(tr) if 'nms_mask_kernel' in r['Kernel_Name']]
+# one mask launch per bench step: the capacity-launch kernel of the sync-free path if present, else the exact one
+marker = 'nms_mask_loop_kernel' if any('nms_mask_loop_kernel' in r['Kernel_Name'] for r in tr) else 'nms_mask_kernel'
+idx = [i for i, r in enumerate(tr) if marker in r['Kernel_Name']]
 with open(dst + '_step.txt', 'w') as f:
     if len(idx) > step + 1:
         a, b = idx[step], idx[step + 1]
