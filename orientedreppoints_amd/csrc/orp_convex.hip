@@ -110,53 +110,7 @@ convex_iou_kernel(const float* __restrict__ pts, int n, const float* __restrict_
     };
     if (area4(q) < 0) { Pt<double> t = q[0]; q[0] = q[3]; q[3] = t; t = q[1]; q[1] = q[2]; q[2] = t; }
     const double s_gt = area4(q);
-    bool far = false;
-    if (active && finite_ok) {
-      double gD = 0.0;
-#pragma unroll
-      for (int t = 0; t < 4; t++) { gD = fmax(gD, fmax(fabs(q[t].x), fabs(q[t].y))); }
-      if (gD < 1e100) {
-        double mx = -1e300, mn = 1e300;
-        for (int v = 0; v < n1; v++) {
-          const Pt<double> p = H.get(v);
-#pragma unroll
-          for (int w = 0; w < 4; w++) {
-            const double x = q[w].x * p.y - p.x * q[w].y;
-            mx = fmax(mx, x); mn = fmin(mn, x);
-          }
-        }
-        if (!(mx > 1e-8)) {
-          far = true;
-        } else {
-          const double E = 5.33e-15 * gD * (hull_mabs + gD) + 1e-7;     // 48 * 2^-53 = 5.33e-15
-          if (mn > E) {
-            // oriented gt edges (tri_term swaps c,d when cross(O,c,d) < 0), their direction and value at the origin
-            bool ok = true;
-#pragma unroll 1
-            for (int t = 0; t < 4; t++) {
-              Pt<double> c = q[0], d = q[1];
-              if (t == 1) { c = q[1]; d = q[2]; } else if (t == 2) { c = q[2]; d = q[3]; } else if (t == 3) { c = q[3]; d = q[0]; }
-              const int s2 = orp::sig(orp::cross3(Pt<double>{0.0, 0.0}, c, d));
-              if (s2 == 0) continue;                       // the reference skips degenerate gt edges
-              if (s2 == -1) { const Pt<double> tmp = c; c = d; d = tmp; }
-              const double bax = d.x - c.x, bay = d.y - c.y;
-              const double c0 = bax * (0.0 - c.y) - (0.0 - c.x) * bay;
-              bool okt = c0 > 1e-8;
-              for (int v = 0; v < n1; v++) {
-                const Pt<double> p = H.get(v);
-                double mnv = 1e300;
-#pragma unroll
-                for (int w = 0; w < 4; w++) mnv = fmin(mnv, q[w].x * p.y - p.x * q[w].y);
-                const double cv = bax * (p.y - c.y) - (p.x - c.x) * bay;
-                okt = okt & ((cv > 1e-8) | ((cv < -1e-8) & (mnv * c0 > E * (c0 - cv))));
-              }
-              ok = ok & okt;
-            }
-            far = ok;
-          }
-        }
-      }
-    }
+    const bool far = active && finite_ok && orp::hull_quad_is_far<double>(H, n1, hull_mabs, q);
     if (active && far) {
       const double inter0 = 0;
       const double uni0 = fabs(s_pred) + fabs(s_gt) - inter0;

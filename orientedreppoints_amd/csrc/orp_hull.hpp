@@ -18,11 +18,11 @@ constexpr int ORP_HULL_MAX = 2 * ORP_HULL_CAP;       // worst-case vertex count 
 
 // (a-o) x (b-o) with every operand promoted to double first
 template <typename T>
-__device__ __forceinline__ double cross_d(Pt<T> o, Pt<T> a, Pt<T> b) {
+ORP_HD double cross_d(Pt<T> o, Pt<T> a, Pt<T> b) {
   return ((double)a.x - (double)o.x) * ((double)b.y - (double)o.y) -
          ((double)b.x - (double)o.x) * ((double)a.y - (double)o.y);
 }
-template <typename T> __device__ __forceinline__ T dis2(Pt<T> a, Pt<T> b) {
+template <typename T> ORP_HD T dis2(Pt<T> a, Pt<T> b) {
   return (a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y);
 }
 
@@ -30,7 +30,7 @@ template <typename T> __device__ __forceinline__ T dis2(Pt<T> a, Pt<T> b) {
 // H  : store receiving the hull (>= ORP_HULL_MAX slots), L: scratch store (>= ORP_HULL_CAP + 1 slots)
 // returns hull size
 template <typename T, typename SI, typename SH, typename SL>
-__device__ __forceinline__ int jarvis_hull(SI& IN, int n, SH& H, SL& L) {
+ORP_HD int jarvis_hull(SI& IN, int n, SH& H, SL& L) {
   Pt<T> p0 = IN.get(0);
   Pt<T> p_max = p0;
   int max_index = 0;

@@ -268,6 +268,49 @@ ORP_HD bool pair_is_far(const T* rvx, const T* rvy, T rm, const FarColT<T>& c) {
   return ok;
 }
 
+// ---- the same classifier for (convex hull of <= 12 vertices, quad) pairs: convex_iou (fp64) -------------------------
+// H.get(v) = hull vertex v (CCW), q[0..3] = the gt quad re-oriented CCW as convex_iou's intersectAreaO does; hull_mabs =
+// max |coordinate| of the hull.  Returns true when every fan term (hull edge i, quad edge j) is exactly 0.  The hull is
+// the "row" (a, b) side and the quad the "column" (c, d) side of the analysis above, with M = hull_mabs, D = max |q|.
+template <typename T, typename HS>
+ORP_HD bool hull_quad_is_far(const HS& H, int n1, T hull_mabs, const Pt<T>* q) {
+  T gD = (T)0;
+  for (int t = 0; t < 4; t++) { const T ax_ = orp_abs(q[t].x), ay_ = orp_abs(q[t].y); gD = (ax_ > gD) ? ax_ : gD; gD = (ay_ > gD) ? ay_ : gD; }
+  if (!(gD < PrecT<T>::fin())) return false;
+  T mx = -PrecT<T>::big(), mn = PrecT<T>::big();
+  for (int v = 0; v < n1; v++) {
+    const Pt<T> p = H.get(v);
+    for (int w = 0; w < 4; w++) {
+      const T x = q[w].x * p.y - p.x * q[w].y;
+      mx = (x > mx) ? x : mx; mn = (x < mn) ? x : mn;
+    }
+  }
+  if (!(mx > (T)1e-8)) return true;                                   // cw_far: every term dies at stage 1
+  const T E = PrecT<T>::e48u() * gD * (hull_mabs + gD) + (T)1e-7;
+  if (!(mn > E)) return false;
+  bool ok = true;
+  for (int t = 0; t < 4; t++) {
+    // oriented gt edge (tri_term swaps c,d when cross(O,c,d) < 0), its direction and value at the origin
+    Pt<T> c = q[t], d = q[(t + 1) & 3];
+    Pt<T> o; o.x = (T)0; o.y = (T)0;
+    const int s2 = sig<T>(cross3<T>(o, c, d));
+    if (s2 == 0) continue;                                            // the reference skips degenerate gt edges
+    if (s2 == -1) { const Pt<T> tmp = c; c = d; d = tmp; }
+    const T bax = d.x - c.x, bay = d.y - c.y;
+    const T c0 = bax * ((T)0 - c.y) - ((T)0 - c.x) * bay;
+    bool okt = pos_(c0);
+    for (int v = 0; v < n1; v++) {
+      const Pt<T> p = H.get(v);
+      T mnv = PrecT<T>::big();
+      for (int w = 0; w < 4; w++) { const T x = q[w].x * p.y - p.x * q[w].y; mnv = (x < mnv) ? x : mnv; }
+      const T cv = bax * (p.y - c.y) - (p.x - c.x) * bay;
+      okt = okt & (pos_(cv) | (neg_(cv) & (mnv * c0 > E * (c0 - cv))));
+    }
+    ok = ok & okt;
+  }
+  return ok;
+}
+
 // Column box held in registers by a lane: the four fan triangles + per-box scalars.
 template <typename T> struct QuadColT {
   FanColT<T> f[4];

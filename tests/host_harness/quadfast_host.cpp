@@ -1,9 +1,11 @@
 // Host build of the DEVICE header orientedreppoints_amd/csrc/orp_quadfast.hpp (test infrastructure only).
 // g++ compiles the very same inline functions hipcc compiles for gfx950, with -ffp-contract=off, so the fp32
 // operation order of the register fast path can be compared bit for bit with the oracle on the CPU.
+#include <math.h>
 #include <stddef.h>
 #include <stdint.h>
 #include "../../orientedreppoints_amd/csrc/orp_quadfast.hpp"
+#include "../../orientedreppoints_amd/csrc/orp_hull.hpp"
 
 extern "C" {
 
@@ -36,6 +38,41 @@ void host_quadfast_matrix_f64(const double* a, int n, const double* b, int k, do
   }
   if (stats) { stats[0] += st[0]; stats[1] += st[1]; }
   delete[] ra;
+}
+
+// convex_iou's pair classifier (hull of 9 points vs gt quad, fp64) exactly as csrc/orp_convex.hip runs it: hull through
+// the float-backed store, CCW re-orientation, then orp::hull_quad_is_far.  flags[n,k] = 1 where it claims inter == 0.
+namespace {
+struct HostStoreF {                       // float storage, widened to double on access (csrc/orp_convex.hip HullStoreF)
+  orp::Pt<float>* base;
+  orp::Pt<double> get(int i) const { orp::Pt<double> r; r.x = (double)base[i].x; r.y = (double)base[i].y; return r; }
+  void set(int i, orp::Pt<double> v) const { base[i].x = (float)v.x; base[i].y = (float)v.y; }
+};
+}
+void host_convex_far_flags(const float* pts, int n, const float* gts, int k, unsigned char* flags) {
+  for (int i = 0; i < n; i++) {
+    orp::Pt<float> in[9], hull[24], left[12];
+    HostStoreF IN{in}, H{hull}, L{left};
+    for (int t = 0; t < 9; t++) { orp::Pt<double> p; p.x = (double)pts[(size_t)i * 18 + 2 * t]; p.y = (double)pts[(size_t)i * 18 + 2 * t + 1]; IN.set(t, p); }
+    int n1 = orp::jarvis_hull<double>(IN, 9, H, L);
+    if (n1 > 12) n1 = 12;
+    double s_pred = orp::poly_area<double>(H, n1);
+    if (s_pred < 0) for (int a = 0, b = n1 - 1; a < b; a++, b--) { orp::Pt<double> tt = H.get(a); H.set(a, H.get(b)); H.set(b, tt); }
+    double mabs = 0.0; bool fin = true;
+    for (int v = 0; v < n1; v++) {
+      const orp::Pt<double> p = H.get(v);
+      mabs = fmax(mabs, fmax(fabs(p.x), fabs(p.y)));
+      fin = fin && (fabs(p.x) < 1e100) && (fabs(p.y) < 1e100);
+    }
+    for (int j = 0; j < k; j++) {
+      orp::Pt<double> q[4];
+      for (int t = 0; t < 4; t++) { q[t].x = (double)gts[(size_t)j * 8 + 2 * t]; q[t].y = (double)gts[(size_t)j * 8 + 2 * t + 1]; }
+      double res = 0;
+      for (int t = 0; t < 4; t++) res += q[t].x * q[(t + 1) & 3].y - q[t].y * q[(t + 1) & 3].x;
+      if (res / 2.0 < 0) { orp::Pt<double> tt = q[0]; q[0] = q[3]; q[3] = tt; tt = q[1]; q[1] = q[2]; q[2] = tt; }
+      flags[(size_t)i * k + j] = (fin && orp::hull_quad_is_far<double>(H, n1, mabs, q)) ? 1 : 0;
+    }
+  }
 }
 
 // the generic path of the same header (quad_iou), for a same-compiler cross-check

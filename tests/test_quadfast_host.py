@@ -18,7 +18,8 @@ SO = os.path.join(HERE, "host_harness", "libquadfast_host.so")
 
 @pytest.fixture(scope="module")
 def harness():
-    hdrs = [os.path.join(HERE, "..", "orientedreppoints_amd", "csrc", h) for h in ("orp_geom.hpp", "orp_quadfast.hpp")]
+    hdrs = [os.path.join(HERE, "..", "orientedreppoints_amd", "csrc", h)
+            for h in ("orp_geom.hpp", "orp_quadfast.hpp", "orp_hull.hpp")]
     if (not os.path.exists(SO)) or any(os.path.getmtime(p) > os.path.getmtime(SO) for p in [SRC] + hdrs):
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
     return ctypes.CDLL(SO)
@@ -122,3 +123,34 @@ def test_fp64_instantiation_matches_polyiou(harness):
                                          out.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p))
         want = np.array([[O.polyiou(q[i], q[j]) for j in range(n)] for i in range(n)])
         assert np.array_equal(out.view(np.uint64), want.view(np.uint64)), name
+
+
+def test_convex_classifier_only_claims_exact_zeros(harness):
+    """convex_iou's fp64 pair classifier (hull vs gt quad), run on the CPU exactly as the kernel runs it: wherever it
+    claims "every fan term is exactly 0" the oracle's IoU must be +0.0 (or NaN for a zero union) -- and it must resolve
+    most pairs of a realistic layout (that is the speed-up)."""
+    rng = np.random.RandomState(1)
+    gts = S.gen_gts(48, 77).astype(np.float32)
+    ctr = gts.reshape(-1, 4, 2).mean(1)
+    sets = {
+        "random": S.gen_pointsets(1500, 3),
+        "on_gts": S.gen_pointsets(960, 1, around=np.repeat(ctr, 20, 0) + rng.normal(0, 8, (960, 2))),
+        "same_ray": S.gen_pointsets(960, 2, around=np.repeat(ctr, 20, 0) * rng.uniform(0.3, 2.5, (960, 1))),
+        "near_origin": S.gen_pointsets(400, 4, around=rng.normal(0, 10, (400, 2))),
+        "negative": S.gen_pointsets(400, 5, around=rng.uniform(-600, 600, (400, 2))),
+        "degenerate": np.concatenate([np.repeat(rng.uniform(0, 1000, (60, 1, 2)), 9, 1).reshape(60, 18), np.zeros((4, 18))]),
+    }
+    resolved = total = 0
+    for name, pts in sets.items():
+        pts = np.ascontiguousarray(pts, np.float32)
+        for g in (gts, (gts - 512).astype(np.float32)):
+            flags = np.zeros((len(pts), len(g)), np.uint8)
+            harness.host_convex_far_flags(pts.ctypes.data_as(ctypes.c_void_p), len(pts), g.ctypes.data_as(ctypes.c_void_p),
+                                          len(g), flags.ctypes.data_as(ctypes.c_void_p))
+            want = O.convex_iou(pts, g)
+            claimed = want[flags.astype(bool)]
+            ok = (claimed.view(np.uint32) == 0) | np.isnan(claimed)
+            assert ok.all(), (name, claimed[~ok][:5])
+            if name == "random":
+                resolved += int(flags.sum()); total += flags.size
+    assert resolved / total > 0.7
