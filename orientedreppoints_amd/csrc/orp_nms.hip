@@ -40,6 +40,7 @@ using orp_tile::tile_pair_iou_quad;
 
 constexpr int kMaskThreads = 256;   // 4 waves per workgroup
 constexpr int kSweepThreads = 1024;
+constexpr int kNzCap = 8192;        // sparse sweep: non-zero mask words kept in LDS (12 B each); more -> dense sweep
 
 __device__ __forceinline__ unsigned int float_flip_desc(float f) {
   // order-preserving float -> uint map, then inverted so that an ASCENDING radix sort yields scores DESCENDING
@@ -69,8 +70,9 @@ __global__ void set_single_segment_kernel(int32_t* seg_off, int n) { seg_off[0] 
 
 // prep[i] = quad_prepare(dets[order[i]][0..7]): orientation, oriented fan triangles, signs, |area| -- once per box
 __global__ void prep_boxes_kernel(const float* __restrict__ dets, const int32_t* __restrict__ order, int n,
-                                  orp::QuadPrep* __restrict__ prep) {
+                                  orp::QuadPrep* __restrict__ prep, int* __restrict__ nz_count) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && nz_count) *nz_count = 0;             // list of non-zero mask words, appended by the mask kernel
   if (i >= n) return;
   const float* s = dets + (size_t)order[i] * 9;
   float q8[8];
@@ -95,7 +97,8 @@ __global__ void prep_boxes_kernel(const float* __restrict__ dets, const int32_t*
 template <bool GUARD>
 __device__ __forceinline__ void mask_tile(TileLds& T, const orp::QuadPrep* __restrict__ prep, int s0, int n, int c,
                                           int row_base, int rpb, int rows_per_wave, int mask_stride, float thr,
-                                          u64* __restrict__ mask, int dbg) {
+                                          u64* __restrict__ mask, int dbg, int* __restrict__ nz_count,
+                                          unsigned* __restrict__ nz_rc, u64* __restrict__ nz_w) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
   // ---- stage the tile's row / column records in LDS (phase B reads them with per-lane indices) ----------------
@@ -178,14 +181,22 @@ __device__ __forceinline__ void mask_tile(TileLds& T, const orp::QuadPrep* __res
     if (live && k == 0 && iou > thr) atomicOr(&T.words[rl], 1ull << cl);
   }
   __syncthreads();
-  if (tid < rpb && row_base + tid < n) mask[(size_t)(s0 + row_base + tid) * mask_stride + c] = T.words[tid];
+  if (tid < rpb && row_base + tid < n) {
+    const u64 w = T.words[tid];
+    mask[(size_t)(s0 + row_base + tid) * mask_stride + c] = w;
+    if (nz_count && w) {                                 // sparse side list for the LDS-resident sweep (single segment)
+      const int pos = atomicAdd(nz_count, 1);
+      if (pos < kNzCap) { nz_rc[pos] = ((unsigned)(row_base + tid) << 11) | (unsigned)c; nz_w[pos] = w; }
+    }
+  }
 }
 
 // exact launch: the host knows the box count -> one workgroup per tile (grid = column blocks x row groups x segments)
 template <bool GUARD>
 __global__ void __launch_bounds__(kMaskThreads, 4)
 nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restrict__ seg_off, int rows_per_wave,
-                int mask_stride, float thr, u64* __restrict__ mask, int dbg) {
+                int mask_stride, float thr, u64* __restrict__ mask, int dbg, int* __restrict__ nz_count,
+                unsigned* __restrict__ nz_rc, u64* __restrict__ nz_w) {
   __shared__ TileLds T;
   const int seg = blockIdx.z;
   const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
@@ -194,7 +205,7 @@ nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restric
   const int row_base = blockIdx.y * rpb;
   if (row_base >= n || c * 64 >= n) return;
   if ((row_base >> 6) > c) return;                       // lower-triangular tile: never read by the sweep
-  mask_tile<GUARD>(T, prep, s0, n, c, row_base, rpb, rows_per_wave, mask_stride, thr, mask, dbg);
+  mask_tile<GUARD>(T, prep, s0, n, c, row_base, rpb, rows_per_wave, mask_stride, thr, mask, dbg, nz_count, nz_rc, nz_w);
 }
 
 // capacity launch: the box count lives in DEVICE memory (seg_off) and the host only knows an upper bound -- a bounded
@@ -203,7 +214,8 @@ nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restric
 template <bool GUARD>
 __global__ void __launch_bounds__(kMaskThreads, 4)
 nms_mask_loop_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restrict__ seg_off, int rows_per_wave,
-                     int mask_stride, float thr, u64* __restrict__ mask, int dbg) {
+                     int mask_stride, float thr, u64* __restrict__ mask, int dbg, int* __restrict__ nz_count,
+                     unsigned* __restrict__ nz_rc, u64* __restrict__ nz_w) {
   __shared__ TileLds T;
   const int seg = blockIdx.z;
   const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
@@ -214,7 +226,7 @@ nms_mask_loop_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __re
     const int c = tile % cbn;
     const int row_base = (tile / cbn) * rpb;
     if ((row_base >> 6) > c) continue;
-    mask_tile<GUARD>(T, prep, s0, n, c, row_base, rpb, rows_per_wave, mask_stride, thr, mask, dbg);
+    mask_tile<GUARD>(T, prep, s0, n, c, row_base, rpb, rows_per_wave, mask_stride, thr, mask, dbg, nz_count, nz_rc, nz_w);
     __syncthreads();                                     // T is reused by the next tile
   }
 }
@@ -299,7 +311,8 @@ __device__ __forceinline__ int popc_scan_emit(const u64* words, int nw, int* tmp
 
 __global__ void __launch_bounds__(kSweepThreads)
 nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order, const int32_t* __restrict__ seg_off,
-                 int mask_stride, int order_out, int64_t* __restrict__ keep_out, int32_t* __restrict__ num_keep) {
+                 int mask_stride, int order_out, int64_t* __restrict__ keep_out, int32_t* __restrict__ num_keep,
+                 const int* __restrict__ nz_count, const unsigned* __restrict__ nz_rc, const u64* __restrict__ nz_w) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int seg = blockIdx.x;
   const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
@@ -315,6 +328,58 @@ nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order
   for (int i = tid; i < cb; i += kSweepThreads) { removed[i] = 0; keepbits[i] = 0; origbits[i] = 0; }
   __syncthreads();
 
+  // ---- sparse sweep: the mask of a detection scene is mostly zeros; the mask kernel appended every non-zero word to a
+  // side list.  If the list fits (<= kNzCap words) the whole greedy pass runs out of LDS: per 64-row block one diagonal
+  // pass (wave 0) and one scan of the list that ORs the kept rows' words into `removed` and files the NEXT block's
+  // diagonal words -- two barriers and no HBM / L2 round trip per block.
+  const int nnz = nz_count ? *nz_count : (kNzCap + 1);
+  const bool sparse = nnz <= kNzCap;
+  if (sparse) {
+    u64* nzw = origbits + cb;
+    unsigned* nzrc = reinterpret_cast<unsigned*>(nzw + kNzCap);
+    u64* diag = reinterpret_cast<u64*>(nzrc + kNzCap);              // [2][64]
+    for (int i = tid; i < nnz; i += kSweepThreads) { nzw[i] = nz_w[i]; nzrc[i] = nz_rc[i]; }
+    if (tid < 128) diag[tid] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < nnz; i += kSweepThreads) {
+      const unsigned rc = nzrc[i];
+      if ((rc >> 17) == 0u && (rc & 2047u) == 0u) diag[(rc >> 11) & 63u] = nzw[i];      // row block 0, column block 0
+    }
+    __syncthreads();
+    for (int blk = 0; blk < cb; blk++) {
+      if (wave == 0) {
+        const u64 d = diag[(blk & 1) * 64 + lane];
+        diag[(blk & 1) * 64 + lane] = 0ull;                       // this buffer is refilled for block blk + 2
+        const u64 cur0 = removed[blk];
+        unsigned clo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur0);
+        unsigned chi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur0 >> 32));
+        u64 cur = ((u64)chi << 32) | clo;
+        const int valid = __builtin_amdgcn_readfirstlane(min(64, n - blk * 64));
+        const u64 vmask = (valid >= 64) ? ~0ull : ((1ull << valid) - 1ull);
+        const int dlo = (int)(unsigned)d, dhi = (int)(unsigned)(d >> 32);
+        u64 todo = __ballot(d != 0ull) & vmask;
+        while (todo) {
+          const int kk = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          if (!((cur >> kk) & 1ull))
+            cur |= ((u64)(unsigned)__builtin_amdgcn_readlane(dhi, kk) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane(dlo, kk);
+        }
+        const u64 kept = ~cur & vmask;
+        if (lane == 0) { *s_kept = kept; keepbits[blk] = kept; }
+      }
+      __syncthreads();
+      const u64 kept = *s_kept;
+      const unsigned ublk = (unsigned)blk;
+      for (int i = tid; i < nnz; i += kSweepThreads) {
+        const unsigned rc = nzrc[i];
+        const unsigned rb = rc >> 17, cc = rc & 2047u, rl = (rc >> 11) & 63u;
+        if (rb == ublk && cc > ublk && ((kept >> rl) & 1ull)) atomicOr(&removed[cc], nzw[i]);
+        if (rb == ublk + 1u && cc == ublk + 1u) diag[((blk + 1) & 1) * 64 + rl] = nzw[i];
+      }
+      __syncthreads();
+    }
+  }
+
   // Block-row sweep, software-pipelined: at the top of iteration blk every thread ISSUES the loads of its share of
   // block-row blk (all 64 rows x the column words right of the diagonal, kept or not -- at most kPre words per thread)
   // and wave 0 the loads of the NEXT diagonal words; the HBM/L2 latency then overlaps the diagonal pass and the
@@ -322,8 +387,8 @@ nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order
   // an empty word cannot suppress anything inside the block), which in practice is a handful per block.
   constexpr int kPre = 8;
   u64 d_next = 0ull;
-  if (wave == 0) { const int row = lane; d_next = (row < n) ? mask[(size_t)(s0 + row) * mask_stride + 0] : 0ull; }
-  for (int blk = 0; blk < cb; blk++) {
+  if (!sparse && wave == 0) { const int row = lane; d_next = (row < n) ? mask[(size_t)(s0 + row) * mask_stride + 0] : 0ull; }
+  for (int blk = 0; !sparse && blk < cb; blk++) {
     const int ncols = cb - (blk + 1);
     int slices = 1, rows_per_slice = 64;
     if (ncols > 0) {
@@ -412,7 +477,8 @@ nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct NmsLayout {
-  size_t off_seg, off_keys_in, off_keys_out, off_vals_in, off_order, off_boxes, off_mask, off_cub, cub_bytes, total;
+  size_t off_seg, off_keys_in, off_keys_out, off_vals_in, off_order, off_boxes, off_mask, off_nzc, off_nzrc, off_nzw, off_cub,
+      cub_bytes, total;
 };
 
 NmsLayout nms_layout(int n_total, int nseg, int max_seg) {
@@ -427,6 +493,9 @@ NmsLayout nms_layout(int n_total, int nseg, int max_seg) {
   L.off_order = o; o += align256(sizeof(int32_t) * n);
   L.off_boxes = o; o += align256(sizeof(orp::QuadPrep) * n);
   L.off_mask = o; o += align256(sizeof(u64) * n * cb);
+  L.off_nzc = o; o += align256(sizeof(int));
+  L.off_nzrc = o; o += align256(sizeof(unsigned) * kNzCap);
+  L.off_nzw = o; o += align256(sizeof(u64) * kNzCap);
   size_t cub = 0;
   hipcub::DeviceRadixSort::SortPairs((void*)nullptr, cub, (const u64*)nullptr, (u64*)nullptr, (const int32_t*)nullptr,
                                      (int32_t*)nullptr, (int)n, 0, 64, (hipStream_t)0);
@@ -434,6 +503,16 @@ NmsLayout nms_layout(int n_total, int nseg, int max_seg) {
   L.off_cub = o; o += align256(cub);
   L.total = o;
   return L;
+}
+
+// dynamic LDS of the sweep: header | removed, keepbits, origbits [cb] | sparse list (12 B x kNzCap) | diag [2][64]
+inline size_t sweep_smem_bytes(int max_cb) {
+  return kSweepHdr + (size_t)max_cb * 3 * sizeof(u64) + (size_t)kNzCap * (sizeof(u64) + sizeof(unsigned)) + 128 * sizeof(u64);
+}
+inline hipError_t sweep_attr() {     // > 64 KB of dynamic LDS needs the attribute; once (not allowed during stream capture)
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_sweep_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return e;
 }
 
 int pick_rows_per_wave(int max_seg, int nseg) {
@@ -465,6 +544,10 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
   int32_t* order = reinterpret_cast<int32_t*>(base + L.off_order);
   orp::QuadPrep* boxes = reinterpret_cast<orp::QuadPrep*>(base + L.off_boxes);
   u64* mask = reinterpret_cast<u64*>(base + L.off_mask);
+  // the sparse side list serves single-segment launches (the inference path); batched segments use the dense sweep
+  int* nz_count = (nseg == 1) ? reinterpret_cast<int*>(base + L.off_nzc) : nullptr;
+  unsigned* nz_rc = reinterpret_cast<unsigned*>(base + L.off_nzrc);
+  u64* nz_w = reinterpret_cast<u64*>(base + L.off_nzw);
   void* cub = base + L.off_cub;
 
   if (single_segment) {
@@ -489,7 +572,7 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
                                                       end_bit, st);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(prep_boxes_kernel, dim3(nb), dim3(tb), 0, st, dets, order, n_total, boxes);
+  hipLaunchKernelGGL(prep_boxes_kernel, dim3(nb), dim3(tb), 0, st, dets, order, n_total, boxes, nz_count);
 
   const int max_cb = (max_seg + 63) / 64;
   // exact_n: max_seg IS the box count (orp_rnms) -> one workgroup per tile.  Otherwise max_seg is only a capacity (the
@@ -509,19 +592,20 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
   {
     OrpProfScope prof(ORP_PROF_NMS_MASK, st);
     if (exact_n) {
-      if (flavor == 0) hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg);
-      else hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg);
+      if (flavor == 0) hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc, nz_w);
+      else hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc, nz_w);
     } else {
-      if (flavor == 0) hipLaunchKernelGGL(nms_mask_loop_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg);
-      else hipLaunchKernelGGL(nms_mask_loop_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg);
+      if (flavor == 0) hipLaunchKernelGGL(nms_mask_loop_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc, nz_w);
+      else hipLaunchKernelGGL(nms_mask_loop_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc, nz_w);
     }
   }
 
-  const size_t smem = kSweepHdr + (size_t)max_cb * 3 * sizeof(u64);
+  const size_t smem = sweep_smem_bytes(max_cb);
+  if (sweep_attr() != hipSuccess) return (int)sweep_attr();
   {
     OrpProfScope prof(ORP_PROF_NMS_SWEEP, st);
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(nseg), dim3(kSweepThreads), smem, st, mask, order, seg, max_cb, order_out,
-                       keep_out, num_keep);
+                       keep_out, num_keep, nz_count, nz_rc, nz_w);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
@@ -619,9 +703,10 @@ int orp_poly_nms_f64(const double* dets_sorted, int n, double iou_thr, int64_t* 
   const int rpb = R * (kMaskThreads / 64);
   hipLaunchKernelGGL(nms_mask_f64_kernel, dim3(max_cb, (n + rpb - 1) / rpb), dim3(kMaskThreads), 0, st, prep, n, R,
                      max_cb, iou_thr, mask);
-  const size_t smem = kSweepHdr + (size_t)max_cb * 3 * sizeof(u64);
+  const size_t smem = sweep_smem_bytes(max_cb);
+  if (sweep_attr() != hipSuccess) return (int)sweep_attr();
   hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(kSweepThreads), smem, st, mask, order, seg, max_cb, 1, keep_out,
-                     num_keep);
+                     num_keep, (const int*)nullptr, (const unsigned*)nullptr, (const u64*)nullptr);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }
