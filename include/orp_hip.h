@@ -143,6 +143,13 @@ int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int bat
                           const float* weight_packed, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
                           int dil_h, int dil_w, int in_layout, int out_layout, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* Extended form: DCNv2 on the same MFMA path (masks_host[i] = modulation [B,kh*kw,Ho,Wo] of level i, or masks_host NULL
+ * for DCNv1), optional bias [Cout] (ModulatedDeformConv's bias, deform_conv.py:411-418) and an optional fused ReLU in
+ * the epilogue (the head applies self.relu right after both DeformConvs, orientedreppoints_head.py:166-170). */
+int orp_dcn_forward_multi_ex(const orp_dcn_level* levels_host, const float* const* masks_host, int nlevels, int batch,
+                             int c_in, int c_out, const float* weight_packed, const float* bias, int relu, int kh, int kw,
+                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout,
+                             int out_layout, void* workspace, size_t workspace_bytes, void* stream);
 int orp_dcn_forward_direct(const float* input, const float* offset, const float* mask, const float* weight,
                            const float* bias, float* output, int batch, int c_in, int height, int width, int c_out,
                            int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,

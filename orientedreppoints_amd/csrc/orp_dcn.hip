@@ -45,6 +45,7 @@ constexpr int kThreads = 256;
 struct LevelDesc {
   const float* x;      // NHWC [B, H, W, Cin]
   const float* off;    // NCHW [B, 2*taps, Ho, Wo]
+  const float* mask;   // DCNv2 modulation, NCHW [B, taps, Ho, Wo], or nullptr (DCNv1)
   float* out;          // NCHW [B, Cout, Ho, Wo] or NHWC [B, Ho, Wo, Cout]
   int H, W, Ho, Wo;
   int tile0;           // first tile of this level
@@ -55,6 +56,8 @@ struct FwdParams {
   int kh, kw, sh, sw, ph, pw, dh, dw;
   const float* w2;     // packed [taps][Cin][Cout]
   const float* w3;     // packed [taps][Cin/4][Cout][4] (second-generation kernel: B fragments straight from L2)
+  const float* bias;   // [Cout] or nullptr (DCNv2 bias)
+  int relu;            // fuse max(., 0) into the epilogue (the head applies ReLU right after both DeformConvs)
 };
 
 // ---- helpers -------------------------------------------------------------------------------------------------
@@ -142,6 +145,10 @@ dcn_fwd_mfma_kernel(const FwdParams P) {
         ix.y = (base + hl) * L.W + whg;
         ix.z = (base + hhg) * L.W + wl;
         ix.w = (base + hhg) * L.W + whg;
+        if (L.mask) {                                     // DCNv2: the sample is scaled by its modulation scalar
+          const float mm = L.mask[((size_t)b * taps + tap) * HoWo + hw];
+          w.x *= mm; w.y *= mm; w.z *= mm; w.w *= mm;
+        }
       }
     }
     sCw[e] = w; sCi[e] = ix;
@@ -269,6 +276,7 @@ dcn_fwd_mfma_kernel(const FwdParams P) {
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
   if (!wave_live) return;
+  auto finish = [&](float v, int ch) { if (P.bias) v += P.bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
   if (OUT_NCHW) {
     // D rows = channels, cols = positions: lane&31 -> position, reg -> channel
     const long p = p0 + (lane & 31);
@@ -278,8 +286,8 @@ dcn_fwd_mfma_kernel(const FwdParams P) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int ch = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n_wave + ch < P.Cout) ob[(size_t)(n_wave + ch) * HoWo] = acc0[r];
-        if (n_wave + 32 + ch < P.Cout) ob[(size_t)(n_wave + 32 + ch) * HoWo] = acc1[r];
+        if (n_wave + ch < P.Cout) ob[(size_t)(n_wave + ch) * HoWo] = finish(acc0[r], n_wave + ch);
+        if (n_wave + 32 + ch < P.Cout) ob[(size_t)(n_wave + 32 + ch) * HoWo] = finish(acc1[r], n_wave + 32 + ch);
       }
     }
   } else {
@@ -289,8 +297,8 @@ dcn_fwd_mfma_kernel(const FwdParams P) {
       const long p = p0 + m;
       if (p < npos) {
         float* ob = L.out + (size_t)p * P.Cout + n_wave + (lane & 31);
-        if (n_wave + (lane & 31) < P.Cout) ob[0] = acc0[r];
-        if (n_wave + 32 + (lane & 31) < P.Cout) ob[32] = acc1[r];
+        if (n_wave + (lane & 31) < P.Cout) ob[0] = finish(acc0[r], n_wave + (lane & 31));
+        if (n_wave + 32 + (lane & 31) < P.Cout) ob[32] = finish(acc1[r], n_wave + 32 + (lane & 31));
       }
     }
   }
@@ -370,6 +378,10 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
         ix.y = (base + hl) * L.W + whg;
         ix.z = (base + hhg) * L.W + wl;
         ix.w = (base + hhg) * L.W + whg;
+        if (L.mask) {                                     // DCNv2: the sample is scaled by its modulation scalar
+          const float mm = L.mask[((size_t)b * taps + tap) * HoWo + hw];
+          w.x *= mm; w.y *= mm; w.z *= mm; w.w *= mm;
+        }
       }
     }
     sCw[e] = w; sCi[e] = ix;
@@ -490,6 +502,7 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
   if (n_wave >= P.Cout) return;
+  auto finish = [&](float v, int ch) { if (P.bias) v += P.bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
 #pragma unroll
   for (int mt = 0; mt < MT; mt++) {
     if (OUT_NCHW) {
@@ -500,7 +513,7 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int ch = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (n_wave + ch < P.Cout) ob[(size_t)(n_wave + ch) * HoWo] = acc[mt][r];
+          if (n_wave + ch < P.Cout) ob[(size_t)(n_wave + ch) * HoWo] = finish(acc[mt][r], n_wave + ch);
         }
       }
     } else {
@@ -508,7 +521,7 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
       for (int r = 0; r < 16; r++) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const long p = p0 + mt * 32 + m;
-        if (p < npos && n_wave + (lane & 31) < P.Cout) L.out[(size_t)p * P.Cout + n_wave + (lane & 31)] = acc[mt][r];
+        if (p < npos && n_wave + (lane & 31) < P.Cout) L.out[(size_t)p * P.Cout + n_wave + (lane & 31)] = finish(acc[mt][r], n_wave + (lane & 31));
       }
     }
   }
@@ -617,6 +630,15 @@ int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int bat
                           const float* weight_packed, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
                           int dil_h, int dil_w, int in_layout, int out_layout, void* workspace, size_t workspace_bytes,
                           void* stream) {
+  return orp_dcn_forward_multi_ex(levels_host, nullptr, nlevels, batch, c_in, c_out, weight_packed, nullptr, 0, kh, kw,
+                                  stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, in_layout, out_layout, workspace,
+                                  workspace_bytes, stream);
+}
+
+int orp_dcn_forward_multi_ex(const orp_dcn_level* levels_host, const float* const* masks_host, int nlevels, int batch,
+                             int c_in, int c_out, const float* weight_packed, const float* bias, int relu, int kh, int kw,
+                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout,
+                             int out_layout, void* workspace, size_t workspace_bytes, void* stream) {
   if (!levels_host || nlevels <= 0 || nlevels > MAX_LEVELS || batch <= 0 || !weight_packed) return ORP_EINVAL;
   if (!orp_dcn_fast_path_ok(c_in, c_out, kh, kw, 1, 1)) return ORP_EINVAL;
   if ((in_layout != 0 && in_layout != 1) || (out_layout != 0 && out_layout != 1)) return ORP_EINVAL;
@@ -626,6 +648,7 @@ int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int bat
   P.kh = kh; P.kw = kw; P.sh = stride_h; P.sw = stride_w; P.ph = pad_h; P.pw = pad_w; P.dh = dil_h; P.dw = dil_w;
   P.w2 = weight_packed;
   P.w3 = weight_packed + (size_t)kh * kw * c_in * c_out;
+  P.bias = bias; P.relu = relu ? 1 : 0;
   if (in_layout == 0 && workspace_bytes < orp_dcn_forward_workspace_bytes(levels_host, nlevels, batch, c_in, 0))
     return ORP_EWORKSPACE;
   char* wsp = reinterpret_cast<char*>(workspace);
@@ -658,6 +681,7 @@ int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int bat
     if (D.Ho <= 0 || D.Wo <= 0) return ORP_EINVAL;
     if ((long)batch * lv.height * lv.width >= (1L << 31)) return ORP_ETOOBIG;
     D.off = lv.offset; D.out = lv.output;
+    D.mask = masks_host ? masks_host[i] : nullptr;
     if (in_layout == 0) {
       float* nhwc = reinterpret_cast<float*>(wsp);
       const int HW = lv.height * lv.width;

@@ -170,12 +170,12 @@ class OrientedRepPointsHead(nn.Module):
                 cls_feat, pts_feat, pts_out_init = self._towers(x)
                 cls_feats.append(cls_feat); pts_feats.append(pts_feat); inits.append(pts_out_init)
         offsets = [init - dcn_base_offset for init in inits]    # (1-g)*p + g*p == p without autograd
-        dcn_cls = self.reppoints_cls_conv.forward_multi(cls_feats, offsets)
-        dcn_pts = self.reppoints_pts_refine_conv.forward_multi(pts_feats, offsets)
+        dcn_cls = self.reppoints_cls_conv.forward_multi(cls_feats, offsets, relu=True)     # ReLU fused in the epilogue
+        dcn_pts = self.reppoints_pts_refine_conv.forward_multi(pts_feats, offsets, relu=True)
         cls_outs, refines = [], []
         for c, p, init in zip(dcn_cls, dcn_pts, inits):
-            cls_outs.append(self.reppoints_cls_out(self.relu(c)))
-            refines.append(self.reppoints_pts_refine_out(self.relu(p)) + init)
+            cls_outs.append(self.reppoints_cls_out(c))
+            refines.append(self.reppoints_pts_refine_out(p) + init)
         return cls_outs, inits, refines, list(feats)
 
     # ---- test-time decode + NMS ------------------------------------------------------------------------------------

@@ -58,8 +58,9 @@ def fast_path_ok(weight, groups, deformable_groups):
     return bool(_lib.lib().orp_dcn_fast_path_ok(cin_g * groups, cout, kh, kw, groups, deformable_groups))
 
 
-def deform_conv_forward_multi(inputs, offsets, weight, stride, padding, dilation):
-    """One DeformConv layer over a list of feature maps (same batch / channels) in ONE launch.  fp32, no autograd."""
+def deform_conv_forward_multi(inputs, offsets, weight, stride, padding, dilation, masks=None, bias=None, relu=False):
+    """One DeformConv layer over a list of feature maps (same batch / channels) in ONE launch.  fp32, no autograd.
+    masks (list of [B,kh*kw,Ho,Wo], DCNv2 modulation) / bias ([Cout]) / relu (fused max(., 0)) are optional."""
     L = _lib.lib()
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     x0 = inputs[0]
@@ -82,14 +83,25 @@ def deform_conv_forward_multi(inputs, offsets, weight, stride, padding, dilation
                           memory_format=torch.channels_last if nhwc else torch.contiguous_format)
         xs.append(x); offs.append(off); outs.append(out)
         levels[i] = _DcnLevel(x.data_ptr(), off.data_ptr(), out.data_ptr(), x.size(2), x.size(3))
+    mask_ptrs, ms = None, []
+    if masks is not None:
+        mask_ptrs = (ctypes.c_void_p * len(inputs))()
+        for i, m in enumerate(masks):
+            m = m.detach().float().contiguous()
+            if tuple(m.shape) != (B, kh * kw, outs[i].size(2), outs[i].size(3)):
+                raise ValueError("mask must be [B, kh*kw, Ho, Wo]")
+            ms.append(m)
+            mask_ptrs[i] = m.data_ptr()
+    b = bias.detach().float().contiguous() if bias is not None else None
     layout = 1 if nhwc else 0
     nbytes = L.orp_dcn_forward_workspace_bytes(levels, len(inputs), B, cin, layout)
     ws = _lib.workspace(x0.device, nbytes)
     with torch.cuda.device(x0.device):
-        rc = L.orp_dcn_forward_multi(levels, len(inputs), B, cin, cout, _lib.ptr(packed), kh, kw, stride[0], stride[1],
-                                     padding[0], padding[1], dilation[0], dilation[1], layout, layout, _lib.ptr(ws),
-                                     ws.numel(), _lib.stream_of(x0))
-    _lib.check(rc, "orp_dcn_forward_multi")
+        rc = L.orp_dcn_forward_multi_ex(levels, mask_ptrs, len(inputs), B, cin, cout, _lib.ptr(packed), _lib.ptr(b),
+                                        1 if relu else 0, kh, kw, stride[0], stride[1], padding[0], padding[1],
+                                        dilation[0], dilation[1], layout, layout, _lib.ptr(ws), ws.numel(),
+                                        _lib.stream_of(x0))
+    _lib.check(rc, "orp_dcn_forward_multi_ex")
     return outs
 
 
@@ -185,8 +197,13 @@ class ModulatedDeformConvFunction(Function):
             raise NotImplementedError
         if weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad:
             ctx.save_for_backward(input, offset, mask, weight, bias if bias is not None else input.new_empty(1))
-        out = _forward_direct(input, offset, mask, weight, bias, _pair(stride), _pair(padding), _pair(dilation),
-                              groups, deformable_groups)
+        if fast_path_ok(weight, groups, deformable_groups):
+            # DCNv2 on the MFMA implicit GEMM: the modulation scalar is folded into the bilinear weights of the tile
+            out = deform_conv_forward_multi([input], [offset], weight, stride, padding, dilation, masks=[mask],
+                                            bias=bias)[0]
+        else:
+            out = _forward_direct(input, offset, mask, weight, bias, _pair(stride), _pair(padding), _pair(dilation),
+                                  groups, deformable_groups)
         return out.to(input.dtype)
 
     @staticmethod
@@ -251,11 +268,14 @@ class DeformConv(nn.Module):
             out = out[:, :, :out.size(2) - pad_h, :out.size(3) - pad_w].contiguous()
         return out
 
-    def forward_multi(self, xs, offsets):
-        """All FPN levels in one launch (inference / no-grad fast path)."""
+    def forward_multi(self, xs, offsets, relu=False):
+        """All FPN levels in one launch (inference / no-grad fast path); relu=True fuses the ReLU the head applies to
+        both DeformConv outputs into the kernel's epilogue."""
         if fast_path_ok(self.weight, self.groups, self.deformable_groups) and not torch.is_grad_enabled():
-            return deform_conv_forward_multi(xs, offsets, self.weight, self.stride, self.padding, self.dilation)
-        return [self.forward(x, o) for x, o in zip(xs, offsets)]
+            return deform_conv_forward_multi(xs, offsets, self.weight, self.stride, self.padding, self.dilation,
+                                             relu=relu)
+        outs = [self.forward(x, o) for x, o in zip(xs, offsets)]
+        return [F.relu(o) for o in outs] if relu else outs
 
 
 class DeformConvPack(DeformConv):

@@ -321,6 +321,26 @@ def test_dcn_forward_multi_level_and_offsets_out_of_range(dev, oracle):
         assert _rel_err(o.cpu().numpy(), oracle.dcn_forward(x, off, w)) <= 1e-4
 
 
+def test_dcn_v2_and_fused_epilogue_on_mfma_path(dev, oracle):
+    """DCNv2 (mask + bias) and the fused ReLU epilogue on both MFMA kernel generations, against the oracle."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv_forward_multi, modulated_deform_conv
+    rng = np.random.RandomState(11)
+    for B, C, H, W, Cout in ((1, 256, 12, 9, 256), (2, 64, 7, 10, 128)):
+        x, off, w = _dcn_case(12, B, C, H, W, Cout)
+        m = rng.uniform(0, 1, size=(B, 9, H, W)).astype(np.float32)
+        b = rng.normal(size=(Cout,)).astype(np.float32)
+        want = oracle.dcn_forward(x, off, w, 1, 1, 1, mask=m, bias=b)
+        got = deform_conv_forward_multi([_t(x, dev)], [_t(off, dev)], _t(w, dev), 1, 1, 1, masks=[_t(m, dev)],
+                                        bias=_t(b, dev))[0].cpu().numpy()
+        assert _rel_err(got, want) <= 1e-4
+        got_r = deform_conv_forward_multi([_t(x, dev)], [_t(off, dev)], _t(w, dev), 1, 1, 1, masks=[_t(m, dev)],
+                                          bias=_t(b, dev), relu=True)[0].cpu().numpy()
+        assert _rel_err(got_r, np.maximum(want, 0)) <= 1e-4
+        # the autograd op takes the same path in its forward
+        y = modulated_deform_conv(_t(x, dev), _t(off, dev), _t(m, dev), _t(w, dev), _t(b, dev), 1, 1, 1, 1, 1)
+        assert _rel_err(y.cpu().numpy(), want) <= 1e-4
+
+
 def test_dcn_direct_paths(dev, oracle):
     """groups / deformable groups / stride / DCNv2 mask + bias go through the direct kernel."""
     from orientedreppoints_amd.mmdet_ops import deform_conv, modulated_deform_conv, DeformConv
