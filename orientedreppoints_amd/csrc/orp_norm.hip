@@ -167,29 +167,33 @@ gn_apply_kernel(const GnParams P) {
   }
 }
 
-// y = act(x * scale[c] + shift[c] (+ residual)), NCHW; hw4 = HW / 4 when HW % 4 == 0 (float4 path), else scalar
+// y = act(x * scale[c] + shift[c] (+ residual)), NCHW.  grid.y = (image, channel) plane, so the per-channel constants are
+// block-uniform scalars and no integer division sits in the element loop; float4 traffic when HW % 4 == 0.
 __global__ void __launch_bounds__(kThreads)
 affine_act_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ scale,
-                  const float* __restrict__ shift, float* __restrict__ y, long total, int C, int hw, int relu) {
+                  const float* __restrict__ shift, float* __restrict__ y, int C, int hw, int relu) {
+  const int plane = blockIdx.y;                       // b * C + c
+  const int c = plane % C;
+  const float a = scale[c], b = shift[c];
+  const size_t base = (size_t)plane * hw;
   if ((hw & 3) == 0) {
-    const long total4 = total >> 2;
     const int hw4 = hw >> 2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-      const int c = (int)((i / hw4) % C);
-      const float a = scale[c], b = shift[c];
-      float4 t = reinterpret_cast<const float4*>(x)[i];
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    const float4* r4 = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
+    float4* y4 = reinterpret_cast<float4*>(y + base);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += gridDim.x * blockDim.x) {
+      float4 t = x4[i];
       t.x = t.x * a + b; t.y = t.y * a + b; t.z = t.z * a + b; t.w = t.w * a + b;
-      if (res) { const float4 r = reinterpret_cast<const float4*>(res)[i]; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
+      if (r4) { const float4 r = r4[i]; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
       if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
-      reinterpret_cast<float4*>(y)[i] = t;
+      y4[i] = t;
     }
   } else {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-      const int c = (int)((i / hw) % C);
-      float t = x[i] * scale[c] + shift[c];
-      if (res) t += res[i];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+      float t = x[base + i] * a + b;
+      if (res) t += res[base + i];
       if (relu) t = fmaxf(t, 0.f);
-      y[i] = t;
+      y[base + i] = t;
     }
   }
 }
@@ -245,12 +249,13 @@ int orp_groupnorm_act_multi(const orp_norm_level* levels, int nlevels, int batch
 int orp_affine_act(const float* x, const float* residual, const float* scale, const float* shift, float* y, int batch,
                    int channels, int hw, int relu, void* stream) {
   if (!x || !scale || !shift || !y || batch <= 0 || channels <= 0 || hw <= 0) return ORP_EINVAL;
-  const long total = (long)batch * channels * hw;
-  long work = ((hw & 3) == 0) ? (total >> 2) : total;
-  long blocks = (work + kThreads - 1) / kThreads;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(affine_act_kernel, dim3((int)blocks), dim3(kThreads), 0, (hipStream_t)stream, x, residual, scale,
-                     shift, y, total, channels, hw, relu);
+  if ((long)batch * channels > 65535L * 1024) return ORP_ETOOBIG;
+  const int per = ((hw & 3) == 0) ? (hw >> 2) : hw;                 // work items per plane
+  int bx = (per + kThreads * 4 - 1) / (kThreads * 4);               // ~4 items per thread
+  if (bx < 1) bx = 1;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(affine_act_kernel, dim3(bx, batch * channels), dim3(kThreads), 0, (hipStream_t)stream, x, residual,
+                     scale, shift, y, channels, hw, relu);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }
