@@ -51,7 +51,9 @@ int orp_rnms(const float* dets, int n, float iou_thr, int flavor, int presorted,
 /* Batched form: `nseg` independent segments (image x class) laid back to back in dets; seg_offsets [nseg+1] int32
  * (device).  keep_out holds, segment after segment at offset seg_offsets[s], the kept ORIGINAL (global) row indices
  * ascending; num_keep [nseg].  One launch sequence for all segments (the (image x class) batching of BASELINE.md
- * section 3).  max_seg = host-known upper bound on a segment's size (sizes the mask tiles). */
+ * section 3).  max_seg = host-known upper bound on a segment's size: the actual sizes are read from seg_offsets ON THE
+ * DEVICE, so a caller that only knows a capacity (sync-free post-processing, hipGraph replay) passes the capacity here
+ * and a device-computed [0, count] pair as seg_offsets; rows past the count must carry a score of -inf. */
 size_t orp_rnms_batched_workspace_bytes(int n_total, int nseg, int max_seg);
 int orp_rnms_batched(const float* dets, int n_total, const int32_t* seg_offsets, int nseg, int max_seg,
                      float iou_thr, int flavor, int64_t* keep_out, int32_t* num_keep,

@@ -5,18 +5,22 @@
 //   DOTA_devkit/poly_nms_gpu/poly_nms_kernel.cu:214-329  poly_nms_kernel + _poly_nms
 //
 // MI355X design (not a translation of the 64-thread CUDA tiling):
-//   1. stable radix sort of (segment, score desc) keys (rocPRIM), gather boxes into an 8-float row layout;
+//   1. stable radix sort of (segment, score desc) keys (rocPRIM);
 //   2. per-box pre-pass (QuadPrep: orientation, oriented origin-fan triangles, signs, |area|), then the mask
 //      kernel: a workgroup owns a (<=64 rows x 64 columns) upper-triangular tile.  Phase A (lane = column, row
 //      wave-uniform through scalar loads) proves for ~84 % of the pairs of a dense scene, without a division,
 //      that every fan term is exactly 0 (orp_quadfast.hpp pair_is_far) and emits their bits by one wavefront
 //      ballot; the remaining pairs are queued in LDS and drained in phase B by quads of lanes running the
 //      register decision tree (no per-lane polygon storage), with the fp32 sum kept in the reference's order
-//      by DPP quad broadcasts.  Lower-triangle tiles exit immediately;
-//   3. sweep kernel: one workgroup per segment walks the 64-row blocks with the next block-row's mask words
-//      prefetched before the (sparse, readlane-based) diagonal pass, ORs the kept rows' words into the LDS
-//      `removed` bitmap, then scatters keep flags back to original indices and compacts them in ascending
-//      order (popcount scan), so the host never sees the mask.
+//      by DPP quad broadcasts.  Two launch forms: exact (host knows the box count: one workgroup per tile) and
+//      capacity (the count lives in device memory -- sync-free / hipGraph callers: a bounded grid loops over the
+//      tiles of the actual count).  Non-zero mask words are also appended to a side list;
+//   3. sweep kernel: one workgroup per segment.  If the side list fits in LDS (<= 8192 words) the whole greedy
+//      pass runs out of LDS (per 64-row block: one readlane-based diagonal pass, one list scan, two barriers);
+//      otherwise the dense pass walks the block rows with the next row's mask words prefetched.  Either way the
+//      keep flags are scattered back to original indices and compacted in ascending order (popcount scan), so
+//      the host never sees the mask;
+//   4. fp64 instantiation of the same core for the merge NMS of the DOTA evaluation workflow (orp_poly_nms_f64).
 // The IoU arithmetic is bit-identical to the reference's fp32 devrIoU / devPolyIoU (see orp_geom.hpp).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
