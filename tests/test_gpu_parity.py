@@ -107,6 +107,29 @@ def test_rnms_class_offset_dense_scene(dev, oracle):
     assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, 0.4))
 
 
+def test_rnms_sparse_and_dense_sweep_paths(dev, oracle):
+    """The sweep runs out of LDS when the mask has <= 8192 non-zero words and falls back to the dense block-row pass
+    otherwise: a heavily overlapping cluster (tens of thousands of hits) must take the fallback and still reproduce
+    the oracle's keep set; a sparse scene of the same size takes the LDS path."""
+    from orientedreppoints_amd.mmdet_ops import rnms
+    rng = np.random.RandomState(8)
+    n = 1800
+    # dense: all boxes within a few pixels of 6 hubs -> almost every pair overlaps
+    hubs = rng.uniform(200, 800, (6, 2))
+    ctr = hubs[rng.randint(0, 6, n)] + rng.normal(0, 3.0, (n, 2))
+    w, h, th = rng.uniform(30, 60, n), rng.uniform(30, 60, n), rng.uniform(-0.3, 0.3, n)
+    c, s_ = np.cos(th), np.sin(th)
+    dx = np.stack([-w / 2, w / 2, w / 2, -w / 2], 1); dy = np.stack([-h / 2, -h / 2, h / 2, h / 2], 1)
+    xs = ctr[:, :1] + c[:, None] * dx - s_[:, None] * dy
+    ys = ctr[:, 1:] + s_[:, None] * dx + c[:, None] * dy
+    dense = np.concatenate([np.stack([xs, ys], 2).reshape(n, 8), rng.uniform(0.05, 1, (n, 1))], 1).astype(np.float32)
+    hits = (oracle.quad_iou_matrix(dense[:, :8], dense[:, :8]) > 0.4).sum()
+    assert hits > 200000                                   # far more non-zero mask words than the LDS list holds
+    for d in (dense, S.gen_polys(n, 4, clustered=False).astype(np.float32)):
+        _, inds = rnms(_t(d, dev), 0.4)
+        assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, 0.4))
+
+
 def test_rnms_ties_and_api_edges(dev, oracle):
     from orientedreppoints_amd.mmdet_ops import rnms, rnms_cuda
     d = S.gen_polys(300, 8, clustered=True).astype(np.float32)
