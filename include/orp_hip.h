@@ -243,6 +243,33 @@ int orp_affine_act(const float* x, const float* residual, const float* scale, co
                    int channels, int hw, int relu, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Fused test-time post-processing around the rotated NMS: replaces the tensor-op chains of
+ * get_bboxes_single (orientedreppoints_head.py:707-779), multiclass_rnms (bbox_nms.py:93-182) and rbbox2result
+ * (transforms.py:356-375) with fixed-shape, stream-ordered kernels -- no host synchronisation, hipGraph-capturable.
+ * All pointers are device pointers unless named *_host.
+ *   orp_pp_gather : cand [m0] int64 = global point indices (levels concatenated, row-major inside a level) of the
+ *     candidates in the reference's order; pts_all [18, n] = the refine offsets of all levels, (y,x)-interleaved channels;
+ *     level tables (host): first point, feature-map width, stride of every level.  Writes pts_xy [m0,18] (grid units,
+ *     (x,y)), centers [m0,2], strides [m0] (inputs of orp_minarearect_decode) and reppoints [m0,18] (image space).
+ *   orp_pp_compact: sig_all [num_classes, n] sigmoid scores, boxes [m0,8] decoded corners.  Emits every (candidate,
+ *     class) pair with score > score_thr, row-major, as dets [capacity,9] = corners + label*(max_coordinate+1), score
+ *     (rows past the count: score -inf), sel_cand / sel_label [capacity], seg2 = {0, count} (the seg_offsets of
+ *     orp_rnms_batched), total[0] = number of pairs found (> capacity = overflow, caller must fall back).
+ *   orp_pp_pack   : keep / num_keep from orp_rnms_batched -> packed [max_out + 1, 28] fp32: rows = [reppoints(18) |
+ *     corners(8) | score | label] in the reference's output order (ascending index, or the max_out highest scores in
+ *     descending order when more survive); last row = (count, overflow, 0...).
+ * ------------------------------------------------------------------------------------------------------- */
+int orp_pp_gather(const float* pts_all, const int64_t* cand, int m0, int n, const int* level_offsets_host,
+                  const int* level_widths_host, const float* level_strides_host, int nlevels, float* pts_xy,
+                  float* centers, float* strides, float* reppoints, void* stream);
+int orp_pp_compact(const float* sig_all, const int64_t* cand, int m0, int n, int num_classes, const float* boxes,
+                   float score_thr, int capacity, float* dets, int32_t* sel_cand, int32_t* sel_label, int32_t* seg2,
+                   int32_t* total, void* stream);
+int orp_pp_pack(const int64_t* keep, const int32_t* num_keep, const float* dets, const int32_t* sel_cand,
+                const int32_t* sel_label, const float* boxes, const float* reppoints, const int32_t* total, int capacity,
+                int max_out, float* packed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Built-in kernel timing (measurement aid for bench.py): when enabled every instrumented launch is bracketed by
  * a HIP event pair recorded on the launch stream.  Slots: 0 nms mask, 1 nms sweep, 2 nms sort, 3 dcn forward,
  * 4 minaerarect, 5 convex_iou, 6 convex_giou, 7 iou matrix, 8 dcn backward.

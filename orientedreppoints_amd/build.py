@@ -26,6 +26,7 @@ SOURCES = [
     ("orp_convex_giou.hip", ["-ffp-contract=off"]),
     ("orp_pointwise.hip", ["-ffp-contract=off"]),
     ("orp_assign.hip", ["-ffp-contract=off"]),
+    ("orp_postproc.hip", ["-ffp-contract=off"]),
     ("orp_soft_rnms.hip", ["-ffp-contract=off"]),
     ("orp_norm.hip", []),
     ("orp_dcn.hip", []),

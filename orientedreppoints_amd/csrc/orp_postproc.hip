@@ -1,0 +1,243 @@
+// orp_postproc.hip -- fused test-time decode / selection / packing around the rotated NMS (gfx950).
+//
+// Replaces the per-level tensor-op chains of OrientedRepPointsHead.get_bboxes_single (mmdet/models/anchor_heads/
+// orientedreppoints_head.py:707-779), multiclass_rnms (mmdet/core/post_processing/bbox_nms.py:93-182) and rbbox2result
+// (mmdet/core/bbox/transforms.py:356-375) -- ~180 small framework kernels per image, 1.1 ms of GPU time plus launch gaps
+// in the round-1 profile -- by three kernels around the existing min-area-rect and NMS kernels.  Semantics are the
+// reference's, order included:
+//   candidates  level-major; inside a level the top-`nms_pre` points in the order torch.topk returned them (computed by
+//               the caller on the sigmoid maxima, exactly as the reference) or all points in grid order;
+//   detections  every (candidate, class) pair with score > score_thr, row-major over (candidate, class) -- the order of
+//               `valid_mask.nonzero()`; one NMS over coords + label * (max_coordinate + 1) (fp32, separate multiply and
+//               add: this file is built with -ffp-contract=off);
+//   output      rows kept by the NMS in ascending index order, or, when more than max_num survive, the max_num highest
+//               scores in descending order; packed as [reppoints(18) | corners(8) | score | label].
+// Everything is fixed-shape and stream-ordered: the box count lives in device memory (orp_rnms_batched reads it), so the
+// whole chain is hipGraph-capturable and costs one D2H copy per image.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/orp_hip.h"
+
+namespace {
+
+constexpr int kMaxLevels = 8;
+constexpr int kScanThreads = 1024;
+
+struct PpParams { int off[kMaxLevels + 1]; int width[kMaxLevels]; float stride[kMaxLevels]; int nlev; };
+
+// ---- candidates: gather the 9 refined points (y,x)-interleaved NCHW -> (x,y) rows, centres, strides, image-space points
+__global__ void pp_gather_kernel(const float* __restrict__ pts_all, const int64_t* __restrict__ cand, int m0, int n,
+                                 PpParams P, float* __restrict__ pts_xy, float* __restrict__ centers,
+                                 float* __restrict__ strides, float* __restrict__ reppoints) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m0) return;
+  const int g = (int)cand[j];
+  int l = 0;
+#pragma unroll 1
+  for (int i = 1; i < P.nlev; i++) if (g >= P.off[i]) l = i;
+  const int local = g - P.off[l];
+  const int y = local / P.width[l], x = local - y * P.width[l];
+  const float st = P.stride[l];
+  const float cx = (float)x * st, cy = (float)y * st;        // PointGenerator.grid_points: arange(W) * stride
+  centers[2 * j] = cx; centers[2 * j + 1] = cy;
+  strides[j] = st;
+#pragma unroll
+  for (int t = 0; t < 9; t++) {
+    const float yv = pts_all[(size_t)(2 * t) * n + g], xv = pts_all[(size_t)(2 * t + 1) * n + g];
+    pts_xy[(size_t)j * 18 + 2 * t] = xv;
+    pts_xy[(size_t)j * 18 + 2 * t + 1] = yv;
+    reppoints[(size_t)j * 18 + 2 * t] = xv * st + cx;        // pts * stride + centre: two roundings, as two tensor ops
+    reppoints[(size_t)j * 18 + 2 * t + 1] = yv * st + cy;
+  }
+}
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < kScanThreads / 64; i++) r = fmaxf(r, red[i]);
+  return r;
+}
+// exclusive scan of one int per thread over the block; returns the exclusive prefix, *total = block sum
+__device__ __forceinline__ int block_excl_scan(int v, int* tmp, int* total) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  tmp[tid] = v;
+  __syncthreads();
+  for (int off = 1; off < kScanThreads; off <<= 1) {
+    const int a = (tid >= off) ? tmp[tid - off] : 0;
+    __syncthreads();
+    tmp[tid] += a;
+    __syncthreads();
+  }
+  *total = tmp[kScanThreads - 1];
+  return tmp[tid] - v;
+}
+
+// ---- detections: (candidate, class) pairs above the threshold, row-major, with the class-offset coordinates --------
+// one workgroup; m0 is a few thousand.  dets rows >= count get score -inf (they sort last and are never evaluated).
+__global__ void __launch_bounds__(kScanThreads)
+pp_compact_kernel(const float* __restrict__ sig_all, const int64_t* __restrict__ cand, int m0, int n, int num_cls,
+                  const float* __restrict__ boxes, float thr, int cap, float* __restrict__ dets,
+                  int32_t* __restrict__ sel_cand, int32_t* __restrict__ sel_label, int32_t* __restrict__ seg,
+                  int32_t* __restrict__ total_out) {
+  __shared__ float red[kScanThreads / 64];
+  __shared__ int tmp[kScanThreads];
+  const int tid = threadIdx.x;
+  // pass 1: max coordinate over the boxes that own at least one detection (bboxes.max() of the expanded set)
+  float mx = -INFINITY;
+  for (int j = tid; j < m0; j += kScanThreads) {
+    const int g = (int)cand[j];
+    bool any = false;
+    for (int c = 0; c < num_cls; c++) any = any || (sig_all[(size_t)c * n + g] > thr);
+    if (any) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) mx = fmaxf(mx, boxes[(size_t)j * 8 + k]);
+    }
+  }
+  const float max_coordinate = block_max(mx, red);
+  const float span = max_coordinate + 1.0f;
+  // pass 2: ordered compaction
+  int running = 0;
+  for (int base = 0; base < m0; base += kScanThreads) {
+    const int j = base + tid;
+    int cnt = 0;
+    int g = 0;
+    if (j < m0) {
+      g = (int)cand[j];
+      for (int c = 0; c < num_cls; c++) cnt += (sig_all[(size_t)c * n + g] > thr) ? 1 : 0;
+    }
+    int chunk_total;
+    int pos = running + block_excl_scan(cnt, tmp, &chunk_total);
+    if (cnt > 0) {
+      float b8[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) b8[k] = boxes[(size_t)j * 8 + k];
+      for (int c = 0; c < num_cls; c++) {
+        const float sc = sig_all[(size_t)c * n + g];
+        if (sc > thr) {
+          if (pos < cap) {
+            const float offs = (float)c * span;              // labels.to(bboxes) * (max_coordinate + 1)
+#pragma unroll
+            for (int k = 0; k < 8; k++) dets[(size_t)pos * 9 + k] = b8[k] + offs;
+            dets[(size_t)pos * 9 + 8] = sc;
+            sel_cand[pos] = j; sel_label[pos] = c;
+          }
+          pos++;
+        }
+      }
+    }
+    running += chunk_total;
+  }
+  const int count = running < cap ? running : cap;
+  for (int r = count + tid; r < cap; r += kScanThreads) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) dets[(size_t)r * 9 + k] = 0.f;
+    dets[(size_t)r * 9 + 8] = -INFINITY;
+    sel_cand[r] = 0; sel_label[r] = 0;
+  }
+  if (tid == 0) { seg[0] = 0; seg[1] = count; total_out[0] = running; }
+}
+
+// ---- packing: NMS survivors -> [reppoints | corners | score | label] rows + (count, overflow) tail row -----------------
+__global__ void pp_pack_kernel(const int64_t* __restrict__ keep, const int32_t* __restrict__ num_keep,
+                               const float* __restrict__ dets, const int32_t* __restrict__ sel_cand,
+                               const int32_t* __restrict__ sel_label, const float* __restrict__ boxes,
+                               const float* __restrict__ reppoints, const int32_t* __restrict__ total, int cap,
+                               int max_out, float* __restrict__ packed) {
+  const int kn = num_keep[0];
+  const int count = kn < max_out ? kn : max_out;
+  const int W = 28;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    float* tail = packed + (size_t)max_out * W;
+    tail[0] = (float)count;
+    tail[1] = (total[0] > cap) ? 1.f : 0.f;
+    for (int k = 2; k < W; k++) tail[k] = 0.f;
+  }
+  // rows past the count are zero
+  if (i < max_out && i >= count) {
+    for (int k = 0; k < W; k++) packed[(size_t)i * W + k] = 0.f;
+  }
+  if (i >= kn) return;
+  int row = i;                                               // <= max_out survivors: ascending-index order
+  const int e = (int)keep[i];
+  if (kn > max_out) {
+    // more survivors than max_num: the max_num highest scores in descending order (bbox_nms.py:175-180); rank by
+    // counting -- O(kn^2) over <= capacity elements, and only on this (rare) branch
+    const float si = dets[(size_t)e * 9 + 8];
+    int rank = 0;
+    for (int k = 0; k < kn; k++) {
+      const float sk = dets[(size_t)keep[k] * 9 + 8];
+      rank += (sk > si || (sk == si && k < i)) ? 1 : 0;
+    }
+    row = rank;
+  }
+  if (row >= max_out) return;
+  const int j = sel_cand[e];
+  float* o = packed + (size_t)row * W;
+#pragma unroll
+  for (int k = 0; k < 18; k++) o[k] = reppoints[(size_t)j * 18 + k];
+#pragma unroll
+  for (int k = 0; k < 8; k++) o[18 + k] = boxes[(size_t)j * 8 + k];
+  o[26] = dets[(size_t)e * 9 + 8];
+  o[27] = (float)sel_label[e];
+}
+
+inline int done() { hipError_t e = hipGetLastError(); return e == hipSuccess ? ORP_OK : (int)e; }
+
+}  // namespace
+
+extern "C" {
+
+int orp_pp_gather(const float* pts_all, const int64_t* cand, int m0, int n, const int* level_offsets_host,
+                  const int* level_widths_host, const float* level_strides_host, int nlevels, float* pts_xy,
+                  float* centers, float* strides, float* reppoints, void* stream) {
+  if (m0 < 0 || n <= 0 || nlevels <= 0 || nlevels > kMaxLevels || !level_offsets_host || !level_widths_host ||
+      !level_strides_host)
+    return ORP_EINVAL;
+  if (m0 == 0) return ORP_OK;
+  if (!pts_all || !cand || !pts_xy || !centers || !strides || !reppoints) return ORP_EINVAL;
+  PpParams P;
+  P.nlev = nlevels;
+  for (int i = 0; i < kMaxLevels; i++) {
+    const int k = i < nlevels ? i : nlevels - 1;
+    P.off[i] = i < nlevels ? level_offsets_host[i] : 0x7fffffff;
+    P.width[i] = level_widths_host[k]; P.stride[i] = level_strides_host[k];
+  }
+  P.off[kMaxLevels] = 0x7fffffff;
+  hipLaunchKernelGGL(pp_gather_kernel, dim3((m0 + 255) / 256), dim3(256), 0, (hipStream_t)stream, pts_all, cand, m0, n,
+                     P, pts_xy, centers, strides, reppoints);
+  return done();
+}
+
+int orp_pp_compact(const float* sig_all, const int64_t* cand, int m0, int n, int num_classes, const float* boxes,
+                   float score_thr, int capacity, float* dets, int32_t* sel_cand, int32_t* sel_label, int32_t* seg2,
+                   int32_t* total, void* stream) {
+  if (m0 < 0 || n <= 0 || num_classes <= 0 || capacity <= 0 || !dets || !sel_cand || !sel_label || !seg2 || !total)
+    return ORP_EINVAL;
+  if (m0 > 0 && (!sig_all || !cand || !boxes)) return ORP_EINVAL;
+  hipLaunchKernelGGL(pp_compact_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, sig_all, cand, m0, n,
+                     num_classes, boxes, score_thr, capacity, dets, sel_cand, sel_label, seg2, total);
+  return done();
+}
+
+int orp_pp_pack(const int64_t* keep, const int32_t* num_keep, const float* dets, const int32_t* sel_cand,
+                const int32_t* sel_label, const float* boxes, const float* reppoints, const int32_t* total, int capacity,
+                int max_out, float* packed, void* stream) {
+  if (capacity <= 0 || max_out <= 0 || !keep || !num_keep || !dets || !sel_cand || !sel_label || !boxes || !reppoints ||
+      !total || !packed)
+    return ORP_EINVAL;
+  const int threads = capacity > max_out ? capacity : max_out;
+  hipLaunchKernelGGL(pp_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, keep, num_keep, dets,
+                     sel_cand, sel_label, boxes, reppoints, total, capacity, max_out, packed);
+  return done();
+}
+
+}  // extern "C"

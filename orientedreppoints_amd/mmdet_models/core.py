@@ -10,6 +10,7 @@ from functools import partial
 import numpy as np
 import torch
 
+from .. import _lib
 from ..mmdet_ops import nms_wrapper
 
 
@@ -179,6 +180,88 @@ def multiclass_rnms_static(multi_bboxes, multi_scores, score_thr, nms_cfg, max_n
     tail[0, 0] = count.to(body.dtype)
     tail[0, 1] = (total > cap).to(body.dtype)
     return torch.cat([body, tail], 0)
+
+
+def fused_postprocess(cls_scores, points_preds, strides, cfg, num_points=9):
+    """get_bboxes_single + multiclass_rnms + packing for ONE image on the fused HIP kernels (csrc/orp_postproc.hip):
+    cls_scores[l] [C,H,W] logits, points_preds[l] [2*num_points,H,W] refine offsets ((y,x)-interleaved, grid units).
+    Same detections in the same order as the tensor-op path (`multiclass_rnms_static`); torch keeps the numerically
+    sensitive pieces (sigmoid, class max, top-k), everything else is three kernels around min-area-rect and the NMS.
+    Returns the packed [max_per_img + 1, 28] tensor of `rbbox2result_packed`."""
+    import ctypes
+    from ..mmdet_ops.minarea_rect import minaerarect_decode
+    assert num_points == 9
+    L = _lib.lib()
+    dev = cls_scores[0].device
+    C = cls_scores[0].size(0)
+    sizes = [int(c.size(1)) * int(c.size(2)) for c in cls_scores]
+    widths = [int(c.size(2)) for c in cls_scores]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    logits = torch.cat([c.reshape(C, -1) for c in cls_scores], 1)                    # [C, N]
+    pts_all = torch.cat([p.reshape(2 * num_points, -1) for p in points_preds], 1).contiguous()   # [18, N]
+    sig = logits.sigmoid()
+    nms_pre = cfg.get('nms_pre', -1)
+    cand = []
+    max_scores = None
+    for l, n_l in enumerate(sizes):
+        if nms_pre > 0 and n_l > nms_pre:
+            if max_scores is None:
+                max_scores = sig.max(dim=0)[0]
+            _, topk_inds = max_scores[int(offs[l]):int(offs[l + 1])].topk(nms_pre)
+            cand.append(topk_inds + int(offs[l]))
+        else:
+            cand.append(_arange_cached(int(offs[l]), int(offs[l + 1]), dev))
+    cand = torch.cat(cand)
+    m0 = cand.numel()
+    f32 = dict(dtype=torch.float32, device=dev)
+    pts_xy = torch.empty((m0, 18), **f32)
+    centers = torch.empty((m0, 2), **f32)
+    strd = torch.empty((m0,), **f32)
+    rep = torch.empty((m0, 18), **f32)
+    lo = (ctypes.c_int * len(sizes))(*[int(o) for o in offs[:-1]])
+    lw = (ctypes.c_int * len(sizes))(*widths)
+    ls = (ctypes.c_float * len(sizes))(*[float(s) for s in strides])
+    st = _lib.stream_of(sig)
+    with torch.cuda.device(dev):
+        _lib.check(L.orp_pp_gather(_lib.ptr(pts_all), _lib.ptr(cand), m0, N, lo, lw, ls, len(sizes), _lib.ptr(pts_xy),
+                                   _lib.ptr(centers), _lib.ptr(strd), _lib.ptr(rep), st), "orp_pp_gather")
+    boxes = minaerarect_decode(pts_xy, centers, strd)                                # [m0, 8]
+    cap = int(min(cfg.get('static_capacity', 8192), m0 * C))
+    max_num = int(cfg.max_per_img)
+    m = int(min(max_num, cap)) if max_num > 0 else cap
+    dets = torch.empty((cap, 9), **f32)
+    sel_cand = torch.empty((cap,), dtype=torch.int32, device=dev)
+    sel_label = torch.empty((cap,), dtype=torch.int32, device=dev)
+    seg = torch.empty((2,), dtype=torch.int32, device=dev)
+    total = torch.empty((1,), dtype=torch.int32, device=dev)
+    nms_cfg_ = dict(cfg.nms)
+    assert nms_cfg_.pop('type', 'rnms') == 'rnms'
+    with torch.cuda.device(dev):
+        _lib.check(L.orp_pp_compact(_lib.ptr(sig), _lib.ptr(cand), m0, N, C, _lib.ptr(boxes), float(cfg.score_thr), cap,
+                                    _lib.ptr(dets), _lib.ptr(sel_cand), _lib.ptr(sel_label), _lib.ptr(seg),
+                                    _lib.ptr(total), st), "orp_pp_compact")
+    keep, num = nms_wrapper.rnms_batched_device(dets, seg, cap, nms_cfg_.get('iou_thr', 0.4))
+    packed = torch.empty((m + 1, 28), **f32)
+    with torch.cuda.device(dev):
+        _lib.check(L.orp_pp_pack(_lib.ptr(keep), _lib.ptr(num), _lib.ptr(dets), _lib.ptr(sel_cand), _lib.ptr(sel_label),
+                                 _lib.ptr(boxes), _lib.ptr(rep), _lib.ptr(total), cap, m, _lib.ptr(packed), st),
+                   "orp_pp_pack")
+    return packed
+
+
+_arange_cache = {}
+
+
+def _arange_cached(a, b, dev):
+    key = (a, b, dev)
+    t = _arange_cache.get(key)
+    if t is None:
+        t = torch.arange(a, b, device=dev)
+        if len(_arange_cache) > 64:
+            _arange_cache.clear()
+        _arange_cache[key] = t
+    return t
 
 
 def rbbox2result_packed(packed, num_classes):

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from ..mmdet_ops.deform_conv import DeformConv
 from ..mmdet_ops.minarea_rect import minaerarect_decode
-from .core import PointGenerator, multi_apply, multiclass_rnms, multiclass_rnms_static
+from .core import PointGenerator, fused_postprocess, multi_apply, multiclass_rnms, multiclass_rnms_static
 from .layers import ConvModule, bias_init_with_prob, normal_init
 from .registry import HEADS, build_loss
 
@@ -199,6 +199,10 @@ class OrientedRepPointsHead(nn.Module):
     def get_bboxes_single(self, cls_scores, points_preds, mlvl_points, img_shape, scale_factor, cfg, rescale=False,
                           nms=True, static=False):
         assert len(cls_scores) == len(points_preds) == len(mlvl_points)
+        if nms and static and self.use_sigmoid_cls and not rescale and cfg.nms.get('type', 'rnms') == 'rnms' \
+                and cfg.get('fused_postprocess', True) and cls_scores[0].is_cuda:
+            # decode -> selection -> NMS -> packing on the fused HIP kernels (same detections, same order)
+            return fused_postprocess(cls_scores, points_preds, self.point_strides, cfg, self.num_points)
         lvl_pts, lvl_scores, lvl_centers, lvl_strides = [], [], [], []
         for i_lvl, (cls_score, points_pred, points) in enumerate(zip(cls_scores, points_preds, mlvl_points)):
             assert cls_score.size()[-2:] == points_pred.size()[-2:]

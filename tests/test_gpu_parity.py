@@ -741,3 +741,44 @@ def test_inference_device_part_is_hipgraph_capturable(dev):
     assert [c.shape for c in got] == [c.shape for c in want]
     for a, b in zip(got, want):
         assert np.allclose(a, b, rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("size,max_per_img,thr_bias", [(256, 2000, -3.3), (384, 150, -3.0), (256, 2000, -9.0)])
+def test_fused_postprocess_equals_tensor_op_path(dev, size, max_per_img, thr_bias):
+    """csrc/orp_postproc.hip (gather / compaction / packing kernels around min-area-rect and the NMS) against the
+    tensor-op static path on the same head outputs: identical detections in identical order -- incl. per-level top-k
+    (nms_pre smaller than a level), the > max_per_img re-sort and the empty case."""
+    from orientedreppoints_amd.dota_configs import r50_model, test_cfg
+    from orientedreppoints_amd.mmdet_models import ConfigDict, build_detector
+    from orientedreppoints_amd.mmdet_models.core import rbbox2result_packed
+    torch.manual_seed(0)
+    cfg = dict(test_cfg)
+    cfg.update(nms_pre=300, max_per_img=max_per_img)
+    model = build_detector(ConfigDict(r50_model), train_cfg=None, test_cfg=ConfigDict(cfg)).to(dev).eval()
+    head = model.bbox_head
+    with torch.no_grad():
+        head.reppoints_cls_out.weight.normal_(0, 0.05)
+        head.reppoints_cls_out.bias.fill_(thr_bias)
+        head.reppoints_pts_init_out.bias.copy_(torch.tensor(
+            [[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 0], [0, 1], [1, -1], [1, 0], [1, 1]],
+            dtype=torch.float32, device=dev).reshape(-1) * 2.0)
+        head.reppoints_pts_refine_out.weight.normal_(0, 0.05)
+    img = torch.randn(1, 3, size, size, device=dev)
+    metas = [dict(img_shape=(size, size, 3), pad_shape=(size, size, 3), scale_factor=1.0, flip=False)]
+    with torch.no_grad():
+        outs = head(model.extract_feat(img))
+        res = {}
+        for fused in (True, False):
+            model.test_cfg['fused_postprocess'] = fused
+            packed = head.get_bboxes(*(tuple(outs) + (metas, model.test_cfg, False)), static=True)[0]
+            res[fused] = rbbox2result_packed(packed, head.num_classes)
+    n_det = sum(len(c) for c in res[False])
+    if thr_bias < -8:
+        assert n_det == 0
+    else:
+        assert n_det > 50
+    for a, b in zip(res[True], res[False]):
+        if max_per_img < 2000 and len(b):                # unstable score order on the re-sort branch: compare as sets
+            assert sorted(map(tuple, a.tolist())) == sorted(map(tuple, b.tolist()))
+        else:
+            assert np.array_equal(a, b)
