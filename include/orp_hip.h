@@ -254,7 +254,8 @@ int orp_affine_act(const float* x, const float* residual, const float* scale, co
  *   orp_pp_compact: sig_all [num_classes, n] sigmoid scores, boxes [m0,8] decoded corners.  Emits every (candidate,
  *     class) pair with score > score_thr, row-major, as dets [capacity,9] = corners + label*(max_coordinate+1), score
  *     (rows past the count: score -inf), sel_cand / sel_label [capacity], seg2 = {0, count} (the seg_offsets of
- *     orp_rnms_batched), total[0] = number of pairs found (> capacity = overflow, caller must fall back).
+ *     orp_rnms_batched), total[0] = number of pairs found (> capacity = overflow, caller must fall back).  num_classes
+ *     <= 32; scratch: orp_pp_compact_scratch_bytes(m0) bytes of device memory.
  *   orp_pp_pack   : keep / num_keep from orp_rnms_batched -> packed [max_out + 1, 28] fp32: rows = [reppoints(18) |
  *     corners(8) | score | label] in the reference's output order (ascending index, or the max_out highest scores in
  *     descending order when more survive); last row = (count, overflow, 0...).
@@ -262,9 +263,10 @@ int orp_affine_act(const float* x, const float* residual, const float* scale, co
 int orp_pp_gather(const float* pts_all, const int64_t* cand, int m0, int n, const int* level_offsets_host,
                   const int* level_widths_host, const float* level_strides_host, int nlevels, float* pts_xy,
                   float* centers, float* strides, float* reppoints, void* stream);
+size_t orp_pp_compact_scratch_bytes(int m0);
 int orp_pp_compact(const float* sig_all, const int64_t* cand, int m0, int n, int num_classes, const float* boxes,
                    float score_thr, int capacity, float* dets, int32_t* sel_cand, int32_t* sel_label, int32_t* seg2,
-                   int32_t* total, void* stream);
+                   int32_t* total, void* scratch, size_t scratch_bytes, void* stream);
 int orp_pp_pack(const int64_t* keep, const int32_t* num_keep, const float* dets, const int32_t* sel_cand,
                 const int32_t* sel_label, const float* boxes, const float* reppoints, const int32_t* total, int capacity,
                 int max_out, float* packed, void* stream);

@@ -53,84 +53,88 @@ __global__ void pp_gather_kernel(const float* __restrict__ pts_all, const int64_
   }
 }
 
-__device__ __forceinline__ float block_max(float v, float* red) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) red[wave] = v;
-  __syncthreads();
-  float r = red[0];
-  for (int i = 1; i < kScanThreads / 64; i++) r = fmaxf(r, red[i]);
-  return r;
-}
-// exclusive scan of one int per thread over the block; returns the exclusive prefix, *total = block sum
-__device__ __forceinline__ int block_excl_scan(int v, int* tmp, int* total) {
-  const int tid = threadIdx.x;
-  __syncthreads();
-  tmp[tid] = v;
-  __syncthreads();
-  for (int off = 1; off < kScanThreads; off <<= 1) {
-    const int a = (tid >= off) ? tmp[tid - off] : 0;
-    __syncthreads();
-    tmp[tid] += a;
-    __syncthreads();
-  }
-  *total = tmp[kScanThreads - 1];
-  return tmp[tid] - v;
-}
+// order-preserving float <-> uint map (for an atomicMax over floats of any sign)
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
-// ---- detections: (candidate, class) pairs above the threshold, row-major, with the class-offset coordinates --------
-// one workgroup; m0 is a few thousand.  dets rows >= count get score -inf (they sort last and are never evaluated).
-__global__ void __launch_bounds__(kScanThreads)
-pp_compact_kernel(const float* __restrict__ sig_all, const int64_t* __restrict__ cand, int m0, int n, int num_cls,
-                  const float* __restrict__ boxes, float thr, int cap, float* __restrict__ dets,
-                  int32_t* __restrict__ sel_cand, int32_t* __restrict__ sel_label, int32_t* __restrict__ seg,
-                  int32_t* __restrict__ total_out) {
-  __shared__ float red[kScanThreads / 64];
-  __shared__ int tmp[kScanThreads];
-  const int tid = threadIdx.x;
-  // pass 1: max coordinate over the boxes that own at least one detection (bboxes.max() of the expanded set)
+// ---- detections, step 1 (parallel): per candidate the bit set of classes above the threshold, and the max coordinate of
+// the boxes that own at least one detection (bboxes.max() of the expanded set) through one atomicMax per workgroup
+__global__ void __launch_bounds__(256)
+pp_flags_kernel(const float* __restrict__ sig_all, const int64_t* __restrict__ cand, int m0, int n, int num_cls,
+                const float* __restrict__ boxes, float thr, unsigned* __restrict__ bits, unsigned* __restrict__ max_ord) {
+  __shared__ float red[4];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
   float mx = -INFINITY;
-  for (int j = tid; j < m0; j += kScanThreads) {
+  if (j < m0) {
     const int g = (int)cand[j];
-    bool any = false;
-    for (int c = 0; c < num_cls; c++) any = any || (sig_all[(size_t)c * n + g] > thr);
-    if (any) {
+    unsigned b = 0;
+    for (int c = 0; c < num_cls; c++) b |= (sig_all[(size_t)c * n + g] > thr) ? (1u << c) : 0u;
+    bits[j] = b;
+    if (b) {
 #pragma unroll
       for (int k = 0; k < 8; k++) mx = fmaxf(mx, boxes[(size_t)j * 8 + k]);
     }
   }
-  const float max_coordinate = block_max(mx, red);
-  const float span = max_coordinate + 1.0f;
-  // pass 2: ordered compaction
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (mx > -INFINITY) atomicMax(max_ord, f2ord(mx));
+  }
+}
+
+// inclusive scan over the workgroup (wave shuffles + one LDS hop): returns the EXCLUSIVE prefix, *total = block sum
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  __syncthreads();                                         // wsum may still be read from the previous chunk
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; w++) { const int t = wsum[w]; if (w < wave) base += t; tot += t; }
+  *total = tot;
+  return base + inc - v;
+}
+
+// ---- detections, step 2 (one workgroup): ordered compaction, row-major over (candidate, class), with the class-offset
+// coordinates.  dets rows >= count get score -inf (they sort last and are never evaluated).
+__global__ void __launch_bounds__(kScanThreads)
+pp_compact_kernel(const float* __restrict__ sig_all, const int64_t* __restrict__ cand, int m0, int n,
+                  const unsigned* __restrict__ bits, const unsigned* __restrict__ max_ord,
+                  const float* __restrict__ boxes, int cap, float* __restrict__ dets, int32_t* __restrict__ sel_cand,
+                  int32_t* __restrict__ sel_label, int32_t* __restrict__ seg, int32_t* __restrict__ total_out) {
+  __shared__ int wsum[kScanThreads / 64];
+  const int tid = threadIdx.x;
+  const float span = ord2f(*max_ord) + 1.0f;                 // max_coordinate + 1
   int running = 0;
   for (int base = 0; base < m0; base += kScanThreads) {
     const int j = base + tid;
-    int cnt = 0;
-    int g = 0;
-    if (j < m0) {
-      g = (int)cand[j];
-      for (int c = 0; c < num_cls; c++) cnt += (sig_all[(size_t)c * n + g] > thr) ? 1 : 0;
-    }
+    const unsigned b = (j < m0) ? bits[j] : 0u;
+    const int cnt = __popc(b);
     int chunk_total;
-    int pos = running + block_excl_scan(cnt, tmp, &chunk_total);
+    int pos = running + block_excl_scan(cnt, wsum, &chunk_total);
     if (cnt > 0) {
+      const int g = (int)cand[j];
       float b8[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) b8[k] = boxes[(size_t)j * 8 + k];
-      for (int c = 0; c < num_cls; c++) {
-        const float sc = sig_all[(size_t)c * n + g];
-        if (sc > thr) {
-          if (pos < cap) {
-            const float offs = (float)c * span;              // labels.to(bboxes) * (max_coordinate + 1)
+      unsigned rem = b;
+      while (rem) {
+        const int c = __ffs((int)rem) - 1;
+        rem &= rem - 1;
+        if (pos < cap) {
+          const float offs = (float)c * span;                // labels.to(bboxes) * (max_coordinate + 1)
 #pragma unroll
-            for (int k = 0; k < 8; k++) dets[(size_t)pos * 9 + k] = b8[k] + offs;
-            dets[(size_t)pos * 9 + 8] = sc;
-            sel_cand[pos] = j; sel_label[pos] = c;
-          }
-          pos++;
+          for (int k = 0; k < 8; k++) dets[(size_t)pos * 9 + k] = b8[k] + offs;
+          dets[(size_t)pos * 9 + 8] = sig_all[(size_t)c * n + g];
+          sel_cand[pos] = j; sel_label[pos] = c;
         }
+        pos++;
       }
     }
     running += chunk_total;
@@ -196,6 +200,8 @@ inline int done() { hipError_t e = hipGetLastError(); return e == hipSuccess ? O
 
 extern "C" {
 
+size_t orp_pp_compact_scratch_bytes(int m0) { return 256 + sizeof(unsigned) * (size_t)(m0 > 0 ? m0 : 1); }
+
 int orp_pp_gather(const float* pts_all, const int64_t* cand, int m0, int n, const int* level_offsets_host,
                   const int* level_widths_host, const float* level_strides_host, int nlevels, float* pts_xy,
                   float* centers, float* strides, float* reppoints, void* stream) {
@@ -219,12 +225,23 @@ int orp_pp_gather(const float* pts_all, const int64_t* cand, int m0, int n, cons
 
 int orp_pp_compact(const float* sig_all, const int64_t* cand, int m0, int n, int num_classes, const float* boxes,
                    float score_thr, int capacity, float* dets, int32_t* sel_cand, int32_t* sel_label, int32_t* seg2,
-                   int32_t* total, void* stream) {
-  if (m0 < 0 || n <= 0 || num_classes <= 0 || capacity <= 0 || !dets || !sel_cand || !sel_label || !seg2 || !total)
+                   int32_t* total, void* scratch, size_t scratch_bytes, void* stream) {
+  if (m0 < 0 || n <= 0 || num_classes <= 0 || num_classes > 32 || capacity <= 0 || !dets || !sel_cand || !sel_label ||
+      !seg2 || !total)
     return ORP_EINVAL;
   if (m0 > 0 && (!sig_all || !cand || !boxes)) return ORP_EINVAL;
-  hipLaunchKernelGGL(pp_compact_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, sig_all, cand, m0, n,
-                     num_classes, boxes, score_thr, capacity, dets, sel_cand, sel_label, seg2, total);
+  if (!scratch || scratch_bytes < orp_pp_compact_scratch_bytes(m0)) return ORP_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* max_ord = reinterpret_cast<unsigned*>(scratch);
+  unsigned* bits = max_ord + 64;
+  // ordered encoding of -inf = ~0xff800000 = 0x007fffff
+  hipError_t e = hipMemsetAsync(max_ord, 0, sizeof(unsigned), st);     // 0 < f2ord(x) for every float x: "no box yet"
+  if (e != hipSuccess) return (int)e;
+  if (m0 > 0)
+    hipLaunchKernelGGL(pp_flags_kernel, dim3((m0 + 255) / 256), dim3(256), 0, st, sig_all, cand, m0, n, num_classes, boxes,
+                       score_thr, bits, max_ord);
+  hipLaunchKernelGGL(pp_compact_kernel, dim3(1), dim3(kScanThreads), 0, st, sig_all, cand, m0, n, bits, max_ord, boxes,
+                     capacity, dets, sel_cand, sel_label, seg2, total);
   return done();
 }
 

@@ -238,9 +238,10 @@ def fused_postprocess(cls_scores, points_preds, strides, cfg, num_points=9):
     nms_cfg_ = dict(cfg.nms)
     assert nms_cfg_.pop('type', 'rnms') == 'rnms'
     with torch.cuda.device(dev):
+        scratch = torch.empty((L.orp_pp_compact_scratch_bytes(m0),), dtype=torch.uint8, device=dev)
         _lib.check(L.orp_pp_compact(_lib.ptr(sig), _lib.ptr(cand), m0, N, C, _lib.ptr(boxes), float(cfg.score_thr), cap,
                                     _lib.ptr(dets), _lib.ptr(sel_cand), _lib.ptr(sel_label), _lib.ptr(seg),
-                                    _lib.ptr(total), st), "orp_pp_compact")
+                                    _lib.ptr(total), _lib.ptr(scratch), scratch.numel(), st), "orp_pp_compact")
     keep, num = nms_wrapper.rnms_batched_device(dets, seg, cap, nms_cfg_.get('iou_thr', 0.4))
     packed = torch.empty((m + 1, 28), **f32)
     with torch.cuda.device(dev):
