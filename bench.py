@@ -182,6 +182,97 @@ def per_op_table(dev, budget_s=2.0):
     return out
 
 
+def main_train(args):
+    """`--mode train`: BASELINE configs[2] -- one SGD iteration (forward, APAA losses, backward, bucketed gradient
+    all-reduce over RCCL for N > 1, optimizer step) on 2 synthetic 1024x1024 images with `--gts` polygons each per GPU.
+    Not the headline metric (that is inference images/sec); same JSON contract, weak scaling."""
+    from orientedreppoints_amd import dist_utils as D
+    from orientedreppoints_amd import synthetic as S
+    from orientedreppoints_amd.dota_configs import train_cfg as TRAIN_CFG
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
+    _lib.lib()
+    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
+    batch = args.batch if args.batch > 1 else 2          # configs[2]: imgs_per_gpu = 2
+
+    torch.manual_seed(0)                                  # identical initial weights on every rank
+    model = build_detector(ConfigDict(r50_model), train_cfg=ConfigDict(TRAIN_CFG),
+                           test_cfg=ConfigDict(TEST_CFG)).to(dev).train()
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-4, momentum=0.9,
+                          weight_decay=1e-4)
+    hook = D.DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2))
+    g = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    data = dict(
+        img=torch.randn(batch, 3, IMG, IMG, generator=g).to(dev),
+        img_meta=[dict(img_shape=(IMG, IMG, 3), pad_shape=(IMG, IMG, 3), scale_factor=1.0, flip=False)] * batch,
+        gt_bboxes=[torch.from_numpy(S.gen_polys(args.gts, 40 + i + 7 * rank, wh=(16, 120))[:, :8]
+                                    .astype(np.float32)).to(dev) for i in range(batch)],
+        gt_labels=[torch.randint(1, 16, (args.gts,), generator=g).to(dev) for _ in range(batch)])
+
+    def step():
+        # parse_losses all-reduces + .item()s the logged scalars every iteration as the reference's batch_processor does
+        return D.train_step(model, opt, data, hook)
+
+    for _ in range(args.warmup):
+        log_vars = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    _lib.lib().orp_profile_enable(1)
+    for s in range(16):
+        read_prof(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        log_vars = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.lib().orp_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = {name: read_prof(slot) for name, slot in (('dcn_fwd', 3), ('minarearect', 4))}
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    out = {
+        'metric': 'training images/sec (OrientedRepPoints R-50 FPN, 1024x1024 DOTA patch, APAA on, SGD step)',
+        'value': round(batch * args.steps * world / elapsed, 3),
+        'unit': 'images/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[2]: train step, %d img/GPU x %d gts, 1024x1024, 15 classes'
+                               % (batch, args.gts),
+                   'imgs_per_gpu': batch, 'gts_per_image': args.gts,
+                   'parallelism': 'dp%d (image-parallel, coalesced gradient all-reduce)' % world},
+        'loss': round(float(log_vars['loss']), 4),
+        'hip_events_ms_per_step': {k: (round(v[0] / args.steps, 3) if v[1] else None) for k, v in prof.items()},
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -195,7 +286,13 @@ def main():
     ap.add_argument('--cudnn-benchmark', type=int, default=0,
                     help='torch.backends.cudnn.benchmark (MIOpen find mode), the reference\'s cfg.cudnn_benchmark '
                          '(tools/test.py:108-110)')
+    ap.add_argument('--mode', choices=('test', 'train'), default='test',
+                    help="test (default): the headline inference step; train: one SGD iteration of BASELINE configs[2] "
+                         "(2 img/GPU, APAA on), gradients all-reduced over RCCL for N > 1")
+    ap.add_argument('--gts', type=int, default=64, help='--mode train: ground-truth polygons per image')
     args = ap.parse_args()
+    if args.mode == 'train':
+        return main_train(args)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
