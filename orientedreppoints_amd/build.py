@@ -15,7 +15,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-          "-Wno-unused-result", "-Wno-unused-value"]
+          "-Wno-unused-result", "-Wno-unused-value",
+          "-Wno-bitwise-instead-of-logical"]   # predicates are combined with & / | on purpose (no short-circuit branches)
 # (source, extra flags)
 SOURCES = [
     ("orp_nms.hip", ["-ffp-contract=off"]),

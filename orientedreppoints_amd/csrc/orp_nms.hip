@@ -10,9 +10,9 @@
 //      kernel: a workgroup owns a (<=64 rows x 64 columns) upper-triangular tile.  Phase A (lane = column, row
 //      wave-uniform through scalar loads) proves for ~84 % of the pairs of a dense scene, without a division,
 //      that every fan term is exactly 0 (orp_quadfast.hpp pair_is_far) and emits their bits by one wavefront
-//      ballot; the remaining pairs are queued in LDS and drained in phase B by quads of lanes running the
-//      register decision tree (no per-lane polygon storage), with the fp32 sum kept in the reference's order
-//      by DPP quad broadcasts.  Two launch forms: exact (host knows the box count: one workgroup per tile) and
+//      ballot; the remaining pairs are queued in LDS and drained in phase B as a TERM queue (orp_tile.hpp): a
+//      per-term exact-zero screen drops half of their 16 fan terms, the others run the register decision tree one
+//      term per lane (no per-lane polygon storage) and are summed per pair in the reference's order.  Two launch forms: exact (host knows the box count: one workgroup per tile) and
 //      capacity (the count lives in device memory -- sync-free / hipGraph callers: a bounded grid loops over the
 //      tiles of the actual count).  Non-zero mask words are also appended to a side list;
 //   3. sweep kernel: one workgroup per segment.  If the side list fits in LDS (<= 8192 words) the whole greedy
@@ -39,8 +39,8 @@ namespace {
 using orp::Pt;
 typedef unsigned long long u64;
 using orp_tile::TileLds;
+using orp_tile::TermLds;
 using orp_tile::pack_signs;
-using orp_tile::tile_pair_iou_quad;
 
 constexpr int kMaskThreads = 256;   // 4 waves per workgroup
 constexpr int kSweepThreads = 1024;
@@ -93,13 +93,14 @@ __global__ void prep_boxes_kernel(const float* __restrict__ dets, const int32_t*
 //   A  lane = column, the wave's row is uniform (scalar loads of its QuadPrep): orp::pair_is_far decides -- without a
 //      division -- that every fan term of the pair is exactly 0 (84 % of the pairs of a dense DOTA scene).  Resolved
 //      pairs set their bit by one wavefront ballot; the others go to a workgroup queue in LDS;
-//   B  the queue is drained by all 256 lanes, one unresolved pair per lane (row and column records come from the
-//      tile's LDS copy), through the register decision tree of orp_quadfast.hpp (generic polygon loop only for the
-//      ~1e-5 of pairs the tree does not cover).  Heavy pairs are thus packed densely into wavefronts instead of
-//      leaving 5 of 6 lanes idle next to them.
+//   B  the queue is drained by all 256 lanes (orp_tile::tile_drain_terms; row and column records come from the tile's
+//      LDS copy): B1 one lane per pair -- per-term exact-zero screen, surviving terms appended to a term queue; B2 one
+//      lane per TERM -- the register decision tree of orp_quadfast.hpp (generic polygon loop only for the ~1e-4 of
+//      terms the tree does not cover); B3 one lane per pair -- ordered sum, threshold, atomicOr into the row's word.
+//      Heavy work is thus packed densely into wavefronts instead of idling next to resolved pairs.
 // one (rpb rows x 64 columns) tile: phase A, queue, phase B, mask words out
 template <bool GUARD>
-__device__ __forceinline__ void mask_tile(TileLds& T, const orp::QuadPrep* __restrict__ prep, int s0, int n, int c,
+__device__ __forceinline__ void mask_tile(TileLds& T, TermLds& X, const orp::QuadPrep* __restrict__ prep, int s0, int n, int c,
                                           int row_base, int rpb, int rows_per_wave, int mask_stride, float thr,
                                           u64* __restrict__ mask, int dbg, int* __restrict__ nz_count,
                                           unsigned* __restrict__ nz_rc, u64* __restrict__ nz_w) {
@@ -123,6 +124,7 @@ __device__ __forceinline__ void mask_tile(TileLds& T, const orp::QuadPrep* __res
       for (int k = 0; k < 4; k++) T.colE[k][lane] = make_float4(cp.ax[k], cp.ay[k], cp.bx[k], cp.by[k]);
       T.colS[lane] = pack_signs(cp);
       T.colArea[lane] = cp.area_abs;
+      X.colM[lane] = cp.mabs;
     }
     if (tid < rpb) {
       const int r = row_base + tid;
@@ -132,10 +134,12 @@ __device__ __forceinline__ void mask_tile(TileLds& T, const orp::QuadPrep* __res
         for (int k = 0; k < 4; k++) T.rowE[k][tid] = make_float4(rp.ax[k], rp.ay[k], rp.bx[k], rp.by[k]);
         T.rowS[tid] = pack_signs(rp);
         T.rowArea[tid] = rp.area_abs;
+        X.rowM[tid] = rp.mabs;
       }
       T.words[tid] = 0ull;
     }
     if (tid == 0) T.qcount = 0;
+    orp_tile::term_lds_reset(X, tid);
   }
   __syncthreads();
   const bool cslow = (T.colS[lane] >> 8) != 0;
@@ -173,17 +177,11 @@ __device__ __forceinline__ void mask_tile(TileLds& T, const orp::QuadPrep* __res
   }
   __syncthreads();
 
-  // ---- phase B: one queued pair per quad of lanes -------------------------------------------------------------
+  // ---- phase B: per-term screen, one surviving fan term per lane, ordered sum per pair (orp_tile.hpp) ----------
   const int nq = (dbg & 1) ? 0 : T.qcount;
-  const int k = lane & 3;
-  for (int q0 = 0; q0 < nq; q0 += kMaskThreads / 4) {    // uniform trip count: DPP needs the whole quad alive
-    const int q = q0 + (tid >> 2);
-    const bool live = q < nq;
-    const int item = live ? T.queue[q] : 0;
-    const int rl = item >> 6, cl = item & 63;
-    const float iou = tile_pair_iou_quad<GUARD>(T, rl, cl, k, live);
-    if (live && k == 0 && iou > thr) atomicOr(&T.words[rl], 1ull << cl);
-  }
+  orp_tile::tile_drain_terms<GUARD>(T, X, nq, [&](int rl, int cl, float iou) {
+    if (iou > thr) atomicOr(&T.words[rl], 1ull << cl);
+  }, dbg);
   __syncthreads();
   if (tid < rpb && row_base + tid < n) {
     const u64 w = T.words[tid];
@@ -202,6 +200,7 @@ nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restric
                 int mask_stride, float thr, u64* __restrict__ mask, int dbg, int* __restrict__ nz_count,
                 unsigned* __restrict__ nz_rc, u64* __restrict__ nz_w) {
   __shared__ TileLds T;
+  __shared__ TermLds X;
   const int seg = blockIdx.z;
   const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
   const int c = blockIdx.x;
@@ -209,7 +208,7 @@ nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restric
   const int row_base = blockIdx.y * rpb;
   if (row_base >= n || c * 64 >= n) return;
   if ((row_base >> 6) > c) return;                       // lower-triangular tile: never read by the sweep
-  mask_tile<GUARD>(T, prep, s0, n, c, row_base, rpb, rows_per_wave, mask_stride, thr, mask, dbg, nz_count, nz_rc, nz_w);
+  mask_tile<GUARD>(T, X, prep, s0, n, c, row_base, rpb, rows_per_wave, mask_stride, thr, mask, dbg, nz_count, nz_rc, nz_w);
 }
 
 // capacity launch: the box count lives in DEVICE memory (seg_off) and the host only knows an upper bound -- a bounded
@@ -221,6 +220,7 @@ nms_mask_loop_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __re
                      int mask_stride, float thr, u64* __restrict__ mask, int dbg, int* __restrict__ nz_count,
                      unsigned* __restrict__ nz_rc, u64* __restrict__ nz_w) {
   __shared__ TileLds T;
+  __shared__ TermLds X;
   const int seg = blockIdx.z;
   const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
   const int rpb = rows_per_wave * (kMaskThreads / 64);
@@ -230,7 +230,7 @@ nms_mask_loop_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __re
     const int c = tile % cbn;
     const int row_base = (tile / cbn) * rpb;
     if ((row_base >> 6) > c) continue;
-    mask_tile<GUARD>(T, prep, s0, n, c, row_base, rpb, rows_per_wave, mask_stride, thr, mask, dbg, nz_count, nz_rc, nz_w);
+    mask_tile<GUARD>(T, X, prep, s0, n, c, row_base, rpb, rows_per_wave, mask_stride, thr, mask, dbg, nz_count, nz_rc, nz_w);
     __syncthreads();                                     // T is reused by the next tile
   }
 }
@@ -592,7 +592,12 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
     if (ntile > cap_wg) ntile = cap_wg;
     grid = dim3((unsigned)ntile, 1, nseg);
   }
-  static const int dbg = getenv("ORP_NMS_DBG") ? atoi(getenv("ORP_NMS_DBG")) : 0;   // dev aid: 1 = skip phase B, 2 = skip classifier
+  static const int dbg = getenv("ORP_NMS_DBG") ? atoi(getenv("ORP_NMS_DBG")) : 0;   // dev aid (timing): 1 = skip phase B, 2 = skip classifier, 4/8/16 = see tile_drain_terms, 32 = print occupancy
+  if (dbg & 32) {                                          // dev aid: resident workgroups per CU
+    int nb = 0;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nms_mask_kernel<false>, kMaskThreads, 0);
+    fprintf(stderr, "nms_mask_kernel: %d workgroups/CU, grid %u x %u x %u, R %d\n", nb, grid.x, grid.y, grid.z, R);
+  }
   {
     OrpProfScope prof(ORP_PROF_NMS_MASK, st);
     if (exact_n) {

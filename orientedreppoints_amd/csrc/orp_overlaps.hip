@@ -4,8 +4,8 @@
 //   DOTA_devkit/poly_nms_gpu/poly_overlaps_kernel.cu:280-427  (RotBox2Poly, devPolyIoU, overlaps_kernel, _overlaps)
 // and provides the all-pairs fp32 quad IoU (devrIoU / devPolyIoU arithmetic) used by tests and by the merge /
 // evaluation tools.  Layout: lane = column (query / b row) so the [N,K] result is written coalesced; a workgroup
-// owns 16 rows x 64 columns and runs the two-phase tile of orp_tile.hpp (exact-zero classifier, then the register
-// decision tree on the queued pairs).
+// owns 16 rows x 64 columns and runs the tile phases of orp_tile.hpp (exact-zero pair classifier, per-term exact-zero
+// screen, then the register decision tree on the surviving fan terms).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -40,7 +40,7 @@ __device__ __forceinline__ void rotbox2poly(const float* dbox, float* p8) {
 // One workgroup = a tile of kRows rows x 64 columns, evaluated like the NMS mask tile (orp_tile.hpp): every box of
 // the tile is prepared once into LDS (orientation, oriented fan triangles, signs, |area|), phase A (lane = column,
 // row wave-uniform) resolves the pairs whose intersection is exactly 0 with the division-free classifier and writes
-// 0/union directly, the rest are queued and evaluated densely by quads of lanes on the register decision tree.
+// 0/union directly, the rest are queued and drained term by term (orp_tile::tile_drain_terms).
 constexpr int kRows = 16;              // 4 rows per wave
 
 struct RowFar { float vx[4], vy[4]; float mabs; int slow; };
@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(kThreads, 4)
 iou_matrix_kernel(const float* __restrict__ a, int n, const float* __restrict__ b, int k, int stride,
                   float* __restrict__ out) {
   __shared__ orp_tile::TileLds T;
+  __shared__ orp_tile::TermLds X;
   __shared__ RowFar rowF[kRows];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = blockIdx.x * 64 + lane;
@@ -79,6 +80,7 @@ iou_matrix_kernel(const float* __restrict__ a, int n, const float* __restrict__ 
       for (int e = 0; e < 4; e++) T.colE[e][lane] = make_float4(cp.ax[e], cp.ay[e], cp.bx[e], cp.by[e]);
       T.colS[lane] = orp_tile::pack_signs(cp);
       T.colArea[lane] = cp.area_abs;
+      X.colM[lane] = cp.mabs;
     }
   }
   if (tid < kRows) {
@@ -106,8 +108,10 @@ iou_matrix_kernel(const float* __restrict__ a, int n, const float* __restrict__ 
     rowF[tid].mabs = rp.mabs; rowF[tid].slow = rp.force_slow;
     T.rowS[tid] = orp_tile::pack_signs(rp);
     T.rowArea[tid] = rp.area_abs;
+    X.rowM[tid] = rp.mabs;
   }
   if (tid == 0) T.qcount = 0;
+  orp_tile::term_lds_reset(X, tid);
   __syncthreads();
   const bool cslow = (T.colS[lane] >> 8) != 0;
   const float carea = T.colArea[lane];
@@ -138,17 +142,11 @@ iou_matrix_kernel(const float* __restrict__ a, int n, const float* __restrict__ 
   }
   __syncthreads();
 
-  // ---- phase B: one queued pair per quad of lanes -------------------------------------------------------------
-  const int nq = T.qcount;
-  const int kq = lane & 3;
-  for (int q0 = 0; q0 < nq; q0 += kThreads / 4) {        // uniform trip count: DPP needs the whole quad alive
-    const int q = q0 + (tid >> 2);
-    const bool live = q < nq;
-    const int item = live ? T.queue[q] : 0;
-    const int rl = item >> 6, cl = item & 63;
-    const float iou = orp_tile::tile_pair_iou_quad<GUARD>(T, rl, cl, kq, live);
-    if (live && kq == 0) out[(size_t)(row_base + rl) * k + blockIdx.x * 64 + cl] = iou;
-  }
+  // ---- phase B: per-term screen, one surviving fan term per lane, ordered sum per pair (orp_tile.hpp) ----------
+  const size_t col0 = (size_t)blockIdx.x * 64;
+  orp_tile::tile_drain_terms<GUARD>(T, X, T.qcount, [&](int rl, int cl, float iou) {
+    out[(size_t)(row_base + rl) * k + col0 + cl] = iou;
+  });
 }
 
 int launch(int mode, int guard, const float* a, int n, const float* b, int k, int stride, float* out, hipStream_t st) {

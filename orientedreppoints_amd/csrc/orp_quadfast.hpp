@@ -268,6 +268,63 @@ ORP_HD bool pair_is_far(const T* rvx, const T* rvy, T rm, const FarColT<T>& c) {
   return ok;
 }
 
+// ---- per-TERM exact-zero screen ("phase B1") ----------------------------------------------------------------------
+// For a pair the classifier leaves unresolved, decides term by term which of the 16 fan terms are exactly 0 -- again
+// without a division -- so that only the others (about 1 in 8 on dense DOTA-like scenes) go through the decision tree:
+//   kill-1: neither fan vertex of the row edge is strictly left of O->c:  ca <= eps and cb <= eps, the test
+//           tri_term_fast_t starts with (<= 2 distinct vertices survive stage 1: area exactly 0);
+//   kill-3: the per-term form of ccw_far above.  With ca, cb > E stage 1 leaves [O, a, b] (plus exact-origin crossings
+//           the de-duplication folds into O); stage 2 can only add points of the segments O-a, a-b, b-O; under
+//           X[v][d] > E and, for v in {a, b},  c(v) > eps  or  (c(v) < -eps and beta * X[v][d] > E, beta = c0/(c0-c(v)))
+//           and c0 > eps, the reference's stage-3 value of every such non-origin vertex is < -1e-8 (same bound as
+//           ccw_far: that analysis is per term, the pair test only ANDs it over the 16 terms with min X in place of
+//           X[v][d]), every denominator of a crossing actually computed exceeds eps, the origin's stage-3 value is an
+//           exact 0, so stage 3 leaves origin points only and the shoelace sum is exactly 0.
+// A term with a degenerate edge (s == 0) is skipped by the reference.  Bit 4*i + j of the result = term (row edge i,
+// column edge j) must be evaluated.  Dropping exact-zero terms does not change the sum: inter starts at +0 and
+// x + (+-0) == x.  Inputs: oriented fan edges (a -> b per row edge, c -> d per column edge), signs, max |coordinate|.
+template <typename T>
+ORP_HD unsigned pair_term_alive_mask(const T* rax, const T* ray, const T* rbx, const T* rby, const int* rs, T rm,
+                                     const T* ccx, const T* ccy, const T* cdx, const T* cdy, const int* cs, T cm) {
+  const T E = PrecT<T>::e48u() * cm * (rm + cm) + (T)1e-7;          // 48 * u * D * (M + D) + 1e-7
+  // row vertex v = start of polygon edge v (the oriented edge is swapped when s == -1)
+  T vx[4], vy[4];
+#pragma unroll
+  for (int v = 0; v < 4; v++) { const bool sw = rs[v] < 0; vx[v] = sw ? rbx[v] : rax[v]; vy[v] = sw ? rby[v] : ray[v]; }
+  unsigned alive = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const T bax2 = cdx[j] - ccx[j], bay2 = cdy[j] - ccy[j];
+    const T c0 = bax2 * ((T)0 - ccy[j]) - ((T)0 - ccx[j]) * bay2;
+    const bool c0_pos = pos_(c0);
+    bool notleft[4], beyond[4];                                      // per row vertex, against column edge j
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const T xc = ccx[j] * vy[v] - vx[v] * ccy[j];                  // the reference's stage-1 value of v
+      const T xd = cdx[j] * vy[v] - vx[v] * cdy[j];
+      const T cv = bax2 * (vy[v] - ccy[j]) - (vx[v] - ccx[j]) * bay2;
+      notleft[v] = !pos_(xc);
+      beyond[v] = (xc > E) & (xd > E) & (pos_(cv) | (neg_(cv) & (xd * c0 > E * (c0 - cv))));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int i1 = (i + 1) & 3;
+      const bool kill1 = notleft[i] & notleft[i1];
+      const bool kill3 = c0_pos & beyond[i] & beyond[i1];
+      const bool live = (rs[i] != 0) & (cs[j] != 0) & !(kill1 | kill3);
+      alive |= live ? (1u << (4 * i + j)) : 0u;
+    }
+  }
+  return alive;
+}
+
+// The composition of the term-queue kernels as one function (what tests/host_harness checks against the oracle):
+// classifier, per-term screen, decision tree for the surviving terms (generic polygon loop for a term the tree does not
+// cover) summed in the reference's order.  stats[0] += classifier-resolved pairs, stats[1] += generic TERMS,
+// stats[2] += terms evaluated, stats[3] += pairs the per-term screen emptied.
+template <typename T, bool GUARD>
+ORP_HD T quad_iou_term_queue_t(const QuadPrepT<T>* r, const QuadPrepT<T>* c, long long* stats = nullptr);
+
 // ---- the same classifier for (convex hull of <= 12 vertices, quad) pairs: convex_iou (fp64) -------------------------
 // H.get(v) = hull vertex v (CCW), q[0..3] = the gt quad re-oriented CCW as convex_iou's intersectAreaO does; hull_mabs =
 // max |coordinate| of the hull.  Returns true when every fan term (hull edge i, quad edge j) is exactly 0.  The hull is
@@ -423,6 +480,48 @@ ORP_HD T quad_iou_two_phase_t(const QuadPrepT<T>* r, const QuadPrepT<T>* c, long
 template <bool GUARD>
 ORP_HD float quad_iou_two_phase(const QuadPrep* r, const QuadPrep* c, long long* stats = nullptr) {
   return quad_iou_two_phase_t<float, GUARD>(r, c, stats);
+}
+
+template <typename T, bool GUARD>
+ORP_HD T quad_iou_term_queue_t(const QuadPrepT<T>* r, const QuadPrepT<T>* c, long long* stats) {
+  const bool forced = (r->force_slow | c->force_slow) != 0;
+  unsigned alive = 0u;
+  if (forced) {
+    for (int t = 0; t < 16; t++) alive |= (r->s[t >> 2] != 0 && c->s[t & 3] != 0) ? (1u << t) : 0u;
+  } else {
+    const FarColT<T> fc = far_col<T>(*c);
+    if (pair_is_far<T>(r->vx, r->vy, r->mabs, fc)) {
+      if (stats) stats[0]++;
+      return iou_of_zero_inter_t<T, GUARD>(r->area_abs, c->area_abs);
+    }
+    alive = pair_term_alive_mask<T>(r->ax, r->ay, r->bx, r->by, r->s, r->mabs, c->ax, c->ay, c->bx, c->by, c->s, c->mabs);
+  }
+  if (alive == 0u) {
+    if (stats) stats[3]++;
+    return iou_of_zero_inter_t<T, GUARD>(r->area_abs, c->area_abs);
+  }
+  PolyPriv<T, ORP_CLIP_CAP> P, Q;
+  T inter = (T)0;
+  for (int t = 0; t < 16; t++) {
+    if (!((alive >> t) & 1u)) continue;
+    const int i = t >> 2, j = t & 3;
+    bool slow = forced;
+    T v = (T)0;
+    if (!slow) v = tri_term_fast_t<T, true>(r->ax[i], r->ay[i], r->bx[i], r->by[i], fan_col<T>(c->ax[j], c->ay[j], c->bx[j], c->by[j]), slow);
+    if (slow) {                                          // this one term through the generic polygon loop
+      Pt<T> a, b, cc, d;
+      a.x = r->ax[i]; a.y = r->ay[i]; b.x = r->bx[i]; b.y = r->by[i];
+      cc.x = c->ax[j]; cc.y = c->ay[j]; d.x = c->bx[j]; d.y = c->by[j];
+      v = tri_term_oriented<T>(P, Q, a, b, cc, d);
+      if (stats) stats[1]++;
+    }
+    if (r->s[i] * c->s[j] == -1) v = -v;
+    inter += v;
+    if (stats) stats[2]++;
+  }
+  const T uni = r->area_abs + c->area_abs - inter;
+  if (GUARD) { if (uni == (T)0) return (inter + (T)1) / (uni + (T)1); }
+  return inter / uni;
 }
 
 }  // namespace orp

@@ -1,6 +1,7 @@
 // orp_tile.hpp -- the (rows x 64 columns) pair tile shared by the rotated-NMS mask kernel and the IoU-matrix kernels
-// (gfx950, device only): LDS records of the tile's prepared boxes, the unresolved-pair queue, and the phase-B
-// evaluation of one queued pair by a quad of lanes.  See orp_quadfast.hpp for the arithmetic contract.
+// (gfx950, device only): LDS records of the tile's prepared boxes, the unresolved-pair queue, and the phase-B drain
+// of that queue as a TERM queue (tile_drain_terms: per-term exact-zero screen, one surviving fan term per lane,
+// ordered sum per pair).  See orp_quadfast.hpp for the arithmetic contract.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -35,74 +36,137 @@ __device__ __forceinline__ int unpack_sign(int packed, int k) {
   return b == 0 ? 0 : (b == 1 ? 1 : -1);
 }
 
-// value of lane (quad base + k) for every lane of a quad (DPP quad_perm broadcast, one VALU op)
-template <int K>
-__device__ __forceinline__ float quad_bcast(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
-}
-template <int K>
-__device__ __forceinline__ int quad_bcast_i(int v) {
-  return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xf, 0xf, true);
+// ---- phase B as a TERM queue ------------------------------------------------------------------------------------
+// Half of the 16 fan terms of an unresolved pair are exact zeros that orp::pair_term_alive_mask recognises from signs
+// (kill-1 / kill-3), and a wave that evaluates whole pairs pays the full decision tree for them anyway.  So:
+//   B1  one lane per queued pair: 16-bit mask of the terms that must be evaluated; the pair's terms get a contiguous
+//       run of the term queue (wave prefix + one LDS atomic per wave); pairs with no term left are decided at once;
+//   B2  one lane per TERM: the register decision tree; a term the tree does not cover (or any term of a box with
+//       non-finite coordinates) is evaluated by the generic polygon loop right there -- per term, not per pair: the
+//       scratch-resident loop is ~100x slower than the tree and one lane walking all 16 terms of a pair used to be
+//       the tail of the whole kernel.  The value (sign applied) replaces the queue entry;
+//   B3  one lane per pair: the values are summed in the reference's order (row edge outer, column edge inner -- the
+//       run is in ascending term order), then `sink`.
+// Chunks of kChunkPairs pairs; kChunkPairs * 16 term slots.
+constexpr int kChunkPairs = 256;
+constexpr int kTermCap = kChunkPairs * 16;
+constexpr int kDrainThreads = 256;          // workgroup size of the callers
+constexpr int kTermGeneric = 1 << 30;       // queue entry flag: skip the tree
+
+struct TermLds {
+  float rowM[kMaxTileRows];          // max |coordinate| per tile row / column (the classifier bound E)
+  float colM[64];
+  int tq[kTermCap];                  // (pair-in-chunk << 4 | term) before B2, float bits of the term's value after
+  int tcount;
+};
+
+// resets the per-chunk counter; call before the barrier that precedes tile_drain_terms
+__device__ __forceinline__ void term_lds_reset(TermLds& X, int tid) {
+  if (tid == 0) X.tcount = 0;
 }
 
-// Phase B: one queued pair per QUAD of lanes -- lane k of the quad evaluates the four fan terms of row edge k, then
-// the 16 values are summed in the reference's order (row edge outer, column edge inner) through quad broadcasts, so
-// the fp32 accumulation is unchanged while the critical path per pair is 4 terms instead of 16.
-// Returns the pair's IoU (valid on every lane of the quad).
-template <bool GUARD>
-__device__ __forceinline__ float tile_pair_iou_quad(const TileLds& T, int rl, int cl, int k, bool live) {
-  const int rs = T.rowS[rl], cs = T.colS[cl];
-  bool slow = live && (((rs | cs) >> 8) != 0);
-  const int s1 = unpack_sign(rs, k);
-  const float4 e = T.rowE[k][rl];
-  float t[4];
-#pragma unroll 1
-  for (int j = 0; j < 4; j++) {
-    const int s2 = unpack_sign(cs, j);
-    float v = 0.f;
-    if (live && s1 != 0 && s2 != 0) {
-      const float4 g = T.colE[j][cl];
-      const orp::FanCol f = orp::fan_col(g.x, g.y, g.z, g.w);
-      v = orp::tri_term_fast(e.x, e.y, e.z, e.w, f, slow);
-      if (s1 * s2 == -1) v = -v;
+// Drains T.queue[0, nq) with a 256-thread workgroup (every thread must call it; contains barriers).  X must have been
+// reset (term_lds_reset + barrier).  sink(rl, cl, iou) is called once per queued pair by one lane.
+// dbg (development aid, timing only): 4 = skip B2, 8 = no per-term screen, 16 = skip B3.
+template <bool GUARD, typename Sink>
+__device__ __forceinline__ void tile_drain_terms(const TileLds& T, TermLds& X, int nq, Sink sink, int dbg = 0) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int q0 = 0; q0 < nq; q0 += kChunkPairs) {
+    if (q0 > 0) {                                        // the previous chunk's B3 still reads tq
+      __syncthreads();
+      term_lds_reset(X, tid);
+      __syncthreads();
     }
-    // static register slot for a dynamic j without private-memory indexing
-    t[0] = (j == 0) ? v : t[0]; t[1] = (j == 1) ? v : t[1]; t[2] = (j == 2) ? v : t[2]; t[3] = (j == 3) ? v : t[3];
-  }
-  // skipped terms contribute +0: inter never holds -0, so x + (+-0) == x and the sum equals the reference's
-  float inter = 0.f;
-  inter += quad_bcast<0>(t[0]); inter += quad_bcast<0>(t[1]); inter += quad_bcast<0>(t[2]); inter += quad_bcast<0>(t[3]);
-  inter += quad_bcast<1>(t[0]); inter += quad_bcast<1>(t[1]); inter += quad_bcast<1>(t[2]); inter += quad_bcast<1>(t[3]);
-  inter += quad_bcast<2>(t[0]); inter += quad_bcast<2>(t[1]); inter += quad_bcast<2>(t[2]); inter += quad_bcast<2>(t[3]);
-  inter += quad_bcast<3>(t[0]); inter += quad_bcast<3>(t[1]); inter += quad_bcast<3>(t[2]); inter += quad_bcast<3>(t[3]);
-  const int sl = slow ? 1 : 0;
-  const int any_slow = quad_bcast_i<0>(sl) | quad_bcast_i<1>(sl) | quad_bcast_i<2>(sl) | quad_bcast_i<3>(sl);
-  if (any_slow && k == 0) {                              // generic polygon loop, scratch-resident (rare)
-    orp::PolyPriv<float, orp::ORP_CLIP_CAP> P, Q;
-    inter = 0.f;
-#pragma unroll 1
-    for (int i = 0; i < 4; i++) {
-      const int si = unpack_sign(rs, i);
-      if (si == 0) continue;
-      const float4 ei = T.rowE[i][rl];
-      Pt<float> a, b;
-      a.x = ei.x; a.y = ei.y; b.x = ei.z; b.y = ei.w;
-#pragma unroll 1
-      for (int j = 0; j < 4; j++) {
-        const int s2 = unpack_sign(cs, j);
-        if (s2 == 0) continue;
-        const float4 g = T.colE[j][cl];
-        Pt<float> cc, d;
-        cc.x = g.x; cc.y = g.y; d.x = g.z; d.y = g.w;
-        float v = orp::tri_term_oriented<float>(P, Q, a, b, cc, d);
-        if (si * s2 == -1) v = -v;
-        inter += v;
+    // ---- B1 ----------------------------------------------------------------------------------------------------
+    const bool live = (tid < kChunkPairs) && (q0 + tid) < nq;
+    const int item = live ? T.queue[q0 + tid] : 0;
+    const int rl = item >> 6, cl = item & 63;
+    unsigned alive = 0u;
+    bool forced = false;
+    if (live) {
+      const int rs = T.rowS[rl], cs = T.colS[cl];
+      float rax[4], ray[4], rbx[4], rby[4], ccx[4], ccy[4], cdx[4], cdy[4];
+      int s1[4], s2[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float4 r4 = T.rowE[e][rl], c4 = T.colE[e][cl];
+        rax[e] = r4.x; ray[e] = r4.y; rbx[e] = r4.z; rby[e] = r4.w;
+        ccx[e] = c4.x; ccy[e] = c4.y; cdx[e] = c4.z; cdy[e] = c4.w;
+        s1[e] = unpack_sign(rs, e); s2[e] = unpack_sign(cs, e);
+      }
+      forced = ((rs | cs) >> 8) != 0;                    // non-finite / huge coordinates: generic loop, every term
+      if (forced || (dbg & 8)) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) alive |= (s1[t >> 2] != 0 && s2[t & 3] != 0) ? (1u << t) : 0u;
+      } else {
+        alive = orp::pair_term_alive_mask<float>(rax, ray, rbx, rby, s1, X.rowM[rl], ccx, ccy, cdx, cdy, s2, X.colM[cl]);
       }
     }
+    const int cnt = __popc(alive);
+    int incl = cnt;                                      // inclusive prefix over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      incl += (lane >= off) ? v : 0;
+    }
+    const int wave_total = __shfl(incl, 63, 64);
+    int wbase = 0;
+    if (wave_total > 0) {
+      if (lane == 0) wbase = atomicAdd(&X.tcount, wave_total);
+      wbase = __builtin_amdgcn_readfirstlane(wbase);
+    }
+    const int base = wbase + incl - cnt;
+    if (live) {
+      if (alive == 0u) {
+        sink(rl, cl, orp::iou_of_zero_inter<GUARD>(T.rowArea[rl], T.colArea[cl]));
+      } else {
+        const int tag = (tid << 4) | (forced ? kTermGeneric : 0);
+        unsigned m = alive;
+        int pos = base;
+        while (m) {
+          const int t = __ffs(m) - 1;
+          m &= m - 1u;
+          X.tq[pos++] = tag | t;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- B2 ----------------------------------------------------------------------------------------------------
+    const int total = (dbg & 4) ? 0 : X.tcount;
+    for (int e = tid; e < total; e += kDrainThreads) {
+      const int ent = X.tq[e];
+      const int p = (ent >> 4) & (kChunkPairs - 1), i = (ent >> 2) & 3, j = ent & 3;
+      const int it2 = T.queue[q0 + p];
+      const int rl2 = it2 >> 6, cl2 = it2 & 63;
+      const float4 r4 = T.rowE[i][rl2];
+      const float4 g = T.colE[j][cl2];
+      const int sg = unpack_sign(T.rowS[rl2], i) * unpack_sign(T.colS[cl2], j);
+      const orp::FanCol f = orp::fan_col(g.x, g.y, g.z, g.w);
+      bool slow = (ent & kTermGeneric) != 0;
+      float v = 0.f;
+      if (!slow) v = orp::tri_term_fast(r4.x, r4.y, r4.z, r4.w, f, slow);
+      if (slow) {                                        // rare: this one term through the generic polygon loop
+        orp::PolyPriv<float, orp::ORP_CLIP_CAP> P, Q;
+        Pt<float> a, b, cc, d;
+        a.x = r4.x; a.y = r4.y; b.x = r4.z; b.y = r4.w;
+        cc.x = g.x; cc.y = g.y; d.x = g.z; d.y = g.w;
+        v = orp::tri_term_oriented<float>(P, Q, a, b, cc, d);
+      }
+      if (sg == -1) v = -v;
+      X.tq[e] = __float_as_int(v);
+    }
+    __syncthreads();
+    // ---- B3 ----------------------------------------------------------------------------------------------------
+    if (live && alive != 0u && !(dbg & 16)) {
+      float inter = 0.f;
+      for (int t = 0; t < cnt; t++) inter += __int_as_float(X.tq[base + t]);
+      const float uni = T.rowArea[rl] + T.colArea[cl] - inter;
+      float iou;
+      if (GUARD && uni == 0.f) iou = (inter + 1.f) / (uni + 1.f);
+      else iou = inter / uni;
+      sink(rl, cl, iou);
+    }
   }
-  const float uni = T.rowArea[rl] + T.colArea[cl] - inter;
-  if (GUARD) { if (uni == 0.f) return (inter + 1.f) / (uni + 1.f); }
-  return inter / uni;
 }
 
 }  // namespace orp_tile

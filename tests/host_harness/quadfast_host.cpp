@@ -26,6 +26,23 @@ void host_quadfast_matrix(const float* a, int n, const float* b, int k, int guar
   delete[] ra;
 }
 
+// the term-queue composition (classifier, per-term exact-zero screen, decision tree on the surviving terms): what the
+// NMS mask kernel runs in phases A / B1 / B2 / B3.  stats[0..3] as in orp::quad_iou_term_queue_t.
+void host_quadterm_matrix(const float* a, int n, const float* b, int k, int guard, float* out, int64_t* stats) {
+  orp::QuadPrep* ra = new orp::QuadPrep[n > 0 ? n : 1];
+  long long st[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n; i++) orp::quad_prepare(a + 8 * (size_t)i, ra[i]);
+  for (int j = 0; j < k; j++) {
+    orp::QuadPrep pc;
+    orp::quad_prepare(b + 8 * (size_t)j, pc);
+    for (int i = 0; i < n; i++)
+      out[(size_t)i * k + j] = guard ? orp::quad_iou_term_queue_t<float, true>(&ra[i], &pc, st)
+                                     : orp::quad_iou_term_queue_t<float, false>(&ra[i], &pc, st);
+  }
+  if (stats) for (int t = 0; t < 4; t++) stats[t] += st[t];
+  delete[] ra;
+}
+
 // fp64 instantiation (DOTA_devkit/polyiou.cpp arithmetic: the merge NMS): out[n,k] = IoU(a[i], b[j]) in double
 void host_quadfast_matrix_f64(const double* a, int n, const double* b, int k, double* out, int64_t* stats) {
   orp::QuadPrepT<double>* ra = new orp::QuadPrepT<double>[n > 0 ? n : 1];
