@@ -160,10 +160,9 @@ convex_iou_kernel(const float* __restrict__ pts, int n, const float* __restrict_
       if (gs[t] == -1) { const Pt<double> tmp = c; c = d; d = tmp; }
       gf[t] = orp::fan_col<double>(c.x, c.y, d.x, d.y);
     }
-    // register decision tree (orp_quadfast.hpp, fp64 instantiation, signed terms); generic polygon loop on the
-    // per-lane LDS columns only if a term falls outside the tree
+    // register decision tree (orp_quadfast.hpp, fp64 instantiation, signed terms); a term that falls outside the tree
+    // goes through the generic polygon loop on the per-lane LDS columns -- that one term, not the whole pair
     double inter = 0;
-    bool slow = false;
     Pt<double> a = HS.get(0);
     const Pt<double> h0 = a;
     for (int i = 0; i < hn; i++) {
@@ -174,26 +173,17 @@ convex_iou_kernel(const float* __restrict__ pts, int n, const float* __restrict_
 #pragma unroll
         for (int t = 0; t < 4; t++) {
           if (gs[t] == 0) continue;
+          bool slow = false;
           double v = orp::tri_term_fast_t<double, false>(ea.x, ea.y, eb.x, eb.y, gf[t], slow);
+          if (slow) {
+            const Pt<double> c{gf[t].cx, gf[t].cy}, d{gf[t].dx, gf[t].dy};
+            v = orp::tri_term_oriented_signed<double>(P, Q, ea, eb, c, d);
+          }
           if (s1 * gs[t] == -1) v = -v;
           inter += v;
         }
       }
       a = b;
-    }
-    if (slow) {
-      inter = 0;
-      a = h0;
-      for (int i = 0; i < hn; i++) {
-        const Pt<double> b = (i + 1 < hn) ? HS.get(i + 1) : h0;
-#pragma unroll 1
-        for (int t = 0; t < 4; t++) {
-          Pt<double> c = q[0], d = q[1];
-          if (t == 1) { c = q[1]; d = q[2]; } else if (t == 2) { c = q[2]; d = q[3]; } else if (t == 3) { c = q[3]; d = q[0]; }
-          inter += orp::tri_term<double, false>(P, Q, a, b, c, d);
-        }
-        a = b;
-      }
     }
     const double uni = fabs(hs) + fabs(s_gt) - inter;
     out[(size_t)(blockIdx.x * kThreads + sl) * k + j] = (float)(inter / uni);

@@ -414,12 +414,18 @@ ORP_HD T quad_iou_prepared_generic_t(const QuadPrepT<T>* r, const QuadColT<T>& c
 }
 
 // IoU of the prepared row box `r` (wave-uniform: scalar loads on the GPU) with the register-resident column box.
-// Term order (row edge outer, column edge inner) and the accumulation order are those of quad_iou().
-// `nslow` (optional, host statistics) counts pairs that took the generic path.
+// Term order (row edge outer, column edge inner) and the accumulation order are those of quad_iou().  A term the
+// decision tree does not cover is evaluated by the generic polygon loop -- that term only.
+// `nslow` (optional, host statistics) counts pairs that needed the generic loop for at least one term.
 template <typename T, bool GUARD>
 ORP_HD T quad_iou_prepared_t(const QuadPrepT<T>* r, const QuadColT<T>& c, int* nslow = nullptr) {
+  if ((r->force_slow | c.force_slow) != 0) {
+    if (nslow) (*nslow)++;
+    return quad_iou_prepared_generic_t<T, GUARD>(r, c);
+  }
+  PolyPriv<T, ORP_CLIP_CAP> P, Q;
   T inter = (T)0;
-  bool slow = (r->force_slow | c.force_slow) != 0;
+  bool any_slow = false;
 #pragma unroll 1
   for (int i = 0; i < 4; i++) {
     const int s1 = r->s[i];
@@ -428,15 +434,20 @@ ORP_HD T quad_iou_prepared_t(const QuadPrepT<T>* r, const QuadColT<T>& c, int* n
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       if (c.s[j] == 0) continue;
+      bool slow = false;
       T t = tri_term_fast_t<T, true>(ax, ay, bx, by, c.f[j], slow);
+      if (slow) {
+        Pt<T> a, b, cc, d;
+        a.x = ax; a.y = ay; b.x = bx; b.y = by;
+        cc.x = c.f[j].cx; cc.y = c.f[j].cy; d.x = c.f[j].dx; d.y = c.f[j].dy;
+        t = tri_term_oriented<T>(P, Q, a, b, cc, d);
+        any_slow = true;
+      }
       if (s1 * c.s[j] == -1) t = -t;
       inter += t;
     }
   }
-  if (slow) {
-    if (nslow) (*nslow)++;
-    return quad_iou_prepared_generic_t<T, GUARD>(r, c);
-  }
+  if (any_slow && nslow) (*nslow)++;
   const T uni = r->area_abs + c.area_abs - inter;
   if (GUARD) { if (uni == (T)0) return (inter + (T)1) / (uni + (T)1); }
   return inter / uni;

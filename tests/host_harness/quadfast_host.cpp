@@ -57,6 +57,20 @@ void host_quadfast_matrix_f64(const double* a, int n, const double* b, int k, do
   delete[] ra;
 }
 
+// fp64 term-queue composition: what nms_mask_f64_kernel evaluates per lane
+void host_quadterm_matrix_f64(const double* a, int n, const double* b, int k, double* out, int64_t* stats) {
+  orp::QuadPrepT<double>* ra = new orp::QuadPrepT<double>[n > 0 ? n : 1];
+  long long st[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n; i++) orp::quad_prepare<double>(a + 8 * (size_t)i, ra[i]);
+  for (int j = 0; j < k; j++) {
+    orp::QuadPrepT<double> pc;
+    orp::quad_prepare<double>(b + 8 * (size_t)j, pc);
+    for (int i = 0; i < n; i++) out[(size_t)i * k + j] = orp::quad_iou_term_queue_t<double, false>(&ra[i], &pc, st);
+  }
+  if (stats) for (int t = 0; t < 4; t++) stats[t] += st[t];
+  delete[] ra;
+}
+
 // convex_iou's pair classifier (hull of 9 points vs gt quad, fp64) exactly as csrc/orp_convex.hip runs it: hull through
 // the float-backed store, CCW re-orientation, then orp::hull_quad_is_far.  flags[n,k] = 1 where it claims inter == 0.
 namespace {

@@ -154,6 +154,12 @@ def test_fp64_instantiation_matches_polyiou(harness):
                                          out.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p))
         want = np.array([[O.polyiou(q[i], q[j]) for j in range(n)] for i in range(n)])
         assert np.array_equal(out.view(np.uint64), want.view(np.uint64)), name
+        # the term-queue composition (what the fp64 merge-NMS kernel evaluates per lane)
+        out2 = np.empty((n, n), np.float64)
+        st4 = np.zeros(4, np.int64)
+        harness.host_quadterm_matrix_f64(q.ctypes.data_as(ctypes.c_void_p), n, q.ctypes.data_as(ctypes.c_void_p), n,
+                                         out2.ctypes.data_as(ctypes.c_void_p), st4.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(out2.view(np.uint64), want.view(np.uint64)), name
 
 
 def test_convex_classifier_only_claims_exact_zeros(harness):
