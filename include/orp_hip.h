@@ -242,6 +242,14 @@ int orp_groupnorm_act_multi(const orp_norm_level* levels_host, int nlevels, int 
 int orp_affine_act(const float* x, const float* residual, const float* scale, const float* shift, float* y, int batch,
                    int channels, int hw, int relu, void* stream);
 
+/* orp_bias_act_multi: y = relu?(x + bias[c] (+ residual)), optionally y2 = y - sub[c], for ALL FPN levels in one launch:
+ *   the passes around the head's bias-carrying output convolutions (orientedreppoints_head.py:156-170): conv bias,
+ *   ReLU, `pts_out_refine + pts_out_init`, `pts_out_init - dcn_base_offset`.  levels_host[i] = {input, residual|NULL,
+ *   output, output2|NULL, height, width}, tensors NCHW [B,C,H,W] fp32 (output may alias input); bias / sub: [C] or NULL. */
+typedef struct { const float* input; const float* residual; float* output; float* output2; int height; int width; } orp_bias_level;
+int orp_bias_act_multi(const orp_bias_level* levels_host, int nlevels, int batch, int channels, const float* bias,
+                       const float* sub, int relu, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Fused test-time post-processing around the rotated NMS: replaces the tensor-op chains of
  * get_bboxes_single (orientedreppoints_head.py:707-779), multiclass_rnms (bbox_nms.py:93-182) and rbbox2result

@@ -15,6 +15,8 @@
 //               then normalises + scales + activates its own chunk with float4 traffic.
 //   orp_affine_act          : y = relu?(x * scale[c] + shift[c] (+ residual)) -- eval-mode BatchNorm folded to a
 //               per-channel affine, fused with the bottleneck's residual add and ReLU; in place allowed.
+//   orp_bias_act_multi      : y = relu?(x + bias[c] (+ residual)), y2 = y - sub[c], all FPN levels in one launch -- the
+//               bias / ReLU / `+ pts_out_init` / `- dcn_base_offset` passes around the head's output convolutions.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -198,6 +200,58 @@ affine_act_kernel(const float* __restrict__ x, const float* __restrict__ res, co
   }
 }
 
+// y = act(x + bias[c] (+ residual)), optionally y2 = y - sub[c]; NCHW, several tensors (FPN levels) per launch.  The
+// head's output convolutions run without their bias and this launch adds it for all five levels at once, together with
+// what follows in OrientedRepPointsHead.forward_single (head :156-170): ReLU, `+ pts_out_init`, `- dcn_base_offset`.
+// Operation order per element is the framework's: fl(x + b), then fl(. + r), then max(., 0), then fl(. - s).
+struct BiasLevel {
+  const float* x; const float* res; float* y; float* y2;
+  int hw;
+  int bx0;                // first blockIdx.x of this level
+};
+struct BiasParams {
+  BiasLevel lv[kMaxLevels];
+  int nlev, C, relu;
+  const float* bias; const float* sub;
+};
+__global__ void __launch_bounds__(kThreads)
+bias_act_multi_kernel(const BiasParams P) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxLevels; i++) l = (i < P.nlev && (int)blockIdx.x >= P.lv[i].bx0) ? i : l;
+  const BiasLevel L = P.lv[l];
+  const int plane = blockIdx.y;                       // b * C + c
+  const int c = plane % P.C;
+  const float b = P.bias ? P.bias[c] : 0.f;
+  const float sb = P.sub ? P.sub[c] : 0.f;
+  const size_t base = (size_t)plane * L.hw;
+  const int bx = blockIdx.x - L.bx0;
+  const int nbx = ((l + 1 < P.nlev) ? P.lv[l + 1].bx0 : (int)gridDim.x) - L.bx0;
+  if ((L.hw & 3) == 0) {
+    const int hw4 = L.hw >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(L.x + base);
+    const float4* r4 = L.res ? reinterpret_cast<const float4*>(L.res + base) : nullptr;
+    float4* y4 = reinterpret_cast<float4*>(L.y + base);
+    float4* z4 = L.y2 ? reinterpret_cast<float4*>(L.y2 + base) : nullptr;
+    for (int i = bx * kThreads + threadIdx.x; i < hw4; i += nbx * kThreads) {
+      float4 t = x4[i];
+      t.x += b; t.y += b; t.z += b; t.w += b;
+      if (r4) { const float4 r = r4[i]; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
+      if (P.relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+      y4[i] = t;
+      if (z4) { t.x -= sb; t.y -= sb; t.z -= sb; t.w -= sb; z4[i] = t; }
+    }
+  } else {
+    for (int i = bx * kThreads + threadIdx.x; i < L.hw; i += nbx * kThreads) {
+      float t = L.x[base + i] + b;
+      if (L.res) t += L.res[base + i];
+      if (P.relu) t = fmaxf(t, 0.f);
+      L.y[base + i] = t;
+      if (L.y2) L.y2[base + i] = t - sb;
+    }
+  }
+}
+
 int fill(const orp_norm_level* levels, int nlevels, int batch, int channels, int groups, GnParams& P) {
   if (!levels || nlevels <= 0 || nlevels > kMaxLevels || batch <= 0 || channels <= 0 || groups <= 0 ||
       channels % groups)
@@ -256,6 +310,32 @@ int orp_affine_act(const float* x, const float* residual, const float* scale, co
   if (bx > 64) bx = 64;
   hipLaunchKernelGGL(affine_act_kernel, dim3(bx, batch * channels), dim3(kThreads), 0, (hipStream_t)stream, x, residual,
                      scale, shift, y, channels, hw, relu);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_bias_act_multi(const orp_bias_level* levels_host, int nlevels, int batch, int channels, const float* bias,
+                       const float* sub, int relu, void* stream) {
+  if (!levels_host || nlevels <= 0 || nlevels > kMaxLevels || batch <= 0 || channels <= 0) return ORP_EINVAL;
+  if ((long)batch * channels > 65535L) return ORP_ETOOBIG;
+  BiasParams P;
+  P.nlev = nlevels; P.C = channels; P.relu = relu ? 1 : 0; P.bias = bias; P.sub = sub;
+  int bx = 0;
+  for (int i = 0; i < nlevels; i++) {
+    const orp_bias_level& lv = levels_host[i];
+    if (!lv.input || !lv.output || lv.height <= 0 || lv.width <= 0 || (lv.output2 && !sub)) return ORP_EINVAL;
+    BiasLevel& L = P.lv[i];
+    L.x = lv.input; L.res = lv.residual; L.y = lv.output; L.y2 = lv.output2;
+    L.hw = lv.height * lv.width;
+    L.bx0 = bx;
+    const int per = ((L.hw & 3) == 0) ? (L.hw >> 2) : L.hw;
+    int nb = (per + kThreads * 4 - 1) / (kThreads * 4);               // ~4 items per thread
+    if (nb < 1) nb = 1;
+    if (nb > 64) nb = 64;
+    bx += nb;
+  }
+  for (int i = nlevels; i < kMaxLevels; i++) { P.lv[i] = P.lv[0]; P.lv[i].bx0 = 0x7fffffff; }
+  hipLaunchKernelGGL(bias_act_multi_kernel, dim3(bx, batch * channels), dim3(kThreads), 0, (hipStream_t)stream, P);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }

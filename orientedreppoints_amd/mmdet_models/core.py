@@ -40,6 +40,18 @@ class PointGenerator(object):
         return (xx, yy) if row_major else (yy, xx)
 
     def grid_points(self, featmap_size, stride=16, device='cuda'):
+        """[H*W, 3] = (x, y, stride) (point_generator.py:14-22).  The grid depends only on (H, W, stride, device): it is
+        built once and the same read-only tensor is handed out afterwards (8 small launches per level otherwise)."""
+        feat_h, feat_w = featmap_size
+        key = (int(feat_h), int(feat_w), float(stride), str(device))
+        cache = self.__dict__.setdefault('_grid_cache', {})
+        if key not in cache:
+            if len(cache) > 32:
+                cache.clear()
+            cache[key] = self._grid_points(featmap_size, stride, device)
+        return cache[key]
+
+    def _grid_points(self, featmap_size, stride, device):
         feat_h, feat_w = featmap_size
         shift_x = torch.arange(0., feat_w, device=device) * stride
         shift_y = torch.arange(0., feat_h, device=device) * stride

@@ -15,6 +15,7 @@ from __future__ import division
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ..mmdet_ops.deform_conv import DeformConv
 from ..mmdet_ops.minarea_rect import minaerarect_decode
@@ -131,7 +132,15 @@ class OrientedRepPointsHead(nn.Module):
         for m in list(self.cls_convs) + list(self.reg_convs):
             if not (m.with_norm and isinstance(m.norm, nn.GroupNorm) and m.with_activation):
                 return False
+        for m in (self.reppoints_pts_init_conv, self.reppoints_pts_init_out, self.reppoints_cls_out,
+                  self.reppoints_pts_refine_out):
+            if not (isinstance(m, nn.Conv2d) and m.bias is not None and m.weight.dtype == torch.float32):
+                return False
         return True
+
+    @staticmethod
+    def _conv_nobias(m, x):
+        return F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
 
     @staticmethod
     def _tower_multi(convs, feats):
@@ -163,19 +172,32 @@ class OrientedRepPointsHead(nn.Module):
         if fused:
             cls_feats = self._tower_multi(self.cls_convs, feats)
             pts_feats = self._tower_multi(self.reg_convs, feats)
-            inits = [self.reppoints_pts_init_out(self.relu(self.reppoints_pts_init_conv(p))) for p in pts_feats]
+            # bias-carrying convolutions: the convolution runs without its bias, ONE launch per layer then adds it for
+            # all levels together with what follows (ReLU / `- dcn_base_offset` / `+ pts_out_init`), same op order
+            from ..mmdet_ops.fused_norm import bias_act_multi
+            hid = bias_act_multi([self._conv_nobias(self.reppoints_pts_init_conv, p) for p in pts_feats],
+                                 self.reppoints_pts_init_conv.bias, relu=True)
+            inits, offsets = bias_act_multi([self._conv_nobias(self.reppoints_pts_init_out, h) for h in hid],
+                                            self.reppoints_pts_init_out.bias, sub=dcn_base_offset)
         else:
             cls_feats, pts_feats, inits = [], [], []
             for x in feats:
                 cls_feat, pts_feat, pts_out_init = self._towers(x)
                 cls_feats.append(cls_feat); pts_feats.append(pts_feat); inits.append(pts_out_init)
-        offsets = [init - dcn_base_offset for init in inits]    # (1-g)*p + g*p == p without autograd
+            # (1-g)*p.detach() + g*p is p up to one rounding; without autograd the two extra passes are skipped
+            offsets = [init - dcn_base_offset for init in inits]
         dcn_cls = self.reppoints_cls_conv.forward_multi(cls_feats, offsets, relu=True)     # ReLU fused in the epilogue
         dcn_pts = self.reppoints_pts_refine_conv.forward_multi(pts_feats, offsets, relu=True)
-        cls_outs, refines = [], []
-        for c, p, init in zip(dcn_cls, dcn_pts, inits):
-            cls_outs.append(self.reppoints_cls_out(c))
-            refines.append(self.reppoints_pts_refine_out(p) + init)
+        if fused:
+            cls_outs = bias_act_multi([self._conv_nobias(self.reppoints_cls_out, c) for c in dcn_cls],
+                                      self.reppoints_cls_out.bias)
+            refines = bias_act_multi([self._conv_nobias(self.reppoints_pts_refine_out, p) for p in dcn_pts],
+                                     self.reppoints_pts_refine_out.bias, residuals=inits)
+        else:
+            cls_outs, refines = [], []
+            for c, p, init in zip(dcn_cls, dcn_pts, inits):
+                cls_outs.append(self.reppoints_cls_out(c))
+                refines.append(self.reppoints_pts_refine_out(p) + init)
         return cls_outs, inits, refines, list(feats)
 
     # ---- test-time decode + NMS ------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 """Fused normalisation + activation passes for inference (include/orp_hip.h `orp_groupnorm_act_multi`,
-`orp_affine_act`): the GroupNorm+ReLU of the dense-head ConvModules for all FPN levels in one launch pair, and the
-eval-mode BatchNorm (+ residual) + ReLU of the ResNet bottlenecks as one pass.  No autograd: callers use them only
+`orp_affine_act`, `orp_bias_act_multi`): the GroupNorm+ReLU of the dense-head ConvModules for all FPN levels in one
+launch pair, the eval-mode BatchNorm (+ residual) + ReLU of the ResNet bottlenecks as one pass, and the bias / ReLU /
+residual / base-offset passes around the head's output convolutions for all levels in one launch.  No autograd: callers use them only
 under torch.no_grad(); with gradients enabled the stock PyTorch modules run."""
 import ctypes
 
@@ -75,3 +76,42 @@ def bn_act(x, bn, residual=None, relu=True):
                                        B, C, H * W, 1 if relu else 0, _lib.stream_of(x))
     _lib.check(rc, "orp_affine_act")
     return x
+
+
+class _BiasLevel(ctypes.Structure):
+    _fields_ = [("input", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("output", ctypes.c_void_p),
+                ("output2", ctypes.c_void_p), ("height", ctypes.c_int), ("width", ctypes.c_int)]
+
+
+def bias_act_multi(xs, bias, relu=False, residuals=None, sub=None):
+    """ys[i] = relu?(xs[i] + bias[c] (+ residuals[i])), in place on xs; with `sub` ([C]) additionally returns
+    zs[i] = ys[i] - sub[c].  xs: fp32 CUDA [B,C,H,W] tensors (one per FPN level), ONE launch for all of them.
+    Same per-element operation order as the separate framework passes (bias add, residual add, ReLU, subtraction)."""
+    x0 = xs[0]
+    B, C = x0.size(0), x0.size(1)
+    levels = (_BiasLevel * len(xs))()
+    ys, zs = [], []
+    keep = []
+    for i, x in enumerate(xs):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.size(0) == B and x.size(1) == C):
+            raise ValueError("bias_act_multi expects fp32 CUDA [B,C,H,W] tensors with equal B and C")
+        x = x.detach().contiguous()
+        r = None
+        if residuals is not None:
+            r = residuals[i].detach().contiguous()
+            if r.shape != x.shape or r.dtype != torch.float32:
+                raise ValueError("bias_act_multi: residual must match x")
+            keep.append(r)
+        z = torch.empty_like(x) if sub is not None else None
+        ys.append(x); zs.append(z)
+        levels[i] = _BiasLevel(x.data_ptr(), r.data_ptr() if r is not None else None, x.data_ptr(),
+                               z.data_ptr() if z is not None else None, x.size(2), x.size(3))
+    b = bias.detach().float().contiguous() if bias is not None else None
+    s = sub.detach().float().reshape(-1).contiguous() if sub is not None else None
+    if (b is not None and b.numel() != C) or (s is not None and s.numel() != C):
+        raise ValueError("bias_act_multi: bias / sub must have C elements")
+    with torch.cuda.device(x0.device):
+        rc = _lib.lib().orp_bias_act_multi(levels, len(xs), B, C, _lib.ptr(b), _lib.ptr(s), 1 if relu else 0,
+                                           _lib.stream_of(x0))
+    _lib.check(rc, "orp_bias_act_multi")
+    return (ys, zs) if sub is not None else ys

@@ -648,6 +648,32 @@ def test_bn_act_vs_torch(dev):
             assert float((bn_act(x.clone(), bn, relu=False) - bn(x)).abs().max()) <= 1e-5
 
 
+def test_bias_act_multi_bit_exact_vs_torch(dev):
+    """One launch for all levels == the separate framework passes (bias add, residual add, ReLU, channel subtraction),
+    bit for bit: the operation order per element is the same."""
+    from orientedreppoints_amd.mmdet_ops.fused_norm import bias_act_multi
+    torch.manual_seed(2)
+    for B, C, sizes in [(1, 18, [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)]), (2, 15, [(9, 7), (3, 5), (1, 1)]),
+                        (1, 256, [(32, 32), (5, 3)])]:
+        xs = [torch.randn(B, C, h, w, device=dev) * 3 for h, w in sizes]
+        rs = [torch.randn(B, C, h, w, device=dev) for h, w in sizes]
+        bias = torch.randn(C, device=dev)
+        sub = torch.randn(1, C, 1, 1, device=dev)
+        bb = bias.view(1, -1, 1, 1)
+        got = bias_act_multi([x.clone() for x in xs], bias, relu=True)
+        for g_, x in zip(got, xs):
+            assert torch.equal(g_, torch.relu(x + bb))
+        got = bias_act_multi([x.clone() for x in xs], bias, residuals=rs)
+        for g_, x, r in zip(got, xs, rs):
+            assert torch.equal(g_, (x + bb) + r)
+        ys, zs = bias_act_multi([x.clone() for x in xs], bias, sub=sub)
+        for y, z, x in zip(ys, zs, xs):
+            assert torch.equal(y, x + bb) and torch.equal(z, (x + bb) - sub)
+        got = bias_act_multi([x.clone() for x in xs], None, relu=True, residuals=rs)
+        for g_, x, r in zip(got, xs, rs):
+            assert torch.equal(g_, torch.relu(x + r))
+
+
 def test_detector_fused_inference_matches_stock_modules(dev):
     """The fused inference forward (GroupNorm+ReLU launch pairs, folded BatchNorm) against the same model run through
     the stock PyTorch modules (the autograd-capable per-level forward)."""
