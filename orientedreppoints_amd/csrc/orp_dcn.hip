@@ -74,14 +74,26 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
   }
 }
 
-// [B][C][HW] -> [B][HW][C] through a 32x33 LDS tile
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int C, int HW, float* __restrict__ out) {
+// [B][C][HW] -> [B][HW][C] through a 32x33 LDS tile, for every level of one launch: blockIdx.x walks the levels'
+// position tiles back to back
+struct TransposeLevels {
+  const float* in[MAX_LEVELS];
+  float* out[MAX_LEVELS];
+  int hw[MAX_LEVELS];
+  int bx0[MAX_LEVELS + 1];            // first blockIdx.x of each level; bx0[nlev] = gridDim.x
+  int nlev;
+};
+__global__ void nchw_to_nhwc_multi_kernel(const TransposeLevels T, int C) {
   __shared__ float tile[32][33];
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_LEVELS; i++) l = (i < T.nlev && (int)blockIdx.x >= T.bx0[i]) ? i : l;
+  const int HW = T.hw[l];
   const int b = blockIdx.z;
-  const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32, p0 = ((int)blockIdx.x - T.bx0[l]) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
-  const float* src = in + (size_t)b * C * HW;
-  float* dst = out + (size_t)b * C * HW;
+  const float* src = T.in[l] + (size_t)b * C * HW;
+  float* dst = T.out[l] + (size_t)b * C * HW;
   for (int r = ty; r < 32; r += 8) {
     const int c = c0 + r, p = p0 + tx;
     tile[r][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.f;
@@ -671,6 +683,8 @@ int orp_dcn_forward_multi_ex(const orp_dcn_level* levels_host, const float* cons
   }
   const int bm = MT > 0 ? 32 * MT : BM;
   int tiles = 0;
+  TransposeLevels TL;
+  int tbx = 0;
   for (int i = 0; i < nlevels; i++) {
     const orp_dcn_level& lv = levels_host[i];
     if (!lv.input || !lv.offset || !lv.output || lv.height <= 0 || lv.width <= 0) return ORP_EINVAL;
@@ -686,8 +700,8 @@ int orp_dcn_forward_multi_ex(const orp_dcn_level* levels_host, const float* cons
       float* nhwc = reinterpret_cast<float*>(wsp);
       const int HW = lv.height * lv.width;
       wsp += align256(sizeof(float) * (size_t)batch * c_in * HW);
-      hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 31) / 32, (c_in + 31) / 32, batch), dim3(256), 0, st, lv.input,
-                         c_in, HW, nhwc);
+      TL.in[i] = lv.input; TL.out[i] = nhwc; TL.hw[i] = HW; TL.bx0[i] = tbx;
+      tbx += (HW + 31) / 32;
       D.x = nhwc;
     } else {
       D.x = lv.input;
@@ -696,6 +710,12 @@ int orp_dcn_forward_multi_ex(const orp_dcn_level* levels_host, const float* cons
     tiles += (int)(((long)batch * D.Ho * D.Wo + bm - 1) / bm);
   }
   for (int i = nlevels; i < MAX_LEVELS; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; }
+  if (in_layout == 0) {                                  // NCHW inputs: one transposition launch for all levels
+    TL.nlev = nlevels;
+    for (int i = nlevels; i <= MAX_LEVELS; i++) TL.bx0[i] = tbx;
+    for (int i = nlevels; i < MAX_LEVELS; i++) { TL.in[i] = TL.in[0]; TL.out[i] = TL.out[0]; TL.hw[i] = 0; }
+    hipLaunchKernelGGL(nchw_to_nhwc_multi_kernel, dim3(tbx, (c_in + 31) / 32, batch), dim3(256), 0, st, TL, c_in);
+  }
   hipError_t e;
   OrpProfScope prof(ORP_PROF_DCN_FWD, st);
   const int nblk_n = (c_out + BN - 1) / BN;
