@@ -250,6 +250,15 @@ typedef struct { const float* input; const float* residual; float* output; float
 int orp_bias_act_multi(const orp_bias_level* levels_host, int nlevels, int batch, int channels, const float* bias,
                        const float* sub, int relu, void* stream);
 
+/* orp_conv3x3_small_multi: 3x3 / stride 1 / pad 1 convolution (no bias) of the SMALL FPN levels -- the 32^2 / 16^2 / 8^2
+ *   maps the head's seven 256->256 convolutions (orientedreppoints_head.py:91-132) also visit -- all levels in ONE
+ *   launch: exact-fp32 MFMA implicit GEMM reading and writing NCHW [B,C,H,W] fp32 (input != output).  weight_packed: the
+ *   buffer produced by orp_dcn_pack_weight for the [Cout,Cin,3,3] weight.  orp_conv3x3_small_ok: Cin % 128 == 0 and
+ *   Cout % 64 == 0.  The big levels stay on the library's Winograd kernels. */
+int orp_conv3x3_small_ok(int c_in, int c_out);
+int orp_conv3x3_small_multi(const orp_norm_level* levels_host, int nlevels, int batch, int c_in, int c_out,
+                            const float* weight_packed, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Fused test-time post-processing around the rotated NMS: replaces the tensor-op chains of
  * get_bboxes_single (orientedreppoints_head.py:707-779), multiclass_rnms (bbox_nms.py:93-182) and rbbox2result

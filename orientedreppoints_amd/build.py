@@ -30,6 +30,7 @@ SOURCES = [
     ("orp_postproc.hip", ["-ffp-contract=off"]),
     ("orp_soft_rnms.hip", ["-ffp-contract=off"]),
     ("orp_norm.hip", []),
+    ("orp_conv_small.hip", []),
     ("orp_dcn.hip", []),
     ("orp_dcn_bwd.hip", []),
     ("orp_prof.hip", []),

@@ -278,7 +278,7 @@ size_t orp_point_assign_workspace_bytes(int n) { return align256(sizeof(u64) * (
 
 int orp_point_assign(const float* points, int n, const float* gts, int k, float scale, int pos_num, int64_t* gt_inds,
                      void* workspace, size_t workspace_bytes, void* stream) {
-  if (n < 0 || k < 0 || pos_num < 1 || !gt_inds && n > 0) return ORP_EINVAL;
+  if (n < 0 || k < 0 || pos_num < 1 || (!gt_inds && n > 0)) return ORP_EINVAL;
   if (n == 0) return ORP_OK;
   hipStream_t st = (hipStream_t)stream;
   if (k == 0) { hipError_t e = hipMemsetAsync(gt_inds, 0, sizeof(int64_t) * (size_t)n, st); return e == hipSuccess ? ORP_OK : (int)e; }

@@ -130,7 +130,7 @@ class OrientedRepPointsHead(nn.Module):
         if not (x.is_cuda and x.dtype == torch.float32):
             return False
         for m in list(self.cls_convs) + list(self.reg_convs):
-            if not (m.with_norm and isinstance(m.norm, nn.GroupNorm) and m.with_activation):
+            if not (m.with_norm and isinstance(m.norm, nn.GroupNorm) and m.with_activation and m.conv.bias is None):
                 return False
         for m in (self.reppoints_pts_init_conv, self.reppoints_pts_init_out, self.reppoints_cls_out,
                   self.reppoints_pts_refine_out):
@@ -144,10 +144,10 @@ class OrientedRepPointsHead(nn.Module):
 
     @staticmethod
     def _tower_multi(convs, feats):
-        from ..mmdet_ops.fused_norm import group_norm_act_multi
+        from ..mmdet_ops.fused_norm import conv3x3_multi, group_norm_act_multi
         cur = list(feats)
         for m in convs:
-            cur = group_norm_act_multi([m.conv(x) for x in cur], m.norm, relu=True, inplace=True)
+            cur = group_norm_act_multi(conv3x3_multi(cur, m.conv), m.norm, relu=True, inplace=True)
         return cur
 
     def forward_single(self, x):
@@ -174,8 +174,8 @@ class OrientedRepPointsHead(nn.Module):
             pts_feats = self._tower_multi(self.reg_convs, feats)
             # bias-carrying convolutions: the convolution runs without its bias, ONE launch per layer then adds it for
             # all levels together with what follows (ReLU / `- dcn_base_offset` / `+ pts_out_init`), same op order
-            from ..mmdet_ops.fused_norm import bias_act_multi
-            hid = bias_act_multi([self._conv_nobias(self.reppoints_pts_init_conv, p) for p in pts_feats],
+            from ..mmdet_ops.fused_norm import bias_act_multi, conv3x3_multi
+            hid = bias_act_multi(conv3x3_multi(pts_feats, self.reppoints_pts_init_conv),
                                  self.reppoints_pts_init_conv.bias, relu=True)
             inits, offsets = bias_act_multi([self._conv_nobias(self.reppoints_pts_init_out, h) for h in hid],
                                             self.reppoints_pts_init_out.bias, sub=dcn_base_offset)

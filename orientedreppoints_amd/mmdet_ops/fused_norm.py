@@ -115,3 +115,42 @@ def bias_act_multi(xs, bias, relu=False, residuals=None, sub=None):
                                            _lib.stream_of(x0))
     _lib.check(rc, "orp_bias_act_multi")
     return (ys, zs) if sub is not None else ys
+
+
+SMALL_LEVEL_POSITIONS = 1024        # H*W up to which a level goes through conv3x3_multi's HIP kernel (32 x 32 at 1024^2)
+
+
+def conv3x3_multi(xs, conv):
+    """[conv(x) without bias for x in xs] for a 3x3 / stride 1 / pad 1 / groups 1 nn.Conv2d, inference only: the small
+    levels (H*W <= SMALL_LEVEL_POSITIONS) share ONE launch of the exact-fp32 MFMA kernel `orp_conv3x3_small_multi`
+    (the framework would issue an im2col + GEMM pair per level), the big levels stay on the library (Winograd)."""
+    import torch.nn.functional as F
+    from .deform_conv import _packed_weight
+    w = conv.weight
+    cout, cin = w.size(0), w.size(1)
+    L = _lib.lib()
+    ok = (tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1) and
+          tuple(conv.dilation) == (1, 1) and conv.groups == 1 and w.dtype == torch.float32 and
+          L.orp_conv3x3_small_ok(cin, cout))
+    outs = [None] * len(xs)
+    small = []
+    for i, x in enumerate(xs):
+        if ok and x.is_cuda and x.dtype == torch.float32 and x.size(2) * x.size(3) <= SMALL_LEVEL_POSITIONS:
+            small.append(i)
+        else:
+            outs[i] = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if small:
+        B = xs[small[0]].size(0)
+        levels = (_NormLevel * len(small))()
+        keep = []
+        for k, i in enumerate(small):
+            x = xs[i].detach().contiguous()
+            y = torch.empty((B, cout, x.size(2), x.size(3)), dtype=torch.float32, device=x.device)
+            keep.append(x); outs[i] = y
+            levels[k] = _NormLevel(x.data_ptr(), y.data_ptr(), x.size(2), x.size(3))
+        packed = _packed_weight(w)
+        x0 = keep[0]
+        with torch.cuda.device(x0.device):
+            rc = L.orp_conv3x3_small_multi(levels, len(small), B, cin, cout, _lib.ptr(packed), _lib.stream_of(x0))
+        _lib.check(rc, "orp_conv3x3_small_multi")
+    return outs

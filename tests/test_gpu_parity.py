@@ -674,6 +674,26 @@ def test_bias_act_multi_bit_exact_vs_torch(dev):
             assert torch.equal(g_, torch.relu(x + r))
 
 
+@pytest.mark.parametrize("B,cin,cout,sizes", [(1, 256, 256, [(128, 128), (32, 32), (16, 16), (8, 8)]),
+                                              (2, 128, 128, [(7, 5), (13, 9), (1, 1), (31, 33)]),
+                                              (3, 384, 64, [(4, 4), (2, 9)]), (1, 64, 64, [(8, 8)])])
+def test_small_level_conv3x3_vs_torch(dev, B, cin, cout, sizes):
+    """The small-level 3x3 convolution (one exact-fp32 MFMA launch for all small levels) against F.conv2d: same zero
+    padding, every level / image / border position; big levels take the library path unchanged."""
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv3x3_multi
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=True).to(dev)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.05)
+    xs = [torch.randn(B, cin, h, w, device=dev) for h, w in sizes]
+    with torch.no_grad():
+        got = conv3x3_multi(xs, conv)
+        want = [torch.nn.functional.conv2d(x.double(), conv.weight.double(), None, padding=1) for x in xs]
+    for g_, w_ in zip(got, want):
+        assert g_.shape == w_.shape
+        assert float((g_.double() - w_).abs().max()) <= 1e-4 * max(1.0, float(w_.abs().max()))
+
+
 def test_detector_fused_inference_matches_stock_modules(dev):
     """The fused inference forward (GroupNorm+ReLU launch pairs, folded BatchNorm) against the same model run through
     the stock PyTorch modules (the autograd-capable per-level forward)."""
