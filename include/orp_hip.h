@@ -239,6 +239,10 @@ size_t orp_groupnorm_workspace_bytes(const orp_norm_level* levels_host, int nlev
 int orp_groupnorm_act_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, int groups,
                             const float* gamma, const float* beta, float eps, int relu, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* per-tensor affine parameters (up to 16 tensors: both towers' five levels in one launch pair) */
+int orp_groupnorm_act_multi_ex(const orp_norm_level* levels, const float* const* gammas_host,
+                               const float* const* betas_host, int nlevels, int batch, int channels, int groups,
+                               float eps, int relu, void* workspace, size_t workspace_bytes, void* stream);
 int orp_affine_act(const float* x, const float* residual, const float* scale, const float* shift, float* y, int batch,
                    int channels, int hw, int relu, void* stream);
 
@@ -258,6 +262,9 @@ int orp_bias_act_multi(const orp_bias_level* levels_host, int nlevels, int batch
 int orp_conv3x3_small_ok(int c_in, int c_out);
 int orp_conv3x3_small_multi(const orp_norm_level* levels_host, int nlevels, int batch, int c_in, int c_out,
                             const float* weight_packed, void* stream);
+/* per-tensor weights (both towers' small levels in one launch): weights_packed_host[i] belongs to levels_host[i] */
+int orp_conv3x3_small_multi_ex(const orp_norm_level* levels_host, const float* const* weights_packed_host, int nlevels,
+                               int batch, int c_in, int c_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Fused test-time post-processing around the rotated NMS: replaces the tensor-op chains of

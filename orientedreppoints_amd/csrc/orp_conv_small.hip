@@ -21,7 +21,7 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int kMaxLevels = 8;
+constexpr int kMaxLevels = 16;             // both towers' levels
 constexpr int kTaps = 9;
 constexpr int kWaves = 8;                     // two per SIMD; wave w contracts the w-th eighth of K = 9 * Cin
 constexpr int kThreads = kWaves * 64;
@@ -30,13 +30,13 @@ constexpr int kTileN = 64;                    // output channels per workgroup (
 
 struct ConvLevel {
   const float* x; float* y;
+  const float* w3;                            // this tensor's weights, [tap][Cin/4][Cout][4]
   int H, W;
   int tile0;                                  // first position tile of this level
 };
 struct ConvParams {
   ConvLevel lv[kMaxLevels];
   int nlev, B, Cin, Cout;
-  const float* w3;                            // [tap][Cin/4][Cout][4]
 };
 
 // one K chunk = 8 input channels of one tap = four v_mfma_f32_32x32x2_f32 steps per accumulator
@@ -74,7 +74,7 @@ conv3x3_small_kernel(const ConvParams P) {
   const float* src1 = xb + (in1 ? hh1 * L.W + ww1 : 0) - (size_t)tap1 * cpt * 8 * HW;
   const int n0 = blockIdx.y * kTileN;
   // weights of chunk g for this lane: float4 #(2g + kh) of output n0 + m  (c4 = (tap*Cin + 8t + 4kh) / 4 = 2g + kh)
-  const float* wq = P.w3 + ((size_t)kh * P.Cout + n0 + m) * 4;
+  const float* wq = L.w3 + ((size_t)kh * P.Cout + n0 + m) * 4;
   const size_t wstep = (size_t)2 * P.Cout * 4;
 
   auto load2 = [&](int g, Chunk2& c) {                  // chunks g, g + 1 (same tap: G and cpt are even)
@@ -156,26 +156,35 @@ extern "C" {
 // Cin % 128: every wave's K slice is a whole number of chunk PAIRS and touches exactly two taps
 int orp_conv3x3_small_ok(int c_in, int c_out) { return (c_in >= 128 && c_in % 128 == 0 && c_out >= 64 && c_out % 64 == 0) ? 1 : 0; }
 
-int orp_conv3x3_small_multi(const orp_norm_level* levels_host, int nlevels, int batch, int c_in, int c_out,
-                            const float* weight_packed, void* stream) {
-  if (!levels_host || nlevels <= 0 || nlevels > kMaxLevels || batch <= 0 || !weight_packed) return ORP_EINVAL;
+int orp_conv3x3_small_multi_ex(const orp_norm_level* levels_host, const float* const* weights_packed_host, int nlevels,
+                               int batch, int c_in, int c_out, void* stream) {
+  if (!levels_host || nlevels <= 0 || nlevels > kMaxLevels || batch <= 0 || !weights_packed_host) return ORP_EINVAL;
   if (!orp_conv3x3_small_ok(c_in, c_out)) return ORP_EINVAL;
   ConvParams P;
   P.nlev = nlevels; P.B = batch; P.Cin = c_in; P.Cout = c_out;
-  P.w3 = weight_packed + (size_t)9 * c_in * c_out;          // second half of orp_dcn_pack_weight's output
   int tiles = 0;
   for (int i = 0; i < nlevels; i++) {
     const orp_norm_level& lv = levels_host[i];
-    if (!lv.input || !lv.output || lv.height <= 0 || lv.width <= 0 || lv.input == lv.output) return ORP_EINVAL;
+    if (!lv.input || !lv.output || lv.height <= 0 || lv.width <= 0 || lv.input == lv.output || !weights_packed_host[i])
+      return ORP_EINVAL;
     if ((long)batch * lv.height * lv.width >= (1L << 30)) return ORP_ETOOBIG;
     ConvLevel& L = P.lv[i];
     L.x = lv.input; L.y = lv.output; L.H = lv.height; L.W = lv.width; L.tile0 = tiles;
+    L.w3 = weights_packed_host[i] + (size_t)9 * c_in * c_out;        // second half of orp_dcn_pack_weight's output
     tiles += (int)(((long)batch * lv.height * lv.width + kTileM - 1) / kTileM);
   }
   for (int i = nlevels; i < kMaxLevels; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; }
   hipLaunchKernelGGL(conv3x3_small_kernel, dim3(tiles, c_out / kTileN), dim3(kThreads), 0, (hipStream_t)stream, P);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_conv3x3_small_multi(const orp_norm_level* levels_host, int nlevels, int batch, int c_in, int c_out,
+                            const float* weight_packed, void* stream) {
+  if (nlevels <= 0 || nlevels > kMaxLevels) return ORP_EINVAL;
+  const float* w[kMaxLevels];
+  for (int i = 0; i < nlevels; i++) w[i] = weight_packed;
+  return orp_conv3x3_small_multi_ex(levels_host, w, nlevels, batch, c_in, c_out, stream);
 }
 
 }  // extern "C"

@@ -26,18 +26,19 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kChunk = 4096;            // floats per workgroup (16 per thread)
-constexpr int kMaxLevels = 8;
+constexpr int kMaxLevels = 8;              // orp_bias_act_multi
+constexpr int kGnMaxLevels = 16;           // GroupNorm: both towers' five levels in one launch pair
 
 struct GnLevel {
   const float* x; float* y;
+  const float* gamma; const float* beta;     // this tensor's affine parameters
   int hw;                 // H*W
   int cpg;                // chunks per (image, group)
   int chunk0;             // first chunk of this level
 };
 struct GnParams {
-  GnLevel lv[kMaxLevels];
+  GnLevel lv[kGnMaxLevels];
   int nlev, B, C, G;
-  const float* gamma; const float* beta;
   float eps; int relu;
   float2* partial;        // [total_chunks] (mean, M2)
 };
@@ -147,7 +148,7 @@ gn_apply_kernel(const GnParams P) {
       const int e = (threadIdx.x + q * kThreads) * 4;
       if (e < g.n) {
         const int c = grp * cg + (g.n0 + e) / L.hw;       // 4 consecutive elements share a channel (hw % 4 == 0)
-        const float a = rstd * P.gamma[c], b = P.beta[c] - mean * a;
+        const float a = rstd * L.gamma[c], b = L.beta[c] - mean * a;
         float4 t = *reinterpret_cast<const float4*>(src + e);
         t.x = t.x * a + b; t.y = t.y * a + b; t.z = t.z * a + b; t.w = t.w * a + b;
         if (P.relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
@@ -160,7 +161,7 @@ gn_apply_kernel(const GnParams P) {
       const int e = threadIdx.x + q * kThreads;
       if (e < g.n) {
         const int c = grp * cg + (g.n0 + e) / L.hw;
-        const float a = rstd * P.gamma[c], b = P.beta[c] - mean * a;
+        const float a = rstd * L.gamma[c], b = L.beta[c] - mean * a;
         float t = src[e] * a + b;
         if (P.relu) t = fmaxf(t, 0.f);
         dst[e] = t;
@@ -253,7 +254,7 @@ bias_act_multi_kernel(const BiasParams P) {
 }
 
 int fill(const orp_norm_level* levels, int nlevels, int batch, int channels, int groups, GnParams& P) {
-  if (!levels || nlevels <= 0 || nlevels > kMaxLevels || batch <= 0 || channels <= 0 || groups <= 0 ||
+  if (!levels || nlevels <= 0 || nlevels > kGnMaxLevels || batch <= 0 || channels <= 0 || groups <= 0 ||
       channels % groups)
     return -1;
   int chunks = 0;
@@ -261,6 +262,7 @@ int fill(const orp_norm_level* levels, int nlevels, int batch, int channels, int
     if (!levels[i].input || !levels[i].output || levels[i].height <= 0 || levels[i].width <= 0) return -1;
     GnLevel& L = P.lv[i];
     L.x = levels[i].input; L.y = levels[i].output;
+    L.gamma = nullptr; L.beta = nullptr;
     L.hw = levels[i].height * levels[i].width;
     const long span = (long)(channels / groups) * L.hw;
     if (span >= (1L << 30)) return -2;
@@ -268,7 +270,7 @@ int fill(const orp_norm_level* levels, int nlevels, int batch, int channels, int
     L.chunk0 = chunks;
     chunks += batch * groups * L.cpg;
   }
-  for (int i = nlevels; i < kMaxLevels; i++) { P.lv[i] = P.lv[0]; P.lv[i].chunk0 = 0x7fffffff; }
+  for (int i = nlevels; i < kGnMaxLevels; i++) { P.lv[i] = P.lv[0]; P.lv[i].chunk0 = 0x7fffffff; }
   P.nlev = nlevels; P.B = batch; P.C = channels; P.G = groups;
   return chunks;
 }
@@ -283,21 +285,35 @@ size_t orp_groupnorm_workspace_bytes(const orp_norm_level* levels, int nlevels, 
   return chunks > 0 ? sizeof(float2) * (size_t)chunks + 256 : 256;
 }
 
-int orp_groupnorm_act_multi(const orp_norm_level* levels, int nlevels, int batch, int channels, int groups,
-                            const float* gamma, const float* beta, float eps, int relu, void* workspace,
-                            size_t workspace_bytes, void* stream) {
+int orp_groupnorm_act_multi_ex(const orp_norm_level* levels, const float* const* gammas_host,
+                               const float* const* betas_host, int nlevels, int batch, int channels, int groups,
+                               float eps, int relu, void* workspace, size_t workspace_bytes, void* stream) {
   GnParams P;
   const int chunks = fill(levels, nlevels, batch, channels, groups, P);
   if (chunks == -2) return ORP_ETOOBIG;
-  if (chunks <= 0 || !gamma || !beta) return ORP_EINVAL;
+  if (chunks <= 0 || !gammas_host || !betas_host) return ORP_EINVAL;
   if (!workspace || workspace_bytes < sizeof(float2) * (size_t)chunks) return ORP_EWORKSPACE;
-  P.gamma = gamma; P.beta = beta; P.eps = eps; P.relu = relu;
+  for (int i = 0; i < nlevels; i++) {
+    if (!gammas_host[i] || !betas_host[i]) return ORP_EINVAL;
+    P.lv[i].gamma = gammas_host[i]; P.lv[i].beta = betas_host[i];
+  }
+  P.eps = eps; P.relu = relu;
   P.partial = reinterpret_cast<float2*>(workspace);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_groupnorm_act_multi(const orp_norm_level* levels, int nlevels, int batch, int channels, int groups,
+                            const float* gamma, const float* beta, float eps, int relu, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (nlevels <= 0 || nlevels > kGnMaxLevels) return ORP_EINVAL;
+  const float* g[kGnMaxLevels]; const float* b[kGnMaxLevels];
+  for (int i = 0; i < nlevels; i++) { g[i] = gamma; b[i] = beta; }
+  return orp_groupnorm_act_multi_ex(levels, g, b, nlevels, batch, channels, groups, eps, relu, workspace, workspace_bytes,
+                                    stream);
 }
 
 int orp_affine_act(const float* x, const float* residual, const float* scale, const float* shift, float* y, int batch,

@@ -132,6 +132,8 @@ class OrientedRepPointsHead(nn.Module):
         for m in list(self.cls_convs) + list(self.reg_convs):
             if not (m.with_norm and isinstance(m.norm, nn.GroupNorm) and m.with_activation and m.conv.bias is None):
                 return False
+        if len(feats) > 16:
+            return False
         for m in (self.reppoints_pts_init_conv, self.reppoints_pts_init_out, self.reppoints_cls_out,
                   self.reppoints_pts_refine_out):
             if not (isinstance(m, nn.Conv2d) and m.bias is not None and m.weight.dtype == torch.float32):
@@ -144,6 +146,10 @@ class OrientedRepPointsHead(nn.Module):
 
     @staticmethod
     def _tower_multi(convs, feats):
+        """One tower over all levels, layer by layer: big-level convolutions on the library, the small levels in one HIP
+        launch, then ONE GroupNorm+ReLU launch pair right behind them while the activations are cache-resident.
+        (Running both towers in lockstep -- one small-level launch / one normalisation pair for ten tensors -- was
+        measured 0.5-1 % slower: the pair then reads 178 MB written two convolutions earlier.)"""
         from ..mmdet_ops.fused_norm import conv3x3_multi, group_norm_act_multi
         cur = list(feats)
         for m in convs:

@@ -16,12 +16,20 @@ class _NormLevel(ctypes.Structure):
 
 
 def group_norm_act_multi(xs, gn, relu=True, inplace=True):
-    """[GroupNorm(+ReLU)(x) for x in xs] -- xs: list of [B,C,H,W] fp32 CUDA tensors (one per FPN level)."""
+    """[GroupNorm(+ReLU)(x) for x in xs] -- xs: list of [B,C,H,W] fp32 CUDA tensors (FPN levels, possibly of several
+    towers: up to 16); gn: one nn.GroupNorm for all of them, or a list with one module per tensor (same num_groups and
+    eps).  ONE launch pair."""
     L = _lib.lib()
     x0 = xs[0]
     B, C = x0.size(0), x0.size(1)
+    gns = list(gn) if isinstance(gn, (list, tuple)) else [gn] * len(xs)
+    if len(gns) != len(xs) or any(g.num_groups != gns[0].num_groups or g.eps != gns[0].eps
+                                  for g in {id(g): g for g in gns}.values()):
+        raise ValueError("group_norm_act_multi: one GroupNorm per tensor, equal num_groups / eps")
     levels = (_NormLevel * len(xs))()
-    ins, outs = [], []
+    gam = (ctypes.c_void_p * len(xs))()
+    bet = (ctypes.c_void_p * len(xs))()
+    ins, outs, keep, seen = [], [], [], {}
     for i, x in enumerate(xs):
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.size(0) == B and x.size(1) == C):
             raise ValueError("group_norm_act_multi expects fp32 CUDA [B,C,H,W] tensors with equal B and C")
@@ -29,14 +37,19 @@ def group_norm_act_multi(xs, gn, relu=True, inplace=True):
         y = x if inplace else torch.empty_like(x)
         ins.append(x); outs.append(y)
         levels[i] = _NormLevel(x.data_ptr(), y.data_ptr(), x.size(2), x.size(3))
-    nbytes = L.orp_groupnorm_workspace_bytes(levels, len(xs), B, C, gn.num_groups)
+        ptrs = seen.get(id(gns[i]))
+        if ptrs is None:                                   # once per distinct module, not per tensor
+            g_ = gns[i].weight.detach().float().contiguous()
+            b_ = gns[i].bias.detach().float().contiguous()
+            keep += [g_, b_]
+            ptrs = seen[id(gns[i])] = (g_.data_ptr(), b_.data_ptr())
+        gam[i], bet[i] = ptrs
+    nbytes = L.orp_groupnorm_workspace_bytes(levels, len(xs), B, C, gns[0].num_groups)
     ws = _lib.workspace(x0.device, nbytes)
-    gamma = gn.weight.detach().float().contiguous()
-    beta = gn.bias.detach().float().contiguous()
     with torch.cuda.device(x0.device):
-        rc = L.orp_groupnorm_act_multi(levels, len(xs), B, C, gn.num_groups, _lib.ptr(gamma), _lib.ptr(beta),
-                                       float(gn.eps), 1 if relu else 0, _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
-    _lib.check(rc, "orp_groupnorm_act_multi")
+        rc = L.orp_groupnorm_act_multi_ex(levels, gam, bet, len(xs), B, C, gns[0].num_groups, float(gns[0].eps),
+                                          1 if relu else 0, _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
+    _lib.check(rc, "orp_groupnorm_act_multi_ex")
     return outs
 
 
@@ -121,36 +134,48 @@ SMALL_LEVEL_POSITIONS = 1024        # H*W up to which a level goes through conv3
 
 
 def conv3x3_multi(xs, conv):
-    """[conv(x) without bias for x in xs] for a 3x3 / stride 1 / pad 1 / groups 1 nn.Conv2d, inference only: the small
-    levels (H*W <= SMALL_LEVEL_POSITIONS) share ONE launch of the exact-fp32 MFMA kernel `orp_conv3x3_small_multi`
-    (the framework would issue an im2col + GEMM pair per level), the big levels stay on the library (Winograd)."""
+    """[conv(x) without bias for x in xs] for 3x3 / stride 1 / pad 1 / groups 1 nn.Conv2d modules, inference only; conv:
+    one module for all tensors or a list with one module per tensor (equal channel counts).  The small levels
+    (H*W <= SMALL_LEVEL_POSITIONS) share ONE launch of the exact-fp32 MFMA kernel `orp_conv3x3_small_multi_ex` (the
+    framework would issue an im2col + GEMM pair per level), the big levels stay on the library (Winograd)."""
     import torch.nn.functional as F
     from .deform_conv import _packed_weight
-    w = conv.weight
-    cout, cin = w.size(0), w.size(1)
+    convs = list(conv) if isinstance(conv, (list, tuple)) else [conv] * len(xs)
+    w0 = convs[0].weight
+    cout, cin = w0.size(0), w0.size(1)
     L = _lib.lib()
-    ok = (tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1) and
-          tuple(conv.dilation) == (1, 1) and conv.groups == 1 and w.dtype == torch.float32 and
-          L.orp_conv3x3_small_ok(cin, cout))
+
+    def eligible(c):
+        w = c.weight
+        return (tuple(w.shape) == (cout, cin, 3, 3) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (1, 1) and
+                tuple(c.dilation) == (1, 1) and c.groups == 1 and w.dtype == torch.float32)
+    ok = bool(L.orp_conv3x3_small_ok(cin, cout)) and all(eligible(c) for c in {id(c): c for c in convs}.values())
     outs = [None] * len(xs)
     small = []
     for i, x in enumerate(xs):
         if ok and x.is_cuda and x.dtype == torch.float32 and x.size(2) * x.size(3) <= SMALL_LEVEL_POSITIONS:
             small.append(i)
         else:
-            outs[i] = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            c = convs[i]
+            outs[i] = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
     if small:
         B = xs[small[0]].size(0)
         levels = (_NormLevel * len(small))()
-        keep = []
+        wts = (ctypes.c_void_p * len(small))()
+        keep, seen = [], {}
         for k, i in enumerate(small):
             x = xs[i].detach().contiguous()
             y = torch.empty((B, cout, x.size(2), x.size(3)), dtype=torch.float32, device=x.device)
+            wp = seen.get(id(convs[i]))
+            if wp is None:                                 # once per distinct module
+                packed = _packed_weight(convs[i].weight)
+                keep.append(packed)
+                wp = seen[id(convs[i])] = packed.data_ptr()
             keep.append(x); outs[i] = y
             levels[k] = _NormLevel(x.data_ptr(), y.data_ptr(), x.size(2), x.size(3))
-        packed = _packed_weight(w)
-        x0 = keep[0]
+            wts[k] = wp
+        x0 = xs[small[0]]
         with torch.cuda.device(x0.device):
-            rc = L.orp_conv3x3_small_multi(levels, len(small), B, cin, cout, _lib.ptr(packed), _lib.stream_of(x0))
-        _lib.check(rc, "orp_conv3x3_small_multi")
+            rc = L.orp_conv3x3_small_multi_ex(levels, wts, len(small), B, cin, cout, _lib.stream_of(x0))
+        _lib.check(rc, "orp_conv3x3_small_multi_ex")
     return outs

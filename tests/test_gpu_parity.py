@@ -694,6 +694,27 @@ def test_small_level_conv3x3_vs_torch(dev, B, cin, cout, sizes):
         assert float((g_.double() - w_).abs().max()) <= 1e-4 * max(1.0, float(w_.abs().max()))
 
 
+def test_multi_launch_ops_with_per_tensor_parameters(dev):
+    """group_norm_act_multi / conv3x3_multi with one module PER TENSOR (the *_ex entry points): each tensor must get
+    its own affine parameters / weights."""
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv3x3_multi, group_norm_act_multi
+    torch.manual_seed(5)
+    gns = [torch.nn.GroupNorm(32, 128).to(dev) for _ in range(3)]
+    convs = [torch.nn.Conv2d(128, 64, 3, padding=1, bias=False).to(dev) for _ in range(3)]
+    with torch.no_grad():
+        for g in gns:
+            g.weight.normal_(1.0, 0.3); g.bias.normal_(0.0, 0.3)
+    xs = [torch.randn(2, 128, h, w, device=dev) for h, w in ((16, 16), (8, 8), (5, 7))]
+    with torch.no_grad():
+        got = group_norm_act_multi([x.clone() for x in xs], gns, relu=True)
+        for g_, x, m in zip(got, xs, gns):
+            assert float((g_ - torch.relu(m(x))).abs().max()) <= 1e-4
+        got = conv3x3_multi(xs, convs)
+        for g_, x, c in zip(got, xs, convs):
+            want = torch.nn.functional.conv2d(x.double(), c.weight.double(), None, padding=1)
+            assert float((g_.double() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
 def test_detector_fused_inference_matches_stock_modules(dev):
     """The fused inference forward (GroupNorm+ReLU launch pairs, folded BatchNorm) against the same model run through
     the stock PyTorch modules (the autograd-capable per-level forward)."""
