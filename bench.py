@@ -5,8 +5,9 @@
 
 Workload (BASELINE.json configs[1]): OrientedRepPoints R-50 FPN inference, 1024x1024 DOTA patch, 15 classes,
 bs = 1 per GPU.  A "step" is one full `simple_test`: stock PyTorch-ROCm ResNet-50 + FPN convolutions (eval BatchNorm +
-residual + ReLU as one fused HIP pass), the dense head (tower convs stock, GroupNorm+ReLU fused HIP launch pairs,
-both DeformConvs on the HIP MFMA kernel), decode (fused min-area-rect kernel), multiclass rotated NMS
+residual + ReLU as one fused HIP pass), the dense head (tower convs: library on the two big levels, one HIP MFMA launch
+for the three small ones; GroupNorm+ReLU and the bias passes as fused HIP launches; both DeformConvs on the HIP MFMA
+kernel), decode (fused min-area-rect kernel), multiclass rotated NMS
 (HIP mask + on-device sweep) and rbbox2result (the D2H the reference's test loop also pays).  Inputs are resident in
 HBM before the timed region.  Random-init weights and a synthetic image (no network): because a random-init head
 scores ~0.01 everywhere and predicts zero-size point sets, two biases are calibrated ONCE before timing so that the
