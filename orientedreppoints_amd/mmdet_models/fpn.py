@@ -1,4 +1,5 @@
 """FPN neck on stock PyTorch-ROCm (mmdet/models/necks/fpn.py:11-178: start_level, add_extra_convs, num_outs, GN)."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -48,14 +49,36 @@ class FPN(nn.Module):
             if isinstance(m, nn.Conv2d):
                 xavier_init(m, distribution='uniform')
 
+    def _fused_ok(self, inputs):
+        """Inference on the GPU with GroupNorm'ed, activation-free ConvModules (the DOTA configs): the lateral / output
+        normalisations of all levels run as ONE launch pair each, the small output levels on the HIP convolution."""
+        x = inputs[0]
+        if torch.is_grad_enabled() or not (x.is_cuda and x.dtype == torch.float32):
+            return False
+        used = len(self.lateral_convs)
+        mods = list(self.lateral_convs) + list(self.fpn_convs[:used])
+        return all(m.with_norm and isinstance(m.norm, nn.GroupNorm) and not m.with_activation and m.conv.bias is None
+                   and m.norm.num_groups == mods[0].norm.num_groups and m.norm.eps == mods[0].norm.eps for m in mods)
+
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        laterals = [lc(inputs[i + self.start_level]) for i, lc in enumerate(self.lateral_convs)]
-        used = len(laterals)
+        used = len(self.lateral_convs)
+        fused = self._fused_ok(inputs)
+        if fused:
+            from ..mmdet_ops.fused_norm import conv3x3_multi, group_norm_act_multi
+            laterals = group_norm_act_multi([lc.conv(inputs[i + self.start_level])
+                                             for i, lc in enumerate(self.lateral_convs)],
+                                            [lc.norm for lc in self.lateral_convs], relu=False, inplace=True)
+        else:
+            laterals = [lc(inputs[i + self.start_level]) for i, lc in enumerate(self.lateral_convs)]
         for i in range(used - 1, 0, -1):
             laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
                                                               mode='nearest')
-        outs = [self.fpn_convs[i](laterals[i]) for i in range(used)]
+        if fused:
+            outs = group_norm_act_multi(conv3x3_multi(laterals, [fc.conv for fc in self.fpn_convs[:used]]),
+                                        [fc.norm for fc in self.fpn_convs[:used]], relu=False, inplace=True)
+        else:
+            outs = [self.fpn_convs[i](laterals[i]) for i in range(used)]
         if self.num_outs > len(outs):
             if not self.add_extra_convs:
                 for i in range(self.num_outs - used):

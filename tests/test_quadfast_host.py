@@ -42,6 +42,20 @@ def _aabb(n, lo, hi, seed):
     return np.stack([x0, y0, x0 + w, y0, x0 + w, y0 + h, x0, y0 + h], 1).astype(np.float32)
 
 
+def _angular(seed, off):
+    """Boxes rotated about the ORIGIN by 1e-9 .. 1e-2 rad and moved along their ray: pairs whose fans barely overlap /
+    barely separate angularly -- the margin region of the classifier's and the per-term screen's kill-3 bound."""
+    r = np.random.RandomState(seed)
+    base = S.gen_polys(40, seed, clustered=True)[:, :8].astype(np.float64) + off
+    sets = [base]
+    for d in 10.0 ** r.uniform(-9, -2, 5):
+        c, s_ = np.cos(d), np.sin(d)
+        p = base.reshape(-1, 4, 2)
+        rot = np.stack([p[..., 0] * c - p[..., 1] * s_, p[..., 0] * s_ + p[..., 1] * c], -1).reshape(-1, 8)
+        sets += [rot, rot * r.uniform(0.3, 3.0)]
+    return np.concatenate(sets).astype(np.float32)
+
+
 def _cases():
     rng = np.random.RandomState(0)
     d = S.gen_polys(200, 1, clustered=True)[:, :8].astype(np.float32)
@@ -73,6 +87,8 @@ def _cases():
         "random_4_points": rng.uniform(0, 50, (300, 8)),
         "random_4_points_int": rng.randint(0, 8, (400, 8)),
         "nan_inf": bad,
+        "angular_margins": _angular(1, 0.0),
+        "angular_margins_class_offset": _angular(2, 15400.0),
     }
 
 
