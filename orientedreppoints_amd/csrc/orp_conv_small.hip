@@ -9,7 +9,7 @@
 // so the A operand of v_mfma_f32_32x32x2_f32 comes straight from L2 -- the three levels are 1.4 MB) and writes NCHW:
 //   workgroup = 32 positions x 64 output channels, eight waves (two per SIMD), wave w contracts the w-th eighth of
 //   K = 9 taps x Cin (the weights are the [tap][c/4][o][4] packing of orp_dcn_pack_weight: one float4 per lane per
-//   4 k-steps, no LDS; three chunk pairs of global loads in flight), then the eight partial tiles are summed through
+//   4 k-steps, no LDS; three chunk pairs of global loads in flight), then the partial tiles are summed through
 //   LDS in a fixed order, so the result is deterministic.
 // No bias / activation here: GroupNorm+ReLU (orp_groupnorm_act_multi) or the bias pass (orp_bias_act_multi) follow.
 #include <hip/hip_runtime.h>
@@ -23,8 +23,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMaxLevels = 16;             // both towers' levels
 constexpr int kTaps = 9;
-constexpr int kWaves = 8;                     // two per SIMD; wave w contracts the w-th eighth of K = 9 * Cin
-constexpr int kThreads = kWaves * 64;
 constexpr int kTileM = 32;                    // positions per workgroup
 constexpr int kTileN = 64;                    // output channels per workgroup (two 32x32 accumulators per wave)
 
@@ -42,9 +40,11 @@ struct ConvParams {
 // one K chunk = 8 input channels of one tap = four v_mfma_f32_32x32x2_f32 steps per accumulator
 struct Chunk2 { float a[2][4]; float4 b0[2], b1[2]; };     // two consecutive chunks
 
-__global__ void __launch_bounds__(kThreads)
+// kWaves waves per workgroup (2 or 4 per SIMD); wave w contracts the w-th slice of K = 9 * Cin
+template <int kWaves>
+__global__ void __launch_bounds__(kWaves * 64)
 conv3x3_small_kernel(const ConvParams P) {
-  __shared__ __attribute__((aligned(16))) float red[kWaves * kTileM * kTileN];   // [wave][r2 = 0..31][lane]
+  extern __shared__ __attribute__((aligned(16))) float red[];                     // [wave][r2 = 0..31][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 31, kh = lane >> 5;
   int l = 0;
@@ -59,7 +59,7 @@ conv3x3_small_kernel(const ConvParams P) {
   const int hw = valid ? (int)(p - (long)b * HW) : 0;
   const int h = hw / L.W, w = hw - h * L.W;
   // K = (tap, channel chunk) linearised: chunk g = tap * cpt + t.  This wave owns chunks [g0, g0 + G); with
-  // G = 9 * cpt / 8 and cpt % 8 == 0 the range touches exactly two taps (boundary gb).
+  // G = 9 * cpt / kWaves <= 1.125 * cpt the range touches at most two taps (boundary gb).
   const int cpt = P.Cin >> 3;                           // chunks per tap
   const int G = (kTaps * cpt) / kWaves;
   const int g0 = wave * G;
@@ -123,8 +123,8 @@ conv3x3_small_kernel(const ConvParams P) {
     mine[(16 + r) * 64 + lane] = acc1[r];
   }
   __syncthreads();
-  // fixed-order sum over the eight K slices; thread e4 owns entries 4*e4 .. 4*e4+3 = (r2, four consecutive lanes)
-  {
+  // fixed-order sum over the K slices; thread e4 owns entries 4*e4 .. 4*e4+3 = (r2, four consecutive lanes)
+  if (tid < kTileM * kTileN / 4) {
     float4 s = *reinterpret_cast<const float4*>(red + 4 * tid);
 #pragma unroll
     for (int t = 1; t < kWaves; t++) {
@@ -153,7 +153,7 @@ conv3x3_small_kernel(const ConvParams P) {
 
 extern "C" {
 
-// Cin % 128: every wave's K slice is a whole number of chunk PAIRS and touches exactly two taps
+// Cin % 128: every wave's K slice (an eighth of 9 * Cin / 8 chunks) is a whole number of chunk PAIRS
 int orp_conv3x3_small_ok(int c_in, int c_out) { return (c_in >= 128 && c_in % 128 == 0 && c_out >= 64 && c_out % 64 == 0) ? 1 : 0; }
 
 int orp_conv3x3_small_multi_ex(const orp_norm_level* levels_host, const float* const* weights_packed_host, int nlevels,
@@ -174,7 +174,9 @@ int orp_conv3x3_small_multi_ex(const orp_norm_level* levels_host, const float* c
     tiles += (int)(((long)batch * lv.height * lv.width + kTileM - 1) / kTileM);
   }
   for (int i = nlevels; i < kMaxLevels; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; }
-  hipLaunchKernelGGL(conv3x3_small_kernel, dim3(tiles, c_out / kTileN), dim3(kThreads), 0, (hipStream_t)stream, P);
+  // eight waves = two per SIMD (sixteen, with Cin % 256, measured slower: 43 us vs 34 us at the 1024^2 shapes)
+  constexpr size_t smem = sizeof(float) * 8 * kTileM * kTileN;                     // 64 KB of partial tiles
+  hipLaunchKernelGGL(conv3x3_small_kernel<8>, dim3(tiles, c_out / kTileN), dim3(8 * 64), smem, (hipStream_t)stream, P);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }
