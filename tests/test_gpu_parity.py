@@ -107,6 +107,30 @@ def test_rnms_class_offset_dense_scene(dev, oracle):
     assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, 0.4))
 
 
+def test_rnms_full_size_and_properties(dev, oracle):
+    """BASELINE's maximum candidate count per image (2000 + 2000 + 1024 + 256 + 64 = 5344 class-offset boxes: 64 x 64
+    tiles, several term-queue chunks per tile) against the oracle, then size-independent properties at 12 000 boxes:
+    keep is ascending and unique, re-running NMS on the kept boxes keeps every one of them (idempotence), and a kept
+    box never overlaps an earlier (higher-score) kept box by more than the threshold."""
+    from orientedreppoints_amd.mmdet_ops import rnms
+    d, _ = S.gen_dense_scene(5344, 1)
+    d = d.astype(np.float32)
+    _, inds = rnms(_t(d, dev), 0.4)
+    assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, 0.4))
+    d, _ = S.gen_dense_scene(12000, 7)
+    d = d.astype(np.float32)
+    kept, inds = rnms(_t(d, dev), 0.4)
+    k = inds.cpu().numpy()
+    assert np.all(np.diff(k) > 0) and k.min() >= 0 and k.max() < len(d)
+    kept2, inds2 = rnms(kept, 0.4)
+    assert inds2.numel() == kept.size(0)
+    kk = kept.cpu().numpy()
+    order = np.argsort(-kk[:, 8], kind="stable")[:600]                 # spot-check the 600 best survivors pairwise
+    iou = oracle.quad_iou_matrix(kk[order, :8], kk[order, :8])
+    iu = np.triu_indices(len(order), 1)
+    assert not np.any(iou[iu] > 0.4)
+
+
 def test_rnms_sparse_and_dense_sweep_paths(dev, oracle):
     """The sweep runs out of LDS when the mask has <= 8192 non-zero words and falls back to the dense block-row pass
     otherwise: a heavily overlapping cluster (tens of thousands of hits) must take the fallback and still reproduce
@@ -342,6 +366,31 @@ def test_dcn_forward_multi_level_and_offsets_out_of_range(dev, oracle):
     outs = deform_conv_forward_multi([_t(c[0], dev) for c in cases], [_t(c[1], dev) for c in cases], _t(w, dev), 1, 1, 1)
     for (x, off, _), o in zip(cases, outs):
         assert _rel_err(o.cpu().numpy(), oracle.dcn_forward(x, off, w)) <= 1e-4
+
+
+def test_dcn_full_size_properties(dev):
+    """BASELINE shapes (all five levels of a 1024^2 image, 256 -> 256, one launch, MT = 3 tiles): with zero offsets the
+    DeformConv IS the plain 3x3 convolution (independent implementation: the library's), and with random offsets it is
+    linear in its input."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv_forward_multi
+    torch.manual_seed(4)
+    w = torch.randn(256, 256, 3, 3, device=dev) * 0.02
+    sizes = (128, 64, 32, 16, 8)
+    xs = [torch.randn(1, 256, h, h, device=dev) for h in sizes]
+    zero = [torch.zeros(1, 18, h, h, device=dev) for h in sizes]
+    with torch.no_grad():
+        got = deform_conv_forward_multi(xs, zero, w, 1, 1, 1)
+        for g_, x in zip(got, xs):
+            want = torch.nn.functional.conv2d(x, w, None, 1, 1)
+            assert float((g_ - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+        offs = [torch.randn(1, 18, h, h, device=dev) * 2.5 for h in sizes]
+        x2 = [torch.randn(1, 256, h, h, device=dev) for h in sizes]
+        a = deform_conv_forward_multi(xs, offs, w, 1, 1, 1)
+        b = deform_conv_forward_multi(x2, offs, w, 1, 1, 1)
+        c = deform_conv_forward_multi([p + 2.0 * q for p, q in zip(xs, x2)], offs, w, 1, 1, 1)
+        for a_, b_, c_ in zip(a, b, c):
+            ref = a_ + 2.0 * b_
+            assert float((c_ - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
 
 
 def test_dcn_v2_and_fused_epilogue_on_mfma_path(dev, oracle):
