@@ -217,6 +217,14 @@ size_t orp_poly_nms_f64_workspace_bytes(int n);
 int orp_poly_nms_f64(const double* dets_sorted, int n, double iou_thr, int64_t* keep_out, int32_t* num_keep,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* Detection -> ground-truth matching of the DOTA Task1 evaluation (DOTA_devkit/dota_evaluation_task1.py:160-206, the
+ * per-detection python loop of voc_eval): for detection d of image det_image[d], over the ground truths
+ * gts[gt_offsets[img] .. gt_offsets[img + 1]) that pass the fp64 horizontal-box pre-filter (`overlaps > 0`, "+ 1." pixel
+ * convention), ovmax[d] = np.max and jmax[d] = np.argmax (image-local index) of polyiou.iou_poly(GT, detection) in fp64;
+ * (-inf, -1) when none passes; a NaN IoU wins as in numpy.  dets [nd,8], gts [ng,8] fp64 device; int32 device arrays. */
+int orp_voc_best_match_f64(const double* dets, const int32_t* det_image, int num_dets, const double* gts,
+                           const int32_t* gt_offsets, int num_images, double* ovmax, int32_t* jmax, void* stream);
+
 /* Soft rotated NMS on the HOST -- replaces rnms_cpu.soft_rnms (mmdet/ops/nms/src/rnms_cpu.cpp:165-333), CPU-only in
  * the reference too.  dets_host [m,9] fp32 (8 corners + score); method 0 = hard, 1 = linear, 2 = gaussian;
  * out_host [m,10] receives the surviving rows (8 corners, rescored score, original index as float) in selection

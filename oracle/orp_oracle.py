@@ -126,6 +126,36 @@ def py_cpu_nms_poly(dets, thr):
     return [int(x) for x in keep[:n]]
 
 
+def voc_best_match(dets, det_img, gts, gt_off):
+    """dota_evaluation_task1.py:160-206 per detection (numpy fp64 HBB pre-filter with the "+ 1." convention, then
+    polyiou.iou_poly(GT, detection) on the survivors, np.max / np.argmax): (ovmax [nd], jmax [nd]); (-inf, -1) when no
+    ground truth of the image passes the pre-filter.  Plain python loop: small cases only."""
+    dets = _f64(dets); gts = _f64(gts)
+    ovmax = np.full(len(dets), -np.inf); jmax = np.full(len(dets), -1, np.int32)
+    for d in range(len(dets)):
+        bb = dets[d]
+        BBGT = gts[gt_off[det_img[d]]:gt_off[det_img[d] + 1]]
+        if BBGT.size == 0:
+            continue
+        BBGT_xmin = np.min(BBGT[:, 0::2], axis=1); BBGT_ymin = np.min(BBGT[:, 1::2], axis=1)
+        BBGT_xmax = np.max(BBGT[:, 0::2], axis=1); BBGT_ymax = np.max(BBGT[:, 1::2], axis=1)
+        bb_xmin = np.min(bb[0::2]); bb_ymin = np.min(bb[1::2]); bb_xmax = np.max(bb[0::2]); bb_ymax = np.max(bb[1::2])
+        ixmin = np.maximum(BBGT_xmin, bb_xmin); iymin = np.maximum(BBGT_ymin, bb_ymin)
+        ixmax = np.minimum(BBGT_xmax, bb_xmax); iymax = np.minimum(BBGT_ymax, bb_ymax)
+        iw = np.maximum(ixmax - ixmin + 1., 0.); ih = np.maximum(iymax - iymin + 1., 0.)
+        inters = iw * ih
+        uni = ((bb_xmax - bb_xmin + 1.) * (bb_ymax - bb_ymin + 1.) +
+               (BBGT_xmax - BBGT_xmin + 1.) * (BBGT_ymax - BBGT_ymin + 1.) - inters)
+        with np.errstate(all='ignore'):
+            overlaps = inters / uni
+        keep = np.where(overlaps > 0)[0]
+        if len(keep) > 0:
+            ov = [polyiou(BBGT[j], bb) for j in keep]
+            ovmax[d] = np.max(ov)
+            jmax[d] = keep[int(np.argmax(ov))]
+    return ovmax, jmax
+
+
 def poly_overlaps(boxes, query):
     b, q = _f32(boxes), _f32(query)
     out = np.empty((b.shape[0], q.shape[0]), np.float32)

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "orp_groupnorm_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "orp_groupnorm_act_multi": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _sz, _vp]),
     "orp_groupnorm_act_multi_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
+    "orp_voc_best_match_f64": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "orp_affine_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "orp_bias_act_multi": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "orp_conv3x3_small_ok": (_i, [_i, _i]),

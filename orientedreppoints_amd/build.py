@@ -29,6 +29,7 @@ SOURCES = [
     ("orp_assign.hip", ["-ffp-contract=off"]),
     ("orp_postproc.hip", ["-ffp-contract=off"]),
     ("orp_soft_rnms.hip", ["-ffp-contract=off"]),
+    ("orp_eval.hip", ["-ffp-contract=off"]),
     ("orp_norm.hip", []),
     ("orp_conv_small.hip", []),
     ("orp_dcn.hip", []),
