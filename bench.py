@@ -13,6 +13,10 @@ HBM before the timed region.  Random-init weights and a synthetic image (no netw
 scores ~0.01 everywhere and predicts zero-size point sets, two biases are calibrated ONCE before timing so that the
 post-processing sees a realistic dense scene (see `calibrate_head`) -- the compute of every layer is unchanged.
 
+The K steps are timed twice: launched eagerly from Python (`eager_ms_per_step`; this loop also provides the live
+HIP-event kernel timings) and as ONE hipGraph replay per step (`mmdet_models.GraphedInference`: same kernels, same
+detections, ~240 launches leave the host) -- the replay is `value` when the capture works (`mode`), else the eager figure.
+
 One JSON line on rank 0: metric/value = whole-job images/sec; plus `roofline` for the dominant hot-path kernel (the
 DeformConv implicit GEMM, timed live with HIP events inside liborp_hip.so over the timed region, MFMA-bound), `nms`
 (the rotated-IoU + NMS stage: us/img, mask/sweep kernel times) and `cpu_baseline` (the CPU oracle port of polyiou +
@@ -281,9 +285,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=1, help='images per GPU per step (config 1: 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--graph', type=int, default=0,
-                    help='1: additionally time the step as ONE hipGraph replay (device part captured once; reported '
-                         'as graph_replay_ms next to the eager measurement)')
+    ap.add_argument('--graph', type=int, default=1,
+                    help='1 (default): after the eager loop, time the same K steps as ONE hipGraph replay each (device '
+                         'part captured once) and report that as `value`; 0: eager only')
     ap.add_argument('--cudnn-benchmark', type=int, default=0,
                     help='torch.backends.cudnn.benchmark (MIOpen find mode), the reference\'s cfg.cudnn_benchmark '
                          '(tools/test.py:108-110)')
@@ -344,38 +348,45 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the same K steps as ONE hipGraph replay each (mmdet_models/graph_inference.py): same kernels, same results, the
+    # ~240 launches per step leave the host.  This is the deployment path and the reported `value` when capture works;
+    # the eager loop above stays in the JSON (`eager_ms_per_step`) and provides the live HIP-event kernel timings.
     graph_ms = None
-    if args.graph and not distributed:
-        # the whole device part (backbone .. packed detections) as one hipGraph; D2H + per-class split stay outside
-        from orientedreppoints_amd.mmdet_models.core import rbbox2result_packed
-        head = model.bbox_head
-        static_img = img.clone()
-
-        def device_part():
-            outs = head(model.extract_feat(static_img))
-            return head.get_bboxes(*(tuple(outs) + (metas, model.test_cfg, False)), static=True)
+    eager_elapsed = elapsed
+    if args.graph:
+        ok = 1
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(3):
-                    device_part()
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g):
-                packed = device_part()
+            from orientedreppoints_amd.mmdet_models import GraphedInference
+            gi = GraphedInference(model, img, metas)
             for _ in range(args.warmup):
-                g.replay()
-                [rbbox2result_packed(p, head.num_classes) for p in packed]
+                gres = gi(img)
+            ngraph = int(sum(sum(len(c) for c in r) for r in gres))
+            if ngraph != ndet:
+                raise RuntimeError('graph replay returned %d detections, eager %d' % (ngraph, ndet))
+        except Exception as e:   # noqa: BLE001  (report, keep the eager measurement)
+            ok = 0
+            graph_ms = 'failed: %s' % (str(e)[:200],)
+        if distributed:                                     # every rank replays, or none does
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
             torch.cuda.synchronize()
+            if distributed:
+                dist.barrier()
             tg = time.perf_counter()
             for _ in range(args.steps):
-                g.replay()
-                [rbbox2result_packed(p, head.num_classes) for p in packed]
+                gi(img)
             torch.cuda.synchronize()
-            graph_ms = (time.perf_counter() - tg) / args.steps * 1e3
-        except Exception as e:   # noqa: BLE001  (report, do not fail the eager measurement)
-            graph_ms = 'failed: %s' % (str(e)[:200],)
+            if distributed:
+                dist.barrier()
+            g_elapsed = time.perf_counter() - tg
+            if distributed:
+                t = torch.tensor([g_elapsed], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                g_elapsed = float(t.item())
+            graph_ms = g_elapsed / args.steps * 1e3
+            elapsed = g_elapsed
 
     prof = {name: read_prof(slot) for name, slot in
             (('nms_mask', 0), ('nms_sweep', 1), ('dcn_fwd', 3), ('minarearect', 4))}
@@ -472,6 +483,8 @@ def main():
         'detections_per_step': ndet,
         'rotated_iou_nms_us_per_img': nms_us, 'nms_boxes': M,
         'kernel_us': {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()},
+        'mode': 'hipgraph replay' if isinstance(graph_ms, float) else 'eager',
+        'eager_ms_per_step': round(eager_elapsed / args.steps * 1e3, 4),
         'graph_replay_ms': graph_ms,
         'roofline': roof, 'nms': nms, 'per_op_us': per_op, 'cpu_baseline': cpu,
     }

@@ -859,6 +859,35 @@ def test_inference_device_part_is_hipgraph_capturable(dev):
         assert np.allclose(a, b, rtol=1e-4, atol=1e-2)
 
 
+def test_graphed_inference_equals_simple_test(dev):
+    """mmdet_models.GraphedInference (the deployment path bench.py times): one hipGraph replay per call must return what
+    simple_test_batch returns -- also for a NEW image of the captured shape, and for two images per call."""
+    from orientedreppoints_amd.dota_configs import r50_model, test_cfg
+    from orientedreppoints_amd.mmdet_models import ConfigDict, GraphedInference, build_detector
+    torch.manual_seed(0)
+    model = build_detector(ConfigDict(r50_model), train_cfg=None, test_cfg=ConfigDict(test_cfg)).to(dev).eval()
+    head = model.bbox_head
+    with torch.no_grad():
+        head.reppoints_cls_out.weight.normal_(0, 0.05)
+        head.reppoints_cls_out.bias.fill_(-3.3)
+        head.reppoints_pts_init_out.bias.copy_(torch.tensor(
+            [[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 0], [0, 1], [1, -1], [1, 0], [1, 1]],
+            dtype=torch.float32, device=dev).reshape(-1) * 2.0)
+    for B in (1, 2):
+        metas = [dict(img_shape=(256, 256, 3), pad_shape=(256, 256, 3), scale_factor=1.0, flip=False)] * B
+        gi = GraphedInference(model, torch.randn(B, 3, 256, 256, device=dev), metas)
+        for seed in (1, 2):
+            img = torch.randn(B, 3, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+            got = gi(img)
+            with torch.no_grad():
+                want = model.simple_test_batch(img, metas)
+            assert len(got) == len(want) == B and sum(len(c) for r in want for c in r) > 0
+            for gr, wr in zip(got, want):
+                assert [c.shape for c in gr] == [c.shape for c in wr]
+                for a, b in zip(gr, wr):
+                    assert np.allclose(a, b, rtol=1e-4, atol=1e-2)
+
+
 @pytest.mark.parametrize("size,max_per_img,thr_bias", [(256, 2000, -3.3), (384, 150, -3.0), (256, 2000, -9.0)])
 def test_fused_postprocess_equals_tensor_op_path(dev, size, max_per_img, thr_bias):
     """csrc/orp_postproc.hip (gather / compaction / packing kernels around min-area-rect and the NMS) against the
