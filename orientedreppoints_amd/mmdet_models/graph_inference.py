@@ -38,7 +38,9 @@ class GraphedInference(object):
                 device_part()
         torch.cuda.current_stream(img.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # thread_local: only this thread's calls are checked during capture (a process-group watchdog thread polling its
+        # events must not abort it)
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.packed = device_part()
 
     def __call__(self, img):
