@@ -184,6 +184,45 @@ def per_op_table(dev, budget_s=2.0):
         gpu_us=gpu_us(lambda: deform_conv_forward_multi(xs, offs, w, 1, 1, 1)),
         cpu_us=cpu_us(lambda: O.dcn_forward(xc, oc, wc, 1, 1, 1)) * scale,
         cpu_sample='16x16 level, 64 -> 64 channels, scaled x%.0f (positions x channel pairs)' % scale)
+    # ---- the training-path ops (configs[2] shapes: 21824 points, 64 gts, 5000 positives) --------------------------
+    from orientedreppoints_amd.mmdet_ops import (ChamferDistance2D, box_iou_rotated, convex_giou, points_in_quad_aligned,
+                                                 sigmoid_focal_loss)
+    from orientedreppoints_amd.mmdet_ops.apaa import max_iou_assign, point_assign
+    t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)   # noqa: E731
+    P, n_s = 5000, 500
+    pp, gg = S.gen_pointsets(P, 2).astype(np.float32), S.gen_gts(P, 3).astype(np.float32)
+    tpp, tgg = t32(pp), t32(gg)
+    out['convex_giou_5000_pairs'] = dict(gpu_us=gpu_us(lambda: convex_giou(tpp, tgg)),
+                                         cpu_us=cpu_us(lambda: O.convex_giou(pp[:n_s], gg[:n_s])) * P / n_s,
+                                         cpu_sample='%d pairs, scaled x%.0f' % (n_s, P / n_s))
+    out['points_in_quad_5000x9'] = dict(gpu_us=gpu_us(lambda: points_in_quad_aligned(tpp, tgg)),
+                                        cpu_us=cpu_us(lambda: O.points_in_quad_aligned(pp, gg)), cpu_sample='full size')
+    rng = np.random.RandomState(0)
+    ca, cb_ = (rng.rand(P, 40, 2) * 100).astype(np.float32), (rng.rand(P, 40, 2) * 100).astype(np.float32)
+    tca, tcb = t32(ca), t32(cb_)
+    out['chamfer_5000x40x40'] = dict(gpu_us=gpu_us(lambda: ChamferDistance2D(tca, tcb)),
+                                     cpu_us=cpu_us(lambda: O.chamfer_forward(ca[:n_s], cb_[:n_s])) * P / n_s,
+                                     cpu_sample='%d samples, scaled x%.0f' % (n_s, P / n_s))
+    N = 2 * 21824
+    lg = rng.randn(N, 15).astype(np.float32); lb = rng.randint(0, 16, N).astype(np.int64)
+    tlg, tlb = t32(lg), torch.from_numpy(lb).to(dev)
+    out['sigmoid_focal_43648x15'] = dict(gpu_us=gpu_us(lambda: sigmoid_focal_loss(tlg, tlb, 2.0, 0.25)),
+                                         cpu_us=cpu_us(lambda: O.focal_forward(lg, lb, 2.0, 0.25)), cpu_sample='full size')
+    pts3 = np.concatenate([np.concatenate([a_ - st / 2.0, np.full((len(a_), 1), st)], 1)
+                           for a_, st in zip(ar, (8, 16, 32, 64, 128))]).astype(np.float32)
+    g64 = S.gen_gts(64, 5).astype(np.float32)
+    tp3, tg64 = t32(pts3), t32(g64)
+    out['point_assign_21824x64'] = dict(gpu_us=gpu_us(lambda: point_assign(tp3, tg64)),
+                                        cpu_us=cpu_us(lambda: O.point_assign(pts3, g64)), cpu_sample='full size')
+    ovl = (rng.rand(21824, 64) * 0.3).astype(np.float32) * (rng.rand(21824, 64) < 0.02)      # [N, K], mostly zero
+    tov = t32(ovl)
+    out['max_iou_assign_21824x64'] = dict(gpu_us=gpu_us(lambda: max_iou_assign(tov, 0.1, 0.1)),
+                                          cpu_us=cpu_us(lambda: O.max_iou_assign(ovl, 0.1, 0.1)), cpu_sample='full size')
+    rb = S.gen_rboxes(1000, 1).astype(np.float32)
+    trb = t32(rb)
+    out['box_iou_rotated_1000x1000'] = dict(gpu_us=gpu_us(lambda: box_iou_rotated(trb, trb)),
+                                            cpu_us=cpu_us(lambda: O.box_iou_rotated(rb[:200], rb)) * 5.0,
+                                            cpu_sample='200 x 1000, scaled x5')
     return out
 
 

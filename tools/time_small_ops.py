@@ -36,8 +36,8 @@ for s in (8, 16, 32, 64, 128):
 points = t(np.concatenate(ar))
 g64 = t(S.gen_gts(64, 5))
 print("point_assign N=21824 K=64: %.1f us" % timeit(lambda: point_assign(points, g64)))
-ov = torch.rand(64, 21824, device=dev) * 0.3
-print("max_iou_assign K=64 N=21824: %.1f us" % timeit(lambda: max_iou_assign(ov, 0.1, 0.1)))
+ov = torch.rand(21824, 64, device=dev) * 0.3              # [N, K] point-major, what convex_iou produces
+print("max_iou_assign N=21824 K=64: %.1f us" % timeit(lambda: max_iou_assign(ov, 0.1, 0.1)))
 q = torch.rand(P, device=dev); pg = torch.randint(1, 65, (P,), device=dev); pl = torch.randint(0, 5, (P,), device=dev, dtype=torch.int32)
 print("apaa_select P=%d K=64: %.1f us" % (P, timeit(lambda: apaa_select(q, pg, pl, 64, 5))))
 feats = [torch.randn(2, 256, 1024 // s, 1024 // s, device=dev) for s in (8, 16, 32, 64, 128)]
