@@ -1,13 +1,13 @@
 """CPU stress of the device header orp_quadfast.hpp (host build, tests/host_harness): the term-queue composition the
 NMS / IoU-matrix kernels run (pair classifier, per-term exact-zero screen, decision tree, per-term generic fallback)
-against the oracle, bit for bit, on many seeded scenes.  usage: python tools/stress_quadfast.py [million_pairs]"""
+against the oracle, bit for bit, on many seeded scenes.  usage: python tests/checks/stress_quadfast.py [million_pairs]"""
 import ctypes, os, subprocess, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from orientedreppoints_amd import synthetic as S
 from oracle import orp_oracle as O
 
-HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "host_harness")
+HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "host_harness")
 SO = os.path.join(HERE, "libquadfast_host.so")
 subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC", "-o", SO,
                        os.path.join(HERE, "quadfast_host.cpp")])

@@ -1,6 +1,6 @@
 """Task1 evaluation matching (orp_voc_best_match_f64) vs the CPU restatement of the reference's per-detection loop (dev aid)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from orientedreppoints_amd import synthetic as S
 from orientedreppoints_amd.dota_devkit.dota_evaluation_task1 import best_match_gpu

@@ -1,6 +1,6 @@
 """Merge-NMS timing: fp64 polygon NMS on the GPU vs the CPU oracle port of py_cpu_nms_poly (dev aid)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from orientedreppoints_amd import synthetic as S
 from orientedreppoints_amd.dota_devkit.result_merge import py_gpu_nms_poly

@@ -1,6 +1,6 @@
 """NMS-stage timing + parity on the GPU box (development aid)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, ctypes
 from orientedreppoints_amd import synthetic as S, _lib
 from orientedreppoints_amd.mmdet_ops.nms_wrapper import rnms_device
