@@ -12,9 +12,9 @@
 //      that every fan term is exactly 0 (orp_quadfast.hpp pair_is_far) and emits their bits by one wavefront
 //      ballot; the remaining pairs are queued in LDS and drained in phase B as a TERM queue (orp_tile.hpp): a
 //      per-term exact-zero screen drops half of their 16 fan terms, the others run the register decision tree one
-//      term per lane (no per-lane polygon storage) and are summed per pair in the reference's order.  Two launch forms: exact (host knows the box count: one workgroup per tile) and
-//      capacity (the count lives in device memory -- sync-free / hipGraph callers: a bounded grid loops over the
-//      tiles of the actual count).  Non-zero mask words are also appended to a side list;
+//      term per lane (no per-lane polygon storage) and are summed per pair in the reference's order.  The box
+//      count is read from device memory (exact or capacity callers alike): a bounded grid of workgroups loops over
+//      the upper-triangular tiles of the actual count.  Non-zero mask words are also appended to a side list;
 //   3. sweep kernel: one workgroup per segment.  If the side list fits in LDS (<= 8192 words) the whole greedy
 //      pass runs out of LDS (per 64-row block: one readlane-based diagonal pass, one list scan, two barriers);
 //      otherwise the dense pass walks the block rows with the next row's mask words prefetched.  Either way the
@@ -193,27 +193,10 @@ __device__ __forceinline__ void mask_tile(TileLds& T, TermLds& X, const orp::Qua
   }
 }
 
-// exact launch: the host knows the box count -> one workgroup per tile (grid = column blocks x row groups x segments)
-template <bool GUARD>
-__global__ void __launch_bounds__(kMaskThreads, 4)
-nms_mask_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restrict__ seg_off, int rows_per_wave,
-                int mask_stride, float thr, u64* __restrict__ mask, int dbg, int* __restrict__ nz_count,
-                unsigned* __restrict__ nz_rc, u64* __restrict__ nz_w) {
-  __shared__ TileLds T;
-  __shared__ TermLds X;
-  const int seg = blockIdx.z;
-  const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
-  const int c = blockIdx.x;
-  const int rpb = rows_per_wave * (kMaskThreads / 64);
-  const int row_base = blockIdx.y * rpb;
-  if (row_base >= n || c * 64 >= n) return;
-  if ((row_base >> 6) > c) return;                       // lower-triangular tile: never read by the sweep
-  mask_tile<GUARD>(T, X, prep, s0, n, c, row_base, rpb, rows_per_wave, mask_stride, thr, mask, dbg, nz_count, nz_rc, nz_w);
-}
-
-// capacity launch: the box count lives in DEVICE memory (seg_off) and the host only knows an upper bound -- a bounded
-// grid whose workgroups loop over the tiles of the actual count (sync-free / hipGraph callers: an 8 K capacity holding
-// 2 K boxes must not pay for 60 K empty workgroups)
+// The box count is read from DEVICE memory (seg_off): the host may only know an upper bound (sync-free / hipGraph callers:
+// an 8 K capacity holding 2 K boxes must not pay for 60 K empty workgroups).  A bounded grid of workgroups loops over the
+// UPPER-TRIANGULAR tiles of the actual count (enumerated in closed form; lower-triangular tiles are never read by the
+// sweep), which also balances the load: 117 -> 83 us at 2000 boxes against one workgroup per tile of the full grid.
 template <bool GUARD>
 __global__ void __launch_bounds__(kMaskThreads, 4)
 nms_mask_loop_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restrict__ seg_off, int rows_per_wave,
@@ -224,14 +207,29 @@ nms_mask_loop_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __re
   const int seg = blockIdx.z;
   const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
   const int rpb = rows_per_wave * (kMaskThreads / 64);
+  if (n <= 0) return;
   const int cbn = (n + 63) >> 6, ngroups = (n + rpb - 1) / rpb;
-  const int total_tiles = cbn * ngroups;
-  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-    const int c = tile % cbn;
-    const int row_base = (tile / cbn) * rpb;
-    if ((row_base >> 6) > c) continue;
-    mask_tile<GUARD>(T, X, prep, s0, n, c, row_base, rpb, rows_per_wave, mask_stride, thr, mask, dbg, nz_count, nz_rc, nz_w);
-    __syncthreads();                                     // T is reused by the next tile
+  // only the upper-triangular tiles exist in this enumeration: the q = 64 / rpb row groups of 64-row batch j own the
+  // columns j .. cbn-1, so before(j) = q * (j * cbn - j (j - 1) / 2) tiles precede batch j (the last batch may be short)
+  const int q = 64 / rpb, last = cbn - 1;
+  auto before = [&](int j) { return (long)q * ((long)j * cbn - (long)j * (j - 1) / 2); };
+  const long t_last = before(last);
+  const long total_tiles = t_last + (ngroups - last * q);
+  for (long t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    int g, c;
+    if (t >= t_last) {
+      g = last * q + (int)(t - t_last); c = last;
+    } else {
+      const double b = 2.0 * cbn + 1.0;
+      int j = (int)((b - sqrt(b * b - 8.0 * (double)t / (double)q)) * 0.5);
+      j = j < 0 ? 0 : (j > last - 1 ? last - 1 : j);
+      while (j > 0 && before(j) > t) j--;
+      while (j + 1 < last && before(j + 1) <= t) j++;
+      const int r = (int)(t - before(j)), w = cbn - j;
+      g = j * q + r / w; c = j + r % w;
+    }
+    mask_tile<GUARD>(T, X, prep, s0, n, c, g * rpb, rpb, rows_per_wave, mask_stride, thr, mask, dbg, nz_count, nz_rc, nz_w);
+    __syncthreads();                                     // the LDS tile is reused by the next tile
   }
 }
 
@@ -582,31 +580,19 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
   // exact_n: max_seg IS the box count (orp_rnms) -> one workgroup per tile.  Otherwise max_seg is only a capacity (the
   // count lives in device memory: batched / sync-free callers): 16-row tiles and a bounded grid whose workgroups loop
   // over the tiles of the actual count -- an 8 K capacity holding 2 K boxes must not pay for 60 K empty workgroups.
+  // exact_n: max_seg IS the box count (orp_rnms); otherwise it is only a capacity (batched / sync-free callers)
   const bool exact_n = single_segment;
   const int R = exact_n ? pick_rows_per_wave(max_seg, nseg) : (max_seg <= 8192 ? (max_seg <= 256 ? 1 : 4) : 16);
   const int rpb = R * (kMaskThreads / 64);
-  dim3 grid(max_cb, (max_seg + rpb - 1) / rpb, nseg);
-  if (!exact_n) {
-    long ntile = (long)max_cb * ((max_seg + rpb - 1) / rpb);
-    const long cap_wg = 8192 / (nseg < 8 ? nseg : 8);
-    if (ntile > cap_wg) ntile = cap_wg;
-    grid = dim3((unsigned)ntile, 1, nseg);
-  }
-  static const int dbg = getenv("ORP_NMS_DBG") ? atoi(getenv("ORP_NMS_DBG")) : 0;   // dev aid (timing): 1 = skip phase B, 2 = skip classifier, 4/8/16 = see tile_drain_terms, 32 = print occupancy
-  if (dbg & 32) {                                          // dev aid: resident workgroups per CU
-    int nb = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nms_mask_kernel<false>, kMaskThreads, 0);
-    fprintf(stderr, "nms_mask_kernel: %d workgroups/CU, grid %u x %u x %u, R %d\n", nb, grid.x, grid.y, grid.z, R);
-  }
+  long ntile = ((long)max_cb * ((max_seg + rpb - 1) / rpb)) / 2 + max_cb;       // ~ the upper-triangular tiles at max_seg
+  const long cap_wg = 4096 / (nseg < 8 ? nseg : 8);
+  if (ntile > cap_wg) ntile = cap_wg;
+  const dim3 grid((unsigned)ntile, 1, nseg);
+  static const int dbg = getenv("ORP_NMS_DBG") ? atoi(getenv("ORP_NMS_DBG")) : 0;   // dev aid (timing): 1 = skip phase B, 2 = skip classifier, 4/8/16 = see tile_drain_terms
   {
     OrpProfScope prof(ORP_PROF_NMS_MASK, st);
-    if (exact_n) {
-      if (flavor == 0) hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc, nz_w);
-      else hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc, nz_w);
-    } else {
-      if (flavor == 0) hipLaunchKernelGGL(nms_mask_loop_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc, nz_w);
-      else hipLaunchKernelGGL(nms_mask_loop_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc, nz_w);
-    }
+    if (flavor == 0) hipLaunchKernelGGL(nms_mask_loop_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc, nz_w);
+    else hipLaunchKernelGGL(nms_mask_loop_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc, nz_w);
   }
 
   const size_t smem = sweep_smem_bytes(max_cb);
