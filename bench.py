@@ -36,13 +36,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from orientedreppoints_amd import _lib  # noqa: E402
-from orientedreppoints_amd.dota_configs import r50_model, test_cfg as TEST_CFG  # noqa: E402
+from orientedreppoints_amd.dota_configs import r50_model, r101_model, test_cfg as TEST_CFG  # noqa: E402
 from orientedreppoints_amd.mmdet_models import ConfigDict, build_detector  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD at 2.4 GHz
-IMG = 1024
+IMG = 1024                       # --size
+MODELS = {'r50': r50_model, 'r101': r101_model}
 TARGET_DETS = 2000               # (point, class) pairs above score_thr per image: the "dense scene" of BASELINE configs
 
 
@@ -226,6 +227,106 @@ def per_op_table(dev, budget_s=2.0):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def maybe_spawn(args):
+    """`python bench.py --gpus N` started by hand (no RANK in the environment) launches its own N ranks, one per GPU,
+    exactly as the reference's tools/dist_train.sh:9-10 does (`python -m torch.distributed.launch --nproc_per_node=N`):
+    re-exec through torch.distributed.run on 127.0.0.1.  Under a launcher (RANK set) this is a no-op."""
+    if args.gpus <= 1 or 'RANK' in os.environ:
+        return
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def init_ranks(args):
+    """(rank, local_rank, world, device, dist-or-None).  The process group exists iff world > 1; `--gpus` must be the
+    world size (a launcher started with a different --nproc-per-node is a usage error, not a silent 1-rank run)."""
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    cpu = args.device == 'cpu'
+    if cpu:
+        dev = torch.device('cpu')
+    else:
+        assert torch.cuda.is_available(), 'bench.py needs a GPU (or --device cpu --dry for the launcher test)'
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo' if cpu else 'nccl', rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
+    return rank, local_rank, world, dev, dist
+
+
+def _sync(dev):
+    if dev.type == 'cuda':
+        torch.cuda.synchronize()
+
+
+def timed_steps(step, args, dev, dist, world):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize; MAX over ranks (seconds)."""
+    for _ in range(args.warmup):
+        step()
+    _sync(dev)
+    if dist is not None:
+        dist.barrier()
+    _sync(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _sync(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def main_dry(args):
+    """`--dry` (with --device cpu: the gloo launcher test that runs without a GPU): the rank / barrier / max-over-ranks
+    / JSON plumbing of the benchmark around a stand-in step that does no hot-path work.  Never a measurement."""
+    rank, local_rank, world, dev, dist = init_ranks(args)
+    x = torch.randn(64, 64, device=dev)
+
+    def step():
+        return (x @ x).sum()
+    elapsed = timed_steps(step, args, dev, dist, world)
+    n = world
+    if dist is not None:
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)                                # every rank took part
+        n = int(t.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'DRY RUN (launcher plumbing only, no hot-path work)', 'value': args.batch * args.steps * world / elapsed,
+                          'unit': 'steps/s', 'n_gpus': n, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': 'dry', 'mode': args.mode, 'device': args.device,
+                                     'parallelism': 'replicas x%d' % world}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main_train(args):
     """`--mode train`: BASELINE configs[2] -- one SGD iteration (forward, APAA losses, backward, bucketed gradient
     all-reduce over RCCL for N > 1, optimizer step) on 2 synthetic 1024x1024 images with `--gts` polygons each per GPU.
@@ -234,22 +335,13 @@ def main_train(args):
     from orientedreppoints_amd import synthetic as S
     from orientedreppoints_amd.dota_configs import train_cfg as TRAIN_CFG
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
+    rank, local_rank, world, dev, dist = init_ranks(args)
     _lib.lib()
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     batch = args.batch if args.batch > 1 else 2          # configs[2]: imgs_per_gpu = 2
 
     torch.manual_seed(0)                                  # identical initial weights on every rank
-    model = build_detector(ConfigDict(r50_model), train_cfg=ConfigDict(TRAIN_CFG),
+    model = build_detector(ConfigDict(MODELS[args.model]), train_cfg=ConfigDict(TRAIN_CFG),
                            test_cfg=ConfigDict(TEST_CFG)).to(dev).train()
     opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-4, momentum=0.9,
                           weight_decay=1e-4)
@@ -293,7 +385,7 @@ def main_train(args):
             dist.destroy_process_group()
         return
     out = {
-        'metric': 'training images/sec (OrientedRepPoints R-50 FPN, 1024x1024 DOTA patch, APAA on, SGD step)',
+        'metric': 'training images/sec (OrientedRepPoints %s FPN, %dx%d DOTA patch, APAA on, SGD step)' % (args.model, IMG, IMG),
         'value': round(batch * args.steps * world / elapsed, 3),
         'unit': 'images/s',
         'n_gpus': world,
@@ -305,8 +397,8 @@ def main_train(args):
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[2]: train step, %d img/GPU x %d gts, 1024x1024, 15 classes'
-                               % (batch, args.gts),
+        'config': {'workload': 'BASELINE configs[2]: train step, %d img/GPU x %d gts, %dx%d, 15 classes'
+                               % (batch, args.gts, IMG, IMG),
                    'imgs_per_gpu': batch, 'gts_per_image': args.gts,
                    'parallelism': 'dp%d (image-parallel, coalesced gradient all-reduce)' % world},
         'loss': round(float(log_vars['loss']), 4),
@@ -320,8 +412,14 @@ def main_train(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--model', choices=sorted(MODELS), default='r50',
+                    help='r50 (default, BASELINE configs[1]); r101 with --batch 2 is the per-GPU load of configs[3]')
+    ap.add_argument('--size', type=int, default=1024, help='square patch size: 1024 (configs[1]) or 1536 (configs[4] shapes)')
+    ap.add_argument('--device', choices=('cuda', 'cpu'), default='cuda', help='cpu only together with --dry (gloo)')
+    ap.add_argument('--dry', action='store_true',
+                    help='launcher / rank / timing plumbing only, stand-in step (the CPU test of the N > 1 path)')
     ap.add_argument('--batch', type=int, default=1, help='images per GPU per step (config 1: 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', type=int, default=1,
@@ -335,25 +433,23 @@ def main():
                          "(2 img/GPU, APAA on), gradients all-reduced over RCCL for N > 1")
     ap.add_argument('--gts', type=int, default=64, help='--mode train: ground-truth polygons per image')
     args = ap.parse_args()
+    global IMG
+    IMG = args.size
+    if args.device == 'cpu' and not args.dry:
+        raise SystemExit('bench.py: the hot path has no CPU fallback; --device cpu is only valid with --dry')
+    maybe_spawn(args)                                     # --gpus N by hand -> N ranks (no-op under a launcher)
+    if args.dry:
+        return main_dry(args)
     if args.mode == 'train':
         return main_train(args)
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank, local_rank, world, dev, dist = init_ranks(args)
     distributed = world > 1
-    assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
     _lib.lib()     # fail loudly if the HIP library is missing
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
 
     torch.manual_seed(0)
-    model = build_detector(ConfigDict(r50_model), train_cfg=None, test_cfg=ConfigDict(TEST_CFG)).to(dev).eval()
+    model = build_detector(ConfigDict(MODELS[args.model]), train_cfg=None, test_cfg=ConfigDict(TEST_CFG)).to(dev).eval()
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
     img = torch.randn(args.batch, 3, IMG, IMG, generator=g).to(dev)
     metas = [dict(img_shape=(IMG, IMG, 3), pad_shape=(IMG, IMG, 3), scale_factor=1.0, flip=False)
@@ -512,12 +608,15 @@ def main():
                           % (reps, M, kept), gpu_stage_us_per_img=nms_us)
 
     out = {
-        'metric': 'images/sec (1024x1024 DOTA, R-50 FPN)', 'value': value, 'unit': 'images/s', 'n_gpus': world,
+        'metric': 'images/sec (%dx%d DOTA, %s FPN)' % (IMG, IMG, {'r50': 'R-50', 'r101': 'R-101'}[args.model]), 'value': value, 'unit': 'images/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'configs[1]: OrientedRepPoints R-50 FPN inference, 1024x1024 patch, 15 classes, '
+        'config': {'workload': '%s: OrientedRepPoints %s FPN inference, %dx%d patch, 15 classes, '
                                'bs=%d/GPU, nms_pre=2000, score_thr=0.05, rnms iou_thr=0.4, max_per_img=2000; '
-                               'random-init weights, head biases calibrated to ~%d dets/img' % (args.batch, TARGET_DETS),
+                               'random-init weights, head biases calibrated to ~%d dets/img'
+                               % ('configs[1]' if (args.model, IMG, args.batch) == ('r50', 1024, 1) else
+                                  ('configs[3] per-GPU load' if (args.model, args.batch) == ('r101', 2) else 'variant'),
+                                  {'r50': 'R-50', 'r101': 'R-101'}[args.model], IMG, IMG, args.batch, TARGET_DETS),
                    'global_batch': args.batch * world, 'parallelism': 'replicas x%d (image-parallel, no collective)' % world},
         'detections_per_step': ndet,
         'rotated_iou_nms_us_per_img': nms_us, 'nms_boxes': M,

@@ -219,6 +219,7 @@ void orc_poly_overlaps(const float* boxes, int n, const float* query, int k, flo
 /* ------------------------------------------------------------------------------------------------------- */
 /* a4: minaerarect  (minarearect_kernel.cu:52-211 minBoundingRect, :343-452 Findminbox)                       */
 /* ------------------------------------------------------------------------------------------------------- */
+static float g_mbr_second_area;   /* second-smallest candidate area of the last min_bounding_rect call (tie diagnostics) */
 static void min_bounding_rect(const f32_pt* ps, int n_points, float* minbox) {
   float edges_angles[24], unique_angles[24];
   const float pi = 3.1415926f;
@@ -252,6 +253,9 @@ static void min_bounding_rect(const f32_pt* ps, int n_points, float* minbox) {
       if (!(isinf(ry) || isnan(ry))) { if (ry < ymin) ymin = ry; if (ry > ymax) ymax = ry; }
     }
     float area = (xmax - xmin) * (ymax - ymin);
+    if (i == 0) g_mbr_second_area = 1e30f;
+    if (area < minarea) { if (minarea < g_mbr_second_area && i > 0) g_mbr_second_area = minarea; }
+    else if (area < g_mbr_second_area) g_mbr_second_area = area;
     if (area < minarea) {
       minarea = area;
       minbox[0] = unique_angles[i]; minbox[1] = xmin; minbox[2] = ymin; minbox[3] = xmax; minbox[4] = ymax;
@@ -278,6 +282,20 @@ static void find_min_box(const float* p, float* out8) {
     s0 = s0 + cx[c] * R00; s0 = s0 + cy[c] * R10;
     s1 = s1 + cx[c] * R01; s1 = s1 + cy[c] * R11;
     out8[2 * c] = s0; out8[2 * c + 1] = s1;
+  }
+}
+/* Tie diagnostics (not a reference function): relative gap between the smallest and the second-smallest candidate
+ * rectangle area of each point set.  The reference keeps the FIRST strict minimum (minarearect_kernel.cu:176-186), so a
+ * gap at rounding level means the returned rectangle depends on the last ulp of cos / atan2. */
+void orc_minarearect_margin(const float* pts, int n, float* margin) {
+  float out8[8];
+  for (int i = 0; i < n; i++) {
+    find_min_box(pts + (size_t)i * 18, out8);
+    float xs[4] = {out8[0], out8[2], out8[4], out8[6]}, ys[4] = {out8[1], out8[3], out8[5], out8[7]};
+    /* area of the returned rectangle = |cross of two adjacent sides| */
+    float a = fabsf((xs[1] - xs[0]) * (ys[2] - ys[1]) - (ys[1] - ys[0]) * (xs[2] - xs[1]));
+    float second = g_mbr_second_area;
+    margin[i] = (second >= 1e29f) ? INFINITY : (second - a) / fmaxf(a, 1e-12f);
   }
 }
 void orc_minarearect(const float* pts, int n, float* out) {

@@ -177,6 +177,14 @@ def minarearect(pts):
     return out
 
 
+def minarearect_margin(pts):
+    """Relative area gap between the best and the second-best candidate rectangle (tie diagnostics for the tests)."""
+    p = _f32(pts)
+    out = np.empty((p.shape[0],), np.float32)
+    lib().orc_minarearect_margin(_p(p), p.shape[0], _p(out))
+    return out
+
+
 def convex_iou(pts, gts):
     p, g = _f32(pts), _f32(gts)
     out = np.empty((p.shape[0], g.shape[0]), np.float32)

@@ -127,13 +127,36 @@ def require_cuda(t, name):
 
 
 _workspaces = {}
+_keepalive = None          # list while a GraphedInference capture collects the cached tensors its graph reads
 
 
 def workspace(device, nbytes):
-    """A cached, growing byte buffer per device (PyTorch's caching allocator is the memory plumbing)."""
-    key = (device.type, device.index)
+    """Scratch bytes for ONE op call on PyTorch's current stream of `device`.
+
+    * eager: a cached, growing buffer per (device, stream).  A buffer is only ever used by work queued on the stream it
+      is keyed by, so replacing it on growth hands the old block back to the caching allocator in stream order (no
+      cross-stream reuse race, no record_stream needed).
+    * during a stream capture: a fresh allocation from the capturing graph's private memory pool -- the graph owns its
+      scratch for as long as it lives, and nothing an eager call does later (a 20 k-box merge NMS growing the cached
+      buffer, a training step, the capacity-overflow fallback) can free or move memory a replay writes to.
+    """
+    nbytes = max(int(nbytes), 1)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(device).cuda_stream)
     w = _workspaces.get(key)
     if w is None or w.numel() < nbytes:
-        w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if len(_workspaces) > 32:                   # short-lived side streams: do not hoard their buffers
+            _workspaces.clear()
+        w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = w
     return w
+
+
+def keep_for_graph(t):
+    """Cached tensors (packed DeformConv weights, folded BatchNorm affines) a captured graph reads must outlive their
+    cache entry: while a GraphedInference capture is collecting, remember them on the graph's owner."""
+    if _keepalive is not None and t is not None:
+        _keepalive.append(t)
+    return t

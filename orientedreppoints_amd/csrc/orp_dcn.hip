@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "../../include/orp_hip.h"
+#include "orp_launch.hpp"
 #include "orp_prof.hpp"
 
 namespace {
@@ -548,9 +549,8 @@ template <int MT, bool OUT_NCHW>
 hipError_t launch_mfma2(const FwdParams& P, int tiles, int nblk_n, hipStream_t st) {
   const size_t smem = mfma2_smem<MT>();
   // once per kernel instantiation (not per launch: the call is not allowed while a stream is being captured)
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma2_kernel<MT, OUT_NCHW>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipError_t e = attr;
+  struct Tag {};
+  hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_mfma2_kernel<MT, OUT_NCHW>), smem);
   if (e != hipSuccess) return e;
   const int per = (tiles + 7) >> 3;
   hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<MT, OUT_NCHW>), dim3(per * 8, nblk_n), dim3(kThreads2), smem, st, P, tiles);
@@ -729,13 +729,13 @@ int orp_dcn_forward_multi_ex(const orp_dcn_level* levels_host, const float* cons
   const size_t smem = sizeof(float) * (2 * BM * ASTR + 2 * KC * BN) + (sizeof(float4) + sizeof(int4)) * BM * MAX_TAPS;
   dim3 grid(tiles, nblk_n);
   if (out_layout == 0) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma_kernel<true>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    struct TagA {};
+    const hipError_t attr = orp::set_max_dynamic_lds_once<TagA>(reinterpret_cast<const void*>(&dcn_fwd_mfma_kernel<true>), smem);
     if (attr != hipSuccess) return (int)attr;
     hipLaunchKernelGGL(dcn_fwd_mfma_kernel<true>, grid, dim3(kThreads), smem, st, P);
   } else {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_mfma_kernel<false>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    struct TagB {};
+    const hipError_t attr = orp::set_max_dynamic_lds_once<TagB>(reinterpret_cast<const void*>(&dcn_fwd_mfma_kernel<false>), smem);
     if (attr != hipSuccess) return (int)attr;
     hipLaunchKernelGGL(dcn_fwd_mfma_kernel<false>, grid, dim3(kThreads), smem, st, P);
   }

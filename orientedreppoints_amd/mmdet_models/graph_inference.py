@@ -10,10 +10,25 @@ buffer, the replay, one D2H copy of the packed detections per image (`rbbox2resu
 """
 import torch
 
+from .. import _lib
 from .core import rbbox2result_packed
 
 
+def _param_fingerprint(tensors):
+    """(storage address, version) of every parameter and buffer: changes when load_state_dict / an optimizer step /
+    .to() replaced or rewrote them (writes through `.data` bypass the version counter: call `recapture()` after those)."""
+    fp = 0
+    for t in tensors:
+        fp = (fp * 1000003 + t.data_ptr() + 7919 * t._version) & 0xFFFFFFFFFFFF
+    return fp
+
+
 class GraphedInference(object):
+    """Owns everything its graph touches: the input buffer, the packed output, the scratch (allocated from the graph's
+    private memory pool while capturing: `_lib.workspace`), and references to the cached packed DeformConv / 3x3 weights
+    and folded BatchNorm affines the captured kernels read (`_lib.keep_for_graph`) -- so no later eager call (a large
+    merge NMS growing the shared scratch, the capacity-overflow fallback, a training step, a cache eviction) can free
+    or move memory a replay uses.  If the model's parameters change, the next call re-captures."""
 
     def __init__(self, model, img, img_metas, warmup=3):
         """model: an eval-mode OrientedRepPointsDetector on a GPU; img [B,3,H,W] (its shape / dtype are captured);
@@ -25,28 +40,53 @@ class GraphedInference(object):
         self.model, self.metas = model, list(img_metas)
         self.num_classes = model.bbox_head.num_classes
         self.static_img = img.clone()
-        head = model.bbox_head
+        self.warmup = max(1, warmup)
+        self.captures = 0
+        self._capture()
 
-        def device_part():
-            outs = head(model.extract_feat(self.static_img))
-            return head.get_bboxes(*(tuple(outs) + (self.metas, model.test_cfg, False)), static=True)
+    def _device_part(self):
+        model, head = self.model, self.model.bbox_head
+        outs = head(model.extract_feat(self.static_img))
+        return head.get_bboxes(*(tuple(outs) + (self.metas, model.test_cfg, False)), static=True)
 
-        side = torch.cuda.Stream(device=img.device)
-        side.wait_stream(torch.cuda.current_stream(img.device))
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(max(1, warmup)):               # library algorithm selection, workspaces, weight packing
-                device_part()
-        torch.cuda.current_stream(img.device).wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: only this thread's calls are checked during capture (a process-group watchdog thread polling its
-        # events must not abort it)
-        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.packed = device_part()
+    def _capture(self):
+        dev = self.static_img.device
+        self.graph = None                                     # release the previous graph (and its pool) first
+        self.packed = None
+        self._refs = []
+        prev, _lib._keepalive = _lib._keepalive, self._refs
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(self.warmup):                  # library algorithm selection, weight packing, BN folding
+                    self._device_part()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: only this thread's calls are checked during capture (a process-group watchdog thread polling
+            # its events must not abort it)
+            with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                self.packed = self._device_part()
+            self.graph = graph
+        finally:
+            _lib._keepalive = prev
+        self._tensors = list(self.model.parameters()) + list(self.model.buffers())
+        self._fingerprint = _param_fingerprint(self._tensors)
+        self.captures += 1
+
+    def recapture(self):
+        """Force a new capture (after parameter writes the version counters do not see, e.g. through `.data`)."""
+        self._capture()
 
     def __call__(self, img):
         """The per-image result lists of `simple_test_batch(img, img_metas)`."""
         self.static_img.copy_(img, non_blocking=True)
         self.graph.replay()
+        # checked while the replay runs (keeps ~50 us of host work off the critical path): if the weights changed, the
+        # packs / folded affines baked into the graph are stale -> capture again and redo this call
+        if _param_fingerprint(self._tensors) != self._fingerprint:
+            self._capture()
+            self.graph.replay()
         results = [rbbox2result_packed(p, self.num_classes) for p in self.packed]
         if any(r is None for r in results):               # more pairs above score_thr than the static capacity holds
             with torch.no_grad():

@@ -132,7 +132,9 @@ def point_samples_selection(head, quality_assess, label, label_weight, rbox_weig
 
 
 def head_loss(head, cls_scores, pts_preds_init, pts_preds_refine, base_features, gt_rbboxes, gt_labels, img_metas, cfg,
-              gt_rbboxes_ignore=None):
+              gt_rbboxes_ignore=None, record=None):
+    """`record` (tests only): a dict that receives the intermediate targets (init / refine assignment, APAA quality and
+    selection per image) so that they can be compared one by one with the reference's."""
     featmap_sizes = [featmap.size()[-2:] for featmap in cls_scores]
     assert len(featmap_sizes) == len(head.point_generators)
     device = cls_scores[0].device
@@ -149,6 +151,9 @@ def head_loss(head, cls_scores, pts_preds_init, pts_preds_refine, base_features,
                                                 label_channels=label_channels, sampling=head.sampling)
     (*_, rbbox_gt_list_init, candidate_list_init, rbox_weights_list_init, num_total_pos_init, num_total_neg_init,
      gt_inds_init) = cls_reg_targets_init
+
+    if record is not None:
+        record['init_target'] = cls_reg_targets_init
 
     # ---- refine stage targets: the init-stage point sets (detached) are the proposals ----------------------------
     center_list, valid_flag_list = get_points(head, featmap_sizes, img_metas, device)
@@ -170,6 +175,10 @@ def head_loss(head, cls_scores, pts_preds_init, pts_preds_refine, base_features,
                                                     sampling=head.sampling)
     (labels_list, label_weights_list, rbox_gt_list_refine, _, rbox_weights_list_refine, pos_inds_list_refine,
      pos_gt_index_list_refine) = cls_reg_targets_refine
+
+    if record is not None:
+        record['refine_target'] = [[t.clone() if torch.is_tensor(t) else t for t in lst] for lst in cls_reg_targets_refine]
+        record['qa'], record['sel'] = [], []
 
     cls_scores = levels_to_images(cls_scores)
     cls_scores = [item.reshape(-1, head.cls_out_channels) for item in cls_scores]
@@ -198,6 +207,10 @@ def head_loss(head, cls_scores, pts_preds_init, pts_preds_refine, base_features,
                 pos_gt_index_list_refine[i], level_of_index, num_level, int(gt_rbboxes[i].shape[0]))
             num_pos = num_pos + npos_i
             pos_normalize_terms.append(pnt)
+            if record is not None:
+                record['qa'].append(qua.clone())
+                record['sel'].append((labels_list[i].clone(), label_weights_list[i].clone(),
+                                      rbox_weights_list_refine[i].clone(), int(npos_i), pnt.clone()))
 
     cls_scores = torch.cat(cls_scores, 0).view(-1, cls_scores[0].size(-1))
     pts_preds_refine_all = torch.cat(pts_refine_img, 0).view(-1, pts_refine_img[0].size(-1))

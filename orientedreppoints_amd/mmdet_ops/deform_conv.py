@@ -29,22 +29,34 @@ _packed_cache = {}
 
 
 def _packed_weight(weight):
-    """[Cout,Cin,kh,kw] -> [kh*kw,Cin,Cout] ++ [kh*kw,Cin/4,Cout,4] (both kernel generations), cached per (storage, version)."""
+    """[Cout,Cin,kh,kw] -> [kh*kw,Cin,Cout] ++ [kh*kw,Cin/4,Cout,4] (both kernel generations).
+
+    Inference (no autograd) caches the pack per (storage, version).  With autograd enabled on a trainable weight the
+    pack is rebuilt on every call: an optimizer / EMA / `reset_parameters` writing through `.data` does not bump the
+    version counter, and a stale pack would make forward and backward disagree (the pack costs ~1 % of the conv)."""
     w = weight.detach()
+    cacheable = not (torch.is_grad_enabled() and weight.requires_grad)
     key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index)
-    hit = _packed_cache.get(id(weight))
+    hit = _packed_cache.get(id(weight)) if cacheable else None
     if hit is not None and hit[0] == key:
-        return hit[1]
+        return _lib.keep_for_graph(hit[1])
     w = w.float().contiguous()
     cout, cin, kh, kw = w.shape
     packed = torch.empty((_lib.lib().orp_dcn_packed_weight_floats(cout, cin, kh, kw),), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
         rc = _lib.lib().orp_dcn_pack_weight(_lib.ptr(w), cout, cin, kh, kw, _lib.ptr(packed), _lib.stream_of(w))
     _lib.check(rc, "orp_dcn_pack_weight")
+    if not cacheable:
+        return packed
     if len(_packed_cache) > 64:
         _packed_cache.clear()
     _packed_cache[id(weight)] = (key, packed)
-    return packed
+    return _lib.keep_for_graph(packed)
+
+
+def invalidate_packed_weights():
+    """Drop every cached weight pack (call after writing parameters through `.data`, which bypasses the version key)."""
+    _packed_cache.clear()
 
 
 def _out_hw(h, w, weight, stride, padding, dilation):

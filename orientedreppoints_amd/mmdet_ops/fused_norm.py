@@ -62,7 +62,7 @@ def _bn_affine(bn):
            bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.running_mean.device.index)
     hit = _affine_cache.get(id(bn))
     if hit is not None and hit[0] == key:
-        return hit[1], hit[2]
+        return _lib.keep_for_graph(hit[1]), _lib.keep_for_graph(hit[2])
     with torch.no_grad():
         rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
         w = bn.weight.float() if bn.weight is not None else torch.ones_like(rstd)
@@ -72,7 +72,7 @@ def _bn_affine(bn):
     if len(_affine_cache) > 512:
         _affine_cache.clear()
     _affine_cache[id(bn)] = (key, scale, shift)
-    return scale, shift
+    return _lib.keep_for_graph(scale), _lib.keep_for_graph(shift)
 
 
 def bn_act(x, bn, residual=None, relu=True):

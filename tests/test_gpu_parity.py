@@ -555,9 +555,11 @@ def test_apaa_feature_dissimilarity_and_selection(dev, oracle, golden_dir):
     assert np.array_equal(keep, oracle.apaa_select(q, gt, lv, 199).astype(bool))
 
 
-def test_points_quality_assessment_vs_reference_python(dev, golden_dir):
-    """Q of every positive (focal + GIoU x2 + chamfer x2 + feature term) against the reference's own
-    points_quality_assessment run on CPU through the oracle ops."""
+def test_points_quality_assessment_vs_reference_python(dev, golden_dir, oracle):
+    """Q of every positive (focal + GIoU x2 + chamfer x2) against the reference's own points_quality_assessment run on
+    CPU through the oracle ops.  This golden fed a ready-made [N,9,32] feature tensor, so the feature term is formed
+    here with the same formula; the whole Q INCLUDING the sampled-feature kernel is compared with the reference's
+    loss() in tests/test_gpu_compose.py::test_head_loss_vs_reference_python."""
     import types
     from orientedreppoints_amd.mmdet_models import orientedreppoints_head_train as T
     from orientedreppoints_amd.mmdet_models.losses import FocalLoss, GIoULoss
@@ -582,10 +584,15 @@ def test_points_quality_assessment_vs_reference_python(dev, golden_dir):
                                         label, _t(g["qa_rbbox_gt"], dev), torch.ones(N, device=dev), rbox_w, pos)
     finally:
         apaa_mod.apaa_feature_dissimilarity = orig
-    # Q sums 15 focal terms + 2 GIoU + 2 chamfer terms (each held to 1e-4 on its own elsewhere); a min-area-rect
-    # first-minimum tie between two edge directions moves one chamfer term by a few 1e-4 -> bar on the sum: 5e-4
+    # bar 1e-4 on every positive; exempt are only PROVABLE min-area-rect ties: the reference keeps the first strict
+    # minimum over the hull's edge directions, and where the two smallest candidate areas agree to rounding
+    # (oracle.minarearect_margin < 1e-5) the chosen rectangle -- hence the chamfer term -- hangs on the last ulp of
+    # cos / atan2, which differ between the device and the host libm
+    posn = g["qa_pos_inds"]
+    tie = np.minimum(oracle.minarearect_margin(g["psets"][posn]), oracle.minarearect_margin(g["qa_pts_refine"][posn])) < 1e-5
     d = np.abs(q.cpu().numpy() - g["qa_out"])
-    assert np.max(d) <= 5e-4 and np.mean(d) <= 2e-6
+    assert np.max(d[~tie], initial=0.0) <= 1e-4 and np.mean(d[~tie]) <= 2e-6
+    assert tie.mean() < 0.1 and np.all(d[tie] <= 2e-2)
     sp = T.sampling_points(_t(g["gts"], dev), 10).cpu().numpy()
     assert np.max(np.abs(sp - g["sampling_points"])) <= 1e-5
 
@@ -886,6 +893,73 @@ def test_graphed_inference_equals_simple_test(dev):
                 assert [c.shape for c in gr] == [c.shape for c in wr]
                 for a, b in zip(gr, wr):
                     assert np.allclose(a, b, rtol=1e-4, atol=1e-2)
+
+
+def test_graphed_inference_owns_its_memory_and_follows_weight_updates(dev):
+    """A captured graph must survive everything an eager caller does afterwards in the same process: scratch growth (a
+    20 k-box fp64 merge NMS, a 16 k-box rnms, the capacity-overflow fallback), cache eviction of the packed weights /
+    folded BatchNorm affines, and parameter updates (re-capture)."""
+    from orientedreppoints_amd import _lib, synthetic as S
+    from orientedreppoints_amd.dota_configs import r50_model, test_cfg
+    from orientedreppoints_amd.dota_devkit.result_merge import py_gpu_nms_poly
+    from orientedreppoints_amd.mmdet_models import ConfigDict, GraphedInference, build_detector
+    import importlib
+    from orientedreppoints_amd.mmdet_ops import rnms
+    DC = importlib.import_module('orientedreppoints_amd.mmdet_ops.deform_conv')      # the package re-exports a function of that name
+    FN = importlib.import_module('orientedreppoints_amd.mmdet_ops.fused_norm')
+    torch.manual_seed(0)
+    model = build_detector(ConfigDict(r50_model), train_cfg=None, test_cfg=ConfigDict(test_cfg)).to(dev).eval()
+    head = model.bbox_head
+    with torch.no_grad():
+        head.reppoints_cls_out.weight.normal_(0, 0.05)
+        head.reppoints_cls_out.bias.fill_(-3.3)
+        head.reppoints_pts_init_out.bias.copy_(torch.tensor(
+            [[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 0], [0, 1], [1, -1], [1, 0], [1, 1]],
+            dtype=torch.float32, device=dev).reshape(-1) * 2.0)
+    metas = [dict(img_shape=(256, 256, 3), pad_shape=(256, 256, 3), scale_factor=1.0, flip=False)]
+    img = torch.randn(1, 3, 256, 256, device=dev)
+    _lib._workspaces.clear()                               # start from a small shared scratch
+    gi = GraphedInference(model, img, metas)
+    with torch.no_grad():
+        want = model.simple_test_batch(img, metas)
+
+    def same(got, ref):
+        assert sum(len(c) for r in ref for c in r) > 0
+        for gr, wr in zip(got, ref):
+            assert [c.shape for c in gr] == [c.shape for c in wr]
+            for a, b in zip(gr, wr):
+                assert np.allclose(a, b, rtol=1e-4, atol=1e-2)
+    same(gi(img), want)
+    # ---- eager work that grows / replaces every shared buffer ---------------------------------------------------------
+    before = {k: v.data_ptr() for k, v in _lib._workspaces.items()}
+    py_gpu_nms_poly(S.gen_polys(20000, 3), 0.3)                                        # 20 k-box merge NMS (fp64)
+    rnms(torch.from_numpy(S.gen_polys(16000, 4, clustered=True).astype(np.float32)).to(dev), 0.4)
+    cur = torch.cuda.current_stream(dev).cuda_stream
+    grown = [k for k, v in _lib._workspaces.items() if k[1] == cur and before.get(k) != v.data_ptr()]
+    assert grown or not before, "the eager scratch was expected to be replaced by a larger one"
+    DC._packed_cache.clear(); FN._affine_cache.clear()                                  # cache eviction
+    junk = [torch.full((1 << 22,), float('nan'), device=dev) for _ in range(8)]        # recycle freed blocks with NaNs
+    del junk
+    torch.cuda.synchronize()
+    same(gi(img), want)                                    # the replay must not have touched freed memory
+    # ---- capacity-overflow fallback inside __call__ (eager simple_test_batch) then a replay again --------------------
+    old_bias = head.reppoints_cls_out.bias.detach().clone()
+    with torch.no_grad():
+        head.reppoints_cls_out.bias.fill_(3.0)             # every (point, class) pair passes score_thr -> overflow
+    n0 = gi.captures
+    res_over = gi(img)                                     # re-captures (weights changed), overflows, falls back
+    assert gi.captures == n0 + 1
+    with torch.no_grad():
+        same(res_over, model.simple_test_batch(img, metas))
+        head.reppoints_cls_out.bias.copy_(old_bias)
+    got = gi(img)                                          # weights changed back -> another capture, then parity
+    assert gi.captures == n0 + 2
+    same(got, want)
+    # an optimizer-style in-place update of a DeformConv weight must reach the graph as well
+    with torch.no_grad():
+        head.reppoints_cls_conv.weight.mul_(1.5)
+        want2 = model.simple_test_batch(img, metas)
+    same(gi(img), want2)
 
 
 @pytest.mark.parametrize("size,max_per_img,thr_bias", [(256, 2000, -3.3), (384, 150, -3.0), (256, 2000, -9.0)])
