@@ -5,21 +5,28 @@
 //   DOTA_devkit/poly_nms_gpu/poly_nms_kernel.cu:214-329  poly_nms_kernel + _poly_nms
 //
 // MI355X design (not a translation of the 64-thread CUDA tiling):
-//   1. stable radix sort of (segment, score desc) keys (rocPRIM);
-//   2. per-box pre-pass (QuadPrep: orientation, oriented origin-fan triangles, signs, |area|), then the mask
-//      kernel: a workgroup owns a (<=64 rows x 64 columns) upper-triangular tile.  Phase A (lane = column, row
-//      wave-uniform through scalar loads) proves for ~84 % of the pairs of a dense scene, without a division,
+//   1. rank + prepare in ONE launch over the whole chip (<= 8192 boxes per segment): the visiting order (score
+//      descending, index ascending -- stable) by rank counting against the segment's keys staged in LDS, 1..64 lanes per
+//      box, and the per-box record (QuadPrep: orientation, oriented origin-fan triangles, signs, |area|) written straight
+//      at its rank.  The box count is read from device memory.  Larger segments use a device-wide radix sort (rocPRIM)
+//      + a prepare launch;
+//   2. mask kernel: a workgroup owns a (<= 64 rows x 64 columns) upper-triangular tile.  Phase A (lane = column, row
+//      wave-uniform through scalar loads) proves for ~80 % of the pairs of a dense scene, without a division,
 //      that every fan term is exactly 0 (orp_quadfast.hpp pair_is_far) and emits their bits by one wavefront
 //      ballot; the remaining pairs are queued in LDS and drained in phase B as a TERM queue (orp_tile.hpp): a
-//      per-term exact-zero screen drops half of their 16 fan terms, the others run the register decision tree one
-//      term per lane (no per-lane polygon storage) and are summed per pair in the reference's order.  The box
-//      count is read from device memory (exact or capacity callers alike): a bounded grid of workgroups loops over
-//      the upper-triangular tiles of the actual count.  Non-zero mask words are also appended to a side list;
-//   3. sweep kernel: one workgroup per segment.  If the side list fits in LDS (<= 8192 words) the whole greedy
-//      pass runs out of LDS (per 64-row block: one readlane-based diagonal pass, one list scan, two barriers);
-//      otherwise the dense pass walks the block rows with the next row's mask words prefetched.  Either way the
-//      keep flags are scattered back to original indices and compacted in ascending order (popcount scan), so
-//      the host never sees the mask;
+//      per-term exact-zero screen drops half of their 16 fan terms, the others (~8 per pair, ~350 VALU instructions
+//      each: 3.4 M terms for 2000 dense boxes, the arithmetic floor of the stage) run the register decision tree one
+//      term per lane out of LDS and are summed per pair in the reference's order.  The box count is read from device
+//      memory (exact or capacity callers alike): a bounded grid of workgroups loops over the upper-triangular tiles of
+//      the actual count.  Non-zero mask words are also filed in a per-segment side list.
+//      (Measured alternative, round 2: classify / screen / terms as three flat launches over global pair and term
+//      queues -- perfectly balanced, but the queue traffic (8 live terms per pair) and ~4 k same-address reservation
+//      atomics cost more than the tile kernel's barriers: 100-140 us against 84 us.  Not kept.)
+//   3. sweep kernel: one workgroup per segment.  If the segment's side list fits in LDS (<= 8192 words) it is bucketed
+//      by 64-row block and the whole greedy pass runs out of LDS (per block: one readlane-based diagonal pass + that
+//      block's words only); otherwise the dense pass walks the block rows with the next row's mask words prefetched.
+//      Either way the keep flags are scattered back to original indices and compacted in ascending order (popcount
+//      scan), so the host never sees the mask;
 //   4. fp64 instantiation of the same core for the merge NMS of the DOTA evaluation workflow (orp_poly_nms_f64).
 // The IoU arithmetic is bit-identical to the reference's fp32 devrIoU / devPolyIoU (see orp_geom.hpp).
 #include <hip/hip_runtime.h>
@@ -32,6 +39,7 @@
 #include "orp_geom.hpp"
 #include "orp_quadfast.hpp"
 #include "orp_tile.hpp"
+#include "orp_launch.hpp"
 #include "orp_prof.hpp"
 
 namespace {
@@ -44,7 +52,8 @@ using orp_tile::pack_signs;
 
 constexpr int kMaskThreads = 256;   // 4 waves per workgroup
 constexpr int kSweepThreads = 1024;
-constexpr int kNzCap = 8192;        // sparse sweep: non-zero mask words kept in LDS (12 B each); more -> dense sweep
+constexpr int kSortMax = 8192;      // boxes per segment the one-launch rank + prepare handles (keys staged in 32 KB of LDS)
+constexpr int kNzCap = 8192;        // sparse sweep: non-zero mask words kept in LDS per segment; more -> dense sweep
 
 __device__ __forceinline__ unsigned int float_flip_desc(float f) {
   // order-preserving float -> uint map, then inverted so that an ASCENDING radix sort yields scores DESCENDING
@@ -53,7 +62,17 @@ __device__ __forceinline__ unsigned int float_flip_desc(float f) {
   return ~(u ^ mask);
 }
 
-// keys[i] = (segment << 32) | flipped score ; vals[i] = i
+// prep[i] = quad_prepare(box): orientation, oriented origin-fan triangles, signs, |area| -- once per box
+__device__ __forceinline__ void prepare_box(const float* __restrict__ s, orp::QuadPrep* __restrict__ prep, int i) {
+  float q8[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) q8[k] = s[k];
+  orp::QuadPrep p;
+  orp::quad_prepare(q8, p);
+  prep[i] = p;
+}
+
+// ---- stage 1, large segments: keys[i] = (segment << 32) | flipped score ; vals[i] = i, device-wide radix sort ----
 __global__ void make_keys_kernel(const float* __restrict__ dets, int n, const int32_t* __restrict__ seg_off, int nseg,
                                  u64* __restrict__ keys, int32_t* __restrict__ vals) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,19 +91,72 @@ __global__ void iota_kernel(int32_t* v, int n) {
 
 __global__ void set_single_segment_kernel(int32_t* seg_off, int n) { seg_off[0] = 0; seg_off[1] = n; }
 
-// prep[i] = quad_prepare(dets[order[i]][0..7]): orientation, oriented fan triangles, signs, |area| -- once per box
 __global__ void prep_boxes_kernel(const float* __restrict__ dets, const int32_t* __restrict__ order, int n,
-                                  orp::QuadPrep* __restrict__ prep, int* __restrict__ nz_count) {
+                                  orp::QuadPrep* __restrict__ prep, int* __restrict__ nz_count, int nseg) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && nz_count) *nz_count = 0;             // list of non-zero mask words, appended by the mask kernel
+  if (nz_count && i < nseg) nz_count[i] = 0;           // per-segment lists of non-zero mask words (filled by the mask kernel)
   if (i >= n) return;
-  const float* s = dets + (size_t)order[i] * 9;
-  float q8[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) q8[k] = s[k];
-  orp::QuadPrep p;
-  orp::quad_prepare(q8, p);
-  prep[i] = p;
+  prepare_box(dets + (size_t)order[i] * 9, prep, i);
+}
+
+// ---- stage 1, the usual case: ONE launch ranks and prepares the segments (<= 8192 boxes each) --------------------------
+// Visiting order by RANK COUNTING over the whole chip instead of a sort inside one workgroup: the rank of box i is the
+// number of boxes that precede it in (score descending, index ascending) order -- the stable tie rule of SURVEY A3.  A
+// workgroup stages the segment's keys in LDS (<= 32 KB); S = 1..64 lanes share one box, each counting over 1/S of the
+// keys with ds_read_b128, then a shuffle reduction; lane 0 of the group writes order[rank] and the box's QuadPrep record
+// straight at its rank.  2000 boxes: 32 workgroups x ~125 LDS reads per lane instead of a 4-pass block radix sort on one
+// CU (30 us -> ~6 us); no second launch has to wait for a complete order[].
+constexpr int kRankThreads = 256;
+__global__ void __launch_bounds__(kRankThreads)
+nms_rankprep_kernel(const float* __restrict__ dets, int32_t* __restrict__ seg_off, int single_n, int presorted,
+                    int32_t* __restrict__ order, orp::QuadPrep* __restrict__ prep, int* __restrict__ nz_count) {
+  __shared__ __attribute__((aligned(16))) unsigned keys[kSortMax];
+  const int seg = blockIdx.y, tid = threadIdx.x;
+  int s0, n;
+  if (single_n >= 0) {                                     // orp_rnms: the segment table is written here (one launch less)
+    s0 = 0; n = single_n;
+    if (blockIdx.x == 0 && tid == 0) { seg_off[0] = 0; seg_off[1] = single_n; }
+  } else {
+    s0 = seg_off[seg]; n = seg_off[seg + 1] - s0;
+  }
+  if (blockIdx.x == 0 && tid == 0) nz_count[seg] = 0;       // this segment's list of non-zero mask words (mask kernel)
+  if (n <= 0) return;
+  // lanes per box: the largest power of two S <= 64 with S * n <= threads launched for this segment
+  const long T = (long)gridDim.x * kRankThreads;
+  int S = 1;
+  while (S < 64 && (long)(2 * S) * n <= T) S <<= 1;
+  const int boxes_per_block = kRankThreads / S;
+  const int first = blockIdx.x * boxes_per_block;
+  if (first >= n) return;
+  const int npad = (n + 3) & ~3;
+  for (int j = tid; j < npad; j += kRankThreads)
+    keys[j] = (j < n) ? float_flip_desc(dets[(size_t)(s0 + j) * 9 + 8]) : 0xFFFFFFFFu;
+  __syncthreads();
+  const int i = first + tid / S, part = tid % S;
+  if (i >= n) return;                                      // whole groups leave together (S divides the wave size)
+  int rank = i;
+  if (!presorted) {
+    const unsigned ki = keys[i];
+    // this lane counts over key quads [q0, q1)
+    const int nq = npad >> 2;
+    const int q0 = (int)((long)nq * part / S), q1 = (int)((long)nq * (part + 1) / S);
+    const uint4* k4 = reinterpret_cast<const uint4*>(keys);
+    int cnt = 0;
+    for (int q = q0; q < q1; q++) {
+      const uint4 k = k4[q];
+      const int j = q << 2;
+      cnt += (int)((k.x < ki) | ((k.x == ki) & (j < i)));
+      cnt += (int)((k.y < ki) | ((k.y == ki) & (j + 1 < i)));
+      cnt += (int)((k.z < ki) | ((k.z == ki) & (j + 2 < i)));
+      cnt += (int)((k.w < ki) | ((k.w == ki) & (j + 3 < i)));
+    }
+    for (int off = S >> 1; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    rank = cnt;                                            // padding keys (0xFFFFFFFF, index >= n) never precede a real box
+  }
+  if (part == 0) {
+    order[s0 + rank] = s0 + i;
+    prepare_box(dets + (size_t)(s0 + i) * 9, prep, s0 + rank);
+  }
 }
 
 // ---- mask kernel -------------------------------------------------------------------------------------------
@@ -103,7 +175,7 @@ template <bool GUARD>
 __device__ __forceinline__ void mask_tile(TileLds& T, TermLds& X, const orp::QuadPrep* __restrict__ prep, int s0, int n, int c,
                                           int row_base, int rpb, int rows_per_wave, int mask_stride, float thr,
                                           u64* __restrict__ mask, int dbg, int* __restrict__ nz_count,
-                                          unsigned* __restrict__ nz_rc, u64* __restrict__ nz_w) {
+                                          unsigned* __restrict__ nz_rc) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
   // ---- stage the tile's row / column records in LDS (phase B reads them with per-lane indices) ----------------
@@ -186,12 +258,13 @@ __device__ __forceinline__ void mask_tile(TileLds& T, TermLds& X, const orp::Qua
   if (tid < rpb && row_base + tid < n) {
     const u64 w = T.words[tid];
     mask[(size_t)(s0 + row_base + tid) * mask_stride + c] = w;
-    if (nz_count && w) {                                 // sparse side list for the LDS-resident sweep (single segment)
+    if (w) {                                             // sparse side list of this segment for the LDS-resident sweep
       const int pos = atomicAdd(nz_count, 1);
-      if (pos < kNzCap) { nz_rc[pos] = ((unsigned)(row_base + tid) << 11) | (unsigned)c; nz_w[pos] = w; }
+      if (pos < kNzCap) nz_rc[pos] = ((unsigned)(row_base + tid) << 11) | (unsigned)c;
     }
   }
 }
+
 
 // The box count is read from DEVICE memory (seg_off): the host may only know an upper bound (sync-free / hipGraph callers:
 // an 8 K capacity holding 2 K boxes must not pay for 60 K empty workgroups).  A bounded grid of workgroups loops over the
@@ -201,7 +274,7 @@ template <bool GUARD>
 __global__ void __launch_bounds__(kMaskThreads, 4)
 nms_mask_loop_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restrict__ seg_off, int rows_per_wave,
                      int mask_stride, float thr, u64* __restrict__ mask, int dbg, int* __restrict__ nz_count,
-                     unsigned* __restrict__ nz_rc, u64* __restrict__ nz_w) {
+                     unsigned* __restrict__ nz_rc) {
   __shared__ TileLds T;
   __shared__ TermLds X;
   const int seg = blockIdx.z;
@@ -228,7 +301,8 @@ nms_mask_loop_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __re
       const int r = (int)(t - before(j)), w = cbn - j;
       g = j * q + r / w; c = j + r % w;
     }
-    mask_tile<GUARD>(T, X, prep, s0, n, c, g * rpb, rpb, rows_per_wave, mask_stride, thr, mask, dbg, nz_count, nz_rc, nz_w);
+    mask_tile<GUARD>(T, X, prep, s0, n, c, g * rpb, rpb, rows_per_wave, mask_stride, thr, mask, dbg, nz_count + seg,
+                     nz_rc + (size_t)seg * kNzCap);
     __syncthreads();                                     // the LDS tile is reused by the next tile
   }
 }
@@ -311,16 +385,138 @@ __device__ __forceinline__ int popc_scan_emit(const u64* words, int nw, int* tmp
   return running;
 }
 
+// ---- sweep of a small segment (<= 4096 boxes, sparse list fits): the serial part by ONE wave ---------------------------
+// LDS (own carve of the dynamic buffer): removed | keepbits | origbits | word prefix [64 each] | bucket ends [64] | list
+// words / coordinates [kNzCap] | diagonal words [64][64].  The whole workgroup fetches the listed words and buckets them
+// by 64-row block (counting sort, 4 barriers); the greedy pass over the blocks is then run by wave 0 alone WITHOUT any
+// workgroup barrier (per block: one broadcast read of removed[blk], the readlane-based diagonal pass, one or two rounds
+// over that block's words); the workgroup comes back for the compaction.  ~8 barriers per call instead of ~110.
+constexpr int kSmallCb = 64;
+inline size_t sweep_small_smem_bytes() {
+  return 16 + sizeof(u64) * 3 * kSmallCb + sizeof(int) * 2 * kSmallCb + (size_t)kNzCap * (sizeof(u64) + sizeof(unsigned)) +
+         sizeof(u64) * kSmallCb * 64;
+}
+__device__ __forceinline__ void wave_lds_sync() {         // orders this wave's LDS writes before its later LDS reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void sweep_small(unsigned char* smem, const u64* __restrict__ mask,
+                                            const int32_t* __restrict__ order, int s0, int n, int cb, int mask_stride,
+                                            int order_out, int64_t* __restrict__ keep_out, int32_t* __restrict__ num_keep,
+                                            int seg, int nnz, const unsigned* __restrict__ my_rc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  u64* removed = reinterpret_cast<u64*>(smem + 16);
+  u64* keepbits = removed + kSmallCb;
+  u64* origbits = keepbits + kSmallCb;
+  int* wpre = reinterpret_cast<int*>(origbits + kSmallCb);
+  int* bend = wpre + kSmallCb;
+  u64* nzw = reinterpret_cast<u64*>(bend + kSmallCb);
+  unsigned* nzrc = reinterpret_cast<unsigned*>(nzw + kNzCap);
+  u64* diagw = reinterpret_cast<u64*>(nzrc + kNzCap);            // [cb][64]: word (row, row >> 6) of every row
+
+  if (tid < kSmallCb) { removed[tid] = 0ull; keepbits[tid] = 0ull; origbits[tid] = 0ull; bend[tid] = 0; }
+  for (int i = tid; i < cb * 64; i += kSweepThreads) diagw[i] = 0ull;
+  __syncthreads();
+  for (int i = tid; i < nnz; i += kSweepThreads) atomicAdd(&bend[my_rc[i] >> 17], 1);
+  __syncthreads();
+  if (wave == 0) {                                         // exclusive scan of the 64 bucket sizes: one shuffle scan
+    const int v = bend[lane];
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      incl += (lane >= off) ? u : 0;
+    }
+    bend[lane] = incl - v;                                 // start of bucket `lane` (becomes its end after the scatter)
+  }
+  __syncthreads();
+  for (int i = tid; i < nnz; i += kSweepThreads) {
+    const unsigned rc = my_rc[i];
+    const unsigned row = rc >> 11, cc = rc & 2047u;
+    const u64 w = mask[(size_t)(s0 + (int)row) * mask_stride + cc];
+    const int pos = atomicAdd(&bend[row >> 6], 1);
+    nzrc[pos] = rc; nzw[pos] = w;
+    if (cc == (row >> 6)) diagw[row] = w;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int blk = 0; blk < cb; blk++) {
+      const u64 d = diagw[blk * 64 + lane];
+      const u64 cur0 = removed[blk];                       // same address for the whole wave: broadcast
+      unsigned clo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur0);
+      unsigned chi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur0 >> 32));
+      u64 cur = ((u64)chi << 32) | clo;
+      const int valid = min(64, n - blk * 64);
+      const u64 vmask = (valid >= 64) ? ~0ull : ((1ull << valid) - 1ull);
+      const int dlo = (int)(unsigned)d, dhi = (int)(unsigned)(d >> 32);
+      u64 todo = __ballot(d != 0ull) & vmask;              // rows that can suppress inside this block
+      while (todo) {                                       // wave-uniform, ascending row order
+        const int kk = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        if (!((cur >> kk) & 1ull))
+          cur |= ((u64)(unsigned)__builtin_amdgcn_readlane(dhi, kk) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane(dlo, kk);
+      }
+      const u64 kept = ~cur & vmask;
+      if (lane == 0) keepbits[blk] = kept;
+      const int b0 = blk ? bend[blk - 1] : 0, b1 = bend[blk];
+      for (int i = b0 + lane; i < b1; i += 64) {
+        const unsigned rc = nzrc[i];
+        const unsigned cc = rc & 2047u, rl = (rc >> 11) & 63u;
+        if (cc > (unsigned)blk && ((kept >> rl) & 1ull)) atomicOr(&removed[cc], nzw[i]);
+      }
+      wave_lds_sync();
+    }
+  }
+  __syncthreads();
+  // ---- compaction ----------------------------------------------------------------------------------------------------------
+  const u64* bits = keepbits;                               // visiting order: positions are the answer's order
+  if (order_out != 1) {                                    // ascending original index: scatter the flags first
+    for (int i = tid; i < n; i += kSweepThreads) {
+      if ((keepbits[i >> 6] >> (i & 63)) & 1ull) {
+        const int o = order[s0 + i] - s0;
+        atomicOr(&origbits[o >> 6], 1ull << (o & 63));
+      }
+    }
+    __syncthreads();
+    bits = origbits;
+  }
+  if (wave == 0) {
+    const int cnt = __popcll(bits[lane]);
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      incl += (lane >= off) ? u : 0;
+    }
+    wpre[lane] = incl - cnt;
+    if (lane == 63) num_keep[seg] = incl;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += kSweepThreads) {
+    const u64 w = bits[i >> 6];
+    if ((w >> (i & 63)) & 1ull) {
+      const int pos = wpre[i >> 6] + __popcll(w & ((1ull << (i & 63)) - 1ull));
+      keep_out[s0 + pos] = (order_out == 1) ? (int64_t)order[s0 + i] : (int64_t)(s0 + i);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(kSweepThreads)
 nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order, const int32_t* __restrict__ seg_off,
                  int mask_stride, int order_out, int64_t* __restrict__ keep_out, int32_t* __restrict__ num_keep,
-                 const int* __restrict__ nz_count, const unsigned* __restrict__ nz_rc, const u64* __restrict__ nz_w) {
+                 const int* __restrict__ nz_count, const unsigned* __restrict__ nz_rc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int seg = blockIdx.x;
   const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (n <= 0) { if (tid == 0) num_keep[seg] = 0; return; }
   const int cb = (n + 63) >> 6;
+  if (cb <= kSmallCb && nz_count && nz_count[seg] <= kNzCap) {     // small segment (uniform branch)
+    sweep_small(smem, mask, order, s0, n, cb, mask_stride, order_out, keep_out, num_keep, seg, nz_count[seg],
+                nz_rc + (size_t)seg * kNzCap);
+    return;
+  }
   u64* s_kept = reinterpret_cast<u64*>(smem);
   int* tmp = reinterpret_cast<int*>(smem + 16);
   u64* removed = reinterpret_cast<u64*>(smem + kSweepHdr);
@@ -330,23 +526,54 @@ nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order
   for (int i = tid; i < cb; i += kSweepThreads) { removed[i] = 0; keepbits[i] = 0; origbits[i] = 0; }
   __syncthreads();
 
-  // ---- sparse sweep: the mask of a detection scene is mostly zeros; the mask kernel appended every non-zero word to a
-  // side list.  If the list fits (<= kNzCap words) the whole greedy pass runs out of LDS: per 64-row block one diagonal
-  // pass (wave 0) and one scan of the list that ORs the kept rows' words into `removed` and files the NEXT block's
-  // diagonal words -- two barriers and no HBM / L2 round trip per block.
-  const int nnz = nz_count ? *nz_count : (kNzCap + 1);
+  // ---- sparse sweep: the mask of a detection scene is mostly zeros; the classify / pairs launches filed the coordinates
+  // of every non-zero word in a per-segment list.  If the list fits (<= kNzCap words) the whole greedy pass runs out of
+  // LDS: the words are fetched once, bucketed by 64-row block (counting sort), and block blk then only touches ITS
+  // words: the diagonal ones feed the readlane-based pass of wave 0, the others are ORed into `removed` for the kept
+  // rows -- two barriers and no HBM / L2 round trip per block.
+  const int nnz = nz_count ? nz_count[seg] : (kNzCap + 1);
   const bool sparse = nnz <= kNzCap;
   if (sparse) {
     u64* nzw = origbits + cb;
     unsigned* nzrc = reinterpret_cast<unsigned*>(nzw + kNzCap);
     u64* diag = reinterpret_cast<u64*>(nzrc + kNzCap);              // [2][64]
-    for (int i = tid; i < nnz; i += kSweepThreads) { nzw[i] = nz_w[i]; nzrc[i] = nz_rc[i]; }
+    int* bend = reinterpret_cast<int*>(diag + 128);                 // [cb]: end of bucket blk after the scatter
+    const unsigned* my_rc = nz_rc + (size_t)seg * kNzCap;
+    for (int i = tid; i < cb; i += kSweepThreads) bend[i] = 0;
     if (tid < 128) diag[tid] = 0ull;
     __syncthreads();
-    for (int i = tid; i < nnz; i += kSweepThreads) {
-      const unsigned rc = nzrc[i];
-      if ((rc >> 17) == 0u && (rc & 2047u) == 0u) diag[(rc >> 11) & 63u] = nzw[i];      // row block 0, column block 0
+    for (int i = tid; i < nnz; i += kSweepThreads) atomicAdd(&bend[my_rc[i] >> 17], 1);
+    __syncthreads();
+    // exclusive scan of the bucket sizes (cb <= 2048), chunk by chunk through tmp
+    {
+      int running = 0;
+      for (int base = 0; base < cb; base += kSweepThreads) {
+        const int i = base + tid;
+        const int v = (i < cb) ? bend[i] : 0;
+        tmp[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < kSweepThreads; off <<= 1) {
+          const int u = (tid >= off) ? tmp[tid - off] : 0;
+          __syncthreads();
+          tmp[tid] += u;
+          __syncthreads();
+        }
+        if (i < cb) bend[i] = running + tmp[tid] - v;               // start of bucket i (becomes its end below)
+        const int chunk_total = tmp[kSweepThreads - 1];
+        __syncthreads();
+        running += chunk_total;
+      }
     }
+    for (int i = tid; i < nnz; i += kSweepThreads) {
+      const unsigned rc = my_rc[i];
+      const int pos = atomicAdd(&bend[rc >> 17], 1);
+      nzrc[pos] = rc;
+      nzw[pos] = mask[(size_t)(s0 + (int)(rc >> 11)) * mask_stride + (rc & 2047u)];
+    }
+    __syncthreads();
+    // block 0's diagonal words
+    for (int i = tid; i < bend[0]; i += kSweepThreads)
+      if ((nzrc[i] & 2047u) == 0u) diag[(nzrc[i] >> 11) & 63u] = nzw[i];
     __syncthreads();
     for (int blk = 0; blk < cb; blk++) {
       if (wave == 0) {
@@ -372,11 +599,13 @@ nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order
       __syncthreads();
       const u64 kept = *s_kept;
       const unsigned ublk = (unsigned)blk;
-      for (int i = tid; i < nnz; i += kSweepThreads) {
+      // this block's words (right of the diagonal) of the kept rows; the next block's diagonal words
+      const int b0 = blk ? bend[blk - 1] : 0, b1 = bend[blk], b2 = (blk + 1 < cb) ? bend[blk + 1] : b1;
+      for (int i = b0 + tid; i < b2; i += kSweepThreads) {
         const unsigned rc = nzrc[i];
-        const unsigned rb = rc >> 17, cc = rc & 2047u, rl = (rc >> 11) & 63u;
-        if (rb == ublk && cc > ublk && ((kept >> rl) & 1ull)) atomicOr(&removed[cc], nzw[i]);
-        if (rb == ublk + 1u && cc == ublk + 1u) diag[((blk + 1) & 1) * 64 + rl] = nzw[i];
+        const unsigned cc = rc & 2047u, rl = (rc >> 11) & 63u;
+        if (i < b1) { if (cc > ublk && ((kept >> rl) & 1ull)) atomicOr(&removed[cc], nzw[i]); }
+        else if (cc == ublk + 1u) diag[((blk + 1) & 1) * 64 + rl] = nzw[i];
       }
       __syncthreads();
     }
@@ -479,7 +708,7 @@ nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct NmsLayout {
-  size_t off_seg, off_keys_in, off_keys_out, off_vals_in, off_order, off_boxes, off_mask, off_nzc, off_nzrc, off_nzw, off_cub,
+  size_t off_seg, off_keys_in, off_keys_out, off_vals_in, off_order, off_boxes, off_mask, off_nzc, off_nzrc, off_cub,
       cub_bytes, total;
 };
 
@@ -487,34 +716,38 @@ NmsLayout nms_layout(int n_total, int nseg, int max_seg) {
   NmsLayout L;
   size_t o = 0;
   const size_t n = (size_t)(n_total > 0 ? n_total : 1);
+  const size_t ns = (size_t)(nseg > 0 ? nseg : 1);
   const size_t cb = (size_t)((max_seg + 63) / 64 > 0 ? (max_seg + 63) / 64 : 1);
-  L.off_seg = o; o += align256(sizeof(int32_t) * (size_t)(nseg + 1));
-  L.off_keys_in = o; o += align256(sizeof(u64) * n);
-  L.off_keys_out = o; o += align256(sizeof(u64) * n);
-  L.off_vals_in = o; o += align256(sizeof(int32_t) * n);
+  L.off_seg = o; o += align256(sizeof(int32_t) * (ns + 1));
+  const bool big = max_seg > kSortMax;                     // device-wide radix sort needed
+  L.off_keys_in = o; o += big ? align256(sizeof(u64) * n) : 0;
+  L.off_keys_out = o; o += big ? align256(sizeof(u64) * n) : 0;
+  L.off_vals_in = o; o += big ? align256(sizeof(int32_t) * n) : 0;
   L.off_order = o; o += align256(sizeof(int32_t) * n);
   L.off_boxes = o; o += align256(sizeof(orp::QuadPrep) * n);
   L.off_mask = o; o += align256(sizeof(u64) * n * cb);
-  L.off_nzc = o; o += align256(sizeof(int));
-  L.off_nzrc = o; o += align256(sizeof(unsigned) * kNzCap);
-  L.off_nzw = o; o += align256(sizeof(u64) * kNzCap);
+  L.off_nzc = o; o += align256(sizeof(int) * ns);
+  L.off_nzrc = o; o += align256(sizeof(unsigned) * kNzCap * ns);
   size_t cub = 0;
-  hipcub::DeviceRadixSort::SortPairs((void*)nullptr, cub, (const u64*)nullptr, (u64*)nullptr, (const int32_t*)nullptr,
-                                     (int32_t*)nullptr, (int)n, 0, 64, (hipStream_t)0);
+  if (big)
+    hipcub::DeviceRadixSort::SortPairs((void*)nullptr, cub, (const u64*)nullptr, (u64*)nullptr, (const int32_t*)nullptr,
+                                       (int32_t*)nullptr, (int)n, 0, 64, (hipStream_t)0);
   L.cub_bytes = cub;
   L.off_cub = o; o += align256(cub);
   L.total = o;
   return L;
 }
 
-// dynamic LDS of the sweep: header | removed, keepbits, origbits [cb] | sparse list (12 B x kNzCap) | diag [2][64]
+// dynamic LDS of the sweep: header | removed, keepbits, origbits [cb] | sparse list (12 B x kNzCap) | diag [2][64] | bucket ends [cb]
 inline size_t sweep_smem_bytes(int max_cb) {
-  return kSweepHdr + (size_t)max_cb * 3 * sizeof(u64) + (size_t)kNzCap * (sizeof(u64) + sizeof(unsigned)) + 128 * sizeof(u64);
+  const size_t general = kSweepHdr + (size_t)max_cb * 3 * sizeof(u64) + (size_t)kNzCap * (sizeof(u64) + sizeof(unsigned)) +
+                         128 * sizeof(u64) + (size_t)max_cb * sizeof(int);
+  const size_t small = sweep_small_smem_bytes();           // the one-wave path carves the same buffer its own way
+  return general > small ? general : small;
 }
-inline hipError_t sweep_attr() {     // > 64 KB of dynamic LDS needs the attribute; once (not allowed during stream capture)
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_sweep_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  return e;
+inline hipError_t sweep_attr() {     // > 64 KB of dynamic LDS needs the attribute: once per device, never during a capture
+  struct Tag {};
+  return orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&nms_sweep_kernel), 160 * 1024);
 }
 
 int pick_rows_per_wave(int max_seg, int nseg) {
@@ -540,47 +773,59 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
   if (!ws || ws_bytes < L.total) return ORP_EWORKSPACE;
   char* base = reinterpret_cast<char*>(ws);
   int32_t* seg = reinterpret_cast<int32_t*>(base + L.off_seg);
-  u64* keys_in = reinterpret_cast<u64*>(base + L.off_keys_in);
-  u64* keys_out = reinterpret_cast<u64*>(base + L.off_keys_out);
-  int32_t* vals_in = reinterpret_cast<int32_t*>(base + L.off_vals_in);
   int32_t* order = reinterpret_cast<int32_t*>(base + L.off_order);
   orp::QuadPrep* boxes = reinterpret_cast<orp::QuadPrep*>(base + L.off_boxes);
   u64* mask = reinterpret_cast<u64*>(base + L.off_mask);
-  // the sparse side list serves single-segment launches (the inference path); batched segments use the dense sweep
-  int* nz_count = (nseg == 1) ? reinterpret_cast<int*>(base + L.off_nzc) : nullptr;
+  int* nz_count = reinterpret_cast<int*>(base + L.off_nzc);
   unsigned* nz_rc = reinterpret_cast<unsigned*>(base + L.off_nzrc);
-  u64* nz_w = reinterpret_cast<u64*>(base + L.off_nzw);
-  void* cub = base + L.off_cub;
 
-  if (single_segment) {
-    hipLaunchKernelGGL(set_single_segment_kernel, dim3(1), dim3(1), 0, st, seg, n_total);
-  } else {
+  const bool one_launch = max_seg <= kSortMax;            // rank + prepare in one launch (also writes the segment table)
+  if (!single_segment) {
     hipError_t e = hipMemcpyAsync(seg, seg_off_dev, sizeof(int32_t) * (size_t)(nseg + 1), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return (int)e;
+  } else if (!one_launch || n_total == 0) {
+    hipLaunchKernelGGL(set_single_segment_kernel, dim3(1), dim3(1), 0, st, seg, n_total);
   }
   if (n_total == 0) {
     hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int32_t) * (size_t)nseg, st);
     return e == hipSuccess ? ORP_OK : (int)e;
   }
-  const int tb = 256, nb = (n_total + tb - 1) / tb;
-  if (presorted) {
-    hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(tb), 0, st, order, n_total);
-  } else {
-    hipLaunchKernelGGL(make_keys_kernel, dim3(nb), dim3(tb), 0, st, dets, n_total, seg, nseg, keys_in, vals_in);
-    size_t cub_bytes = L.cub_bytes;
-    int end_bit = 32;
-    { int s = nseg - 1; while (s > 0) { end_bit++; s >>= 1; } }
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(cub, cub_bytes, keys_in, keys_out, vals_in, order, n_total, 0,
-                                                      end_bit, st);
-    if (e != hipSuccess) return (int)e;
+  // ---- stage 1: visiting order + per-box records ----------------------------------------------------------------------
+  {
+    OrpProfScope prof(ORP_PROF_NMS_SORT, st);
+    if (one_launch) {
+      // threads per segment: 4 lanes per box up to 2048 boxes of capacity, then enough for <= ~512 keys per lane
+      long thr_seg = (long)max_seg * (max_seg <= 2048 ? 4 : (max_seg + 511) / 512);
+      if (thr_seg < kRankThreads) thr_seg = kRankThreads;
+      const unsigned gx = (unsigned)((thr_seg + kRankThreads - 1) / kRankThreads);
+      hipLaunchKernelGGL(nms_rankprep_kernel, dim3(gx, nseg), dim3(kRankThreads), 0, st, dets, seg,
+                         single_segment ? n_total : -1, presorted, order, boxes, nz_count);
+    } else {
+      const int tb = 256;
+      const int nb = ((n_total > nseg ? n_total : nseg) + tb - 1) / tb;
+      if (presorted) {
+        hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(tb), 0, st, order, n_total);
+      } else {
+        u64* keys_in = reinterpret_cast<u64*>(base + L.off_keys_in);
+        u64* keys_out = reinterpret_cast<u64*>(base + L.off_keys_out);
+        int32_t* vals_in = reinterpret_cast<int32_t*>(base + L.off_vals_in);
+        hipLaunchKernelGGL(make_keys_kernel, dim3(nb), dim3(tb), 0, st, dets, n_total, seg, nseg, keys_in, vals_in);
+        size_t cub_bytes = L.cub_bytes;
+        int end_bit = 32;
+        { int s = nseg - 1; while (s > 0) { end_bit++; s >>= 1; } }
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(base + L.off_cub, cub_bytes, keys_in, keys_out, vals_in, order,
+                                                          n_total, 0, end_bit, st);
+        if (e != hipSuccess) return (int)e;
+      }
+      hipLaunchKernelGGL(prep_boxes_kernel, dim3(nb), dim3(tb), 0, st, dets, order, n_total, boxes, nz_count, nseg);
+    }
   }
-  hipLaunchKernelGGL(prep_boxes_kernel, dim3(nb), dim3(tb), 0, st, dets, order, n_total, boxes, nz_count);
 
+  // ---- stage 2: the suppression mask ---------------------------------------------------------------------------------------
   const int max_cb = (max_seg + 63) / 64;
-  // exact_n: max_seg IS the box count (orp_rnms) -> one workgroup per tile.  Otherwise max_seg is only a capacity (the
-  // count lives in device memory: batched / sync-free callers): 16-row tiles and a bounded grid whose workgroups loop
-  // over the tiles of the actual count -- an 8 K capacity holding 2 K boxes must not pay for 60 K empty workgroups.
-  // exact_n: max_seg IS the box count (orp_rnms); otherwise it is only a capacity (batched / sync-free callers)
+  // exact_n: max_seg IS the box count (orp_rnms); otherwise it is only a capacity (batched / sync-free callers: the
+  // count lives in device memory): 16-row tiles and a bounded grid whose workgroups loop over the tiles of the actual
+  // count -- an 8 K capacity holding 2 K boxes must not pay for 60 K empty workgroups
   const bool exact_n = single_segment;
   const int R = exact_n ? pick_rows_per_wave(max_seg, nseg) : (max_seg <= 8192 ? (max_seg <= 256 ? 1 : 4) : 16);
   const int rpb = R * (kMaskThreads / 64);
@@ -591,16 +836,17 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
   static const int dbg = getenv("ORP_NMS_DBG") ? atoi(getenv("ORP_NMS_DBG")) : 0;   // dev aid (timing): 1 = skip phase B, 2 = skip classifier, 4/8/16 = see tile_drain_terms
   {
     OrpProfScope prof(ORP_PROF_NMS_MASK, st);
-    if (flavor == 0) hipLaunchKernelGGL(nms_mask_loop_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc, nz_w);
-    else hipLaunchKernelGGL(nms_mask_loop_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc, nz_w);
+    if (flavor == 0) hipLaunchKernelGGL(nms_mask_loop_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc);
+    else hipLaunchKernelGGL(nms_mask_loop_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc);
   }
 
+  // ---- stage 3: greedy sweep + compaction ------------------------------------------------------------------------------------
   const size_t smem = sweep_smem_bytes(max_cb);
   if (sweep_attr() != hipSuccess) return (int)sweep_attr();
   {
     OrpProfScope prof(ORP_PROF_NMS_SWEEP, st);
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(nseg), dim3(kSweepThreads), smem, st, mask, order, seg, max_cb, order_out,
-                       keep_out, num_keep, nz_count, nz_rc, nz_w);
+                       keep_out, num_keep, nz_count, nz_rc);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
@@ -701,7 +947,7 @@ int orp_poly_nms_f64(const double* dets_sorted, int n, double iou_thr, int64_t* 
   const size_t smem = sweep_smem_bytes(max_cb);
   if (sweep_attr() != hipSuccess) return (int)sweep_attr();
   hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(kSweepThreads), smem, st, mask, order, seg, max_cb, 1, keep_out,
-                     num_keep, (const int*)nullptr, (const unsigned*)nullptr, (const u64*)nullptr);
+                     num_keep, (const int*)nullptr, (const unsigned*)nullptr);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }

@@ -18,16 +18,17 @@ for n in (2000, 5344):
     t = torch.from_numpy(d.astype(np.float32)).to(dev)
     for _ in range(3): rnms_device(t, 0.4)
     torch.cuda.synchronize()
-    _lib.lib().orp_profile_enable(1); prof(0); prof(1)
+    _lib.lib().orp_profile_enable(1); prof(0); prof(1); prof(2)
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20): rnms_device(t, 0.4)
     e1.record(); torch.cuda.synchronize()
-    print("  n=%%d total %%.1f us mask %%.1f sweep %%.1f" %% (n, e0.elapsed_time(e1) / 20 * 1e3, prof(0), prof(1)))
+    print("  n=%%d total %%.1f us sort+prep %%.1f mask %%.1f sweep %%.1f" %% (n, e0.elapsed_time(e1) / 20 * 1e3, prof(2), prof(0), prof(1)))
     _lib.lib().orp_profile_enable(0)
 ''' % os.path.abspath(__file__)
-for env in ({}, {'ORP_NMS_DBG': '1'}, {'ORP_NMS_DBG': '3'}, {'ORP_NMS_DBG': '4'}, {'ORP_NMS_DBG': '20'}, {'ORP_NMS_DBG': '8'},
-            {'ORP_NMS_ROWS': '1'}, {'ORP_NMS_ROWS': '2'}, {'ORP_NMS_ROWS': '8'}, {'ORP_NMS_ROWS': '16'}):
+cfgs = [{}] + [{'ORP_NMS_DBG': v} for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else [{}]
+rows = sys.argv[2].split(',') if len(sys.argv) > 2 else []
+for env in cfgs + [{'ORP_NMS_ROWS': r} for r in rows]:
     print(env, flush=True)
     e = dict(os.environ); e.update(env)
     subprocess.run([sys.executable, '-c', code], env=e)
