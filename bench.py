@@ -552,33 +552,40 @@ def main():
         nms_us = e0.elapsed_time(e1) / 20 * 1e3
 
     # ---- roofline of the dominant hot-path kernel: the DeformConv implicit GEMM (exact-fp32 MFMA) -------------------
-    # algorithmic flops per launch = 2 * positions * Cout * Cin * taps, all FPN levels in one launch;
-    # algorithmic bytes = 4 * (x + offsets + packed weights + out).  `traffic` = HBM bytes per launch from the
-    # rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE).
+    # ONE launch per image runs both DeformConvs of the head (cls + refine share their offsets: orp_dcn_forward_pair) over
+    # all FPN levels.  algorithmic flops per launch = layers * 2 * positions * Cout * Cin * taps;
+    # algorithmic bytes = 4 * (layers * (x + packed weights + out) + offsets).  `traffic` = HBM bytes per launch from the
+    # rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), null
+    # when no PMC pass of this round's kernel is committed.
     dcn_ms, dcn_n = prof['dcn_fwd']
     roof = None
     npos = args.batch * sum((IMG // s_) ** 2 for s_ in (8, 16, 32, 64, 128))
     cin = cout = 256
+    layers = 2
     if dcn_n > 0:
         avg_s = dcn_ms / dcn_n * 1e-3
-        flops = 2.0 * npos * cout * cin * 9
-        alg_bytes = 4.0 * (npos * cin + npos * 18 + 9 * cin * cout + npos * cout)
+        flops = layers * 2.0 * npos * cout * cin * 9
+        alg_bytes = 4.0 * (layers * (npos * cin + 9 * cin * cout + npos * cout) + npos * 18)
         achieved = flops / avg_s / 1e12
-        traffic = None
-        pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc.json')
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, 'profiles', 'r02_pmc.json')
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                if args.batch == pmc.get('dcn_fwd', {}).get('batch'):
-                    traffic = pmc['dcn_fwd']['hbm_bytes_per_launch']
+                d = pmc.get('dcn_fwd_pair', {})
+                if args.batch == d.get('batch') and IMG == d.get('img', 1024):
+                    traffic = d['hbm_bytes_per_launch']
+                    traffic_src = 'profiles/r02_pmc.json (rocprofv3 --pmc pass of this kernel, collected separately)'
             except Exception:
                 traffic = None
-        roof = dict(kernel='dcn_fwd_mfma2_kernel', bound='mfma', achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS,
-                    unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=traffic, avg_launch_us=avg_s * 1e6,
-                    launches=dcn_n, positions_per_launch=npos, algorithmic_flops_per_launch=flops,
+        roof = dict(kernel='dcn_fwd_mfma2_kernel<3, nchw, 2 layers>', bound='mfma', achieved=achieved,
+                    peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=traffic,
+                    traffic_source=traffic_src, avg_launch_us=avg_s * 1e6, launches=dcn_n, layers_per_launch=layers,
+                    positions_per_launch=npos, algorithmic_flops_per_launch=flops,
                     algorithmic_bytes_per_launch=alg_bytes,
-                    note='exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense = the fp32 vector peak); two '
-                         'launches per image (cls + refine DeformConv)')
+                    note='exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense = the fp32 vector peak; a register-'
+                         'operand microbenchmark of the instruction sustains 146-156 TFLOP/s on this part: '
+                         'tests/checks/mfma_rate.hip); one launch per image = cls + refine DeformConv over all levels')
     # ---- the rotated-IoU + NMS stage (HBM is the formal bound, the work is fp32 VALU) --------------------------------
     mask_ms, mask_n = prof['nms_mask']
     nms = None

@@ -152,6 +152,15 @@ int orp_dcn_forward_multi_ex(const orp_dcn_level* levels_host, const float* cons
                              int c_in, int c_out, const float* weight_packed, const float* bias, int relu, int kh, int kw,
                              int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout,
                              int out_layout, void* workspace, size_t workspace_bytes, void* stream);
+/* Two DeformConv layers that share their offsets (and masks) in ONE launch: the head's reppoints_cls_conv and
+ * reppoints_pts_refine_conv both take `dcn_offset` (orientedreppoints_head.py:164-170).  levels_a[i] / levels_b[i] carry
+ * each layer's input and output of level i (levels_b[i].offset is ignored); the bilinear coefficient table of a tile
+ * is built once for both.  Requires c_in % 256 == 0 (else ORP_EINVAL: call orp_dcn_forward_multi_ex twice). */
+int orp_dcn_forward_pair(const orp_dcn_level* levels_a, const orp_dcn_level* levels_b, const float* const* masks_host,
+                         int nlevels, int batch, int c_in, int c_out, const float* weight_a_packed,
+                         const float* weight_b_packed, const float* bias_a, const float* bias_b, int relu, int kh, int kw,
+                         int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout,
+                         int out_layout, void* workspace, size_t workspace_bytes, void* stream);
 int orp_dcn_forward_direct(const float* input, const float* offset, const float* mask, const float* weight,
                            const float* bias, float* output, int batch, int c_in, int height, int width, int c_out,
                            int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liborp_hip.so")
+LIB_PATH = os.environ.get("ORP_HIP_LIB") or os.path.join(_HERE, "csrc", "liborp_hip.so")   # ORP_HIP_LIB: dev aid (instrumented builds)
 
 ORP_OK, ORP_EINVAL, ORP_EWORKSPACE, ORP_ETOOBIG = 0, -1, -2, -3
 ORP_NMS_MAX_BOXES = 131072
@@ -55,6 +55,7 @@ _SIGNATURES = {
     "orp_dcn_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "orp_dcn_forward_multi": (_i, [_vp, _i, _i, _i, _i, _vp] + [_i] * 10 + [_vp, _sz, _vp]),
     "orp_dcn_forward_multi_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp]),
+    "orp_dcn_forward_pair": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp]),
     "orp_dcn_im2col": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp]),
     "orp_dcn_col2im": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp, _vp]),
     "orp_dcn_col2im_nhwc": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp, _vp, _vp]),

@@ -30,6 +30,10 @@
 #include "orp_launch.hpp"
 #include "orp_prof.hpp"
 
+#ifndef ORP_DCN_DBG
+#define ORP_DCN_DBG 0      // dev aid, compile-time (timing only, wrong results): 1 = no A gather, 2 = no weight loads, 4 = no per-tap barriers / LDS refill, 8 = no MFMA
+#endif
+
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -48,6 +52,8 @@ struct LevelDesc {
   const float* off;    // NCHW [B, 2*taps, Ho, Wo]
   const float* mask;   // DCNv2 modulation, NCHW [B, taps, Ho, Wo], or nullptr (DCNv1)
   float* out;          // NCHW [B, Cout, Ho, Wo] or NHWC [B, Ho, Wo, Cout]
+  const float* x2;     // second layer of a pair launch (same offsets / mask): its input ...
+  float* out2;         // ... and output
   int H, W, Ho, Wo;
   int tile0;           // first tile of this level
 };
@@ -59,6 +65,9 @@ struct FwdParams {
   const float* w3;     // packed [taps][Cin/4][Cout][4] (second-generation kernel: B fragments straight from L2)
   const float* bias;   // [Cout] or nullptr (DCNv2 bias)
   int relu;            // fuse max(., 0) into the epilogue (the head applies ReLU right after both DeformConvs)
+  int nconv;           // 1, or 2: a second layer (w3b, bias2, LevelDesc::x2 / out2) over the same offsets in the same launch
+  const float* w3b;
+  const float* bias2;
 };
 
 // ---- helpers -------------------------------------------------------------------------------------------------
@@ -77,18 +86,18 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
 
 // [B][C][HW] -> [B][HW][C] through a 32x33 LDS tile, for every level of one launch: blockIdx.x walks the levels'
 // position tiles back to back
-struct TransposeLevels {
-  const float* in[MAX_LEVELS];
-  float* out[MAX_LEVELS];
-  int hw[MAX_LEVELS];
-  int bx0[MAX_LEVELS + 1];            // first blockIdx.x of each level; bx0[nlev] = gridDim.x
+struct TransposeLevels {               // up to MAX_LEVELS levels of up to two layers
+  const float* in[2 * MAX_LEVELS];
+  float* out[2 * MAX_LEVELS];
+  int hw[2 * MAX_LEVELS];
+  int bx0[2 * MAX_LEVELS + 1];        // first blockIdx.x of each tensor; bx0[nlev] = gridDim.x
   int nlev;
 };
 __global__ void nchw_to_nhwc_multi_kernel(const TransposeLevels T, int C) {
   __shared__ float tile[32][33];
   int l = 0;
 #pragma unroll
-  for (int i = 1; i < MAX_LEVELS; i++) l = (i < T.nlev && (int)blockIdx.x >= T.bx0[i]) ? i : l;
+  for (int i = 1; i < 2 * MAX_LEVELS; i++) l = (i < T.nlev && (int)blockIdx.x >= T.bx0[i]) ? i : l;
   const int HW = T.hw[l];
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * 32, p0 = ((int)blockIdx.x - T.bx0[l]) * 32;
@@ -334,7 +343,7 @@ dcn_fwd_mfma_kernel(const FwdParams P) {
 constexpr int KC2 = 16;          // input channels per weight chunk
 constexpr int kThreads2 = 512;
 
-template <int MT, bool OUT_NCHW>
+template <int MT, bool OUT_NCHW, int NCONV>
 __global__ void __launch_bounds__(kThreads2)
 dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   constexpr int BM2 = 32 * MT;
@@ -401,6 +410,14 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   }
   __syncthreads();
 
+  // a pair launch runs its two layers one after the other on the SAME coefficient table (same offsets / masks)
+#pragma unroll 1
+  for (int conv = 0; conv < NCONV; conv++) {
+  const float* xin = conv ? L.x2 : L.x;
+  const float* w3 = conv ? P.w3b : P.w3;
+  const float* bias = conv ? P.bias2 : P.bias;
+  float* outp = conv ? L.out2 : L.out;
+  if (conv) __syncthreads();                                // every wave is past its last read of the previous layer's A tile
   const int ncb = P.Cin / CB;                        // 256-channel blocks per tap (Cin % 256 == 0 on this path)
   const int nphase = taps * ncb;
   constexpr int NCHUNK = CB / KC2;                   // 16 chunks per phase
@@ -409,7 +426,10 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   auto gather_issue = [&](int phase, int m, float4 (&g)[4]) {
     const int tap = phase / ncb, cb = phase - tap * ncb;
     const int4 ix = sCi[m * taps + tap];
-    const float* base = L.x + cb * CB + lane * 4;
+    const float* base = xin + cb * CB + lane * 4;
+#if ORP_DCN_DBG & 1
+    g[0] = g[1] = g[2] = g[3] = make_float4(1.f, 1.f, 1.f, 1.f); return;
+#endif
     g[0] = *reinterpret_cast<const float4*>(base + (size_t)ix.x * P.Cin);
     g[1] = *reinterpret_cast<const float4*>(base + (size_t)ix.y * P.Cin);
     g[2] = *reinterpret_cast<const float4*>(base + (size_t)ix.z * P.Cin);
@@ -418,11 +438,11 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   auto combine = [&](int phase, int m, const float4 (&g)[4]) {
     const int tap = phase / ncb;
     const float4 wgt = sCw[m * taps + tap];
-    float4 v;
-    v.x = wgt.x * g[0].x + wgt.y * g[1].x + wgt.z * g[2].x + wgt.w * g[3].x;
-    v.y = wgt.x * g[0].y + wgt.y * g[1].y + wgt.z * g[2].y + wgt.w * g[3].y;
-    v.z = wgt.x * g[0].z + wgt.y * g[1].z + wgt.z * g[2].z + wgt.w * g[3].z;
-    v.w = wgt.x * g[0].w + wgt.y * g[1].w + wgt.z * g[2].w + wgt.w * g[3].w;
+    float4 v;                                             // explicit fma chain: every instantiation rounds identically
+    v.x = __builtin_fmaf(wgt.w, g[3].x, __builtin_fmaf(wgt.z, g[2].x, __builtin_fmaf(wgt.y, g[1].x, wgt.x * g[0].x)));
+    v.y = __builtin_fmaf(wgt.w, g[3].y, __builtin_fmaf(wgt.z, g[2].y, __builtin_fmaf(wgt.y, g[1].y, wgt.x * g[0].y)));
+    v.z = __builtin_fmaf(wgt.w, g[3].z, __builtin_fmaf(wgt.z, g[2].z, __builtin_fmaf(wgt.y, g[1].z, wgt.x * g[0].z)));
+    v.w = __builtin_fmaf(wgt.w, g[3].w, __builtin_fmaf(wgt.z, g[2].w, __builtin_fmaf(wgt.y, g[1].w, wgt.x * g[0].w)));
     return v;
   };
   // B fragments never touch LDS: wave w only ever needs its own 32 output channels, and with the [tap][c/4][o][4]
@@ -434,7 +454,10 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   auto load_bq = [&](int phase, int j, float4 (&r)[2]) {
     const int tap = phase / ncb, cb = phase - tap * ncb;
     const size_t c4 = (size_t)(tap * P.Cin + cb * CB + j * KC2 + 4 * kh) >> 2;
-    const float* base = P.w3 + (c4 * P.Cout + n_wave + mrow) * 4;
+    const float* base = w3 + (c4 * P.Cout + n_wave + mrow) * 4;
+#if ORP_DCN_DBG & 2
+    r[0] = r[1] = make_float4(1.f, 1.f, 1.f, 1.f); return;
+#endif
     if (n_ok) {
       r[0] = *reinterpret_cast<const float4*>(base);
       r[1] = *reinterpret_cast<const float4*>(base + (size_t)8 * P.Cout);     // channels + 8 -> c4 + 2
@@ -494,6 +517,9 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
               const float av = (i == 0) ? a4[mt].x : (i == 1) ? a4[mt].y : (i == 2) ? a4[mt].z : a4[mt].w;
+#if ORP_DCN_DBG & 8
+              acc[mt][0] += av * b0; continue;
+#endif
               if (OUT_NCHW) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, av, acc[mt], 0, 0, 0);   // D[channel][position]
               else          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[mt], 0, 0, 0);   // D[position][channel]
             }
@@ -504,7 +530,7 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
       bq[0] = bn[0]; bq[1] = bn[1];
     }
     // two barriers per tap: every wave is past its last read of this tap's A tile -> overwrite it with the next tap's rows
-    if (next_phase) {
+    if (next_phase && !(ORP_DCN_DBG & 4)) {
       __syncthreads();
 #pragma unroll
       for (int rr = 0; rr < ROWS; rr++)
@@ -514,15 +540,15 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
-  if (n_wave >= P.Cout) return;
-  auto finish = [&](float v, int ch) { if (P.bias) v += P.bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
+  if (n_wave >= P.Cout) continue;                          // idle wave: it still meets the other waves at every barrier above
+  auto finish = [&](float v, int ch) { if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
 #pragma unroll
   for (int mt = 0; mt < MT; mt++) {
     if (OUT_NCHW) {
       const long p = p0 + mt * 32 + (lane & 31);
       if (p < npos) {
         const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
-        float* ob = L.out + (size_t)b * P.Cout * HoWo + hw;
+        float* ob = outp + (size_t)b * P.Cout * HoWo + hw;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int ch = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -534,9 +560,10 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
       for (int r = 0; r < 16; r++) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const long p = p0 + mt * 32 + m;
-        if (p < npos && n_wave + (lane & 31) < P.Cout) L.out[(size_t)p * P.Cout + n_wave + (lane & 31)] = finish(acc[mt][r], n_wave + (lane & 31));
+        if (p < npos && n_wave + (lane & 31) < P.Cout) outp[(size_t)p * P.Cout + n_wave + (lane & 31)] = finish(acc[mt][r], n_wave + (lane & 31));
       }
     }
+  }
   }
 }
 
@@ -545,16 +572,20 @@ size_t mfma2_smem() {
   return sizeof(float) * ((size_t)32 * MT * ASTR) + (sizeof(float4) + sizeof(int4)) * 32 * MT * MAX_TAPS;
 }
 
-template <int MT, bool OUT_NCHW>
-hipError_t launch_mfma2(const FwdParams& P, int tiles, int nblk_n, hipStream_t st) {
+template <int MT, bool OUT_NCHW, int NCONV>
+hipError_t launch_mfma2_n(const FwdParams& P, int tiles, int nblk_n, hipStream_t st) {
   const size_t smem = mfma2_smem<MT>();
   // once per kernel instantiation (not per launch: the call is not allowed while a stream is being captured)
   struct Tag {};
-  hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_mfma2_kernel<MT, OUT_NCHW>), smem);
+  hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_mfma2_kernel<MT, OUT_NCHW, NCONV>), smem);
   if (e != hipSuccess) return e;
   const int per = (tiles + 7) >> 3;
-  hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<MT, OUT_NCHW>), dim3(per * 8, nblk_n), dim3(kThreads2), smem, st, P, tiles);
+  hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<MT, OUT_NCHW, NCONV>), dim3(per * 8, nblk_n), dim3(kThreads2), smem, st, P, tiles);
   return hipGetLastError();
+}
+template <int MT, bool OUT_NCHW>
+hipError_t launch_mfma2(const FwdParams& P, int tiles, int nblk_n, hipStream_t st) {
+  return P.nconv == 2 ? launch_mfma2_n<MT, OUT_NCHW, 2>(P, tiles, nblk_n, st) : launch_mfma2_n<MT, OUT_NCHW, 1>(P, tiles, nblk_n, st);
 }
 
 // ---- direct kernel: every configuration (groups, deformable groups, DCNv2 mask + bias), NCHW in / out -----------
@@ -647,28 +678,33 @@ int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int bat
                                   workspace_bytes, stream);
 }
 
-int orp_dcn_forward_multi_ex(const orp_dcn_level* levels_host, const float* const* masks_host, int nlevels, int batch,
-                             int c_in, int c_out, const float* weight_packed, const float* bias, int relu, int kh, int kw,
-                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout,
-                             int out_layout, void* workspace, size_t workspace_bytes, void* stream) {
+// One or two DeformConv layers (nconv) over the same levels / offsets / masks.  levels2_host, weight2, bias2: the second
+// layer (nconv == 2), else ignored.
+static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_level* levels2_host,
+                            const float* const* masks_host, int nlevels, int batch, int c_in, int c_out,
+                            const float* weight_packed, const float* weight2_packed, const float* bias, const float* bias2,
+                            int relu, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
+                            int dil_w, int in_layout, int out_layout, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+  const int nconv = levels2_host ? 2 : 1;
   if (!levels_host || nlevels <= 0 || nlevels > MAX_LEVELS || batch <= 0 || !weight_packed) return ORP_EINVAL;
+  if (nconv == 2 && !weight2_packed) return ORP_EINVAL;
   if (!orp_dcn_fast_path_ok(c_in, c_out, kh, kw, 1, 1)) return ORP_EINVAL;
   if ((in_layout != 0 && in_layout != 1) || (out_layout != 0 && out_layout != 1)) return ORP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  FwdParams P;
-  P.nlev = nlevels; P.B = batch; P.Cin = c_in; P.Cout = c_out;
-  P.kh = kh; P.kw = kw; P.sh = stride_h; P.sw = stride_w; P.ph = pad_h; P.pw = pad_w; P.dh = dil_h; P.dw = dil_w;
-  P.w2 = weight_packed;
-  P.w3 = weight_packed + (size_t)kh * kw * c_in * c_out;
-  P.bias = bias; P.relu = relu ? 1 : 0;
-  if (in_layout == 0 && workspace_bytes < orp_dcn_forward_workspace_bytes(levels_host, nlevels, batch, c_in, 0))
+  const size_t w3_off = (size_t)kh * kw * c_in * c_out;
+  if (in_layout == 0 && workspace_bytes < (size_t)nconv * orp_dcn_forward_workspace_bytes(levels_host, nlevels, batch, c_in, 0))
     return ORP_EWORKSPACE;
   char* wsp = reinterpret_cast<char*>(workspace);
-  // tile height: the second-generation kernel (MT*32 positions per workgroup) when Cin is a multiple of 256; MT is
-  // chosen to minimise rounds x tile height on 256 CUs (B=1, 1024x1024: MT = 3 -> 228 tiles, one round)
-  static const int force_mt = getenv("ORP_DCN_MT") ? atoi(getenv("ORP_DCN_MT")) : -1;   // dev aid: 0 = first-generation kernel
+  // kernel generation: 2 (MT*32-position tiles, 256-channel phases, one or two layers per launch) when Cin is a multiple
+  // of 256, else 1.  ORP_DCN_MT: dev aid.
+  static const int force_mt = getenv("ORP_DCN_MT") ? atoi(getenv("ORP_DCN_MT")) : -1;   // 0 = first-generation kernel
+  int gen = (c_in % CB == 0) ? 2 : 1;
+  if (nconv == 2 && gen != 2) return ORP_EINVAL;
+  // tile height: MT*32 positions per workgroup, chosen to minimise rounds x tile height on 256 CUs (B=1, 1024x1024:
+  // MT = 3 -> 228 tiles, one round)
   int MT = 0;
-  if (c_in % CB == 0) {
+  if (gen >= 2) {
     long npos_all = 0;
     for (int i = 0; i < nlevels; i++)
       npos_all += (long)batch * out_dim(levels_host[i].height, pad_h, dil_h, kh, stride_h) *
@@ -679,15 +715,26 @@ int orp_dcn_forward_multi_ex(const orp_dcn_level* levels_host, const float* cons
       const long cost = ((t + 255) / 256) * mt * 100 + (mt == 1 ? 40 : mt == 2 ? 10 : 0);   // small bias to taller tiles
       if (best < 0 || cost < best) { best = cost; MT = mt; }
     }
-    if (force_mt >= 0 && force_mt <= 3) MT = force_mt;
+    if (force_mt >= 1 && force_mt <= 3) MT = force_mt;
+    if (force_mt == 0 && nconv == 1) { gen = 1; MT = 0; }
   }
   const int bm = MT > 0 ? 32 * MT : BM;
   int tiles = 0;
+  FwdParams P;
+  P.nlev = nlevels; P.B = batch; P.Cin = c_in; P.Cout = c_out;
+  P.kh = kh; P.kw = kw; P.sh = stride_h; P.sw = stride_w; P.ph = pad_h; P.pw = pad_w; P.dh = dil_h; P.dw = dil_w;
+  P.w2 = weight_packed; P.w3 = weight_packed + w3_off; P.bias = bias; P.relu = relu ? 1 : 0;
+  P.nconv = nconv;
+  P.w3b = weight2_packed ? weight2_packed + w3_off : P.w3;
+  P.bias2 = bias2;
   TransposeLevels TL;
-  int tbx = 0;
+  int tbx = 0, ntl = 0;
   for (int i = 0; i < nlevels; i++) {
     const orp_dcn_level& lv = levels_host[i];
     if (!lv.input || !lv.offset || !lv.output || lv.height <= 0 || lv.width <= 0) return ORP_EINVAL;
+    if (nconv == 2 && (!levels2_host[i].input || !levels2_host[i].output || levels2_host[i].height != lv.height ||
+                       levels2_host[i].width != lv.width))
+      return ORP_EINVAL;
     LevelDesc& D = P.lv[i];
     D.H = lv.height; D.W = lv.width;
     D.Ho = out_dim(lv.height, pad_h, dil_h, kh, stride_h);
@@ -696,31 +743,36 @@ int orp_dcn_forward_multi_ex(const orp_dcn_level* levels_host, const float* cons
     if ((long)batch * lv.height * lv.width >= (1L << 31)) return ORP_ETOOBIG;
     D.off = lv.offset; D.out = lv.output;
     D.mask = masks_host ? masks_host[i] : nullptr;
-    if (in_layout == 0) {
-      float* nhwc = reinterpret_cast<float*>(wsp);
-      const int HW = lv.height * lv.width;
-      wsp += align256(sizeof(float) * (size_t)batch * c_in * HW);
-      TL.in[i] = lv.input; TL.out[i] = nhwc; TL.hw[i] = HW; TL.bx0[i] = tbx;
-      tbx += (HW + 31) / 32;
-      D.x = nhwc;
-    } else {
-      D.x = lv.input;
+    D.out2 = nconv == 2 ? levels2_host[i].output : lv.output;
+    for (int cv = 0; cv < nconv; cv++) {
+      const float* src = cv ? levels2_host[i].input : lv.input;
+      if (in_layout == 0) {
+        if (ntl >= 2 * MAX_LEVELS) return ORP_EINVAL;
+        float* nhwc = reinterpret_cast<float*>(wsp);
+        const int HW = lv.height * lv.width;
+        wsp += align256(sizeof(float) * (size_t)batch * c_in * HW);
+        TL.in[ntl] = src; TL.out[ntl] = nhwc; TL.hw[ntl] = HW; TL.bx0[ntl] = tbx;
+        tbx += (HW + 31) / 32;
+        ntl++;
+        src = nhwc;
+      }
+      if (cv == 0) { D.x = src; D.x2 = src; } else { D.x2 = src; }
     }
     D.tile0 = tiles;
     tiles += (int)(((long)batch * D.Ho * D.Wo + bm - 1) / bm);
   }
   for (int i = nlevels; i < MAX_LEVELS; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; }
-  if (in_layout == 0) {                                  // NCHW inputs: one transposition launch for all levels
-    TL.nlev = nlevels;
-    for (int i = nlevels; i <= MAX_LEVELS; i++) TL.bx0[i] = tbx;
-    for (int i = nlevels; i < MAX_LEVELS; i++) { TL.in[i] = TL.in[0]; TL.out[i] = TL.out[0]; TL.hw[i] = 0; }
+  if (in_layout == 0) {                                  // NCHW inputs: one transposition launch for all levels / layers
+    TL.nlev = ntl;
+    for (int i = ntl; i <= 2 * MAX_LEVELS; i++) TL.bx0[i] = tbx;
+    for (int i = ntl; i < 2 * MAX_LEVELS; i++) { TL.in[i] = TL.in[0]; TL.out[i] = TL.out[0]; TL.hw[i] = 0; }
     hipLaunchKernelGGL(nchw_to_nhwc_multi_kernel, dim3(tbx, (c_in + 31) / 32, batch), dim3(256), 0, st, TL, c_in);
   }
   hipError_t e;
   OrpProfScope prof(ORP_PROF_DCN_FWD, st);
   const int nblk_n = (c_out + BN - 1) / BN;
-  if (MT > 0) {
-    const bool nchw = out_layout == 0;
+  const bool nchw = out_layout == 0;
+  if (gen == 2) {
     if (MT == 1) e = nchw ? launch_mfma2<1, true>(P, tiles, nblk_n, st) : launch_mfma2<1, false>(P, tiles, nblk_n, st);
     else if (MT == 2) e = nchw ? launch_mfma2<2, true>(P, tiles, nblk_n, st) : launch_mfma2<2, false>(P, tiles, nblk_n, st);
     else e = nchw ? launch_mfma2<3, true>(P, tiles, nblk_n, st) : launch_mfma2<3, false>(P, tiles, nblk_n, st);
@@ -741,6 +793,27 @@ int orp_dcn_forward_multi_ex(const orp_dcn_level* levels_host, const float* cons
   }
   e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_dcn_forward_multi_ex(const orp_dcn_level* levels_host, const float* const* masks_host, int nlevels, int batch,
+                             int c_in, int c_out, const float* weight_packed, const float* bias, int relu, int kh, int kw,
+                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout,
+                             int out_layout, void* workspace, size_t workspace_bytes, void* stream) {
+  return dcn_forward_impl(levels_host, nullptr, masks_host, nlevels, batch, c_in, c_out, weight_packed, nullptr, bias,
+                          nullptr, relu, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, in_layout, out_layout,
+                          workspace, workspace_bytes, stream);
+}
+
+int orp_dcn_forward_pair(const orp_dcn_level* levels_a, const orp_dcn_level* levels_b, const float* const* masks_host,
+                         int nlevels, int batch, int c_in, int c_out, const float* weight_a_packed,
+                         const float* weight_b_packed, const float* bias_a, const float* bias_b, int relu, int kh, int kw,
+                         int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout,
+                         int out_layout, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!levels_b) return ORP_EINVAL;
+  if (c_in % CB != 0) return ORP_EINVAL;
+  return dcn_forward_impl(levels_a, levels_b, masks_host, nlevels, batch, c_in, c_out, weight_a_packed, weight_b_packed,
+                          bias_a, bias_b, relu, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, in_layout,
+                          out_layout, workspace, workspace_bytes, stream);
 }
 
 int orp_dcn_forward_direct(const float* input, const float* offset, const float* mask, const float* weight,

@@ -156,6 +156,17 @@ class OrientedRepPointsHead(nn.Module):
             cur = group_norm_act_multi(conv3x3_multi(cur, m.conv), m.norm, relu=True, inplace=True)
         return cur
 
+    def _dcn_pair(self, cls_feats, pts_feats, offsets):
+        a, b = self.reppoints_cls_conv, self.reppoints_pts_refine_conv
+        from ..mmdet_ops.deform_conv import deform_conv_forward_pair, fast_path_ok
+        same = (a.stride == b.stride and a.padding == b.padding and a.dilation == b.dilation and
+                a.weight.shape == b.weight.shape)
+        if same and cls_feats[0].is_cuda and fast_path_ok(a.weight, a.groups, a.deformable_groups) and \
+                fast_path_ok(b.weight, b.groups, b.deformable_groups):
+            return deform_conv_forward_pair(cls_feats, pts_feats, offsets, a.weight, b.weight, a.stride, a.padding,
+                                            a.dilation, relu=True)
+        return a.forward_multi(cls_feats, offsets, relu=True), b.forward_multi(pts_feats, offsets, relu=True)
+
     def forward_single(self, x):
         """One level, autograd-capable (reference forward_single, head :148-171)."""
         dcn_base_offset = self._base_offset_on(x)
@@ -192,8 +203,8 @@ class OrientedRepPointsHead(nn.Module):
                 cls_feats.append(cls_feat); pts_feats.append(pts_feat); inits.append(pts_out_init)
             # (1-g)*p.detach() + g*p is p up to one rounding; without autograd the two extra passes are skipped
             offsets = [init - dcn_base_offset for init in inits]
-        dcn_cls = self.reppoints_cls_conv.forward_multi(cls_feats, offsets, relu=True)     # ReLU fused in the epilogue
-        dcn_pts = self.reppoints_pts_refine_conv.forward_multi(pts_feats, offsets, relu=True)
+        # both DeformConvs take the same offsets: ONE launch for the two layers and all levels, ReLU fused in the epilogue
+        dcn_cls, dcn_pts = self._dcn_pair(cls_feats, pts_feats, offsets)
         if fused:
             cls_outs = bias_act_multi([self._conv_nobias(self.reppoints_cls_out, c) for c in dcn_cls],
                                       self.reppoints_cls_out.bias)

@@ -117,6 +117,62 @@ def deform_conv_forward_multi(inputs, offsets, weight, stride, padding, dilation
     return outs
 
 
+def deform_conv_forward_pair(inputs_a, inputs_b, offsets, weight_a, weight_b, stride, padding, dilation, masks=None,
+                             bias_a=None, bias_b=None, relu=False):
+    """Two DeformConv layers with the SAME offsets (the head's cls / refine pair) over a list of feature maps in ONE
+    launch (`orp_dcn_forward_pair`): the bilinear coefficient table of every tile is built once for both layers.
+    fp32, no autograd.  Returns (outs_a, outs_b).  Falls back to two `deform_conv_forward_multi` launches when the
+    channel count is not a multiple of 256."""
+    L = _lib.lib()
+    stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    x0 = inputs_a[0]
+    B, cin = x0.size(0), x0.size(1)
+    cout, _, kh, kw = weight_a.shape
+    if cin % 256 != 0 or tuple(weight_b.shape) != tuple(weight_a.shape):
+        return (deform_conv_forward_multi(inputs_a, offsets, weight_a, stride, padding, dilation, masks, bias_a, relu),
+                deform_conv_forward_multi(inputs_b, offsets, weight_b, stride, padding, dilation, masks, bias_b, relu))
+    nhwc = all(x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+               for x in list(inputs_a) + list(inputs_b))
+    pa, pb = _packed_weight(weight_a), _packed_weight(weight_b)
+    n = len(inputs_a)
+    lev_a, lev_b = (_DcnLevel * n)(), (_DcnLevel * n)()
+    keep, outs_a, outs_b = [], [], []
+    for i in range(n):
+        xa, xb, off = inputs_a[i].detach().float(), inputs_b[i].detach().float(), offsets[i].detach().float().contiguous()
+        assert xa.shape == xb.shape and xa.size(0) == B and xa.size(1) == cin
+        xa = xa if nhwc else xa.contiguous()
+        xb = xb if nhwc else xb.contiguous()
+        ho, wo = _out_hw(xa.size(2), xa.size(3), weight_a, stride, padding, dilation)
+        if off.size(1) != 2 * kh * kw or off.size(2) != ho or off.size(3) != wo:
+            raise ValueError("offset must be [B, 2*kh*kw, Ho, Wo]")
+        fmt = torch.channels_last if nhwc else torch.contiguous_format
+        oa = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=xa.device, memory_format=fmt)
+        ob = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=xa.device, memory_format=fmt)
+        keep += [xa, xb, off]; outs_a.append(oa); outs_b.append(ob)
+        lev_a[i] = _DcnLevel(xa.data_ptr(), off.data_ptr(), oa.data_ptr(), xa.size(2), xa.size(3))
+        lev_b[i] = _DcnLevel(xb.data_ptr(), off.data_ptr(), ob.data_ptr(), xb.size(2), xb.size(3))
+    mask_ptrs = None
+    if masks is not None:
+        mask_ptrs = (ctypes.c_void_p * n)()
+        for i, m in enumerate(masks):
+            m = m.detach().float().contiguous()
+            if tuple(m.shape) != (B, kh * kw, outs_a[i].size(2), outs_a[i].size(3)):
+                raise ValueError("mask must be [B, kh*kw, Ho, Wo]")
+            keep.append(m)
+            mask_ptrs[i] = m.data_ptr()
+    ba = bias_a.detach().float().contiguous() if bias_a is not None else None
+    bb = bias_b.detach().float().contiguous() if bias_b is not None else None
+    layout = 1 if nhwc else 0
+    nbytes = 2 * L.orp_dcn_forward_workspace_bytes(lev_a, n, B, cin, layout)
+    ws = _lib.workspace(x0.device, nbytes)
+    with torch.cuda.device(x0.device):
+        rc = L.orp_dcn_forward_pair(lev_a, lev_b, mask_ptrs, n, B, cin, cout, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(ba),
+                                    _lib.ptr(bb), 1 if relu else 0, kh, kw, stride[0], stride[1], padding[0], padding[1],
+                                    dilation[0], dilation[1], layout, layout, _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
+    _lib.check(rc, "orp_dcn_forward_pair")
+    return outs_a, outs_b
+
+
 def _forward_direct(input, offset, mask, weight, bias, stride, padding, dilation, groups, deformable_groups):
     x = input.detach().float().contiguous()
     off = offset.detach().float().contiguous()

@@ -368,6 +368,38 @@ def test_dcn_forward_multi_level_and_offsets_out_of_range(dev, oracle):
         assert _rel_err(o.cpu().numpy(), oracle.dcn_forward(x, off, w)) <= 1e-4
 
 
+def test_dcn_pair_launch_equals_two_launches_and_oracle(dev, oracle):
+    """orp_dcn_forward_pair: the head's two DeformConvs (same offsets) in ONE launch -- against the oracle on a small
+    multi-level case, and bit-identical to two single launches of the same kernel generation at the head's channel
+    count (the per-layer accumulation order is the same)."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv_forward_multi, deform_conv_forward_pair
+    rng = np.random.RandomState(11)
+    shapes = [(10, 12), (5, 7), (3, 3)]
+    xa = [rng.normal(size=(2, 128, h, w)).astype(np.float32) for h, w in shapes]
+    xb = [rng.normal(size=(2, 128, h, w)).astype(np.float32) for h, w in shapes]
+    off = [rng.normal(0, 2.5, size=(2, 18, h, w)).astype(np.float32) for h, w in shapes]      # incl. out-of-range samples
+    wa = rng.normal(0, 0.05, size=(64, 128, 3, 3)).astype(np.float32)
+    wb = rng.normal(0, 0.05, size=(64, 128, 3, 3)).astype(np.float32)
+    oa, ob = deform_conv_forward_pair([_t(a, dev) for a in xa], [_t(b, dev) for b in xb], [_t(o, dev) for o in off],
+                                      _t(wa, dev), _t(wb, dev), 1, 1, 1, relu=False)
+    for i in range(len(shapes)):
+        assert _rel_err(oa[i].cpu().numpy(), oracle.dcn_forward(xa[i], off[i], wa, 1, 1, 1)) <= 1e-4
+        assert _rel_err(ob[i].cpu().numpy(), oracle.dcn_forward(xb[i], off[i], wb, 1, 1, 1)) <= 1e-4
+    # head shapes (256 -> 256, three levels incl. a ragged last tile), channels-last, fused ReLU
+    torch.manual_seed(3)
+    sizes = [(40, 40), (20, 20), (7, 9)]
+    fa = [torch.randn(1, 256, h, w, device=dev).contiguous(memory_format=torch.channels_last) for h, w in sizes]
+    fb = [torch.randn(1, 256, h, w, device=dev).contiguous(memory_format=torch.channels_last) for h, w in sizes]
+    of = [torch.randn(1, 18, h, w, device=dev) * 1.5 for h, w in sizes]
+    w1, w2 = torch.randn(256, 256, 3, 3, device=dev) * 0.02, torch.randn(256, 256, 3, 3, device=dev) * 0.02
+    pa, pb = deform_conv_forward_pair(fa, fb, of, w1, w2, 1, 1, 1, relu=True)
+    sa = deform_conv_forward_multi(fa, of, w1, 1, 1, 1, relu=True)
+    sb = deform_conv_forward_multi(fb, of, w2, 1, 1, 1, relu=True)
+    for x, y in zip(pa + pb, sa + sb):
+        assert x.is_contiguous(memory_format=torch.channels_last) and torch.equal(x, y)
+    assert float(pa[0].min()) >= 0.0
+
+
 def test_dcn_full_size_properties(dev):
     """BASELINE shapes (all five levels of a 1024^2 image, 256 -> 256, one launch, MT = 3 tiles): with zero offsets the
     DeformConv IS the plain 3x3 convolution (independent implementation: the library's), and with random offsets it is
