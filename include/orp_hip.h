@@ -77,6 +77,9 @@ int orp_poly_overlaps(const float* boxes, int n, const float* query, int k, floa
 /* orp_box_iou_rotated: box_iou_rotated (mmdet/ops/box_iou_rotated/src/box_iou_rotated_cuda.cu:14-94,
  *   box_iou_rotated_utils.h:314-341): boxes1 [n,5], boxes2 [k,5] (cx,cy,w,h,theta radians) -> [n,k]. */
 int orp_box_iou_rotated(const float* boxes1, int n, const float* boxes2, int k, float* out, void* stream);
+/* CPU branch of the reference's dispatcher (box_iou_rotated.h:20-33 -> box_iou_rotated_cpu.cpp): HOST pointers,
+ * the same per-pair arithmetic compiled for the host (the reference API accepts CPU tensors here). */
+int orp_box_iou_rotated_host(const float* boxes1, int n, const float* boxes2, int k, float* out);
 
 /* ---------------------------------------------------------------------------------------------------------
  * minaerarect: convex hull of 9 points -> minimum-area enclosing rectangle -> 4 corners.

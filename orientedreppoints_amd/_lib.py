@@ -31,6 +31,7 @@ _SIGNATURES = {
     "orp_quad_iou_matrix": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "orp_poly_overlaps": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "orp_box_iou_rotated": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "orp_box_iou_rotated_host": (_i, [_vp, _i, _vp, _i, _vp]),
     "orp_minarearect": (_i, [_vp, _i, _vp, _vp]),
     "orp_minarearect_decode": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "orp_convex_iou": (_i, [_vp, _i, _vp, _i, _vp, _vp]),

@@ -57,6 +57,10 @@ __global__ void pp_gather_kernel(const float* __restrict__ pts_all, const int64_
 __device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
+// max that PROPAGATES NaN like Tensor.max() does (fmaxf drops it): a NaN coordinate from a diverged model must poison
+// max_coordinate -- and with it every class offset -- exactly as in the reference (bbox_nms.py:156-158)
+__device__ __forceinline__ float max_nan(float a, float b) { return (a != a || b != b) ? __uint_as_float(0x7fc00000u) : fmaxf(a, b); }
+
 // ---- detections, step 1 (parallel): per candidate the bit set of classes above the threshold, and the max coordinate of
 // the boxes that own at least one detection (bboxes.max() of the expanded set) through one atomicMax per workgroup
 __global__ void __launch_bounds__(256)
@@ -72,16 +76,16 @@ pp_flags_kernel(const float* __restrict__ sig_all, const int64_t* __restrict__ c
     bits[j] = b;
     if (b) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) mx = fmaxf(mx, boxes[(size_t)j * 8 + k]);
+      for (int k = 0; k < 8; k++) mx = max_nan(mx, boxes[(size_t)j * 8 + k]);
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  for (int o = 32; o > 0; o >>= 1) mx = max_nan(mx, __shfl_xor(mx, o, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
   __syncthreads();
   if (threadIdx.x == 0) {
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (mx > -INFINITY) atomicMax(max_ord, f2ord(mx));
+    mx = max_nan(max_nan(red[0], red[1]), max_nan(red[2], red[3]));
+    if (mx > -INFINITY || mx != mx) atomicMax(max_ord, f2ord(mx));      // +NaN maps above +inf in the ordered space
   }
 }
 

@@ -113,12 +113,30 @@ class ResNet(nn.Module):
                 param.requires_grad = False
 
     def init_weights(self, pretrained=None):
-        # no network here: `pretrained` (e.g. 'torchvision://resnet50') is accepted and ignored unless it is a file
-        if isinstance(pretrained, str) and pretrained.endswith(('.pth', '.pt')):
-            import torch
-            sd = torch.load(pretrained, map_location='cpu')
-            self.load_state_dict(sd.get('state_dict', sd), strict=False)
-            return
+        """`pretrained`: a local checkpoint file, or a model-zoo URI of the reference configs ('torchvision://resnet50',
+        'open-mmlab://...').  There is no network here: a URI is resolved through the environment variable
+        ORP_PRETRAINED_DIR (<dir>/<name>.pth) and, when no such file exists, a warning says that the backbone -- whose
+        stem and layer1 the DOTA configs FREEZE -- stays at its random initialisation."""
+        if isinstance(pretrained, str):
+            import os
+            import warnings
+            path = pretrained
+            if '://' in pretrained:
+                name = pretrained.split('://', 1)[1].replace('/', '_')
+                root = os.environ.get('ORP_PRETRAINED_DIR', '')
+                path = os.path.join(root, name + '.pth') if root else ''
+            if path and os.path.isfile(path):
+                sd = torch.load(path, map_location='cpu')
+                sd = sd.get('state_dict', sd)
+                missing, unexpected = self.load_state_dict(sd, strict=False)
+                unexpected = [k for k in unexpected if not k.startswith('fc.')]      # the classifier head is not part of it
+                if missing or unexpected:
+                    warnings.warn('ResNet.init_weights(%r): missing keys %s, unexpected keys %s'
+                                  % (pretrained, list(missing)[:8], unexpected[:8]))
+                return
+            warnings.warn('ResNet.init_weights: pretrained=%r was NOT loaded (no such file%s); the backbone keeps its '
+                          'random initialisation, frozen_stages=%d of it frozen'
+                          % (pretrained, '' if '://' not in pretrained else '; set ORP_PRETRAINED_DIR', self.frozen_stages))
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 kaiming_init(m)

@@ -60,3 +60,74 @@ def test_poly_overlaps(ref):
     a = S.gen_rboxes(70, 51).astype(np.float32)
     b = S.gen_rboxes(50, 52).astype(np.float32)
     assert np.array_equal(ref.poly_overlaps(a, b), ref.ref_poly_overlaps(a, b), equal_nan=True)
+
+
+def test_convex_giou_values_and_gradients(ref):
+    # convex_giou_kernel.cu:20-804: [P,19] = 18 gradient components + GIoU
+    gts = S.gen_gts(40, 61).astype(np.float32)
+    ctr = np.repeat(gts.reshape(-1, 4, 2).mean(1), 10, axis=0)
+    pts = S.gen_pointsets(400, 62, around=ctr).astype(np.float32)
+    g = np.repeat(gts, 10, axis=0)
+    a, b = ref.convex_giou(pts, g), ref.ref_convex_giou(pts, g)
+    assert a.shape == b.shape == (400, 19)
+    assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_points_justify(ref):
+    # points_justify_kernel.cu:25-102 incl. the reference's own 5 x 3 demo of mmdet/ops/point_justify/test.py:10-17
+    rng = np.random.RandomState(71)
+    polys = S.gen_gts(30, 72).astype(np.float32)
+    pts = np.concatenate([polys.reshape(-1, 2)[:60], rng.uniform(0, 1024, (500, 2)).astype(np.float32),
+                          polys.reshape(-1, 4, 2).mean(1)])          # vertices (boundary hits), random, centres
+    assert np.array_equal(ref.points_justify(pts, polys), ref.ref_points_justify(pts, polys))
+
+
+def test_chamfer_nearest_neighbour(ref):
+    # chamfer_2d.cu:12-124 NmDistanceKernel: squared distance + index of the nearest point, both directions
+    rng = np.random.RandomState(81)
+    a = (rng.rand(37, 40, 2) * 100).astype(np.float32)
+    b = (rng.rand(37, 40, 2) * 100).astype(np.float32)
+    b[:5] = a[:5]                                                     # exact ties / zero distances
+    d1, d2, i1, i2 = ref.chamfer_forward(a, b)
+    rd1, ri1 = ref.ref_chamfer_nn(a, b)
+    rd2, ri2 = ref.ref_chamfer_nn(b, a)
+    assert np.array_equal(d1, rd1) and np.array_equal(i1, ri1)
+    assert np.array_equal(d2, rd2) and np.array_equal(i2, ri2)
+
+
+def test_sigmoid_focal_loss(ref):
+    # sigmoid_focal_loss_cuda.cu:23-97 forward / backward
+    rng = np.random.RandomState(91)
+    x = rng.normal(0, 3, size=(500, 15)).astype(np.float32)
+    x[:4] = np.array([-90.0, -20.0, 20.0, 90.0], np.float32)[:, None]    # saturated logits
+    t = rng.randint(0, 16, size=500).astype(np.int64)
+    assert np.array_equal(ref.focal_forward(x, t, 2.0, 0.25), ref.ref_focal_forward(x, t, 2.0, 0.25))
+    g = rng.normal(size=(500, 15)).astype(np.float32)
+    assert np.array_equal(ref.focal_backward(x, t, g, 2.0, 0.25), ref.ref_focal_backward(x, t, g, 2.0, 0.25))
+
+
+def test_deform_conv_im2col_and_backward(ref):
+    # deform_conv_cuda_kernel.cu:190-243 (im2col), :279-436 (col2im / coordinate gradients) through the reference's own
+    # device functions; DCN GEMMs follow deform_conv_cuda.cpp:262-488
+    rng = np.random.RandomState(101)
+    x = rng.normal(size=(2, 8, 9, 11)).astype(np.float32)
+    off = rng.normal(0, 2.5, size=(2, 18, 9, 11)).astype(np.float32)       # incl. samples outside (-1, H) x (-1, W)
+    w = rng.normal(0, 0.2, size=(6, 8, 3, 3)).astype(np.float32)
+    a = ref.dcn_im2col(x, off, 3, 3, 1, 1, 1)
+    b = ref.dcn_im2col(x, off, 3, 3, 1, 1, 1, use_ref=True)
+    assert np.array_equal(a, b)
+    go = rng.normal(size=(2, 6, 9, 11)).astype(np.float32)
+    gi, goff, gw = ref.dcn_backward(x, off, w, go)
+    ri, roff, rw = ref.dcn_backward(x, off, w, go, use_ref=True)
+    # the scatter into grad_input accumulates in a different order (atomics in the reference): 1e-5 relative
+    for u, v in ((gi, ri), (goff, roff), (gw, rw)):
+        assert np.max(np.abs(u - v)) <= 1e-5 * max(1.0, float(np.max(np.abs(v))))
+
+
+def test_box_iou_rotated(ref):
+    # box_iou_rotated_utils.h:314-341 single_box_iou_rotated
+    a = S.gen_rboxes(60, 111).astype(np.float32)
+    b = S.gen_rboxes(40, 112).astype(np.float32)
+    b[:20, :2] = a[:20, :2] + 3
+    u, v = ref.box_iou_rotated(a, b), ref.box_iou_rotated(a, b, use_ref=True)
+    assert np.max(np.abs(u - v)) <= 1e-6
