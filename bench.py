@@ -19,8 +19,10 @@ detections, ~240 launches leave the host) -- the replay is `value` when the capt
 
 One JSON line on rank 0: metric/value = whole-job images/sec; plus `roofline` for the dominant hot-path kernel (the
 DeformConv implicit GEMM, timed live with HIP events inside liborp_hip.so over the timed region, MFMA-bound), `nms`
-(the rotated-IoU + NMS stage: us/img, mask/sweep kernel times) and `cpu_baseline` (the CPU oracle port of polyiou +
-py_cpu_nms_poly timed on the host on one image's detections).
+(the rotated-IoU + NMS stage: us/img, mask/sweep kernel times), `nms_batched_16_images` (the (image x class)-batched
+form of BASELINE.md section 3) and `cpu_baseline` (polyiou + py_cpu_nms_poly on the host cores on one image's detections:
+the reference's own polyiou.cpp when oracle/_ref is present, the oracle's C port otherwise, plus the fast / Pool / fp32
+variants of SURVEY 8d).
 """
 import argparse
 import ctypes
@@ -89,6 +91,13 @@ def nms_inputs_of_one_image(model, img, metas):
         captured['thr'] = iou_thr
         return orig(dets, iou_thr, device_id)
     nms_wrapper.rnms = spy
+    from orientedreppoints_amd.mmdet_models import orientedreppoints_head as head_mod
+    orig_mc = head_mod.multiclass_rnms
+
+    def spy_mc(multi_bboxes, multi_scores, score_thr, *a, **k):
+        captured['labels'] = (multi_scores[:, 1:] > score_thr).nonzero()[:, 1].detach().clone()
+        return orig_mc(multi_bboxes, multi_scores, score_thr, *a, **k)
+    head_mod.multiclass_rnms = spy_mc
     static = model.test_cfg.get('static_postprocess', True)
     model.test_cfg['static_postprocess'] = False      # the reference-shaped path hands the [M,9] dets to `rnms`
     try:
@@ -96,23 +105,121 @@ def nms_inputs_of_one_image(model, img, metas):
             model.simple_test(img, metas)
     finally:
         nms_wrapper.rnms = orig
+        head_mod.multiclass_rnms = orig_mc
         model.test_cfg['static_postprocess'] = static
     return captured
 
 
-def cpu_baseline(dets_np, thr, budget_s=10.0):
-    """polyiou (fp64) + py_cpu_nms_poly greedy loop, C port of the reference's CPU path, 1 host core.  Repeated on
-    the image's detections until ~budget_s of CPU work is spent; returns (mean seconds per image, kept, repeats)."""
-    from oracle import orp_oracle as O
-    O.build()
-    d64 = dets_np.astype(np.float64)
-    total, reps, keep = 0.0, 0, []
-    while total < budget_s and reps < 64:
+def _timed(fn, budget_s, max_reps=64):
+    total, reps, out = 0.0, 0, None
+    while total < budget_s and reps < max_reps:
         t0 = time.perf_counter()
-        keep = O.py_cpu_nms_poly(d64, thr)
+        out = fn()
         total += time.perf_counter() - t0
         reps += 1
-    return total / reps, len(keep), reps
+    return total / reps, out, reps
+
+
+def _pool_nms(args):
+    """Pool worker (module level: picklable): one class's detections through the CPU NMS."""
+    from oracle import orp_oracle as O
+    d64, thr, use_ref = args
+    return len(O.ref_py_cpu_nms_poly(d64, thr) if use_ref else O.py_cpu_nms_poly(d64, thr))
+
+
+def cpu_baselines(dets_np, labels_np, thr, budget_s=6.0):
+    """The CPU side of SURVEY 8d on ONE image's detections (the [M,9] class-offset set multiclass_rnms hands to rnms),
+    each variant repeated until ~budget_s of CPU work is spent:
+      B0  polyiou.cpp iou_poly + the py_cpu_nms_poly greedy loop (ResultMerge.py:18-41), fp64, 1 core -- with the
+          REFERENCE's own polyiou.cpp compiled in oracle/_ref when that library travelled here (kind "reference"), and
+          with the oracle's C restatement of it (kind "port");
+      B0' py_cpu_nms_poly_fast (ResultMerge_multi_process.py:60-121: polyiou only where the HBBs overlap), 1 core;
+      B1  the per-class multiprocessing.Pool split of ResultMerge_multi_process.py:225-231 over the host cores (<= 16);
+      B2  rnms_cpu.cpp's fp32 rotate_iou, hard NMS (soft_rnms method 0 semantics), 1 core;
+      B3  microseconds per polyiou call.
+    The loops are C (no SWIG / numpy overhead per pair): a conservative -- i.e. fast -- statement of the reference."""
+    import multiprocessing as mp
+    from oracle import orp_oracle as O
+    O.build()
+    have_ref = O.ref() is not None and hasattr(O.ref(), 'ref_py_cpu_nms_poly')
+    d64 = np.ascontiguousarray(dets_np, np.float64)
+    M = d64.shape[0]
+    v = {}
+    dt_port, keep, reps = _timed(lambda: O.py_cpu_nms_poly(d64, thr), budget_s)
+    v['B0 polyiou + py_cpu_nms_poly, oracle C port, 1 core'] = dict(us_per_img=dt_port * 1e6, kept=len(keep), repeats=reps)
+    dt_ref = None
+    if have_ref:
+        dt_ref, keep_r, reps = _timed(lambda: O.ref_py_cpu_nms_poly(d64, thr), budget_s)
+        v['B0 polyiou + py_cpu_nms_poly, reference polyiou.cpp, 1 core'] = dict(us_per_img=dt_ref * 1e6, kept=len(keep_r), repeats=reps)
+    dt_fast, keep_f, reps = _timed(lambda: O.py_cpu_nms_poly_fast(d64, thr, use_ref=have_ref), min(budget_s, 2.0))
+    v["B0' py_cpu_nms_poly_fast (HBB prefilter), 1 core"] = dict(us_per_img=dt_fast * 1e6, kept=len(keep_f), repeats=reps)
+    if have_ref:
+        d32 = np.ascontiguousarray(dets_np, np.float32)
+        ds = np.ascontiguousarray(d32[O.sort_order(d32[:, 8])])
+        dt2, keep2, reps = _timed(lambda: O.ref_rnms_cpu_hard(ds, thr), budget_s)
+        v['B2 rnms_cpu.cpp rotate_iou fp32 hard NMS, 1 core'] = dict(us_per_img=dt2 * 1e6, kept=len(keep2), repeats=reps)
+        rng = np.random.RandomState(0)
+        ia, ib = rng.randint(0, M, 200000), rng.randint(0, M, 200000)
+        pa, pb = np.ascontiguousarray(d64[ia, :8]), np.ascontiguousarray(d64[ib, :8])
+        t0 = time.perf_counter(); O.ref_polyiou_many(pa, pb); t1 = time.perf_counter() - t0
+        v['B3 polyiou.cpp iou_poly'] = dict(us_per_iou=t1 / 200000 * 1e6, pairs=200000)
+    cores = max(1, min(16, os.cpu_count() or 1))          # the reference uses Pool(16)
+    if labels_np is not None and cores > 1:
+        parts = [(np.ascontiguousarray(d64[labels_np == c]), thr, have_ref) for c in np.unique(labels_np)]
+        try:
+            ctx = mp.get_context('fork')
+            with ctx.Pool(cores) as pool:
+                pool.map(_pool_nms, parts)                # warm the workers
+                dt1, kept1, reps = _timed(lambda: sum(pool.map(_pool_nms, parts)), min(budget_s, 3.0))
+            v['B1 per-class Pool(%d)' % cores] = dict(us_per_img=dt1 * 1e6, kept=kept1, repeats=reps, cores=cores,
+                                                      classes=len(parts))
+        except Exception as e:   # noqa: BLE001
+            v['B1 per-class Pool(%d)' % cores] = 'failed: %s' % (str(e)[:120],)
+    head = dt_ref if dt_ref is not None else dt_port
+    return dict(value=head * 1e6, unit='us/img (rotated-IoU + poly NMS stage)', cores=1,
+                kind='reference' if dt_ref is not None else 'port',
+                sample='1 image, %d class-offset detections (the set multiclass_rnms hands to rnms), thr %.2f; every '
+                       'variant repeated for <= %.0f s of CPU work' % (M, thr, budget_s),
+                host_cores=os.cpu_count(), variants=v)
+
+
+def batched_nms_line(dev, images=16, boxes=2000, thr=0.4):
+    """BASELINE.md section 3 / configs[3]: the rotated NMS of a 16-image batch as (image x class) segments in ONE
+    orp_rnms_batched launch sequence (dense clustered scenes of `boxes` detections per image, 15 classes)."""
+    from orientedreppoints_amd import synthetic as S
+    from orientedreppoints_amd.mmdet_ops.nms_wrapper import rnms_batched_device
+    parts, sizes = [], []
+    for im in range(images):
+        d, lab = S.gen_dense_scene(boxes, 100 + im)
+        for c in range(15):
+            sel = d[lab == c]
+            parts.append(sel); sizes.append(len(sel))
+    d = torch.from_numpy(np.concatenate(parts).astype(np.float32)).to(dev)
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)).to(dev)
+    max_seg = int(max(sizes))
+    for _ in range(3):
+        keep, num = rnms_batched_device(d, off, max_seg, thr)
+    _lib.lib().orp_profile_enable(1)
+    for sl in (0, 1, 2):
+        read_prof(sl)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    iters = 20
+    for _ in range(iters):
+        keep, num = rnms_batched_device(d, off, max_seg, thr)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    k = {name: (lambda t: t[0] / t[1] * 1e3 if t[1] else None)(read_prof(sl)) for name, sl in (('mask', 0), ('sweep', 1), ('rank_prepare', 2))}
+    _lib.lib().orp_profile_enable(0)
+    M = int(d.shape[0])
+    pairs = float(sum(n * (n - 1) / 2 for n in sizes))
+    alg = 36.0 * M + 8.0 * int(num.sum().item())          # SURVEY 8d: read 36 B per box, write 8 B per kept index
+    return dict(images=images, segments=len(sizes), boxes=M, max_segment=max_seg, kept=int(num.sum().item()),
+                us_per_batch=us, us_per_img=us / images, kernel_us=k, pairs=pairs, gpairs_per_s=pairs / us / 1e3,
+                algorithmic_bytes=alg, hbm_gbs=alg / us / 1e3, hbm_frac=alg / us / 1e3 / HBM_PEAK_GBS,
+                note='one launch sequence (rank+prepare, mask, sweep) for all %d (image x class) segments; per-segment '
+                     'keep sets are checked against the oracle in tests/test_gpu_parity.py' % len(sizes))
 
 
 def per_op_table(dev, budget_s=2.0):
@@ -524,7 +631,7 @@ def main():
             elapsed = g_elapsed
 
     prof = {name: read_prof(slot) for name, slot in
-            (('nms_mask', 0), ('nms_sweep', 1), ('dcn_fwd', 3), ('minarearect', 4))}
+            (('nms_mask', 0), ('nms_sweep', 1), ('nms_rank_prepare', 2), ('dcn_fwd', 3), ('minarearect', 4))}
     if rank != 0:
         if distributed:
             dist.destroy_process_group()
@@ -608,11 +715,15 @@ def main():
             per_op = 'failed: %s' % (str(e)[:200],)
     cpu = None
     if not args.no_cpu_baseline and M > 0:
-        dt, kept, reps = cpu_baseline(dets.cpu().numpy(), cap['thr'])
-        cpu = dict(value=dt * 1e6, unit='us/img (rotated-IoU + poly NMS stage)', cores=1, kind='port',
-                   sample='%d repeats of 1 image, %d class-offset detections, fp64 polyiou + py_cpu_nms_poly greedy '
-                          'loop (C port of DOTA_devkit/polyiou.cpp + ResultMerge.py:18-41), kept %d'
-                          % (reps, M, kept), gpu_stage_us_per_img=nms_us)
+        labels = cap.get('labels')
+        cpu = cpu_baselines(dets.cpu().numpy(), labels.cpu().numpy() if labels is not None else None, cap['thr'])
+        cpu['gpu_stage_us_per_img'] = nms_us
+    batched = None
+    if not args.no_cpu_baseline:
+        try:
+            batched = batched_nms_line(dev)
+        except Exception as e:   # noqa: BLE001
+            batched = 'failed: %s' % (str(e)[:200],)
 
     out = {
         'metric': 'images/sec (%dx%d DOTA, %s FPN)' % (IMG, IMG, {'r50': 'R-50', 'r101': 'R-101'}[args.model]), 'value': value, 'unit': 'images/s', 'n_gpus': world,
@@ -631,7 +742,7 @@ def main():
         'mode': 'hipgraph replay' if isinstance(graph_ms, float) else 'eager',
         'eager_ms_per_step': round(eager_elapsed / args.steps * 1e3, 4),
         'graph_replay_ms': graph_ms,
-        'roofline': roof, 'nms': nms, 'per_op_us': per_op, 'cpu_baseline': cpu,
+        'roofline': roof, 'nms': nms, 'nms_batched_16_images': batched, 'per_op_us': per_op, 'cpu_baseline': cpu,
     }
     print(json.dumps(out))
     if distributed:

@@ -178,6 +178,38 @@ int orc_py_cpu_nms_poly(const double* dets, int n, const int64_t* order, double 
   return nk;
 }
 
+/* py_cpu_nms_poly_fast (DOTA_devkit/ResultMerge_multi_process.py:60-121): fp64 polyiou only for pairs whose horizontal
+ * bounding boxes overlap; every other pair keeps its HBB overlap of 0.  Same visiting order convention as above. */
+int orc_py_cpu_nms_poly_fast(const double* dets, int n, const int64_t* order, double thr, int64_t* keep_out) {
+  unsigned char* removed = (unsigned char*)calloc(n > 0 ? n : 1, 1);
+  double* bb = (double*)malloc(sizeof(double) * 5 * (size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) {
+    const double* d = dets + (size_t)i * 9;
+    double xa = fmin(fmin(d[0], d[2]), fmin(d[4], d[6])), xb = fmax(fmax(d[0], d[2]), fmax(d[4], d[6]));
+    double ya = fmin(fmin(d[1], d[3]), fmin(d[5], d[7])), yb = fmax(fmax(d[1], d[3]), fmax(d[5], d[7]));
+    bb[5 * i] = xa; bb[5 * i + 1] = ya; bb[5 * i + 2] = xb; bb[5 * i + 3] = yb; bb[5 * i + 4] = (xb - xa + 1) * (yb - ya + 1);
+  }
+  int nk = 0;
+  for (int a = 0; a < n; a++) {
+    if (removed[a]) continue;
+    int64_t i = order[a];
+    keep_out[nk++] = i;
+    for (int b = a + 1; b < n; b++) {
+      if (removed[b]) continue;
+      int64_t j = order[b];
+      double w = fmax(0.0, fmin(bb[5 * i + 2], bb[5 * j + 2]) - fmax(bb[5 * i], bb[5 * j]));
+      double h = fmax(0.0, fmin(bb[5 * i + 3], bb[5 * j + 3]) - fmax(bb[5 * i + 1], bb[5 * j + 1]));
+      double hi = w * h;
+      double ovr = hi / (bb[5 * i + 4] + bb[5 * j + 4] - hi);
+      if (ovr > 0) ovr = orc_polyiou_f64(dets + (size_t)i * 9, dets + (size_t)j * 9);
+      if (!(ovr <= thr)) removed[b] = 1;
+    }
+  }
+  free(bb);
+  free(removed);
+  return nk;
+}
+
 /* ------------------------------------------------------------------------------------------------------- */
 /* a8: poly_overlaps over (cx,cy,w,h,theta) boxes  (poly_overlaps_kernel.cu:280-328)                          */
 /* ------------------------------------------------------------------------------------------------------- */

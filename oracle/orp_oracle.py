@@ -126,6 +126,40 @@ def py_cpu_nms_poly(dets, thr):
     return [int(x) for x in keep[:n]]
 
 
+def py_cpu_nms_poly_fast(dets, thr, use_ref=False):
+    """ResultMerge_multi_process.py:60-121: polyiou only where the HBBs overlap.  dets [n,9] fp64 -> kept indices."""
+    d = _f64(dets)
+    order = np.ascontiguousarray(d[:, 8].argsort()[::-1], np.int64)
+    keep = np.empty(d.shape[0], np.int64)
+    fn = ref().ref_py_cpu_nms_poly_fast if use_ref else lib().orc_py_cpu_nms_poly_fast
+    n = fn(_p(d), d.shape[0], _p(order), ctypes.c_double(thr), _p(keep))
+    return keep[:n].copy()
+
+
+def ref_py_cpu_nms_poly(dets, thr):
+    """The greedy loop around the REFERENCE's own polyiou.cpp iou_poly (oracle/_ref)."""
+    d = _f64(dets)
+    order = np.ascontiguousarray(d[:, 8].argsort()[::-1], np.int64)
+    keep = np.empty(d.shape[0], np.int64)
+    n = ref().ref_py_cpu_nms_poly(_p(d), d.shape[0], _p(order), ctypes.c_double(thr), _p(keep))
+    return keep[:n].copy()
+
+
+def ref_rnms_cpu_hard(dets_sorted, thr):
+    """Hard NMS with rnms_cpu.cpp's own fp32 rotate_iou over score-sorted dets [n,9] -> kept positions."""
+    d = _f32(dets_sorted)
+    keep = np.empty(d.shape[0], np.int32)
+    n = ref().ref_rnms_cpu_hard(_p(d), d.shape[0], ctypes.c_float(thr), _p(keep))
+    return keep[:n].copy()
+
+
+def ref_polyiou_many(a, b):
+    a, b = _f64(a), _f64(b)
+    out = np.empty(a.shape[0], np.float64)
+    ref().ref_polyiou_many(_p(a), _p(b), a.shape[0], _p(out))
+    return out
+
+
 def voc_best_match(dets, det_img, gts, gt_off):
     """dota_evaluation_task1.py:160-206 per detection (numpy fp64 HBB pre-filter with the "+ 1." convention, then
     polyiou.iou_poly(GT, detection) on the survivors, np.max / np.argmax): (ovmax [nd], jmax [nd]); (-inf, -1) when no

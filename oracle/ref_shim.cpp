@@ -146,6 +146,82 @@ int ref_nms_sorted(const float* dets, int n, float thr, int which, int* keep_out
   return nk;
 }
 
+// ---- CPU baselines of bench.py: the reference's OWN polyiou.cpp / rnms_cpu.cpp arithmetic ----------------
+// The greedy loops are the reference's Python loops (ResultMerge.py:18-41, ResultMerge_multi_process.py:60-121) restated
+// in C++ around the reference's own iou_poly -- i.e. WITHOUT the SWIG / numpy call overhead of the real script, which
+// makes this a conservative (fast) baseline.  dets [n,9] fp64, order = numpy's scores.argsort()[::-1].
+int ref_py_cpu_nms_poly(const double* dets, int n, const int64_t* order, double thr, int64_t* keep_out) {
+  std::vector<std::vector<double> > polys(n);
+  for (int i = 0; i < n; i++) polys[i].assign(dets + (size_t)i * 9, dets + (size_t)i * 9 + 8);
+  std::vector<unsigned char> removed(n, 0);
+  int nk = 0;
+  for (int a = 0; a < n; a++) {
+    if (removed[a]) continue;
+    const int64_t i = order[a];
+    keep_out[nk++] = i;
+    for (int b = a + 1; b < n; b++) {
+      if (removed[b]) continue;
+      const double v = nsref_polyiou::iou_poly(polys[i], polys[order[b]]);
+      if (!(v <= thr)) removed[b] = 1;                      // inds = np.where(ovr <= thresh)
+    }
+  }
+  return nk;
+}
+// py_cpu_nms_poly_fast: polyiou only where the horizontal bounding boxes overlap (hbb_ovr > 0), else the HBB IoU (0)
+int ref_py_cpu_nms_poly_fast(const double* dets, int n, const int64_t* order, double thr, int64_t* keep_out) {
+  std::vector<std::vector<double> > polys(n);
+  std::vector<double> x1(n), y1(n), x2(n), y2(n), area(n);
+  for (int i = 0; i < n; i++) {
+    const double* d = dets + (size_t)i * 9;
+    polys[i].assign(d, d + 8);
+    x1[i] = std::min(std::min(d[0], d[2]), std::min(d[4], d[6])); x2[i] = std::max(std::max(d[0], d[2]), std::max(d[4], d[6]));
+    y1[i] = std::min(std::min(d[1], d[3]), std::min(d[5], d[7])); y2[i] = std::max(std::max(d[1], d[3]), std::max(d[5], d[7]));
+    area[i] = (x2[i] - x1[i] + 1) * (y2[i] - y1[i] + 1);
+  }
+  std::vector<unsigned char> removed(n, 0);
+  int nk = 0;
+  for (int a = 0; a < n; a++) {
+    if (removed[a]) continue;
+    const int64_t i = order[a];
+    keep_out[nk++] = i;
+    for (int b = a + 1; b < n; b++) {
+      if (removed[b]) continue;
+      const int64_t j = order[b];
+      const double w = std::max(0.0, std::min(x2[i], x2[j]) - std::max(x1[i], x1[j]));
+      const double h = std::max(0.0, std::min(y2[i], y2[j]) - std::max(y1[i], y1[j]));
+      const double hi = w * h;
+      double ovr = hi / (area[i] + area[j] - hi);
+      if (ovr > 0) ovr = nsref_polyiou::iou_poly(polys[i], polys[j]);
+      if (!(ovr <= thr)) removed[b] = 1;
+    }
+  }
+  return nk;
+}
+// hard NMS (soft_rnms method 0) with rnms_cpu.cpp's own fp32 rotate_iou over SORTED dets [n,9]
+int ref_rnms_cpu_hard(const float* dets, int n, float thr, int* keep_out) {
+  std::vector<unsigned char> removed(n, 0);
+  int nk = 0;
+  for (int i = 0; i < n; i++) {
+    if (removed[i]) continue;
+    keep_out[nk++] = i;
+    const float* p = dets + (size_t)i * 9;
+    for (int j = i + 1; j < n; j++) {
+      if (removed[j]) continue;
+      const float* q = dets + (size_t)j * 9;
+      const float v = nsref_rnms_cpu::rotate_iou(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]);
+      if (v > thr) removed[j] = 1;
+    }
+  }
+  return nk;
+}
+// n independent pairs through polyiou.cpp's iou_poly (us per IoU)
+void ref_polyiou_many(const double* a, const double* b, int n, double* out) {
+  for (int i = 0; i < n; i++) {
+    std::vector<double> P(a + (size_t)i * 8, a + (size_t)i * 8 + 8), Q(b + (size_t)i * 8, b + (size_t)i * 8 + 8);
+    out[i] = nsref_polyiou::iou_poly(P, Q);
+  }
+}
+
 // ---- element-wise kernels: emulate <<<n blocks, 1 thread>>> ------------------------------------------------
 void ref_points_justify(const float* points, int rows, const float* polys, int cols, float* out) {
   int n = rows * cols;

@@ -827,7 +827,8 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
   // count lives in device memory): 16-row tiles and a bounded grid whose workgroups loop over the tiles of the actual
   // count -- an 8 K capacity holding 2 K boxes must not pay for 60 K empty workgroups
   const bool exact_n = single_segment;
-  const int R = exact_n ? pick_rows_per_wave(max_seg, nseg) : (max_seg <= 8192 ? (max_seg <= 256 ? 1 : 4) : 16);
+  // capacity callers: 16-row tiles (a 4-row tile spends its time staging: 201 -> measured below for 240 segments of <= 168)
+  const int R = exact_n ? pick_rows_per_wave(max_seg, nseg) : (max_seg <= 8192 ? 4 : 16);
   const int rpb = R * (kMaskThreads / 64);
   long ntile = ((long)max_cb * ((max_seg + rpb - 1) / rpb)) / 2 + max_cb;       // ~ the upper-triangular tiles at max_seg
   const long cap_wg = 4096 / (nseg < 8 ? nseg : 8);

@@ -400,6 +400,121 @@ def test_dcn_pair_launch_equals_two_launches_and_oracle(dev, oracle):
     assert float(pa[0].min()) >= 0.0
 
 
+def _dcn_torch_reference(x, off, w):
+    """Plain PyTorch fp32 DeformConv forward (3x3, stride 1, pad 1, dil 1): explicit bilinear gather + einsum."""
+    B, C, H, W = x.shape
+    ys, xs = torch.meshgrid(torch.arange(H, device=x.device, dtype=torch.float32),
+                            torch.arange(W, device=x.device, dtype=torch.float32), indexing='ij')
+    xf = x.reshape(B, C, H * W)
+    out = torch.zeros(B, w.size(0), H, W, device=x.device)
+    for t in range(9):
+        ki, kj = t // 3, t % 3
+        h = ys[None] - 1 + ki + off[:, 2 * t]
+        ww = xs[None] - 1 + kj + off[:, 2 * t + 1]
+        ok = (h > -1) & (ww > -1) & (h < H) & (ww < W)
+        h0, w0 = torch.floor(h), torch.floor(ww)
+        lh, lw = h - h0, ww - w0
+        samp = torch.zeros(B, C, H, W, device=x.device)
+        for dh, dw, wt in ((0, 0, (1 - lh) * (1 - lw)), (0, 1, (1 - lh) * lw), (1, 0, lh * (1 - lw)), (1, 1, lh * lw)):
+            hh, wx = h0 + dh, w0 + dw
+            inb = ok & (hh >= 0) & (hh <= H - 1) & (wx >= 0) & (wx <= W - 1)
+            idx = (hh.clamp(0, H - 1) * W + wx.clamp(0, W - 1)).long().reshape(B, 1, H * W).expand(B, C, H * W)
+            v = torch.gather(xf, 2, idx).reshape(B, C, H, W)
+            samp = samp + v * (wt * inb)[:, None]
+        out = out + torch.einsum('oc,bchw->bohw', w[:, :, ki, kj], samp)
+    return out
+
+
+def test_dcn_pair_at_1536_patch_shapes_vs_torch_reference(dev, oracle):
+    """BASELINE configs[4] shapes: a 1536x1536 patch = levels 192^2 .. 12^2 = 49 104 positions, both head DeformConvs in
+    one launch (tile table, MT selection and the XCD map at 512 tiles / two rounds).  Checker: a plain PyTorch fp32
+    DeformConv, itself pinned to the oracle on a small case first."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv_forward_pair
+    rng = np.random.RandomState(21)
+    xs_, of_, ws_ = rng.normal(size=(1, 32, 9, 11)).astype(np.float32), rng.normal(0, 2.5, size=(1, 18, 9, 11)).astype(np.float32), \
+        rng.normal(0, 0.1, size=(16, 32, 3, 3)).astype(np.float32)
+    ref_small = _dcn_torch_reference(_t(xs_, dev), _t(of_, dev), _t(ws_, dev)).cpu().numpy()
+    assert _rel_err(ref_small, oracle.dcn_forward(xs_, of_, ws_, 1, 1, 1)) <= 1e-5
+    torch.manual_seed(5)
+    sizes = [1536 // s for s in (8, 16, 32, 64, 128)]
+    fa = [torch.randn(1, 256, n, n, device=dev).contiguous(memory_format=torch.channels_last) for n in sizes]
+    fb = [torch.randn(1, 256, n, n, device=dev).contiguous(memory_format=torch.channels_last) for n in sizes]
+    of = [torch.randn(1, 18, n, n, device=dev) * 2 for n in sizes]
+    w1, w2 = torch.randn(256, 256, 3, 3, device=dev) * 0.02, torch.randn(256, 256, 3, 3, device=dev) * 0.02
+    pa, pb = deform_conv_forward_pair(fa, fb, of, w1, w2, 1, 1, 1, relu=False)
+    for lvl in range(5):
+        for got, x, w in ((pa[lvl], fa[lvl], w1), (pb[lvl], fb[lvl], w2)):
+            want = _dcn_torch_reference(x.contiguous(), of[lvl], w)
+            scale = float(want.abs().max())
+            assert float((got - want).abs().max()) <= 1e-4 * scale, lvl
+
+
+def test_postprocess_at_1536_patch_shapes(dev, oracle):
+    """configs[4] shapes through decode -> multiclass rotated NMS: 6 720 candidates.  The fused static kernels, the static
+    tensor-op path and the reference-shaped dynamic path agree; min-area-rect of every candidate and the rnms keep set
+    of the image's class-offset detections agree with the oracle."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import compose_inputs as CI
+    from orientedreppoints_amd.dota_configs import r50_model, test_cfg
+    from orientedreppoints_amd.mmdet_models import ConfigDict
+    from orientedreppoints_amd.mmdet_models.core import rbbox2result_packed
+    from orientedreppoints_amd.mmdet_models.registry import build_head
+    from orientedreppoints_amd.mmdet_ops import nms_wrapper
+    head = build_head(ConfigDict(r50_model['bbox_head'])).to(dev).eval()
+    cls, pts = CI.postprocess_scene(1536, 77)
+    cls_t = [torch.from_numpy(c)[None].to(dev) for c in cls]
+    pts_t = [torch.from_numpy(p)[None].to(dev) for p in pts]
+    assert sum(min(2000, c.shape[1] * c.shape[2]) for c in cls) == 6720
+    metas = [CI.img_meta(1536)]
+    captured = {}
+    orig = nms_wrapper.rnms
+
+    def spy(dets, iou_thr, device_id=None):
+        captured['dets'] = dets.detach().cpu().numpy()
+        return orig(dets, iou_thr, device_id)
+    nms_wrapper.rnms = spy
+    try:
+        with torch.no_grad():
+            dets, labels = head.get_bboxes(cls_t, None, pts_t, None, metas, ConfigDict(test_cfg))[0]
+    finally:
+        nms_wrapper.rnms = orig
+    d = captured['dets']
+    assert d.shape[0] > 1000
+    want_keep = oracle.rnms(d, 0.4)
+    assert dets.shape[0] == min(len(want_keep), 2000)
+    for fused in (True, False):
+        cfg = ConfigDict(dict(test_cfg)); cfg['fused_postprocess'] = fused
+        with torch.no_grad():
+            packed = head.get_bboxes(cls_t, None, pts_t, None, metas, cfg, static=True)[0]
+        host = packed.cpu().numpy()
+        n = int(host[-1, 0])
+        assert host[-1, 1] == 0 and n == dets.shape[0]
+        assert np.array_equal(host[:n, -1].astype(np.int64), labels.cpu().numpy())
+        assert np.array_equal(host[:n, :-1], dets.cpu().numpy())
+        assert rbbox2result_packed(packed, 16) is not None
+
+
+def test_rnms_batched_16_images_as_image_class_segments(dev, oracle):
+    """BASELINE.md section 3 / configs[3]: 16 dense images x ~2000 detections as 240 (image x class) segments in ONE
+    orp_rnms_batched launch sequence; every segment's keep set equals the oracle's."""
+    from orientedreppoints_amd.mmdet_ops.nms_wrapper import rnms_batched_device
+    parts, sizes = [], []
+    for im in range(16):
+        d, lab = S.gen_dense_scene(2000, 100 + im)
+        for c in range(15):
+            sel = d[lab == c].astype(np.float32)
+            parts.append(sel); sizes.append(len(sel))
+    d = np.concatenate(parts, 0)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    keep, num = rnms_batched_device(_t(d, dev), torch.from_numpy(off), max(sizes), 0.4)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    assert len(sizes) == 240 and int(num.sum()) > 0
+    for s, n in enumerate(sizes):
+        want = oracle.rnms(parts[s], 0.4) + off[s]
+        assert num[s] == len(want) and np.array_equal(keep[off[s]:off[s] + num[s]], want), s
+
+
 def test_dcn_full_size_properties(dev):
     """BASELINE shapes (all five levels of a 1024^2 image, 256 -> 256, one launch, MT = 3 tiles): with zero offsets the
     DeformConv IS the plain 3x3 convolution (independent implementation: the library's), and with random offsets it is
