@@ -292,6 +292,11 @@ def per_op_table(dev, budget_s=2.0):
         gpu_us=gpu_us(lambda: deform_conv_forward_multi(xs, offs, w, 1, 1, 1)),
         cpu_us=cpu_us(lambda: O.dcn_forward(xc, oc, wc, 1, 1, 1)) * scale,
         cpu_sample='16x16 level, 64 -> 64 channels, scaled x%.0f (positions x channel pairs)' % scale)
+    # the same layer in fp16 / bf16 (the reference's half dispatch; BASELINE configs[4]): v_mfma_f32_32x32x16, fp32 accumulate
+    for dt, nm in ((torch.float16, 'fp16'), (torch.bfloat16, 'bf16')):
+        hx, ho, hw = [x.to(dt) for x in xs], [o.to(dt) for o in offs], w.to(dt)
+        out['deform_conv_%s_21824_positions' % nm] = dict(gpu_us=gpu_us(lambda: deform_conv_forward_multi(hx, ho, hw, 1, 1, 1)),
+                                                         cpu_us=None, cpu_sample='(no CPU half path in the reference)')
     # ---- the training-path ops (configs[2] shapes: 21824 points, 64 gts, 5000 positives) --------------------------
     from orientedreppoints_amd.mmdet_ops import (ChamferDistance2D, box_iou_rotated, convex_giou, points_in_quad_aligned,
                                                  sigmoid_focal_loss)

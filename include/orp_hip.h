@@ -164,6 +164,20 @@ int orp_dcn_forward_pair(const orp_dcn_level* levels_a, const orp_dcn_level* lev
                          const float* weight_b_packed, const float* bias_a, const float* bias_b, int relu, int kh, int kw,
                          int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout,
                          int out_layout, void* workspace, size_t workspace_bytes, void* stream);
+/* fp16 / bf16 DeformConv forward on v_mfma_f32_32x32x16_{f16,bf16} (the reference dispatches its DCN kernels over float
+ * AND half: deform_conv_cuda_kernel.cu:259,353,451,781,813 AT_DISPATCH_FLOATING_TYPES_AND_HALF; BASELINE configs[4]).
+ * dtype: 1 = fp16, 2 = bf16 -- inputs, offsets, masks, bias, packed weights and outputs are all of that type; the bilinear
+ * combine and the accumulation are fp32.  Requires c_in % 256 == 0, c_out % 64 == 0, groups = deformable_groups = 1
+ * (orp_dcn_half_path_ok); other configurations: convert to fp32 and use the entries above.
+ * packed weights: c_out * c_in * kh * kw elements, layout [tap][c_in/16][2][c_out][8]. */
+typedef struct { const void* input; const void* offset; void* output; int height; int width; } orp_dcn_level_h;
+int orp_dcn_half_path_ok(int c_in, int c_out, int kh, int kw, int groups, int deformable_groups);
+int orp_dcn_pack_weight_h(const void* weight, int c_out, int c_in, int kh, int kw, void* packed, int dtype, void* stream);
+size_t orp_dcn_forward_h_workspace_bytes(const orp_dcn_level_h* levels_host, int nlevels, int batch, int c_in, int in_layout);
+int orp_dcn_forward_multi_h(const orp_dcn_level_h* levels_host, const void* const* masks_host, int nlevels, int batch, int c_in,
+                            int c_out, const void* weight_packed, const void* bias, int relu, int kh, int kw, int stride_h,
+                            int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout, int out_layout, int dtype,
+                            void* workspace, size_t workspace_bytes, void* stream);
 int orp_dcn_forward_direct(const float* input, const float* offset, const float* mask, const float* weight,
                            const float* bias, float* output, int batch, int c_in, int height, int width, int c_out,
                            int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,

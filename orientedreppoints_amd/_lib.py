@@ -57,6 +57,10 @@ _SIGNATURES = {
     "orp_dcn_forward_multi": (_i, [_vp, _i, _i, _i, _i, _vp] + [_i] * 10 + [_vp, _sz, _vp]),
     "orp_dcn_forward_multi_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp]),
     "orp_dcn_forward_pair": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp]),
+    "orp_dcn_half_path_ok": (_i, [_i, _i, _i, _i, _i, _i]),
+    "orp_dcn_pack_weight_h": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "orp_dcn_forward_h_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "orp_dcn_forward_multi_h": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),
     "orp_dcn_im2col": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp]),
     "orp_dcn_col2im": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp, _vp]),
     "orp_dcn_col2im_nhwc": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp, _vp, _vp]),

@@ -33,6 +33,7 @@ SOURCES = [
     ("orp_norm.hip", []),
     ("orp_conv_small.hip", []),
     ("orp_dcn.hip", []),
+    ("orp_dcn_half.hip", []),
     ("orp_dcn_bwd.hip", []),
     ("orp_prof.hip", []),
 ]

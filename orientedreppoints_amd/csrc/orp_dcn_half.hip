@@ -1,0 +1,420 @@
+// orp_dcn_half.hip -- deformable convolution forward (DCNv1 / DCNv2) in fp16 / bf16 for gfx950 (MI355X).
+//
+// The reference dispatches its DeformConv kernels over float AND half (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+// mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:259,353,451,781,813) and runs the im2col in half, the GEMM in the library's
+// half path.  Here (BASELINE configs[4]: "DCNv2 MFMA path + fp16"):
+//   * same implicit GEMM as orp_dcn.hip (A = bilinear samples, never written to HBM; all FPN levels in one launch;
+//     NHWC inputs so that a wave fetches one neighbour of one position as a coalesced 512 B row of 256 channels),
+//     on v_mfma_f32_32x32x16_{f16,bf16}: 16 k-values per instruction, 16x the fp32 matrix rate, fp32 accumulation;
+//   * the bilinear combine is done in fp32 on the four gathered neighbours and rounded ONCE to the storage type (the
+//     reference rounds every partial product in half) -- closer to the fp32 result than the reference's own half path;
+//   * at this matrix rate one kernel tap of MFMA work (16 chunks x 3 instructions x 32 clk) is SHORTER than an L2 round
+//     trip, so the pipeline is organised per TAP, not per chunk: at the top of a tap a wave issues ALL gathers of the
+//     next tap's A rows (12 rows x 4 neighbours, 96 VGPRs in flight), the weight fragment of chunk j is reloaded for
+//     the next tap right after chunk j has used it (in-place register ring, prefetch distance = one whole tap), and the
+//     gathered rows are combined and written to the single LDS A tile between two barriers at the end of the tap.
+// Tolerance (tests): |out - fp32 oracle on the same rounded inputs| <= 2e-3 (fp16) / 1.6e-2 (bf16) of the output scale.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/orp_hip.h"
+#include "orp_launch.hpp"
+#include "orp_prof.hpp"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+constexpr int MAX_TAPS = 9;
+constexpr int MAX_LEVELS = 8;
+constexpr int CBH = 256;          // input channels per tap phase
+constexpr int ASTRH = CBH + 8;    // padded A row stride in ELEMENTS (132 dwords: conflict-free ds_read_b128 / ds_write_b64)
+constexpr int KCH = 16;           // input channels per MFMA
+constexpr int kThreadsH = 512;    // 8 waves: wave w owns output channels [32w, 32w+32)
+
+// element type traits: storage <-> float, MFMA
+template <typename T> struct Elem;
+template <> struct Elem<_Float16> {
+  typedef half8 v8;
+  static __device__ __forceinline__ float to_f(_Float16 x) { return (float)x; }
+  static __device__ __forceinline__ _Float16 from_f(float x) { return (_Float16)x; }
+  static __device__ __forceinline__ floatx16 mfma(v8 a, v8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Elem<__bf16> {
+  typedef bf8 v8;
+  static __device__ __forceinline__ float to_f(__bf16 x) { return (float)x; }
+  static __device__ __forceinline__ __bf16 from_f(float x) { return (__bf16)x; }
+  static __device__ __forceinline__ floatx16 mfma(v8 a, v8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+struct LevelH {
+  const void* x;       // NHWC [B, H, W, Cin]
+  const void* off;     // NCHW [B, 2*taps, Ho, Wo]
+  const void* mask;    // DCNv2 modulation or nullptr
+  void* out;           // NCHW or NHWC
+  int H, W, Ho, Wo;
+  int tile0;
+};
+struct FwdH {
+  LevelH lv[MAX_LEVELS];
+  int nlev, B, Cin, Cout;
+  int kh, kw, sh, sw, ph, pw, dh, dw;
+  const void* wp;      // packed [tap][Cin/16][2][Cout][8]
+  const void* bias;    // [Cout] or nullptr
+  int relu;
+};
+
+// w [o][c][tap] -> wp [tap][c/16][kg][o][8]   (kg = (c % 16) / 8, e = c % 8): lane (o, kg) of a wave reads its 8 k-values of a
+// 16-channel chunk as ONE 16 B load, lanes 0-31 / 32-63 two contiguous 512 B segments
+template <typename T>
+__global__ void pack_weight_h_kernel(const T* __restrict__ w, int cout, int cin, int taps, T* __restrict__ wp) {
+  const long total = (long)cout * cin * taps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7);
+    long r = i >> 3;
+    const int o = (int)(r % cout); r /= cout;
+    const int kg = (int)(r & 1); r >>= 1;
+    const int cblk = (int)(r % (cin / 16)), tap = (int)(r / (cin / 16));
+    const int c = cblk * 16 + kg * 8 + e;
+    wp[i] = w[((long)o * cin + c) * taps + tap];
+  }
+}
+
+// [B][C][HW] -> [B][HW][C] for 2-byte elements, all levels in one launch
+struct TransposeH {
+  const void* in[MAX_LEVELS];
+  void* out[MAX_LEVELS];
+  int hw[MAX_LEVELS];
+  int bx0[MAX_LEVELS + 1];
+  int nlev;
+};
+__global__ void nchw_to_nhwc_h_kernel(const TransposeH T, int C) {
+  __shared__ unsigned short tile[32][33];
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_LEVELS; i++) l = (i < T.nlev && (int)blockIdx.x >= T.bx0[i]) ? i : l;
+  const int HW = T.hw[l];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * 32, p0 = ((int)blockIdx.x - T.bx0[l]) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const unsigned short* src = reinterpret_cast<const unsigned short*>(T.in[l]) + (size_t)b * C * HW;
+  unsigned short* dst = reinterpret_cast<unsigned short*>(T.out[l]) + (size_t)b * C * HW;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    tile[r][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : (unsigned short)0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    if (p < HW && c < C) dst[(size_t)p * C + c] = tile[tx][r];
+  }
+}
+
+template <typename T, int MT, bool OUT_NCHW>
+__global__ void __launch_bounds__(kThreadsH)
+dcn_fwd_half_kernel(const FwdH P, int total_tiles) {
+  typedef typename Elem<T>::v8 v8;
+  constexpr int BMH = 32 * MT;
+  constexpr int ROWS = BMH / 8;                                              // A rows produced per wave per tap
+  constexpr int NCHUNK = CBH / KCH;                                          // 16 MFMA steps per tap
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* sA = reinterpret_cast<T*>(smem);                                        // [BMH][ASTRH]
+  float4* sCw = reinterpret_cast<float4*>(sA + BMH * ASTRH);                 // [BMH * taps] bilinear weights (fp32)
+  int4* sCi = reinterpret_cast<int4*>(sCw + BMH * MAX_TAPS);                 // [BMH * taps] pixel indices
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int taps = P.kh * P.kw;
+  int tile;
+  {                                                                          // XCD-aware remap: XCD x takes a contiguous slab
+    const int b = blockIdx.x, per = (total_tiles + 7) >> 3;
+    tile = (b & 7) * per + (b >> 3);
+    if (tile >= total_tiles) return;
+  }
+  int lvl = 0;
+#pragma unroll 1
+  for (int i = 1; i < P.nlev; i++) if (tile >= P.lv[i].tile0) lvl = i;
+  const LevelH L = P.lv[lvl];
+  const int HoWo = L.Ho * L.Wo;
+  const long npos = (long)P.B * HoWo;
+  const long p0 = (long)(tile - L.tile0) * BMH;
+  const int nb = blockIdx.y;
+  const T* xin = reinterpret_cast<const T*>(L.x);
+  const T* offp = reinterpret_cast<const T*>(L.off);
+  const T* maskp = reinterpret_cast<const T*>(L.mask);
+
+  // ---- bilinear coefficient table (fp32), one entry per (position, tap) --------------------------------------------------
+  for (int e = tid; e < BMH * taps; e += kThreadsH) {
+    const int m = e / taps, tap = e - m * taps;
+    const long p = p0 + m;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 ix = make_int4(0, 0, 0, 0);
+    if (p < npos) {
+      const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+      const int ho = hw / L.Wo, wo = hw - ho * L.Wo;
+      const int ki = tap / P.kw, kj = tap - ki * P.kw;
+      const T* ob = offp + ((size_t)b * 2 * taps + 2 * tap) * HoWo + hw;
+      const float off_h = Elem<T>::to_f(ob[0]), off_w = Elem<T>::to_f(ob[HoWo]);
+      const float h_im = (float)(ho * P.sh - P.ph + ki * P.dh) + off_h;
+      const float w_im = (float)(wo * P.sw - P.pw + kj * P.dw) + off_w;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)L.H && w_im < (float)L.W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+        const float hh = 1.f - lh, hw_ = 1.f - lw;
+        const bool t_ok = h_low >= 0, b_ok = h_high <= L.H - 1, l_ok = w_low >= 0, r_ok = w_high <= L.W - 1;
+        const int hl = t_ok ? h_low : 0, hhg = b_ok ? h_high : L.H - 1, wl = l_ok ? w_low : 0, whg = r_ok ? w_high : L.W - 1;
+        w.x = (t_ok && l_ok) ? hh * hw_ : 0.f;
+        w.y = (t_ok && r_ok) ? hh * lw : 0.f;
+        w.z = (b_ok && l_ok) ? lh * hw_ : 0.f;
+        w.w = (b_ok && r_ok) ? lh * lw : 0.f;
+        const int base = b * L.H;
+        ix.x = (base + hl) * L.W + wl;
+        ix.y = (base + hl) * L.W + whg;
+        ix.z = (base + hhg) * L.W + wl;
+        ix.w = (base + hhg) * L.W + whg;
+        if (maskp) {                                      // DCNv2: the sample is scaled by its modulation scalar
+          const float mm = Elem<T>::to_f(maskp[((size_t)b * taps + tap) * HoWo + hw]);
+          w.x *= mm; w.y *= mm; w.z *= mm; w.w *= mm;
+        }
+      }
+    }
+    sCw[e] = w; sCi[e] = ix;
+  }
+  __syncthreads();
+
+  const int ncb = P.Cin / CBH;                       // 256-channel blocks per tap
+  const int nphase = taps * ncb;
+  // one A row = 256 channels = 64 lanes x 4 elements (8 B): four coalesced 512 B neighbour rows
+  auto gather_issue = [&](int phase, int m, uint2 (&g)[4]) {
+    const int tap = phase / ncb, cb = phase - tap * ncb;
+    const int4 ix = sCi[m * taps + tap];
+    const T* base = xin + cb * CBH + lane * 4;
+    g[0] = *reinterpret_cast<const uint2*>(base + (size_t)ix.x * P.Cin);
+    g[1] = *reinterpret_cast<const uint2*>(base + (size_t)ix.y * P.Cin);
+    g[2] = *reinterpret_cast<const uint2*>(base + (size_t)ix.z * P.Cin);
+    g[3] = *reinterpret_cast<const uint2*>(base + (size_t)ix.w * P.Cin);
+  };
+  auto combine_store = [&](int phase, int m, const uint2 (&g)[4]) {
+    const int tap = phase / ncb;
+    const float4 wgt = sCw[m * taps + tap];
+    union { uint2 u; T h[4]; } n0, n1, n2, n3, o;
+    n0.u = g[0]; n1.u = g[1]; n2.u = g[2]; n3.u = g[3];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float v = __builtin_fmaf(wgt.w, Elem<T>::to_f(n3.h[q]), __builtin_fmaf(wgt.z, Elem<T>::to_f(n2.h[q]),
+                      __builtin_fmaf(wgt.y, Elem<T>::to_f(n1.h[q]), wgt.x * Elem<T>::to_f(n0.h[q]))));
+      o.h[q] = Elem<T>::from_f(v);                          // ONE rounding to the storage type
+    }
+    *reinterpret_cast<uint2*>(sA + (size_t)m * ASTRH + lane * 4) = o.u;
+  };
+  // weight fragment of (phase, chunk j): lane (n = lane & 31, kg = lane >> 5) -> 8 k-values, one 16 B load
+  const int n_wave = nb * 256 + wave * 32;
+  const int mrow = lane & 31, kg = lane >> 5;
+  const bool live = n_wave < P.Cout;                      // c_out % 64 == 0: a wave is live or idle as a whole
+  const T* wp = reinterpret_cast<const T*>(P.wp);
+  auto load_b = [&](int phase, int j) -> v8 {
+    const int tap = phase / ncb, cb = phase - tap * ncb;
+    const size_t blk = (size_t)tap * (P.Cin / 16) + cb * (CBH / 16) + j;
+    return *reinterpret_cast<const v8*>(wp + ((blk * 2 + kg) * P.Cout + (live ? n_wave : 0) + mrow) * 8);
+  };
+
+  // ---- prologue: A tile of phase 0, all weight fragments of phase 0 ----------------------------------------------------------
+  v8 bq[NCHUNK];
+#pragma unroll
+  for (int j = 0; j < NCHUNK; j++) bq[j] = load_b(0, j);
+  {
+    uint2 g[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) gather_issue(0, r * 8 + wave, g[r]);
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) combine_store(0, r * 8 + wave, g[r]);
+  }
+  __syncthreads();
+
+  floatx16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) acc[mt] = floatx16{0};
+
+#pragma unroll 1
+  for (int phase = 0; phase < nphase; phase++) {
+    const bool next_phase = phase + 1 < nphase;
+    // (1) every gather of the NEXT tap's A rows goes out now: a whole tap of MFMA work to land
+    uint2 g[ROWS][4];
+    if (next_phase) {
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) gather_issue(phase + 1, r * 8 + wave, g[r]);
+    }
+    // (2) the tap: one MFMA per (chunk, row block); the weight register of chunk j is refilled for the next tap at once
+    const T* arow = sA + (size_t)mrow * ASTRH + 8 * kg;
+#pragma unroll
+    for (int j = 0; j < NCHUNK; j++) {
+      v8 a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) a[mt] = *reinterpret_cast<const v8*>(arow + (size_t)mt * 32 * ASTRH + j * KCH);
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) {
+        if (OUT_NCHW) acc[mt] = Elem<T>::mfma(bq[j], a[mt], acc[mt]);     // D[channel][position]
+        else          acc[mt] = Elem<T>::mfma(a[mt], bq[j], acc[mt]);     // D[position][channel]
+      }
+      if (next_phase) bq[j] = load_b(phase + 1, j);
+    }
+    // (3) two barriers per tap: every wave is past its last read of the A tile -> overwrite it with the next tap's rows
+    if (next_phase) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) combine_store(phase + 1, r * 8 + wave, g[r]);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: fp32 accumulators (+ bias, ReLU) rounded once to the storage type -------------------------------------------
+  if (!live) return;
+  const T* biasp = reinterpret_cast<const T*>(P.bias);
+  T* outp = reinterpret_cast<T*>(L.out);
+  auto finish = [&](float v, int ch) { if (biasp) v += Elem<T>::to_f(biasp[ch]); return Elem<T>::from_f(P.relu ? fmaxf(v, 0.f) : v); };
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) {
+    if (OUT_NCHW) {
+      const long p = p0 + mt * 32 + (lane & 31);
+      if (p < npos) {
+        const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+        T* ob = outp + (size_t)b * P.Cout * HoWo + hw;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int ch = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          ob[(size_t)(n_wave + ch) * HoWo] = finish(acc[mt][r], n_wave + ch);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const long p = p0 + mt * 32 + m;
+        if (p < npos) outp[(size_t)p * P.Cout + n_wave + (lane & 31)] = finish(acc[mt][r], n_wave + (lane & 31));
+      }
+    }
+  }
+}
+
+template <int MT>
+size_t half_smem() { return 2 * ((size_t)32 * MT * ASTRH) + (sizeof(float4) + sizeof(int4)) * 32 * MT * MAX_TAPS; }
+
+template <typename T, int MT, bool OUT_NCHW>
+hipError_t launch_half(const FwdH& P, int tiles, int nblk_n, hipStream_t st) {
+  const size_t smem = half_smem<MT>();
+  struct Tag {};
+  hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_half_kernel<T, MT, OUT_NCHW>), smem);
+  if (e != hipSuccess) return e;
+  const int per = (tiles + 7) >> 3;
+  hipLaunchKernelGGL((dcn_fwd_half_kernel<T, MT, OUT_NCHW>), dim3(per * 8, nblk_n), dim3(kThreadsH), smem, st, P, tiles);
+  return hipGetLastError();
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int out_dim(int in, int pad, int dil, int k, int stride) { return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1; }
+
+}  // namespace
+
+extern "C" {
+
+int orp_dcn_half_path_ok(int c_in, int c_out, int kh, int kw, int groups, int deformable_groups) {
+  return (groups == 1 && deformable_groups == 1 && kh * kw <= MAX_TAPS && c_in % CBH == 0 && c_out % 64 == 0 && c_out >= 64) ? 1 : 0;
+}
+
+int orp_dcn_pack_weight_h(const void* weight, int c_out, int c_in, int kh, int kw, void* packed, int dtype, void* stream) {
+  if (!weight || !packed || c_out <= 0 || c_in <= 0 || c_in % 16 || kh <= 0 || kw <= 0 || (dtype != 1 && dtype != 2)) return ORP_EINVAL;
+  const long total = (long)c_out * c_in * kh * kw;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  if (dtype == 1)
+    hipLaunchKernelGGL(pack_weight_h_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)weight, c_out, c_in, kh * kw, (_Float16*)packed);
+  else
+    hipLaunchKernelGGL(pack_weight_h_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)weight,
+                       c_out, c_in, kh * kw, (__bf16*)packed);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+size_t orp_dcn_forward_h_workspace_bytes(const orp_dcn_level_h* levels_host, int nlevels, int batch, int c_in, int in_layout) {
+  if (in_layout == 1 || !levels_host) return 256;
+  size_t tot = 0;
+  for (int i = 0; i < nlevels; i++) tot += align256((size_t)2 * batch * c_in * levels_host[i].height * levels_host[i].width);
+  return tot + 256;
+}
+
+int orp_dcn_forward_multi_h(const orp_dcn_level_h* levels_host, const void* const* masks_host, int nlevels, int batch, int c_in,
+                            int c_out, const void* weight_packed, const void* bias, int relu, int kh, int kw, int stride_h,
+                            int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout, int out_layout, int dtype,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (!levels_host || nlevels <= 0 || nlevels > MAX_LEVELS || batch <= 0 || !weight_packed) return ORP_EINVAL;
+  if (!orp_dcn_half_path_ok(c_in, c_out, kh, kw, 1, 1) || (dtype != 1 && dtype != 2)) return ORP_EINVAL;
+  if ((in_layout != 0 && in_layout != 1) || (out_layout != 0 && out_layout != 1)) return ORP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (in_layout == 0 && workspace_bytes < orp_dcn_forward_h_workspace_bytes(levels_host, nlevels, batch, c_in, 0)) return ORP_EWORKSPACE;
+  char* wsp = reinterpret_cast<char*>(workspace);
+  long npos_all = 0;
+  for (int i = 0; i < nlevels; i++)
+    npos_all += (long)batch * out_dim(levels_host[i].height, pad_h, dil_h, kh, stride_h) *
+                out_dim(levels_host[i].width, pad_w, dil_w, kw, stride_w);
+  int MT = 1;
+  long best = -1;
+  for (int mt = 1; mt <= 3; mt++) {
+    const long t = (npos_all + 32 * mt - 1) / (32 * mt) + nlevels;
+    const long cost = ((t + 255) / 256) * mt * 100 + (mt == 1 ? 40 : mt == 2 ? 10 : 0);
+    if (best < 0 || cost < best) { best = cost; MT = mt; }
+  }
+  FwdH P;
+  P.nlev = nlevels; P.B = batch; P.Cin = c_in; P.Cout = c_out;
+  P.kh = kh; P.kw = kw; P.sh = stride_h; P.sw = stride_w; P.ph = pad_h; P.pw = pad_w; P.dh = dil_h; P.dw = dil_w;
+  P.wp = weight_packed; P.bias = bias; P.relu = relu ? 1 : 0;
+  TransposeH TL;
+  int tbx = 0, tiles = 0;
+  const int bm = 32 * MT;
+  for (int i = 0; i < nlevels; i++) {
+    const orp_dcn_level_h& lv = levels_host[i];
+    if (!lv.input || !lv.offset || !lv.output || lv.height <= 0 || lv.width <= 0) return ORP_EINVAL;
+    LevelH& D = P.lv[i];
+    D.H = lv.height; D.W = lv.width;
+    D.Ho = out_dim(lv.height, pad_h, dil_h, kh, stride_h);
+    D.Wo = out_dim(lv.width, pad_w, dil_w, kw, stride_w);
+    if (D.Ho <= 0 || D.Wo <= 0) return ORP_EINVAL;
+    if ((long)batch * lv.height * lv.width >= (1L << 31)) return ORP_ETOOBIG;
+    D.off = lv.offset; D.out = lv.output;
+    D.mask = masks_host ? masks_host[i] : nullptr;
+    if (in_layout == 0) {
+      const int HW = lv.height * lv.width;
+      TL.in[i] = lv.input; TL.out[i] = wsp; TL.hw[i] = HW; TL.bx0[i] = tbx;
+      tbx += (HW + 31) / 32;
+      D.x = wsp;
+      wsp += align256((size_t)2 * batch * c_in * HW);
+    } else {
+      D.x = lv.input;
+    }
+    D.tile0 = tiles;
+    tiles += (int)(((long)batch * D.Ho * D.Wo + bm - 1) / bm);
+  }
+  for (int i = nlevels; i < MAX_LEVELS; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; }
+  if (in_layout == 0) {
+    TL.nlev = nlevels;
+    for (int i = nlevels; i <= MAX_LEVELS; i++) TL.bx0[i] = tbx;
+    for (int i = nlevels; i < MAX_LEVELS; i++) { TL.in[i] = TL.in[0]; TL.out[i] = TL.out[0]; TL.hw[i] = 0; }
+    hipLaunchKernelGGL(nchw_to_nhwc_h_kernel, dim3(tbx, (c_in + 31) / 32, batch), dim3(256), 0, st, TL, c_in);
+  }
+  OrpProfScope prof(ORP_PROF_DCN_FWD, st);
+  const int nblk_n = (c_out + 255) / 256;
+  const bool nchw = out_layout == 0;
+  hipError_t e;
+#define ORP_LAUNCH_H(TT) \
+  (MT == 1 ? (nchw ? launch_half<TT, 1, true>(P, tiles, nblk_n, st) : launch_half<TT, 1, false>(P, tiles, nblk_n, st)) \
+   : MT == 2 ? (nchw ? launch_half<TT, 2, true>(P, tiles, nblk_n, st) : launch_half<TT, 2, false>(P, tiles, nblk_n, st)) \
+             : (nchw ? launch_half<TT, 3, true>(P, tiles, nblk_n, st) : launch_half<TT, 3, false>(P, tiles, nblk_n, st)))
+  e = dtype == 1 ? ORP_LAUNCH_H(_Float16) : ORP_LAUNCH_H(__bf16);
+#undef ORP_LAUNCH_H
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+}  // extern "C"

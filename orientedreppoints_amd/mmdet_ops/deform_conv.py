@@ -73,6 +73,8 @@ def fast_path_ok(weight, groups, deformable_groups):
 def deform_conv_forward_multi(inputs, offsets, weight, stride, padding, dilation, masks=None, bias=None, relu=False):
     """One DeformConv layer over a list of feature maps (same batch / channels) in ONE launch.  fp32, no autograd.
     masks (list of [B,kh*kw,Ho,Wo], DCNv2 modulation) / bias ([Cout]) / relu (fused max(., 0)) are optional."""
+    if inputs[0].dtype in _HALF_CODES and weight.dtype == inputs[0].dtype and half_path_ok(weight, 1, 1):
+        return deform_conv_forward_multi_half(inputs, offsets, weight, stride, padding, dilation, masks, bias, relu)
     L = _lib.lib()
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     x0 = inputs[0]
@@ -114,6 +116,94 @@ def deform_conv_forward_multi(inputs, offsets, weight, stride, padding, dilation
                                         dilation[0], dilation[1], layout, layout, _lib.ptr(ws), ws.numel(),
                                         _lib.stream_of(x0))
     _lib.check(rc, "orp_dcn_forward_multi_ex")
+    return outs
+
+
+_HALF_CODES = {torch.float16: 1, torch.bfloat16: 2}
+_packed_cache_h = {}
+
+
+def _packed_weight_h(weight):
+    """[Cout,Cin,kh,kw] fp16 / bf16 -> [tap][Cin/16][2][Cout][8] (orp_dcn_pack_weight_h), cached like the fp32 pack."""
+    w = weight.detach()
+    cacheable = not (torch.is_grad_enabled() and weight.requires_grad)
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index, w.dtype)
+    hit = _packed_cache_h.get(id(weight)) if cacheable else None
+    if hit is not None and hit[0] == key:
+        return _lib.keep_for_graph(hit[1])
+    w = w.contiguous()
+    cout, cin, kh, kw = w.shape
+    packed = torch.empty((cout * cin * kh * kw,), dtype=w.dtype, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.lib().orp_dcn_pack_weight_h(_lib.ptr(w), cout, cin, kh, kw, _lib.ptr(packed), _HALF_CODES[w.dtype],
+                                              _lib.stream_of(w))
+    _lib.check(rc, "orp_dcn_pack_weight_h")
+    if cacheable:
+        if len(_packed_cache_h) > 64:
+            _packed_cache_h.clear()
+        _packed_cache_h[id(weight)] = (key, packed)
+    return _lib.keep_for_graph(packed) if cacheable else packed
+
+
+def half_path_ok(weight, groups, deformable_groups):
+    cout, cin_g, kh, kw = weight.shape
+    return weight.dtype in _HALF_CODES and bool(_lib.lib().orp_dcn_half_path_ok(cin_g * groups, cout, kh, kw, groups,
+                                                                               deformable_groups))
+
+
+def deform_conv_forward_multi_half(inputs, offsets, weight, stride, padding, dilation, masks=None, bias=None, relu=False):
+    """`deform_conv_forward_multi` for fp16 / bf16 tensors (the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF
+    branch; BASELINE configs[4]): v_mfma_f32_32x32x16_{f16,bf16}, fp32 bilinear combine and accumulation, outputs in the
+    input dtype.  All tensors (inputs, offsets, masks, bias, weight) must share that dtype."""
+    L = _lib.lib()
+    stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    x0 = inputs[0]
+    dt = x0.dtype
+    code = _HALF_CODES[dt]
+    B, cin = x0.size(0), x0.size(1)
+    cout, _, kh, kw = weight.shape
+    if weight.dtype != dt:
+        raise TypeError("deform_conv (half): weight dtype %s != input dtype %s" % (weight.dtype, dt))
+    nhwc = all(x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+               for x in inputs)
+    packed = _packed_weight_h(weight)
+
+    class _LevelH(ctypes.Structure):
+        _fields_ = [("input", ctypes.c_void_p), ("offset", ctypes.c_void_p), ("output", ctypes.c_void_p),
+                    ("height", ctypes.c_int), ("width", ctypes.c_int)]
+    levels = (_LevelH * len(inputs))()
+    keep, outs = [], []
+    for i, (x, off) in enumerate(zip(inputs, offsets)):
+        assert x.size(0) == B and x.size(1) == cin and x.dtype == dt
+        x = x.detach()
+        x = x if nhwc else x.contiguous()
+        off = off.detach().to(dt).contiguous()
+        ho, wo = _out_hw(x.size(2), x.size(3), weight, stride, padding, dilation)
+        if off.size(1) != 2 * kh * kw or off.size(2) != ho or off.size(3) != wo:
+            raise ValueError("offset must be [B, 2*kh*kw, Ho, Wo]")
+        out = torch.empty((B, cout, ho, wo), dtype=dt, device=x.device,
+                          memory_format=torch.channels_last if nhwc else torch.contiguous_format)
+        keep += [x, off]; outs.append(out)
+        levels[i] = _LevelH(x.data_ptr(), off.data_ptr(), out.data_ptr(), x.size(2), x.size(3))
+    mask_ptrs = None
+    if masks is not None:
+        mask_ptrs = (ctypes.c_void_p * len(inputs))()
+        for i, m in enumerate(masks):
+            m = m.detach().to(dt).contiguous()
+            if tuple(m.shape) != (B, kh * kw, outs[i].size(2), outs[i].size(3)):
+                raise ValueError("mask must be [B, kh*kw, Ho, Wo]")
+            keep.append(m)
+            mask_ptrs[i] = m.data_ptr()
+    b = bias.detach().to(dt).contiguous() if bias is not None else None
+    layout = 1 if nhwc else 0
+    nbytes = L.orp_dcn_forward_h_workspace_bytes(levels, len(inputs), B, cin, layout)
+    ws = _lib.workspace(x0.device, nbytes)
+    with torch.cuda.device(x0.device):
+        rc = L.orp_dcn_forward_multi_h(levels, mask_ptrs, len(inputs), B, cin, cout, _lib.ptr(packed), _lib.ptr(b),
+                                       1 if relu else 0, kh, kw, stride[0], stride[1], padding[0], padding[1],
+                                       dilation[0], dilation[1], layout, layout, code, _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_of(x0))
+    _lib.check(rc, "orp_dcn_forward_multi_h")
     return outs
 
 

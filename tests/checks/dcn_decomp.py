@@ -25,6 +25,14 @@ torch.cuda.synchronize()
 us = prof(3)
 npos = sum((IMG // st) ** 2 for st in (8, 16, 32, 64, 128))
 print("  dcn fwd %%d positions: %%.1f us  %%.1f TF/s  frac %%.3f" %% (npos, us, 2.0 * npos * 256 * 2304 / us / 1e6, 2.0 * npos * 256 * 2304 / us / 1e6 / 157.3))
+for dt in (torch.float16, torch.bfloat16):
+    hx = [x.to(dt) for x in xs]; ho = [o.to(dt) for o in offs]; hw = w.to(dt)
+    for _ in range(3): deform_conv_forward_multi(hx, ho, hw, 1, 1, 1, relu=True)
+    torch.cuda.synchronize(); prof(3)
+    for _ in range(20): deform_conv_forward_multi(hx, ho, hw, 1, 1, 1, relu=True)
+    torch.cuda.synchronize()
+    ush = prof(3)
+    print("  dcn fwd %%s: %%.1f us  %%.1f TF/s" %% (str(dt), ush, 2.0 * npos * 256 * 2304 / ush / 1e6))
 from orientedreppoints_amd.mmdet_ops import deform_conv_forward_pair
 xs2 = [torch.randn_like(x) for x in xs]
 w2 = torch.randn(256, 256, 3, 3, device=dev) * 0.01

@@ -515,6 +515,46 @@ def test_rnms_batched_16_images_as_image_class_segments(dev, oracle):
         assert num[s] == len(want) and np.array_equal(keep[off[s]:off[s] + num[s]], want), s
 
 
+@pytest.mark.parametrize("dtype,tol", [("float16", 2e-3), ("bfloat16", 1.6e-2)])
+def test_dcn_forward_half_precision_vs_fp32_oracle(dev, oracle, dtype, tol):
+    """a2 "fp32 / fp16 dispatch" (AT_DISPATCH_FLOATING_TYPES_AND_HALF) / BASELINE configs[4]: the fp16 and bf16 DeformConv
+    forward on v_mfma_f32_32x32x16_{f16,bf16} against the fp32 oracle evaluated on the SAME rounded inputs.  Stated
+    tolerance: 2e-3 (fp16) / 1.6e-2 (bf16) of the output scale -- the A samples and the outputs are rounded once to the
+    storage type (eps 4.9e-4 / 3.9e-3), everything in between is fp32.  DCNv1 multi-level + DCNv2 (mask, bias, ReLU)."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv_forward_multi
+    dt = getattr(torch, dtype)
+    rng = np.random.RandomState(31)
+    shapes = [(9, 12), (5, 5), (2, 3)]
+    q = lambda a: torch.from_numpy(a).to(dev).to(dt)                     # noqa: E731  (round to the storage type)
+    f = lambda t: t.float().cpu().numpy()                                # noqa: E731
+    xs = [q(rng.normal(size=(2, 256, h, w)).astype(np.float32)) for h, w in shapes]
+    offs = [q(rng.normal(0, 2.0, size=(2, 18, h, w)).astype(np.float32)) for h, w in shapes]
+    w = q(rng.normal(0, 0.05, size=(64, 256, 3, 3)).astype(np.float32))
+    outs = deform_conv_forward_multi(xs, offs, w, 1, 1, 1)
+    for x, o, got in zip(xs, offs, outs):
+        assert got.dtype == dt
+        want = oracle.dcn_forward(f(x), f(o), f(w), 1, 1, 1)
+        assert np.max(np.abs(f(got) - want)) <= tol * np.max(np.abs(want))
+    # channels-last in / out, DCNv2 mask + bias + fused ReLU
+    xs_cl = [x.contiguous(memory_format=torch.channels_last) for x in xs[:2]]
+    masks = [q(rng.uniform(0, 1, size=(2, 9, h, w_)).astype(np.float32)) for h, w_ in shapes[:2]]
+    bias = q(rng.normal(0, 0.5, size=(64,)).astype(np.float32))
+    outs2 = deform_conv_forward_multi(xs_cl, offs[:2], w, 1, 1, 1, masks=masks, bias=bias, relu=True)
+    for x, o, m, got in zip(xs[:2], offs[:2], masks, outs2):
+        assert got.is_contiguous(memory_format=torch.channels_last)
+        want = np.maximum(oracle.dcn_forward(f(x), f(o), f(w), 1, 1, 1, mask=f(m), bias=f(bias)), 0.0)
+        assert np.max(np.abs(f(got) - want)) <= tol * max(1.0, np.max(np.abs(want)))
+    # the head's shape: 256 -> 256, against the fp32 MFMA path on the same rounded inputs
+    torch.manual_seed(7)
+    big = [torch.randn(1, 256, n, n, device=dev).to(dt).contiguous(memory_format=torch.channels_last) for n in (64, 32, 16)]
+    boff = [(torch.randn(1, 18, n, n, device=dev) * 2).to(dt) for n in (64, 32, 16)]
+    bw = (torch.randn(256, 256, 3, 3, device=dev) * 0.02).to(dt)
+    hout = deform_conv_forward_multi(big, boff, bw, 1, 1, 1)
+    fout = deform_conv_forward_multi([b.float() for b in big], [o.float() for o in boff], bw.float(), 1, 1, 1)
+    for a, b in zip(hout, fout):
+        assert float((a.float() - b).abs().max()) <= tol * float(b.abs().max())
+
+
 def test_dcn_full_size_properties(dev):
     """BASELINE shapes (all five levels of a 1024^2 image, 256 -> 256, one launch, MT = 3 tiles): with zero offsets the
     DeformConv IS the plain 3x3 convolution (independent implementation: the library's), and with random offsets it is
