@@ -8,13 +8,18 @@ which = sys.argv[1] if len(sys.argv) > 1 else 'all'
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device('cuda:0')
 if which in ('dcn', 'all'):
-    from orientedreppoints_amd.mmdet_ops import deform_conv_forward_multi
+    from orientedreppoints_amd.mmdet_ops import deform_conv_forward_multi, deform_conv_forward_pair
     torch.manual_seed(0)
     w = torch.randn(256, 256, 3, 3, device=dev) * 0.01
+    w2 = torch.randn(256, 256, 3, 3, device=dev) * 0.01
     xs = [torch.randn(1, 256, h, h, device=dev).contiguous(memory_format=torch.channels_last) for h in (128, 64, 32, 16, 8)]
+    xs2 = [torch.randn_like(x) for x in xs]
     offs = [torch.randn(1, 18, h, h, device=dev) * 2 for h in (128, 64, 32, 16, 8)]
     for _ in range(iters):
-        deform_conv_forward_multi(xs, offs, w, 1, 1, 1)
+        deform_conv_forward_pair(xs, xs2, offs, w, w2, 1, 1, 1, relu=True)      # the head's launch: both layers, all levels
+    hx, ho, hw = [x.half() for x in xs], [o.half() for o in offs], w.half()
+    for _ in range(iters):
+        deform_conv_forward_multi(hx, ho, hw, 1, 1, 1)                          # fp16 path
 if which in ('nms', 'all'):
     from orientedreppoints_amd.mmdet_ops.nms_wrapper import rnms_device
     d, _ = S.gen_dense_scene(2000, 1)
