@@ -183,6 +183,24 @@ int orp_dcn_forward_direct(const float* input, const float* offset, const float*
                            int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                            int groups, int deformable_groups, void* stream);
 
+/* Deformable convolution (DCNv1) backward as two MFMA implicit GEMMs, no column buffer in HBM
+ * (deform_conv_backward_input_cuda + deform_conv_backward_parameters_cuda, deform_conv_cuda.cpp:262-488), all levels of
+ * one layer in one call.  Requires orp_dcn_backward_mfma_ok (c_in = c_out = 256, groups = deformable_groups = 1,
+ * kh*kw <= 9); every other configuration: the column entries below.  All tensors NCHW fp32:
+ *   input [B,256,H,W], offset [B,2*kh*kw,Ho,Wo], grad_output [B,256,Ho,Wo] ->
+ *   grad_input [B,256,H,W], grad_offset [B,2*kh*kw,Ho,Wo] (both OVERWRITTEN; written when need_input_grads != 0),
+ *   grad_weight [256,256,kh,kw] (OVERWRITTEN; NULL = not wanted) = sum over levels and images, added in a fixed order.
+ * weight is the layer's [256,256,kh,kw] tensor.  workspace: orp_dcn_backward_workspace_bytes() bytes. */
+typedef struct { const float* input; const float* offset; const float* grad_output; float* grad_input; float* grad_offset;
+                 int height; int width; } orp_dcn_bwd_level;
+int orp_dcn_backward_mfma_ok(int c_in, int c_out, int kh, int kw, int groups, int deformable_groups);
+size_t orp_dcn_backward_workspace_bytes(const orp_dcn_bwd_level* levels_host, int nlevels, int batch, int kh, int kw,
+                                        int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w);
+int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, int batch, int c_in, int c_out,
+                           const float* weight, float* grad_weight, int need_input_grads, int kh, int kw, int stride_h,
+                           int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* Deformable convolution backward, column formulation (deform_conv_cuda.cpp:262-488, kernels
  * deform_conv_cuda_kernel.cu:190-465 and the modulated twins :570-867).  NCHW fp32.
  * orp_dcn_im2col: columns [Cin*kh*kw, B*Ho*Wo] (x mask when mask != NULL) -- feeds grad_W = grad_out . columns^T.

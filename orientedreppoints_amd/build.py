@@ -35,6 +35,7 @@ SOURCES = [
     ("orp_dcn.hip", []),
     ("orp_dcn_half.hip", []),
     ("orp_dcn_bwd.hip", []),
+    ("orp_dcn_bwd_mfma.hip", []),
     ("orp_prof.hip", []),
 ]
 HEADERS = ["orp_geom.hpp", "orp_quadfast.hpp", "orp_tile.hpp", "orp_hull.hpp", "orp_prof.hpp", "orp_launch.hpp", os.path.join("..", "..", "include", "orp_hip.h")]

@@ -1,0 +1,580 @@
+// orp_dcn_bwd_mfma.hip -- deformable convolution (DCNv1) backward for gfx950 as two MFMA implicit GEMMs.
+//
+// Replaces deform_conv_backward_input_cuda + deform_conv_backward_parameters_cuda (mmdet/ops/dcn/src/deform_conv_cuda.cpp:
+// 262-488) and their kernels deformable_im2col / deformable_col2im / deformable_col2im_coord
+// (deform_conv_cuda_kernel.cu:190-465) for the head's configuration (Cin = Cout = 256, groups = deformable_groups = 1).
+// The reference (and orp_dcn_bwd.hip's column formulation) writes the [Cin*9, B*Ho*Wo] column buffers to HBM twice
+// (grad columns = W^T . grad_out, and im2col for grad_W) around two library GEMMs; here neither buffer exists:
+//
+//   kernel A  (grad_input, grad_offset)   per tile of MT*32 positions and per kernel tap t:
+//       G_t[p, c] = sum_o  go[p, o] * W[o, c, t]                      (v_mfma_f32_32x32x2_f32, K = 256 output channels)
+//     the grad_out tile stays in LDS for all nine taps, wave w owns input channels [32w, 32w+32) and streams its W^T
+//     fragments L2 -> registers; the accumulator of a tap is consumed in place: four bilinear-weighted atomic adds into
+//     grad_input (NHWC: one half-wave = one 128-byte row segment) and the two coordinate derivatives
+//     (get_coordinate_weight, deform_conv_cuda_kernel.cu:145-188), reduced over the 32 lanes with DPP and over the 8 waves
+//     in LDS.
+//   kernel B  (grad_weight)   workgroup (split s, tap t):
+//       gW_t[o, c] = sum_p  go[p, o] * col_t[p, c],    col_t[p, c] = bilinear(x[:, c], p + t + offset)
+//     K = positions, walked in 32-position chunks: the col tile is gathered exactly like the forward's A tile (coalesced
+//     1 KB NHWC rows, wave-uniform weights) into LDS next to the grad_out rows; 64 accumulator tiles (256 x 256) live in
+//     the 8 waves' registers.  Splits write partial sums, a second kernel adds them in FIXED order (deterministic).
+//
+// Inputs arrive NCHW (autograd); x and grad_out are transposed to NHWC in the workspace, grad_input is accumulated NHWC
+// and transposed back.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/orp_hip.h"
+#include "orp_launch.hpp"
+#include "orp_prof.hpp"
+
+#ifndef ORP_BWD_DBG
+#define ORP_BWD_DBG 0      // dev aid, compile-time (timing only, wrong results): 1 = no grad_input atomics, 2 = no x loads / derivative reduction
+#endif
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int CH = 256;          // Cin = Cout on this path
+constexpr int MAXL = 8;
+constexpr int MAXT = 9;
+constexpr int ASTR = CH + 4;     // kernel A: grad_out tile row stride (conflict-free ds_read_b128 of the permuted K order)
+constexpr int RS = CH + 32;      // kernel B: row stride with RS % 64 == 32 (two half-waves read rows k, k+1 conflict-free)
+constexpr int kThreads = 512;
+
+struct BLevel {
+  const float* x;      // NHWC [B, H, W, 256]
+  const float* go;     // NHWC [B, Ho, Wo, 256]
+  const float* off;    // NCHW [B, 2*taps, Ho, Wo]
+  float* gx;           // NHWC [B, H, W, 256], zeroed
+  float* goff;         // NCHW [B, 2*taps, Ho, Wo]
+  int H, W, Ho, Wo;
+  int tile0;           // kernel A: first tile of this level
+  int chunk0;          // kernel B: first 32-position chunk of this level
+};
+struct BwdParams {
+  BLevel lv[MAXL];
+  int nlev, B;
+  int kh, kw, sh, sw, ph, pw, dh, dw;
+  const float* wT;     // [tap][o/4][c][4]
+  float* partial;      // [nsplit][tap][o][c]
+  int nsplit, total_chunks;
+};
+
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+inline int out_dim(int in, int pad, int dil, int k, int stride) { return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1; }
+
+// ---- batched [B][R][S] -> [B][S][R] for up to 16 tensors in one launch -------------------------------------------
+struct TransposeSet {
+  const float* in[2 * MAXL];
+  float* out[2 * MAXL];
+  int R[2 * MAXL], S[2 * MAXL];
+  int t0[2 * MAXL + 1];
+  int n;
+};
+__global__ void transpose_set_kernel(const TransposeSet T) {
+  __shared__ float tile[32][33];
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < 2 * MAXL; k++) i = (k < T.n && (int)blockIdx.x >= T.t0[k]) ? k : i;
+  const int R = T.R[i], S = T.S[i];
+  const int ts_n = (S + 31) >> 5;
+  const int t = (int)blockIdx.x - T.t0[i];
+  const int r0 = (t / ts_n) * 32, s0 = (t % ts_n) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* src = T.in[i] + (size_t)blockIdx.y * R * S;
+  float* dst = T.out[i] + (size_t)blockIdx.y * R * S;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, s = s0 + tx;
+    tile[k][tx] = (r < R && s < S) ? src[(size_t)r * S + s] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int s = s0 + k, r = r0 + tx;
+    if (s < S && r < R) dst[(size_t)s * R + r] = tile[tx][k];
+  }
+}
+
+// w [o][c][tap] -> wT [tap][o/4][c][4]
+__global__ void pack_wT_kernel(const float* __restrict__ w, int taps, float* __restrict__ wT) {
+  const int total = CH * CH * taps;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int q = i & 3, c = (i >> 2) % CH, og = ((i >> 2) / CH) % (CH / 4), tap = (i >> 2) / (CH * (CH / 4));
+    wT[i] = w[((size_t)(og * 4 + q) * CH + c) * taps + tap];
+  }
+}
+
+// sum_s partial[s][tap][o][c] -> gw[o][c][tap], s in ascending order
+__global__ void reduce_partial_kernel(const float* __restrict__ partial, int nsplit, int taps, float* __restrict__ gw) {
+  const int total = taps * CH * CH;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int s = 0; s < nsplit; s++) acc += partial[(size_t)s * total + i];
+    const int c = i % CH, o = (i / CH) % CH, tap = i / (CH * CH);
+    gw[((size_t)o * CH + c) * taps + tap] = acc;
+  }
+}
+
+// the sampling point of (position p of level L, kernel tap): fractional parts and the four pixel indices, -1 = that
+// corner contributes nothing (outside the map); everything -1 when the point is outside (-1, H) x (-1, W)
+__device__ inline void sample_point(const BwdParams& P, const BLevel& L, long p, int tap, int taps, int HoWo, int4& ix,
+                                    float2& frac) {
+  ix = make_int4(-1, -1, -1, -1);
+  frac = make_float2(0.f, 0.f);
+  const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+  const int ho = hw / L.Wo, wo = hw - ho * L.Wo;
+  const int ki = tap / P.kw, kj = tap - ki * P.kw;
+  const float* ob = L.off + ((size_t)b * 2 * taps + 2 * tap) * HoWo + hw;
+  const float h_im = (float)(ho * P.sh - P.ph + ki * P.dh) + ob[0];
+  const float w_im = (float)(wo * P.sw - P.pw + kj * P.dw) + ob[HoWo];
+  if (h_im > -1.f && w_im > -1.f && h_im < (float)L.H && w_im < (float)L.W) {
+    const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hh = hl + 1, wh = wl + 1;
+    frac.x = h_im - (float)hl; frac.y = w_im - (float)wl;
+    const bool t_ok = hl >= 0, b_ok = hh <= L.H - 1, l_ok = wl >= 0, r_ok = wh <= L.W - 1;
+    const int base = b * L.H;
+    if (t_ok && l_ok) ix.x = (base + hl) * L.W + wl;
+    if (t_ok && r_ok) ix.y = (base + hl) * L.W + wh;
+    if (b_ok && l_ok) ix.z = (base + hh) * L.W + wl;
+    if (b_ok && r_ok) ix.w = (base + hh) * L.W + wh;
+  }
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// sum over the 32 lanes of each half-wave; valid in lanes 16..31 and 48..63
+__device__ inline float half_wave_sum(float v) {
+  v = dpp_add<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);    // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);    // row_mirror
+  v = dpp_add<0x142, 0xa>(v);    // row_bcast15 into rows 1 and 3
+  return v;
+}
+
+// ---- kernel A: grad_input + grad_offset ---------------------------------------------------------------------------
+template <int MT>
+__global__ void __launch_bounds__(kThreads)
+dcn_bwd_input_kernel(const BwdParams P, int total_tiles) {
+  constexpr int BM2 = 32 * MT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sG = reinterpret_cast<float*>(smem);                       // [BM2][ASTR] grad_out rows
+  int4* sCi = reinterpret_cast<int4*>(sG + BM2 * ASTR);             // [BM2 * taps]
+  float2* sCl = reinterpret_cast<float2*>(sCi + BM2 * MAXT);        // [BM2 * taps] (lh, lw)
+  float* sGO = reinterpret_cast<float*>(sCl + BM2 * MAXT);          // [BM2][taps][2] grad_offset of the tile
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int taps = P.kh * P.kw;
+  int tile;
+  {
+    const int b = blockIdx.x, per = (total_tiles + 7) >> 3;         // XCD x takes the contiguous tiles [x*per, (x+1)*per)
+    tile = (b & 7) * per + (b >> 3);
+    if (tile >= total_tiles) return;
+  }
+  int lvl = 0;
+#pragma unroll 1
+  for (int i = 1; i < P.nlev; i++) if (tile >= P.lv[i].tile0) lvl = i;
+  const BLevel L = P.lv[lvl];
+  const int HoWo = L.Ho * L.Wo;
+  const long npos = (long)P.B * HoWo;
+  const long p0 = (long)(tile - L.tile0) * BM2;
+
+  for (int e = tid; e < BM2 * taps; e += kThreads) {
+    const int m = e / taps, tap = e - m * taps;
+    int4 ix = make_int4(-1, -1, -1, -1);
+    float2 fr = make_float2(0.f, 0.f);
+    if (p0 + m < npos) sample_point(P, L, p0 + m, tap, taps, HoWo, ix, fr);
+    sCi[e] = ix; sCl[e] = fr;
+    sGO[2 * e] = 0.f; sGO[2 * e + 1] = 0.f;
+  }
+  for (int r = wave; r < BM2; r += 8) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p0 + r < npos) v = *reinterpret_cast<const float4*>(L.go + (size_t)(p0 + r) * CH + lane * 4);
+    *reinterpret_cast<float4*>(sG + (size_t)r * ASTR + lane * 4) = v;
+  }
+  __syncthreads();
+
+  const int mrow = lane & 31, kh = lane >> 5;
+  const int c = wave * 32 + mrow;                                   // this lane's input channel
+  auto load_bq = [&](int tap, int j, float4 (&r)[2]) {
+    const float* base = P.wT + (((size_t)tap * (CH / 4) + j * 4 + kh) * CH + c) * 4;
+    r[0] = *reinterpret_cast<const float4*>(base);
+    r[1] = *reinterpret_cast<const float4*>(base + (size_t)2 * CH * 4);
+  };
+  float4 bq[2];
+  load_bq(0, 0, bq);
+
+#pragma unroll 1
+  for (int tap = 0; tap < taps; tap++) {
+    floatx16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] = floatx16{0};
+#pragma unroll
+    for (int j = 0; j < CH / 16; j++) {
+      float4 bn[2];
+      const bool last = (j + 1 == CH / 16);
+      if (!(last && tap + 1 == taps)) load_bq(last ? tap + 1 : tap, last ? 0 : j + 1, bn);
+      else bn[0] = bn[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* arow = sG + (size_t)mrow * ASTR + j * 16 + 4 * kh;
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        float4 a4[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) a4[mt] = *reinterpret_cast<const float4*>(arow + (size_t)mt * 32 * ASTR + 8 * t);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float b0 = (i == 0) ? bq[t].x : (i == 1) ? bq[t].y : (i == 2) ? bq[t].z : bq[t].w;
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++) {
+            const float av = (i == 0) ? a4[mt].x : (i == 1) ? a4[mt].y : (i == 2) ? a4[mt].z : a4[mt].w;
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[mt], 0, 0, 0);       // D[position][channel]
+          }
+        }
+      }
+      bq[0] = bn[0]; bq[1] = bn[1];
+    }
+    // ---- consume G_t: scatter into grad_input, coordinate derivatives into the tile's grad_offset ---------------
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+#pragma unroll 4
+      for (int r = 0; r < 16; r++) {
+        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int e = m * taps + tap;
+        const int4 ix = sCi[e];
+        const float2 fr = sCl[e];
+        const float g = acc[mt][r];
+        const float lh = fr.x, lw = fr.y, uh = 1.f - lh, uw = 1.f - lw;
+        const size_t o1 = (size_t)(ix.x < 0 ? 0 : ix.x) * CH + c, o2 = (size_t)(ix.y < 0 ? 0 : ix.y) * CH + c;
+        const size_t o3 = (size_t)(ix.z < 0 ? 0 : ix.z) * CH + c, o4 = (size_t)(ix.w < 0 ? 0 : ix.w) * CH + c;
+#if ORP_BWD_DBG & 2
+        const float v1 = uh, v2 = uw, v3 = lh, v4 = lw;
+#else
+        const float v1 = ix.x >= 0 ? L.x[o1] : 0.f, v2 = ix.y >= 0 ? L.x[o2] : 0.f;
+        const float v3 = ix.z >= 0 ? L.x[o3] : 0.f, v4 = ix.w >= 0 ? L.x[o4] : 0.f;
+#endif
+#if !(ORP_BWD_DBG & 1)
+        if (ix.x >= 0) atomicAdd(L.gx + o1, uh * uw * g);
+        if (ix.y >= 0) atomicAdd(L.gx + o2, uh * lw * g);
+        if (ix.z >= 0) atomicAdd(L.gx + o3, lh * uw * g);
+        if (ix.w >= 0) atomicAdd(L.gx + o4, lh * lw * g);
+#endif
+        float dh = g * (-uw * v1 - lw * v2 + uw * v3 + lw * v4);
+        float dw = g * (-uh * v1 + uh * v2 - lh * v3 + lh * v4);
+        dh = half_wave_sum(dh);
+        dw = half_wave_sum(dw);
+        if (mrow == 31) { atomicAdd(sGO + 2 * e, dh); atomicAdd(sGO + 2 * e + 1, dw); }
+      }
+    }
+  }
+  __syncthreads();
+  // grad_offset [B, 2*taps, Ho, Wo]: plane-major so that consecutive lanes write consecutive positions
+  for (int e2 = tid; e2 < BM2 * taps * 2; e2 += kThreads) {
+    const int plane = e2 / BM2, m = e2 - plane * BM2;
+    const long p = p0 + m;
+    if (p < npos) {
+      const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+      L.goff[((size_t)b * 2 * taps + plane) * HoWo + hw] = sGO[m * 2 * taps + plane];
+    }
+  }
+}
+
+template <int MT>
+size_t input_smem() {
+  return sizeof(float) * (size_t)32 * MT * ASTR + (sizeof(int4) + sizeof(float2) + 2 * sizeof(float)) * 32 * MT * MAXT;
+}
+
+// ---- kernel B: grad_weight partial sums ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+dcn_bwd_weight_kernel(const BwdParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sG = reinterpret_cast<float*>(smem);                       // [32][RS] grad_out rows of the chunk
+  float* sC = sG + 32 * RS;                                         // [32][RS] sampled columns of the chunk (this tap)
+  float4* sCw = reinterpret_cast<float4*>(sC + 32 * RS);            // [2][32] bilinear weights
+  int4* sCi = reinterpret_cast<int4*>(sCw + 64);                    // [2][32] pixel indices (clamped)
+  long* sRow = reinterpret_cast<long*>(sCi + 64);                   // [2][32] grad_out row (level-linear position), -1 = none
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int taps = P.kh * P.kw, tap = blockIdx.y;
+  const int per = (P.total_chunks + P.nsplit - 1) / P.nsplit;
+  const int c_begin = blockIdx.x * per;
+  const int c_end = (c_begin + per < P.total_chunks) ? c_begin + per : P.total_chunks;
+
+  auto level_of = [&](int chunk) {
+    int lvl = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.nlev; i++) if (chunk >= P.lv[i].chunk0) lvl = i;
+    return lvl;
+  };
+  auto make_coef = [&](int chunk, int buf) {                         // threads 0..31
+    const BLevel& L = P.lv[level_of(chunk)];
+    const int HoWo = L.Ho * L.Wo;
+    const long p = (long)(chunk - L.chunk0) * 32 + tid;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 ixc = make_int4(0, 0, 0, 0);
+    long row = -1;
+    if (p < (long)P.B * HoWo) {
+      int4 ix; float2 fr;
+      sample_point(P, L, p, tap, taps, HoWo, ix, fr);
+      const float lh = fr.x, lw = fr.y, uh = 1.f - lh, uw = 1.f - lw;
+      w.x = ix.x >= 0 ? uh * uw : 0.f; w.y = ix.y >= 0 ? uh * lw : 0.f;
+      w.z = ix.z >= 0 ? lh * uw : 0.f; w.w = ix.w >= 0 ? lh * lw : 0.f;
+      ixc = make_int4(ix.x < 0 ? 0 : ix.x, ix.y < 0 ? 0 : ix.y, ix.z < 0 ? 0 : ix.z, ix.w < 0 ? 0 : ix.w);
+      row = p;
+    }
+    sCw[buf * 32 + tid] = w; sCi[buf * 32 + tid] = ixc; sRow[buf * 32 + tid] = row;
+  };
+  auto gather_issue = [&](int chunk, int buf, int row, float4 (&g)[4], float4& gr) {
+    const BLevel& L = P.lv[level_of(chunk)];
+    const int4 ix = sCi[buf * 32 + row];
+    const long prow = sRow[buf * 32 + row];
+    const float* base = L.x + lane * 4;
+    g[0] = *reinterpret_cast<const float4*>(base + (size_t)ix.x * CH);
+    g[1] = *reinterpret_cast<const float4*>(base + (size_t)ix.y * CH);
+    g[2] = *reinterpret_cast<const float4*>(base + (size_t)ix.z * CH);
+    g[3] = *reinterpret_cast<const float4*>(base + (size_t)ix.w * CH);
+    gr = prow >= 0 ? *reinterpret_cast<const float4*>(L.go + (size_t)prow * CH + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto combine = [&](int buf, int row, const float4 (&g)[4]) {
+    const float4 wgt = sCw[buf * 32 + row];
+    float4 v;
+    v.x = __builtin_fmaf(wgt.w, g[3].x, __builtin_fmaf(wgt.z, g[2].x, __builtin_fmaf(wgt.y, g[1].x, wgt.x * g[0].x)));
+    v.y = __builtin_fmaf(wgt.w, g[3].y, __builtin_fmaf(wgt.z, g[2].y, __builtin_fmaf(wgt.y, g[1].y, wgt.x * g[0].y)));
+    v.z = __builtin_fmaf(wgt.w, g[3].z, __builtin_fmaf(wgt.z, g[2].z, __builtin_fmaf(wgt.y, g[1].z, wgt.x * g[0].z)));
+    v.w = __builtin_fmaf(wgt.w, g[3].w, __builtin_fmaf(wgt.z, g[2].w, __builtin_fmaf(wgt.y, g[1].w, wgt.x * g[0].w)));
+    return v;
+  };
+
+  floatx16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc[i] = floatx16{0};
+  const int mrow = lane & 31, kh = lane >> 5;
+  const int wo = wave >> 1, wc = wave & 1;                          // output-channel blocks 2wo, 2wo+1; input-channel blocks 4wc..4wc+3
+
+  if (c_begin < c_end) {
+    if (tid < 32) { make_coef(c_begin, 0); if (c_begin + 1 < c_end) make_coef(c_begin + 1, 1); }
+    __syncthreads();
+    {
+      float4 g[4][4], gr[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) gather_issue(c_begin, 0, u * 8 + wave, g[u], gr[u]);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int row = u * 8 + wave;
+        *reinterpret_cast<float4*>(sC + (size_t)row * RS + lane * 4) = combine(0, row, g[u]);
+        *reinterpret_cast<float4*>(sG + (size_t)row * RS + lane * 4) = gr[u];
+      }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int chunk = c_begin; chunk < c_end; chunk++) {
+      const int it = chunk - c_begin;
+      const bool have_next = chunk + 1 < c_end;
+      const int nbuf = (it + 1) & 1;
+      float4 holdc[4], holdg[4];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        float4 g[4];
+        const bool do_row = have_next && j < 4;
+        if (do_row) gather_issue(chunk + 1, nbuf, j * 8 + wave, g, holdg[j < 4 ? j : 0]);
+        const float* ga = sG + (size_t)(2 * j + kh) * RS + (2 * wo) * 32 + mrow;
+        const float* cb = sC + (size_t)(2 * j + kh) * RS + (4 * wc) * 32 + mrow;
+        const float a0 = ga[0], a1 = ga[32];
+        const float b0 = cb[0], b1 = cb[32], b2 = cb[64], b3 = cb[96];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);             // D[o][c]
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[4], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[5], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[6], 0, 0, 0);
+        acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, acc[7], 0, 0, 0);
+        if (do_row) holdc[j < 4 ? j : 0] = combine(nbuf, j * 8 + wave, g);
+      }
+      if (have_next) {
+        __syncthreads();                                             // every wave is past its last read of this chunk
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int row = u * 8 + wave;
+          *reinterpret_cast<float4*>(sC + (size_t)row * RS + lane * 4) = holdc[u];
+          *reinterpret_cast<float4*>(sG + (size_t)row * RS + lane * 4) = holdg[u];
+        }
+        if (tid < 32 && chunk + 2 < c_end) make_coef(chunk + 2, it & 1);
+        __syncthreads();
+      }
+    }
+  }
+
+  float* outp = P.partial + ((size_t)blockIdx.x * taps + tap) * CH * CH;
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int o = (2 * wo + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        outp[(size_t)o * CH + (4 * wc + q) * 32 + mrow] = acc[a * 4 + q][r];
+      }
+}
+
+constexpr size_t weight_smem() { return sizeof(float) * 2 * 32 * RS + (sizeof(float4) + sizeof(int4) + sizeof(long)) * 64; }
+
+int device_cus() {
+  static int cus[32] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
+struct Plan {
+  size_t x_off[MAXL], go_off[MAXL], gx_off[MAXL];
+  size_t gx_begin, gx_bytes, wT_off, partial_off, total;
+  int Ho[MAXL], Wo[MAXL];
+  int total_chunks, nsplit;
+};
+int make_plan(const orp_dcn_bwd_level* lv, int nlevels, int batch, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+              int dw, int cus, Plan& pl) {
+  size_t cur = 0;
+  pl.total_chunks = 0;
+  for (int i = 0; i < nlevels; i++) {
+    if (lv[i].height <= 0 || lv[i].width <= 0) return ORP_EINVAL;
+    pl.Ho[i] = out_dim(lv[i].height, ph, dh, kh, sh); pl.Wo[i] = out_dim(lv[i].width, pw, dw, kw, sw);
+    if (pl.Ho[i] <= 0 || pl.Wo[i] <= 0) return ORP_EINVAL;
+    if ((long)batch * lv[i].height * lv[i].width >= (1L << 31) / CH) return ORP_ETOOBIG;
+    pl.x_off[i] = cur; cur += align256(sizeof(float) * (size_t)batch * lv[i].height * lv[i].width * CH);
+    pl.go_off[i] = cur; cur += align256(sizeof(float) * (size_t)batch * pl.Ho[i] * pl.Wo[i] * CH);
+    pl.total_chunks += (int)(((long)batch * pl.Ho[i] * pl.Wo[i] + 31) / 32);
+  }
+  pl.gx_begin = cur;
+  for (int i = 0; i < nlevels; i++) { pl.gx_off[i] = cur; cur += align256(sizeof(float) * (size_t)batch * lv[i].height * lv[i].width * CH); }
+  pl.gx_bytes = cur - pl.gx_begin;
+  pl.wT_off = cur; cur += align256(sizeof(float) * (size_t)CH * CH * kh * kw);
+  int ns = cus / (kh * kw); if (ns < 1) ns = 1;
+  if (ns > pl.total_chunks) ns = pl.total_chunks;
+  pl.nsplit = ns;
+  pl.partial_off = cur; cur += align256(sizeof(float) * (size_t)ns * kh * kw * CH * CH);
+  pl.total = cur + 256;
+  return ORP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orp_dcn_backward_mfma_ok(int c_in, int c_out, int kh, int kw, int groups, int deformable_groups) {
+  return (groups == 1 && deformable_groups == 1 && c_in == CH && c_out == CH && kh > 0 && kw > 0 && kh * kw <= MAXT) ? 1 : 0;
+}
+
+size_t orp_dcn_backward_workspace_bytes(const orp_dcn_bwd_level* levels_host, int nlevels, int batch, int kh, int kw,
+                                        int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w) {
+  if (!levels_host || nlevels <= 0 || nlevels > MAXL || batch <= 0) return 0;
+  Plan pl;
+  if (make_plan(levels_host, nlevels, batch, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, device_cus(), pl) != ORP_OK)
+    return 0;
+  return pl.total;
+}
+
+int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, int batch, int c_in, int c_out,
+                           const float* weight, float* grad_weight, int need_input_grads, int kh, int kw, int stride_h,
+                           int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (!levels_host || nlevels <= 0 || nlevels > MAXL || batch <= 0 || !weight || !workspace) return ORP_EINVAL;
+  if (!orp_dcn_backward_mfma_ok(c_in, c_out, kh, kw, 1, 1)) return ORP_EINVAL;
+  if (!grad_weight && !need_input_grads) return ORP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  Plan pl;
+  int rc = make_plan(levels_host, nlevels, batch, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, device_cus(), pl);
+  if (rc != ORP_OK) return rc;
+  if (workspace_bytes < pl.total) return ORP_EWORKSPACE;
+  char* ws = reinterpret_cast<char*>(workspace);
+  const int taps = kh * kw;
+
+  static const int force_mt = getenv("ORP_DCN_BWD_MT") ? atoi(getenv("ORP_DCN_BWD_MT")) : 0;
+  const int MT = (force_mt == 1 || force_mt == 2) ? force_mt : 2;
+  BwdParams P;
+  P.nlev = nlevels; P.B = batch;
+  P.kh = kh; P.kw = kw; P.sh = stride_h; P.sw = stride_w; P.ph = pad_h; P.pw = pad_w; P.dh = dil_h; P.dw = dil_w;
+  P.wT = reinterpret_cast<float*>(ws + pl.wT_off);
+  P.partial = reinterpret_cast<float*>(ws + pl.partial_off);
+  P.nsplit = pl.nsplit; P.total_chunks = pl.total_chunks;
+  TransposeSet TI, TO;
+  int ti = 0, tiles = 0, chunks = 0, tin = 0, tout = 0;
+  for (int i = 0; i < nlevels; i++) {
+    const orp_dcn_bwd_level& lv = levels_host[i];
+    if (!lv.input || !lv.offset || !lv.grad_output) return ORP_EINVAL;
+    if (need_input_grads && (!lv.grad_input || !lv.grad_offset)) return ORP_EINVAL;
+    BLevel& D = P.lv[i];
+    D.H = lv.height; D.W = lv.width; D.Ho = pl.Ho[i]; D.Wo = pl.Wo[i];
+    D.x = reinterpret_cast<float*>(ws + pl.x_off[i]);
+    D.go = reinterpret_cast<float*>(ws + pl.go_off[i]);
+    D.gx = reinterpret_cast<float*>(ws + pl.gx_off[i]);
+    D.off = lv.offset; D.goff = lv.grad_offset;
+    D.tile0 = tiles; D.chunk0 = chunks;
+    const long npos = (long)batch * D.Ho * D.Wo;
+    tiles += (int)((npos + 32 * MT - 1) / (32 * MT));
+    chunks += (int)((npos + 31) / 32);
+    const int HW = lv.height * lv.width, HoWo = D.Ho * D.Wo;
+    TI.in[ti] = lv.input; TI.out[ti] = const_cast<float*>(D.x); TI.R[ti] = CH; TI.S[ti] = HW; TI.t0[ti] = tin;
+    tin += ((HW + 31) / 32) * (CH / 32); ti++;
+    TI.in[ti] = lv.grad_output; TI.out[ti] = const_cast<float*>(D.go); TI.R[ti] = CH; TI.S[ti] = HoWo; TI.t0[ti] = tin;
+    tin += ((HoWo + 31) / 32) * (CH / 32); ti++;
+    TO.in[i] = D.gx; TO.out[i] = lv.grad_input; TO.R[i] = HW; TO.S[i] = CH; TO.t0[i] = tout;
+    tout += ((HW + 31) / 32) * (CH / 32);
+  }
+  for (int i = nlevels; i < MAXL; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; P.lv[i].chunk0 = 0x7fffffff; }
+  TI.n = ti; TO.n = nlevels;
+  for (int i = ti; i <= 2 * MAXL; i++) TI.t0[i] = tin;
+  for (int i = nlevels; i <= 2 * MAXL; i++) TO.t0[i] = tout;
+  for (int i = ti; i < 2 * MAXL; i++) { TI.in[i] = TI.in[0]; TI.out[i] = TI.out[0]; TI.R[i] = TI.S[i] = 0; }
+  for (int i = nlevels; i < 2 * MAXL; i++) { TO.in[i] = TO.in[0]; TO.out[i] = TO.out[0]; TO.R[i] = TO.S[i] = 0; }
+
+  OrpProfScope prof(ORP_PROF_DCN_BWD, st);
+  hipLaunchKernelGGL(transpose_set_kernel, dim3(tin, batch), dim3(256), 0, st, TI);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+
+  if (need_input_grads) {
+    e = hipMemsetAsync(ws + pl.gx_begin, 0, pl.gx_bytes, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pack_wT_kernel, dim3(1024), dim3(256), 0, st, weight, taps, const_cast<float*>(P.wT));
+    const int per = (tiles + 7) >> 3;
+    if (MT == 1) {
+      struct T1 { int unused; };
+      e = orp::set_max_dynamic_lds_once<T1>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<1>), input_smem<1>());
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(dcn_bwd_input_kernel<1>, dim3(per * 8), dim3(kThreads), input_smem<1>(), st, P, tiles);
+    } else {
+      struct T2 { int unused; };
+      e = orp::set_max_dynamic_lds_once<T2>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<2>), input_smem<2>());
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(dcn_bwd_input_kernel<2>, dim3(per * 8), dim3(kThreads), input_smem<2>(), st, P, tiles);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(transpose_set_kernel, dim3(tout, batch), dim3(256), 0, st, TO);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  if (grad_weight) {
+    struct TW { int unused; };
+    e = orp::set_max_dynamic_lds_once<TW>(reinterpret_cast<const void*>(&dcn_bwd_weight_kernel), weight_smem());
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(pl.nsplit, taps), dim3(kThreads), weight_smem(), st, P);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3(1024), dim3(256), 0, st, P.partial, pl.nsplit, taps, grad_weight);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return ORP_OK;
+}
+
+}  // extern "C"

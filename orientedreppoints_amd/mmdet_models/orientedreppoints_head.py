@@ -179,8 +179,29 @@ class OrientedRepPointsHead(nn.Module):
         pts_out_refine = pts_out_refine + pts_out_init.detach()
         return cls_out, pts_out_init, pts_out_refine, x
 
+    def forward_train_multi(self, feats):
+        """Training forward with the two DeformConvs of ALL levels as one autograd node (one pair launch forward, the MFMA
+        backward over all levels at once); per level the same operations as forward_single, in the same order."""
+        from ..mmdet_ops.deform_conv import deform_conv_pair
+        dcn_base_offset = self._base_offset_on(feats[0])
+        cls_feats, pts_feats, inits, offsets = [], [], [], []
+        for x in feats:
+            cls_feat, pts_feat, pts_out_init = self._towers(x)
+            grad_mul = (1 - self.gradient_mul) * pts_out_init.detach() + self.gradient_mul * pts_out_init
+            cls_feats.append(cls_feat); pts_feats.append(pts_feat); inits.append(pts_out_init)
+            offsets.append(grad_mul - dcn_base_offset)
+        a, b = self.reppoints_cls_conv, self.reppoints_pts_refine_conv
+        dcn_cls, dcn_pts = deform_conv_pair(cls_feats, pts_feats, offsets, a.weight, b.weight, a.stride, a.padding,
+                                            a.dilation)
+        cls_outs = [self.reppoints_cls_out(torch.relu(c)) for c in dcn_cls]
+        refines = [self.reppoints_pts_refine_out(torch.relu(p)) + init.detach() for p, init in zip(dcn_pts, inits)]
+        return cls_outs, inits, refines, list(feats)
+
     def forward(self, feats):
         if torch.is_grad_enabled():
+            from ..mmdet_ops.deform_conv import pair_autograd_ok
+            if all(pair_autograd_ok(self.reppoints_cls_conv, self.reppoints_pts_refine_conv, x) for x in feats):
+                return self.forward_train_multi(feats)
             return multi_apply(self.forward_single, feats)
         # inference: same arithmetic, but every layer covers all levels at once: the tower ConvModules run their
         # GroupNorm+ReLU as one fused HIP launch pair over the five levels, each DeformConv is ONE launch

@@ -11,5 +11,6 @@ from .chamfer_distance import ChamferDistance2D, Chamfer2D  # noqa: F401
 from .point_justify import pointsJf, points_in_quad_aligned  # noqa: F401
 from .sigmoid_focal_loss import SigmoidFocalLoss, sigmoid_focal_loss  # noqa: F401
 from .deform_conv import (DeformConv, DeformConvPack, ModulatedDeformConv, ModulatedDeformConvPack,  # noqa: F401
-                          deform_conv, modulated_deform_conv, deform_conv_forward_multi, deform_conv_forward_multi_half, deform_conv_forward_pair)
+                          deform_conv, modulated_deform_conv, deform_conv_forward_multi, deform_conv_forward_multi_half, deform_conv_forward_pair,
+                          deform_conv_pair)
 from .box_iou_rotated import box_iou_rotated  # noqa: F401

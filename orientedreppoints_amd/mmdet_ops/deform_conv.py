@@ -377,6 +377,60 @@ class ModulatedDeformConvFunction(Function):
         return (gi, go, gm, gw, gb, None, None, None, None, None)
 
 
+class DeformConvPairFunction(Function):
+    """The head's two DeformConvs (same offsets) over ALL levels as one autograd node: forward = ONE pair launch
+    (`orp_dcn_forward_pair`), backward = one `orp_dcn_backward_multi` call per layer (MFMA implicit GEMMs, every level in
+    the same launches), the two layers' offset gradients added.  Inputs after the constants: weight_a, weight_b, then
+    n inputs of layer a, n inputs of layer b, n offsets.  Returns the 2n outputs."""
+
+    @staticmethod
+    def forward(ctx, stride, padding, dilation, n, weight_a, weight_b, *tensors):
+        ctx.stride, ctx.padding, ctx.dilation, ctx.n = _pair(stride), _pair(padding), _pair(dilation), n
+        xa, xb, offs = list(tensors[:n]), list(tensors[n:2 * n]), list(tensors[2 * n:])
+        ctx.save_for_backward(weight_a, weight_b, *tensors)
+        oa, ob = deform_conv_forward_pair(xa, xb, offs, weight_a, weight_b, ctx.stride, ctx.padding, ctx.dilation)
+        return tuple(oa) + tuple(ob)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        from . import deform_conv_backward as bw
+        n = ctx.n
+        weight_a, weight_b = ctx.saved_tensors[:2]
+        tensors = ctx.saved_tensors[2:]
+        xa, xb, offs = list(tensors[:n]), list(tensors[n:2 * n]), list(tensors[2 * n:])
+        need_in = any(ctx.needs_input_grad[6:])
+        res = []
+        for w, xs, gs, wi in ((weight_a, xa, grads[:n], 4), (weight_b, xb, grads[n:], 5)):
+            gs = [g if g is not None else torch.zeros((x.size(0), w.size(0)) + tuple(o.shape[2:]), device=x.device)
+                  for g, x, o in zip(gs, xs, offs)]
+            res.append(bw.backward_mfma(xs, offs, w, gs, ctx.stride, ctx.padding, ctx.dilation, need_input=need_in,
+                                        need_weight=ctx.needs_input_grad[wi]))
+        (gia, goa, gwa), (gib, gob, gwb) = res
+        goff = [a + b for a, b in zip(goa, gob)] if need_in else [None] * n
+        if not need_in:
+            gia, gib = [None] * n, [None] * n
+        return (None, None, None, None, gwa, gwb) + tuple(gia) + tuple(gib) + tuple(goff)
+
+
+def deform_conv_pair(inputs_a, inputs_b, offsets, weight_a, weight_b, stride=1, padding=0, dilation=1):
+    """Autograd-capable pair launch over a list of levels (training path of the head): (outs_a, outs_b)."""
+    n = len(inputs_a)
+    outs = DeformConvPairFunction.apply(stride, padding, dilation, n, weight_a, weight_b, *inputs_a, *inputs_b, *offsets)
+    return list(outs[:n]), list(outs[n:])
+
+
+def pair_autograd_ok(conv_a, conv_b, x):
+    """True when the two DeformConv modules can run as one `deform_conv_pair` node on x's device / dtype."""
+    from . import deform_conv_backward as bw
+    same = (conv_a.stride == conv_b.stride and conv_a.padding == conv_b.padding and conv_a.dilation == conv_b.dilation and
+            conv_a.weight.shape == conv_b.weight.shape and conv_a.groups == conv_b.groups == 1 and
+            conv_a.deformable_groups == conv_b.deformable_groups == 1)
+    return bool(same and x.is_cuda and x.dtype == torch.float32 and conv_a.weight.size(1) % 256 == 0 and
+                fast_path_ok(conv_a.weight, 1, 1) and bw.mfma_ok(conv_a.weight, 1, 1) and
+                min(x.size(2), x.size(3)) >= conv_a.kernel_size[0])
+
+
 deform_conv = DeformConvFunction.apply
 modulated_deform_conv = ModulatedDeformConvFunction.apply
 

@@ -1,9 +1,62 @@
 """Backward of DeformConv / ModulatedDeformConv (deform_conv_backward_input_cuda, deform_conv_backward_parameters_cuda,
-modulated_deform_conv_cuda_backward; mmdet/ops/dcn/src/deform_conv_cuda.cpp:262-488, 592-685) in the column
-formulation: HIP sampling kernels (csrc/orp_dcn_bwd.hip) around two library GEMMs."""
+modulated_deform_conv_cuda_backward; mmdet/ops/dcn/src/deform_conv_cuda.cpp:262-488, 592-685).
+
+The head's configuration (256 -> 256 channels, groups = deformable_groups = 1) runs as two MFMA implicit GEMMs without any
+column buffer (csrc/orp_dcn_bwd_mfma.hip, `backward_mfma`); every other configuration uses the column formulation: HIP
+sampling kernels (csrc/orp_dcn_bwd.hip) around two library GEMMs."""
+import ctypes
+
 import torch
 
 from .. import _lib
+
+
+class _BwdLevel(ctypes.Structure):
+    _fields_ = [("input", ctypes.c_void_p), ("offset", ctypes.c_void_p), ("grad_output", ctypes.c_void_p),
+                ("grad_input", ctypes.c_void_p), ("grad_offset", ctypes.c_void_p), ("height", ctypes.c_int),
+                ("width", ctypes.c_int)]
+
+
+USE_MFMA = True          # False: force the column formulation (comparisons in tests / tools)
+
+
+def mfma_ok(weight, groups, deformable_groups):
+    if not USE_MFMA:
+        return False
+    cout, cin_g, kh, kw = weight.shape
+    return bool(_lib.lib().orp_dcn_backward_mfma_ok(cin_g * groups, cout, kh, kw, groups, deformable_groups))
+
+
+def backward_mfma(inputs, offsets, weight, grad_outputs, stride, padding, dilation, need_input=True, need_weight=True):
+    """All levels of ONE DeformConv layer in one call: lists of NCHW inputs / offsets / grad_outputs ->
+    (grad_inputs, grad_offsets, grad_weight); grad_weight is summed over the levels in a fixed order."""
+    L = _lib.lib()
+    w = weight.detach().float().contiguous()
+    cout, cin, kh, kw = w.shape
+    B = inputs[0].size(0)
+    n = len(inputs)
+    levels = (_BwdLevel * n)()
+    keep, gis, gos = [], [], []
+    for i, (x, off, go) in enumerate(zip(inputs, offsets, grad_outputs)):
+        x, off, go = x.detach().float().contiguous(), off.detach().float().contiguous(), go.detach().float().contiguous()
+        gi = torch.empty_like(x) if need_input else None
+        goff = torch.empty_like(off) if need_input else None
+        keep.append((x, off, go))
+        gis.append(gi)
+        gos.append(goff)
+        levels[i] = _BwdLevel(_lib.ptr(x), _lib.ptr(off), _lib.ptr(go), _lib.ptr(gi), _lib.ptr(goff), x.size(2), x.size(3))
+    gw = torch.empty_like(w) if need_weight else None
+    nbytes = L.orp_dcn_backward_workspace_bytes(levels, n, B, kh, kw, stride[0], stride[1], padding[0], padding[1],
+                                                dilation[0], dilation[1])
+    if nbytes == 0:
+        raise ValueError("orp_dcn_backward_workspace_bytes: invalid geometry")
+    with torch.cuda.device(w.device):
+        ws = _lib.workspace(w.device, nbytes)
+        rc = L.orp_dcn_backward_multi(levels, n, B, cin, cout, _lib.ptr(w), _lib.ptr(gw), 1 if need_input else 0, kh, kw,
+                                      stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                                      _lib.ptr(ws), nbytes, _lib.stream_of(w))
+    _lib.check(rc, "orp_dcn_backward_multi")
+    return gis, gos, gw
 
 
 def _geo(input, weight, stride, padding, dilation):
@@ -71,6 +124,9 @@ def _backward_input_nhwc(input, offset, weight, grad_output, stride, padding, di
 
 
 def backward_input(input, offset, weight, grad_output, stride, padding, dilation, groups, deformable_groups):
+    if mfma_ok(weight, groups, deformable_groups):
+        gi, go, _ = backward_mfma([input], [offset], weight, [grad_output], stride, padding, dilation, True, False)
+        return gi[0], go[0]
     input, offset, weight, grad_output = _prep(input, offset, weight, grad_output)
     if groups == 1 and deformable_groups == 1:
         return _backward_input_nhwc(input, offset, weight, grad_output, stride, padding, dilation)
@@ -80,6 +136,8 @@ def backward_input(input, offset, weight, grad_output, stride, padding, dilation
 
 
 def backward_parameters(input, offset, weight, grad_output, stride, padding, dilation, groups, deformable_groups):
+    if mfma_ok(weight, groups, deformable_groups):
+        return backward_mfma([input], [offset], weight, [grad_output], stride, padding, dilation, False, True)[2]
     input, offset, weight, grad_output = _prep(input, offset, weight, grad_output)
     col = _im2col(input, offset, None, weight, stride, padding, dilation, deformable_groups)
     return _grad_weight(col, weight, grad_output, groups)

@@ -1,0 +1,54 @@
+"""Timing of the DeformConv backward at the training configuration (2 images x 1024^2: levels 128^2 .. 8^2, 256 -> 256):
+MFMA implicit GEMMs (one call for the five levels) vs the column formulation (per level), HIP-event timed.
+    python tests/checks/time_dcn_backward.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from orientedreppoints_amd.mmdet_ops import deform_conv_backward as bw  # noqa: E402
+
+
+def timed(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+def main():
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    B = int(os.environ.get('B', 2))
+    std = float(os.environ.get('OFF_STD', 2.0))
+    xs = [torch.randn(B, 256, s, s, device=dev) for s in (128, 64, 32, 16, 8)]
+    offs = [torch.randn(B, 18, s, s, device=dev) * std for s in (128, 64, 32, 16, 8)]
+    gos = [torch.randn(B, 256, s, s, device=dev) for s in (128, 64, 32, 16, 8)]
+    w = torch.randn(256, 256, 3, 3, device=dev) * 0.05
+    args = ((1, 1), (1, 1), (1, 1))
+    t_all = timed(lambda: bw.backward_mfma(xs, offs, w, gos, *args))
+    t_in = timed(lambda: bw.backward_mfma(xs, offs, w, gos, *args, need_input=True, need_weight=False))
+    t_w = timed(lambda: bw.backward_mfma(xs, offs, w, gos, *args, need_input=False, need_weight=True))
+    bw.USE_MFMA = False
+
+    def column():
+        for x, o, g in zip(xs, offs, gos):
+            bw.backward_input(x, o, w, g, *args, 1, 1)
+            bw.backward_parameters(x, o, w, g, *args, 1, 1)
+    t_col = timed(column)
+    npos = sum(B * s * s for s in (128, 64, 32, 16, 8))
+    fl = 2.0 * npos * 2304 * 256
+    print("positions %d  mfma all %.1f us (input %.1f us = %.1f TF/s, weight %.1f us = %.1f TF/s)   column formulation %.1f us"
+          % (npos, t_all, t_in, fl / t_in * 1e-6, t_w, fl / t_w * 1e-6, t_col))
+
+
+if __name__ == '__main__':
+    main()

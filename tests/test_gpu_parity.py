@@ -814,6 +814,96 @@ def test_dcn_backward(dev, oracle):
     assert torch.isfinite(x2.grad).all() and torch.isfinite(off2.grad).all() and torch.isfinite(w2.grad).all()
 
 
+def test_dcn_backward_mfma_vs_oracle(dev, oracle):
+    """orp_dcn_backward_multi (two MFMA implicit GEMMs, no column buffer; deform_conv_cuda.cpp:262-488) against the oracle's
+    column formulation (pinned to the reference's col2im / col2im_coord kernels in tests/test_oracle_vs_ref.py): <= 1e-4
+    of each gradient's scale.  Multi-level call incl. offsets far outside the map, tiles that straddle images, and the
+    autograd route (DeformConvFunction.backward) at the head's 256 -> 256 channels."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv, deform_conv_backward as bw
+    shapes = [(10, 12), (7, 9), (3, 3), (1, 2)]
+    cases = [_dcn_case(20 + i, 2, 256, h, w, 256, std_off=(2.0 if i != 1 else 6.0)) for i, (h, w) in enumerate(shapes)]
+    w = cases[0][2]
+    gos = [np.random.RandomState(30 + i).normal(size=(2, 256, h, ww)).astype(np.float32) for i, (h, ww) in enumerate(shapes)]
+    assert bw.mfma_ok(_t(w, dev), 1, 1)
+    gis, goffs, gw = bw.backward_mfma([_t(c[0], dev) for c in cases], [_t(c[1], dev) for c in cases], _t(w, dev),
+                                      [_t(g, dev) for g in gos], (1, 1), (1, 1), (1, 1))
+    want_gw = np.zeros_like(w)
+    for c, g, gi, goff in zip(cases, gos, gis, goffs):
+        wi, woff, wgw = oracle.dcn_backward(c[0], c[1], w, g)
+        want_gw += wgw
+        assert _rel_err(gi.cpu().numpy(), wi) <= 1e-4
+        assert _rel_err(goff.cpu().numpy(), woff) <= 1e-4
+    assert _rel_err(gw.cpu().numpy(), want_gw) <= 1e-4
+    # deterministic: the same call twice gives the same grad_weight bits (fixed-order split reduction)
+    gw2 = bw.backward_mfma([_t(c[0], dev) for c in cases], [_t(c[1], dev) for c in cases], _t(w, dev),
+                           [_t(g, dev) for g in gos], (1, 1), (1, 1), (1, 1), need_input=False)[2]
+    assert torch.equal(gw, gw2)
+    # autograd route, and agreement with the column formulation at a larger map
+    x, off, w2 = _dcn_case(41, 2, 256, 32, 32, 256, std_off=3.0)
+    go = np.random.RandomState(42).normal(size=(2, 256, 32, 32)).astype(np.float32)
+    grads = {}
+    for use in (True, False):
+        bw.USE_MFMA = use
+        try:
+            tx, toff, tw = (_t(a, dev).requires_grad_(True) for a in (x, off, w2))
+            deform_conv(tx, toff, tw, 1, 1, 1, 1, 1, 64).backward(_t(go, dev))
+            grads[use] = [t.grad.cpu().numpy() for t in (tx, toff, tw)]
+        finally:
+            bw.USE_MFMA = True
+    for a, b in zip(grads[True], grads[False]):
+        assert _rel_err(a, b) <= 1e-4
+    wi, woff, wgw = oracle.dcn_backward(x, off, w2, go)
+    for a, b in zip(grads[True], (wi, woff, wgw)):
+        assert _rel_err(a, b) <= 1e-4
+
+
+def test_head_training_forward_all_levels_as_one_dcn_node(dev):
+    """Training forward of the head with both DeformConvs of all levels as ONE autograd node (pair launch forward, MFMA
+    backward over all levels) == the per-level forward_single route on the column-formulation backward: outputs equal,
+    every parameter gradient and the input gradients within 1e-4 of their scale."""
+    from orientedreppoints_amd.dota_configs import r50_model
+    from orientedreppoints_amd.mmdet_models import ConfigDict, build_head
+    from orientedreppoints_amd.mmdet_models.orientedreppoints_head import multi_apply
+    from orientedreppoints_amd.mmdet_ops import deform_conv_backward as bw
+    torch.manual_seed(3)
+    cfg = dict(r50_model['bbox_head'])
+    head = build_head(ConfigDict(cfg)).to(dev)
+    head.init_weights()
+    head.train()
+    with torch.no_grad():
+        head.reppoints_pts_init_out.weight.normal_(0, 0.05)          # offsets of a few pixels, some outside the small maps
+    feats0 = [torch.randn(2, 256, s, s, device=dev) for s in (24, 12, 6, 3)]
+    seeds = None
+    results = {}
+    for route in ("multi", "single"):
+        head.zero_grad()
+        feats = [f.clone().requires_grad_(True) for f in feats0]
+        if route == "multi":
+            outs = head.forward(feats)
+        else:
+            bw.USE_MFMA = False
+            outs = multi_apply(head.forward_single, feats)
+        if seeds is None:
+            seeds = [[torch.randn_like(o) for o in outs[k]] for k in range(3)]
+        try:
+            loss = sum((o * s_).sum() for k in range(3) for o, s_ in zip(outs[k], seeds[k]))
+            loss.backward()
+        finally:
+            bw.USE_MFMA = True
+        results[route] = ([o.detach().clone() for k in range(3) for o in outs[k]],
+                          {n: p.grad.detach().clone() for n, p in head.named_parameters() if p.grad is not None},
+                          [f.grad.detach().clone() for f in feats])
+    om, gm, fm = results["multi"]
+    os_, gs, fs = results["single"]
+    for a, b in zip(om, os_):
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+    assert set(gm) == set(gs) and 'reppoints_cls_conv.weight' in gm and 'reppoints_pts_refine_conv.weight' in gm
+    for n in gm:
+        assert float((gm[n] - gs[n]).abs().max()) <= 1e-4 * max(1e-6, float(gs[n].abs().max())), n
+    for a, b in zip(fm, fs):
+        assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(b.abs().max()))
+
+
 # ---- end to end: one training step of the detector ---------------------------------------------------------------------
 def test_detector_train_step_and_inference(dev):
     from orientedreppoints_amd.dota_configs import r50_model, train_cfg, test_cfg
