@@ -21,6 +21,16 @@
 //
 // Inputs arrive NCHW (autograd); x and grad_out are transposed to NHWC in the workspace, grad_input is accumulated NHWC
 // and transposed back.
+//
+// Row sparsity: a detection head's regression branch only receives gradient at its positive points (a few hundred of the
+// 43 648 positions of two 1024^2 images), so most grad_out rows are exactly zero.  The transposition pass records which
+// 32-position chunks hold any non-zero value, an ordered compaction turns the flags into the list of ACTIVE chunks, and
+// both kernels walk that list only (dense gradients: the list is the identity).  Deterministic: the list is in chunk order.
+//
+// Measured and rejected for kernel A (round 2, tests/checks/atomic_rate.hip and the ORP_BWD_DBG switches): pre-accumulating
+// grad_input in LDS rows found through a per-tile hash table.  An fp32 global atomic costs one L2-channel clock per LANE
+// (313 G lane-atomics/s, agent and workgroup scope alike) -- but ds_add_f32 ran at the same ~310 G lanes/s on this part,
+// and the 112 KB of rows cut the occupancy from three workgroups per CU to one: 2.56 ms vs 1.40 ms without.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -61,6 +71,7 @@ struct BwdParams {
   const float* wT;     // [tap][o/4][c][4]
   float* partial;      // [nsplit][tap][o][c]
   int nsplit, total_chunks;
+  const int* active;   // [total_chunks] chunk indices with a non-zero grad_out row, ascending; active[total_chunks] = count
 };
 
 inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -72,7 +83,9 @@ struct TransposeSet {
   float* out[2 * MAXL];
   int R[2 * MAXL], S[2 * MAXL];
   int t0[2 * MAXL + 1];
+  int chunk0[2 * MAXL];          // >= 0: tensor i is a grad_out [256][HoWo]; flags[chunk0 + (b*S + s) / 32] = 1 where non-zero
   int n;
+  int* flags;
 };
 __global__ void transpose_set_kernel(const TransposeSet T) {
   __shared__ float tile[32][33];
@@ -91,10 +104,41 @@ __global__ void transpose_set_kernel(const TransposeSet T) {
     tile[k][tx] = (r < R && s < S) ? src[(size_t)r * S + s] : 0.f;
   }
   __syncthreads();
+  const int c0 = T.chunk0[i];
   for (int k = ty; k < 32; k += 8) {
     const int s = s0 + k, r = r0 + tx;
-    if (s < S && r < R) dst[(size_t)s * R + r] = tile[tx][k];
+    const float v = tile[tx][k];
+    if (s < S && r < R) dst[(size_t)s * R + r] = v;
+    if (c0 >= 0) {                                                  // lanes 0-31 / 32-63 of a wave = 32 channels of ONE position
+      const unsigned long long nz = __ballot(v != 0.f);
+      const bool mine = (threadIdx.x & 32) ? (nz >> 32) != 0 : (nz & 0xffffffffull) != 0;
+      if (mine && tx == 0 && s < S) T.flags[c0 + (int)(((long)blockIdx.y * S + s) >> 5)] = 1;
+    }
   }
+}
+
+// flags[n] -> ascending list of the set indices, list[n] = count (one workgroup; n is a few thousand)
+__global__ void __launch_bounds__(1024) compact_flags_kernel(const int* __restrict__ flags, int n, int* __restrict__ list) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    const bool f = i < n && flags[i] != 0;
+    const unsigned long long m = __ballot(f);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    if (f) list[off + before] = i;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < 16; w++) t += wsum[w]; base += t; }
+    __syncthreads();
+  }
+  if (tid == 0) list[n] = base;
 }
 
 // w [o][c][tap] -> wT [tap][o/4][c][4]
@@ -156,23 +200,29 @@ __device__ inline float half_wave_sum(float v) {
 }
 
 // ---- kernel A: grad_input + grad_offset ---------------------------------------------------------------------------
+// One tile = one 32-position chunk (MT = 1: three workgroups per CU hide the epilogue's load / atomic latency; two
+// sub-tiles per workgroup measured 5 % slower).
 template <int MT>
 __global__ void __launch_bounds__(kThreads)
-dcn_bwd_input_kernel(const BwdParams P, int total_tiles) {
+dcn_bwd_input_kernel(const BwdParams P) {
   constexpr int BM2 = 32 * MT;
+  static_assert(MT == 1, "the active-chunk list is in units of 32 positions");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sG = reinterpret_cast<float*>(smem);                       // [BM2][ASTR] grad_out rows
   int4* sCi = reinterpret_cast<int4*>(sG + BM2 * ASTR);             // [BM2 * taps]
   float2* sCl = reinterpret_cast<float2*>(sCi + BM2 * MAXT);        // [BM2 * taps] (lh, lw)
   float* sGO = reinterpret_cast<float*>(sCl + BM2 * MAXT);          // [BM2][taps][2] grad_offset of the tile
+  int* sNZ = reinterpret_cast<int*>(sGO + BM2 * MAXT * 2);          // [BM2] row has a non-zero grad_out value
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int taps = P.kh * P.kw;
   int tile;
   {
-    const int b = blockIdx.x, per = (total_tiles + 7) >> 3;         // XCD x takes the contiguous tiles [x*per, (x+1)*per)
-    tile = (b & 7) * per + (b >> 3);
-    if (tile >= total_tiles) return;
+    const int n_active = P.active[P.total_chunks];
+    const int b = blockIdx.x, per = (n_active + 7) >> 3;            // XCD x takes the contiguous active tiles [x*per, (x+1)*per)
+    const int idx = (b & 7) * per + (b >> 3);
+    if ((b >> 3) >= per || idx >= n_active) return;
+    tile = P.active[idx];
   }
   int lvl = 0;
 #pragma unroll 1
@@ -194,6 +244,8 @@ dcn_bwd_input_kernel(const BwdParams P, int total_tiles) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p0 + r < npos) v = *reinterpret_cast<const float4*>(L.go + (size_t)(p0 + r) * CH + lane * 4);
     *reinterpret_cast<float4*>(sG + (size_t)r * ASTR + lane * 4) = v;
+    const unsigned long long nz = __ballot((v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f));
+    if (lane == 0) sNZ[r] = nz != 0;
   }
   __syncthreads();
 
@@ -243,7 +295,9 @@ dcn_bwd_input_kernel(const BwdParams P, int total_tiles) {
       for (int r = 0; r < 16; r++) {
         const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         const int e = m * taps + tap;
-        const int4 ix = sCi[e];
+        const bool live = sNZ[m] != 0;                              // a zero grad_out row gives G = 0: nothing to add
+        if (__ballot(live) == 0) continue;
+        const int4 ix = live ? sCi[e] : make_int4(-1, -1, -1, -1);
         const float2 fr = sCl[e];
         const float g = acc[mt][r];
         const float lh = fr.x, lw = fr.y, uh = 1.f - lh, uw = 1.f - lw;
@@ -283,7 +337,8 @@ dcn_bwd_input_kernel(const BwdParams P, int total_tiles) {
 
 template <int MT>
 size_t input_smem() {
-  return sizeof(float) * (size_t)32 * MT * ASTR + (sizeof(int4) + sizeof(float2) + 2 * sizeof(float)) * 32 * MT * MAXT;
+  return sizeof(float) * (size_t)32 * MT * ASTR + (sizeof(int4) + sizeof(float2) + 2 * sizeof(float)) * 32 * MT * MAXT +
+         sizeof(int) * 32 * MT;
 }
 
 // ---- kernel B: grad_weight partial sums ---------------------------------------------------------------------------------
@@ -298,9 +353,10 @@ dcn_bwd_weight_kernel(const BwdParams P) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int taps = P.kh * P.kw, tap = blockIdx.y;
-  const int per = (P.total_chunks + P.nsplit - 1) / P.nsplit;
+  const int n_active = P.active[P.total_chunks];                    // this split walks active[c_begin, c_end)
+  const int per = (n_active + P.nsplit - 1) / P.nsplit;
   const int c_begin = blockIdx.x * per;
-  const int c_end = (c_begin + per < P.total_chunks) ? c_begin + per : P.total_chunks;
+  const int c_end = (c_begin + per < n_active) ? c_begin + per : n_active;
 
   auto level_of = [&](int chunk) {
     int lvl = 0;
@@ -308,7 +364,8 @@ dcn_bwd_weight_kernel(const BwdParams P) {
     for (int i = 1; i < P.nlev; i++) if (chunk >= P.lv[i].chunk0) lvl = i;
     return lvl;
   };
-  auto make_coef = [&](int chunk, int buf) {                         // threads 0..31
+  auto make_coef = [&](int ci, int buf) {                            // threads 0..31; ci indexes the active list
+    const int chunk = P.active[ci];
     const BLevel& L = P.lv[level_of(chunk)];
     const int HoWo = L.Ho * L.Wo;
     const long p = (long)(chunk - L.chunk0) * 32 + tid;
@@ -326,8 +383,8 @@ dcn_bwd_weight_kernel(const BwdParams P) {
     }
     sCw[buf * 32 + tid] = w; sCi[buf * 32 + tid] = ixc; sRow[buf * 32 + tid] = row;
   };
-  auto gather_issue = [&](int chunk, int buf, int row, float4 (&g)[4], float4& gr) {
-    const BLevel& L = P.lv[level_of(chunk)];
+  auto gather_issue = [&](int ci, int buf, int row, float4 (&g)[4], float4& gr) {
+    const BLevel& L = P.lv[level_of(P.active[ci])];
     const int4 ix = sCi[buf * 32 + row];
     const long prow = sRow[buf * 32 + row];
     const float* base = L.x + lane * 4;
@@ -436,7 +493,7 @@ int device_cus() {
 
 struct Plan {
   size_t x_off[MAXL], go_off[MAXL], gx_off[MAXL];
-  size_t gx_begin, gx_bytes, wT_off, partial_off, total;
+  size_t gx_begin, gx_bytes, wT_off, partial_off, flags_off, list_off, total;
   int Ho[MAXL], Wo[MAXL];
   int total_chunks, nsplit;
 };
@@ -461,6 +518,8 @@ int make_plan(const orp_dcn_bwd_level* lv, int nlevels, int batch, int kh, int k
   if (ns > pl.total_chunks) ns = pl.total_chunks;
   pl.nsplit = ns;
   pl.partial_off = cur; cur += align256(sizeof(float) * (size_t)ns * kh * kw * CH * CH);
+  pl.flags_off = cur; cur += align256(sizeof(int) * (size_t)pl.total_chunks);
+  pl.list_off = cur; cur += align256(sizeof(int) * ((size_t)pl.total_chunks + 1));
   pl.total = cur + 256;
   return ORP_OK;
 }
@@ -497,14 +556,15 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
   char* ws = reinterpret_cast<char*>(workspace);
   const int taps = kh * kw;
 
-  static const int force_mt = getenv("ORP_DCN_BWD_MT") ? atoi(getenv("ORP_DCN_BWD_MT")) : 0;
-  const int MT = (force_mt == 1 || force_mt == 2) ? force_mt : 2;
+  constexpr int MT = 1;
   BwdParams P;
   P.nlev = nlevels; P.B = batch;
   P.kh = kh; P.kw = kw; P.sh = stride_h; P.sw = stride_w; P.ph = pad_h; P.pw = pad_w; P.dh = dil_h; P.dw = dil_w;
   P.wT = reinterpret_cast<float*>(ws + pl.wT_off);
   P.partial = reinterpret_cast<float*>(ws + pl.partial_off);
   P.nsplit = pl.nsplit; P.total_chunks = pl.total_chunks;
+  int* flags = reinterpret_cast<int*>(ws + pl.flags_off);
+  P.active = reinterpret_cast<int*>(ws + pl.list_off);
   TransposeSet TI, TO;
   int ti = 0, tiles = 0, chunks = 0, tin = 0, tout = 0;
   for (int i = 0; i < nlevels; i++) {
@@ -523,40 +583,44 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
     chunks += (int)((npos + 31) / 32);
     const int HW = lv.height * lv.width, HoWo = D.Ho * D.Wo;
     TI.in[ti] = lv.input; TI.out[ti] = const_cast<float*>(D.x); TI.R[ti] = CH; TI.S[ti] = HW; TI.t0[ti] = tin;
+    TI.chunk0[ti] = -1;
     tin += ((HW + 31) / 32) * (CH / 32); ti++;
     TI.in[ti] = lv.grad_output; TI.out[ti] = const_cast<float*>(D.go); TI.R[ti] = CH; TI.S[ti] = HoWo; TI.t0[ti] = tin;
+    TI.chunk0[ti] = D.chunk0;
     tin += ((HoWo + 31) / 32) * (CH / 32); ti++;
-    TO.in[i] = D.gx; TO.out[i] = lv.grad_input; TO.R[i] = HW; TO.S[i] = CH; TO.t0[i] = tout;
+    TO.in[i] = D.gx; TO.out[i] = lv.grad_input; TO.R[i] = HW; TO.S[i] = CH; TO.t0[i] = tout; TO.chunk0[i] = -1;
     tout += ((HW + 31) / 32) * (CH / 32);
   }
   for (int i = nlevels; i < MAXL; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; P.lv[i].chunk0 = 0x7fffffff; }
   TI.n = ti; TO.n = nlevels;
   for (int i = ti; i <= 2 * MAXL; i++) TI.t0[i] = tin;
   for (int i = nlevels; i <= 2 * MAXL; i++) TO.t0[i] = tout;
-  for (int i = ti; i < 2 * MAXL; i++) { TI.in[i] = TI.in[0]; TI.out[i] = TI.out[0]; TI.R[i] = TI.S[i] = 0; }
-  for (int i = nlevels; i < 2 * MAXL; i++) { TO.in[i] = TO.in[0]; TO.out[i] = TO.out[0]; TO.R[i] = TO.S[i] = 0; }
+  for (int i = ti; i < 2 * MAXL; i++) { TI.in[i] = TI.in[0]; TI.out[i] = TI.out[0]; TI.R[i] = TI.S[i] = 0; TI.chunk0[i] = -1; }
+  for (int i = nlevels; i < 2 * MAXL; i++) { TO.in[i] = TO.in[0]; TO.out[i] = TO.out[0]; TO.R[i] = TO.S[i] = 0; TO.chunk0[i] = -1; }
+  TI.flags = flags; TO.flags = flags;
 
   OrpProfScope prof(ORP_PROF_DCN_BWD, st);
+  hipError_t e = hipMemsetAsync(flags, 0, sizeof(int) * (size_t)pl.total_chunks, st);
+  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(transpose_set_kernel, dim3(tin, batch), dim3(256), 0, st, TI);
-  hipError_t e = hipGetLastError();
+  hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, st, flags, pl.total_chunks, const_cast<int*>(P.active));
+  e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
 
   if (need_input_grads) {
     e = hipMemsetAsync(ws + pl.gx_begin, 0, pl.gx_bytes, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pack_wT_kernel, dim3(1024), dim3(256), 0, st, weight, taps, const_cast<float*>(P.wT));
-    const int per = (tiles + 7) >> 3;
-    if (MT == 1) {
-      struct T1 { int unused; };
-      e = orp::set_max_dynamic_lds_once<T1>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<1>), input_smem<1>());
+    // grad_offset of the chunks that are skipped is zero
+    for (int i = 0; i < nlevels; i++) {
+      e = hipMemsetAsync(levels_host[i].grad_offset, 0, sizeof(float) * (size_t)batch * 2 * taps * pl.Ho[i] * pl.Wo[i], st);
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(dcn_bwd_input_kernel<1>, dim3(per * 8), dim3(kThreads), input_smem<1>(), st, P, tiles);
-    } else {
-      struct T2 { int unused; };
-      e = orp::set_max_dynamic_lds_once<T2>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<2>), input_smem<2>());
-      if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(dcn_bwd_input_kernel<2>, dim3(per * 8), dim3(kThreads), input_smem<2>(), st, P, tiles);
     }
+    const int per = (tiles + 7) >> 3;
+    struct T1 { int unused; };
+    e = orp::set_max_dynamic_lds_once<T1>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT>), input_smem<MT>());
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dcn_bwd_input_kernel<MT>, dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(transpose_set_kernel, dim3(tout, batch), dim3(256), 0, st, TO);

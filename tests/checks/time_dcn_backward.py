@@ -32,6 +32,18 @@ def main():
     xs = [torch.randn(B, 256, s, s, device=dev) for s in (128, 64, 32, 16, 8)]
     offs = [torch.randn(B, 18, s, s, device=dev) * std for s in (128, 64, 32, 16, 8)]
     gos = [torch.randn(B, 256, s, s, device=dev) for s in (128, 64, 32, 16, 8)]
+    positives = int(os.environ.get('POSITIVES', 0))          # > 0: only that many clustered positions per level keep a gradient
+    if positives:
+        for g in gos:
+            s_ = g.size(2)
+            keep = torch.zeros(B, 1, s_, s_, device=dev)
+            n_obj = max(1, min(positives, s_ * s_) // 9)
+            cy = torch.randint(1, max(2, s_ - 1), (B, n_obj))
+            cx = torch.randint(1, max(2, s_ - 1), (B, n_obj))
+            for b in range(B):
+                for y, x_ in zip(cy[b].tolist(), cx[b].tolist()):
+                    keep[b, 0, max(0, y - 1):y + 2, max(0, x_ - 1):x_ + 2] = 1.0
+            g.mul_(keep)
     w = torch.randn(256, 256, 3, 3, device=dev) * 0.05
     args = ((1, 1), (1, 1), (1, 1))
     t_all = timed(lambda: bw.backward_mfma(xs, offs, w, gos, *args))

@@ -824,6 +824,12 @@ def test_dcn_backward_mfma_vs_oracle(dev, oracle):
     cases = [_dcn_case(20 + i, 2, 256, h, w, 256, std_off=(2.0 if i != 1 else 6.0)) for i, (h, w) in enumerate(shapes)]
     w = cases[0][2]
     gos = [np.random.RandomState(30 + i).normal(size=(2, 256, h, ww)).astype(np.float32) for i, (h, ww) in enumerate(shapes)]
+    # a regression branch only has gradient at its positive points: level 0 keeps three non-zero positions (two of them
+    # in one 32-position chunk, one in the second image), level 2 is all zero -> chunks skipped through the active list
+    keep = np.zeros((2, 1, 10, 12), np.float32)
+    keep[0, 0, 2, 3] = keep[0, 0, 2, 9] = keep[1, 0, 7, 11] = 1.0
+    gos[0] *= keep
+    gos[2] *= 0.0
     assert bw.mfma_ok(_t(w, dev), 1, 1)
     gis, goffs, gw = bw.backward_mfma([_t(c[0], dev) for c in cases], [_t(c[1], dev) for c in cases], _t(w, dev),
                                       [_t(g, dev) for g in gos], (1, 1), (1, 1), (1, 1))
@@ -833,6 +839,8 @@ def test_dcn_backward_mfma_vs_oracle(dev, oracle):
         want_gw += wgw
         assert _rel_err(gi.cpu().numpy(), wi) <= 1e-4
         assert _rel_err(goff.cpu().numpy(), woff) <= 1e-4
+        if not g.any():
+            assert not gi.any() and not goff.any()
     assert _rel_err(gw.cpu().numpy(), want_gw) <= 1e-4
     # deterministic: the same call twice gives the same grad_weight bits (fixed-order split reduction)
     gw2 = bw.backward_mfma([_t(c[0], dev) for c in cases], [_t(c[1], dev) for c in cases], _t(w, dev),
