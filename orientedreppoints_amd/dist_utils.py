@@ -60,23 +60,149 @@ def allreduce_grads(params, coalesce=True, bucket_size_mb=-1):
             dist.all_reduce(tensor.div_(world_size))
 
 
-class DistOptimizerHook(object):
-    """zero_grad -> backward -> (all-reduce unless the model is DDP-wrapped) -> clip -> step."""
+class OverlappedGradientReducer(object):
+    """Bucketed gradient averaging that runs WHILE backward is still producing gradients (the role of the DDP wrapper in
+    mmdet/apis/train.py:137-141), sized for MI355X: xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring
+    all-reduce is per-link bound and wants few, large messages -- 32 MB buckets: R-50's ~146 MB of fp32 gradients are
+    5 collectives, each long enough to stay bandwidth-bound, the first issued after the head's backward.
 
-    def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1, ddp_wrapped=False):
+    * every bucket is ONE flat buffer; `param.grad` are views into it, so nothing is copied before or after a collective;
+    * parameters are bucketed in reverse registration order (~ the order backward produces them); a per-parameter
+      post-accumulate hook counts arrivals, a complete bucket is pre-divided by the world size and all-reduced with
+      async_op=True (RCCL's own stream: it overlaps the rest of backward);
+    * buckets are ALWAYS issued in index order and `finish()` issues whatever is left (parameters that took no part in
+      this iteration on this rank contribute zeros), so every rank issues the same sequence of collectives even when
+      their autograd graphs differ (an image without positives)."""
+
+    def __init__(self, params, bucket_cap_mb=32):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        cap = int(bucket_cap_mb * 1024 * 1024)
+        self.buckets = []                                 # dicts: flat, params, pending, launched, handle
+        cur, cur_bytes, key = [], 0, None
+        for p in reversed(self.params):
+            k = (p.dtype, p.device)
+            nbytes = p.numel() * p.element_size()
+            if cur and (k != key or cur_bytes + nbytes > cap):
+                self._close(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+            key = k
+        if cur:
+            self._close(cur)
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b['params']:
+                self._bucket_of[id(p)] = bi
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._next = 0
+        self.zero_grad()
+
+    def _close(self, plist):
+        flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
+        self.buckets.append(dict(flat=flat, params=list(plist), pending=0, ready=False, handle=None))
+
+    def zero_grad(self):
+        """Zero the flat buffers and (re)attach the gradient views; call instead of optimizer.zero_grad()."""
+        for b in self.buckets:
+            b['flat'].zero_()
+            off = 0
+            for p in b['params']:
+                p.grad = b['flat'][off:off + p.numel()].view_as(p)
+                off += p.numel()
+            b['pending'], b['ready'], b['handle'] = len(b['params']), False, None
+        self._next = 0
+        self._used = set()
+
+    def _launch_ready(self):
+        while self._next < len(self.buckets) and self.buckets[self._next]['ready']:
+            b = self.buckets[self._next]
+            if self.world > 1:
+                b['flat'].div_(self.world)
+                b['handle'] = dist.all_reduce(b['flat'], async_op=True)
+            self._next += 1
+
+    def _on_grad(self, p):
+        b = self.buckets[self._bucket_of[id(p)]]
+        if p.grad.data_ptr() != b['flat'].data_ptr() + self._offset_bytes(b, p):    # autograd replaced the view: copy back
+            self._reattach(b, p)
+        self._used.add(id(p))
+        b['pending'] -= 1
+        if b['pending'] == 0:
+            b['ready'] = True
+            self._launch_ready()
+
+    @staticmethod
+    def _offset_bytes(b, p):
+        off = 0
+        for q in b['params']:
+            if q is p:
+                return off * p.element_size()
+            off += q.numel()
+        raise KeyError
+
+    def _reattach(self, b, p):
+        off = self._offset_bytes(b, p) // p.element_size()
+        view = b['flat'][off:off + p.numel()].view_as(p)
+        view.copy_(p.grad)
+        p.grad = view
+
+    def finish(self):
+        """Issue the buckets backward did not complete (unused parameters), then wait for every collective."""
+        for b in self.buckets:
+            b['ready'] = True
+        self._launch_ready()
+        for b in self.buckets:
+            if b['handle'] is not None:
+                b['handle'].wait()
+                b['handle'] = None
+        # a parameter no rank produced a gradient for keeps grad = None, as after a plain backward (the optimizer then
+        # skips it: no momentum / weight-decay step); one small MAX all-reduce of the "used" bitmap decides
+        used = torch.tensor([1.0 if id(p) in self._used else 0.0 for p in self.params], device=self.params[0].device)
+        if self.world > 1:
+            dist.all_reduce(used, op=dist.ReduceOp.MAX)
+        for p, u in zip(self.params, used.tolist()):
+            if u == 0.0:
+                p.grad = None
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+class DistOptimizerHook(object):
+    """zero_grad -> backward -> (all-reduce unless the model is DDP-wrapped) -> clip -> step.
+    overlap=True: the all-reduce runs bucket by bucket during backward (OverlappedGradientReducer)."""
+
+    def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1, ddp_wrapped=False, overlap=False):
         self.grad_clip = grad_clip
         self.coalesce = coalesce
         self.bucket_size_mb = bucket_size_mb
         self.ddp_wrapped = ddp_wrapped
+        self.overlap = overlap
+        self._reducer = None
 
     def clip_grads(self, params):
         return clip_grad.clip_grad_norm_(filter(lambda p: p.requires_grad and p.grad is not None, params),
                                          **self.grad_clip)
 
     def after_train_iter(self, model, optimizer, loss):
+        _, world = get_dist_info()
+        if self.overlap and world > 1 and not self.ddp_wrapped:
+            if self._reducer is None:
+                self._reducer = OverlappedGradientReducer(model.parameters(),
+                                                          self.bucket_size_mb if self.bucket_size_mb > 0 else 32)
+            self._reducer.zero_grad()
+            loss.backward()
+            self._reducer.finish()
+            if self.grad_clip is not None:
+                self.clip_grads(list(model.parameters()))
+            optimizer.step()
+            return
         optimizer.zero_grad()
         loss.backward()
-        _, world = get_dist_info()
         if world > 1 and not self.ddp_wrapped:
             allreduce_grads(model.parameters(), self.coalesce, self.bucket_size_mb)
         if self.grad_clip is not None:

@@ -73,6 +73,76 @@ def test_two_rank_gradient_allreduce_and_sharding():
     assert tmax0 == tmax1 == 2.0
 
 
+def _overlap_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from orientedreppoints_amd import dist_utils as D
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    D.init_dist(backend='gloo')
+
+    class Net(torch.nn.Module):                            # a head that only some ranks use: different autograd graphs
+        def __init__(self):
+            super().__init__()
+            self.stem = torch.nn.Conv2d(3, 8, 3, padding=1)
+            self.body = torch.nn.Sequential(torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1))
+            self.head_a = torch.nn.Conv2d(8, 2, 1)
+            self.head_b = torch.nn.Conv2d(8, 2, 1)
+            self.unused = torch.nn.Parameter(torch.ones(5))
+
+        def forward(self, img, use_b):
+            f = self.body(torch.relu(self.stem(img)))
+            loss = self.head_a(f).pow(2).mean()
+            if use_b:
+                loss = loss + self.head_b(f).abs().mean()
+            return {'loss_cls': loss}
+
+    results = {}
+    # 'plain' / 'overlap': the same graphs on both ranks (the reference-style path needs that); 'ragged': overlap only,
+    # rank 1 skips head_b in two of the three iterations
+    for mode in ('plain', 'overlap', 'ragged'):
+        torch.manual_seed(0)
+        net = Net()
+        opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+        hook = D.DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2), overlap=(mode != 'plain'), bucket_size_mb=0.001)
+        g = torch.Generator().manual_seed(100 + rank)
+        for it in range(3):
+            x = torch.randn(2, 3, 8, 8, generator=g)
+            use_b = (it == 1) if mode != 'ragged' else (rank == 0 or it == 1)
+            D.train_step(net, opt, dict(img=x, use_b=use_b), hook)
+        results[mode] = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        if mode == 'overlap':
+            nb = len(hook._reducer.buckets)
+    same = True
+    for mode in ('overlap', 'ragged'):
+        flat = results[mode]
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        same = same and bool(torch.equal(gathered[0], gathered[1]))
+    q.put((rank, float((results['plain'] - results['overlap']).abs().max()), same, nb))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucketed_allreduce_matches_the_plain_path():
+    """OverlappedGradientReducer (async bucketed all-reduce from grad hooks, issued in a fixed order) == the reference-style
+    all-reduce after backward, over three SGD steps, with a parameter that never gets a gradient and a head that only one
+    rank uses in some iterations (the ranks' autograd graphs differ; the collectives must still match up)."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, diff, same, nb in out:
+        assert diff <= 1e-6 and same and nb >= 3
+
+
 def test_shard_indices_padding():
     from orientedreppoints_amd.dist_utils import shard_indices
     parts = [shard_indices(7, r, 4, seed=1, samples_per_gpu=2) for r in range(4)]
