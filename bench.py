@@ -513,7 +513,7 @@ def main_train(args):
         'config': {'workload': 'BASELINE configs[2]: train step, %d img/GPU x %d gts, %dx%d, 15 classes'
                                % (batch, args.gts, IMG, IMG),
                    'imgs_per_gpu': batch, 'gts_per_image': args.gts,
-                   'parallelism': 'dp%d (image-parallel, coalesced gradient all-reduce)' % world},
+                   'parallelism': 'dp%d (image-parallel, bucketed gradient all-reduce overlapped with backward)' % world},
         'loss': round(float(log_vars['loss']), 4),
         'hip_events_ms_per_step': {k: (round(v[0] / args.steps, 3) if v[1] else None) for k, v in prof.items()},
     }
