@@ -323,6 +323,11 @@ int orp_conv3x3_small_multi_ex(const orp_norm_level* levels_host, const float* c
  * get_bboxes_single (orientedreppoints_head.py:707-779), multiclass_rnms (bbox_nms.py:93-182) and rbbox2result
  * (transforms.py:356-375) with fixed-shape, stream-ordered kernels -- no host synchronisation, hipGraph-capturable.
  * All pointers are device pointers unless named *_host.
+ *   orp_pp_select : the candidate list itself (head :730-737: `scores.max(dim=1)`, `max_scores.topk(nms_pre)` per level):
+ *     sig_all [num_classes, n] sigmoid scores of all levels; per level with more than nms_pre points the nms_pre points
+ *     with the highest class-maximum score in DESCENDING score order (exact ties: ascending index), other levels in grid
+ *     order; cand [sum_l min(n_l, nms_pre)] int64 global point indices.  nms_pre <= 4096; scratch:
+ *     orp_pp_select_scratch_bytes(n, nms_pre, nlevels) bytes.
  *   orp_pp_gather : cand [m0] int64 = global point indices (levels concatenated, row-major inside a level) of the
  *     candidates in the reference's order; pts_all [18, n] = the refine offsets of all levels, (y,x)-interleaved channels;
  *     level tables (host): first point, feature-map width, stride of every level.  Writes pts_xy [m0,18] (grid units,
@@ -336,6 +341,9 @@ int orp_conv3x3_small_multi_ex(const orp_norm_level* levels_host, const float* c
  *     corners(8) | score | label] in the reference's output order (ascending index, or the max_out highest scores in
  *     descending order when more survive); last row = (count, overflow, 0...).
  * ------------------------------------------------------------------------------------------------------- */
+size_t orp_pp_select_scratch_bytes(int n, int nms_pre, int nlevels);
+int orp_pp_select(const float* sig_all, int num_classes, int n, const int* level_offsets_host, int nlevels, int nms_pre,
+                  int64_t* cand, void* scratch, size_t scratch_bytes, void* stream);
 int orp_pp_gather(const float* pts_all, const int64_t* cand, int m0, int n, const int* level_offsets_host,
                   const int* level_widths_host, const float* level_strides_host, int nlevels, float* pts_xy,
                   float* centers, float* strides, float* reppoints, void* stream);

@@ -198,6 +198,189 @@ __global__ void pp_pack_kernel(const int64_t* __restrict__ keep, const int32_t* 
   o[27] = (float)sel_label[e];
 }
 
+
+// ---- candidate selection: per level the top-k points by the class-maximum score, in descending score order ------------
+// Replaces `scores.max(dim=1)` + `max_scores.topk(nms_pre)` per level (head :730-737) -- 15 framework kernels, ~150 us per
+// image (two library sorts of 16 384 / 4 096 keys to keep 2 000) -- by an exact radix SELECT (three histogram passes over
+// the order-preserving integer image of the fp32 scores find the k-th key; an ordered compaction keeps everything above
+// it plus the first ties by index) and a counting rank of the k survivors (descending score, ties by ascending index: what
+// a stable descending sort gives; torch.topk leaves the order of exact ties unspecified).  NaN scores rank highest, as in
+// torch.  Levels with at most k points pass through in grid order.
+struct SelParams {
+  int off[kMaxLevels + 1];       // first point of each level
+  int out_off[kMaxLevels + 1];   // first candidate slot of each level
+  int sel_slot[kMaxLevels];      // index among the levels that need a selection, or -1
+  int blk0[kMaxLevels + 1];      // pp_keys_kernel: first block of each level
+  int nlev, k;
+};
+
+__device__ __forceinline__ unsigned ord_key(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// wave 0: the highest bin b with count(bins > b) < need <= count(bins >= b); returns b, need -= count(bins > b)
+__device__ inline void find_bin(const unsigned* hist, int nbins, int& need, int& bin, int* s_out) {
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    const int per = nbins / 64;
+    unsigned mine = 0;
+    for (int j = 0; j < per; j++) mine += hist[lane * per + j];
+    unsigned above = 0;                                             // sum of the lanes above mine (they hold the higher bins)
+    for (int l2 = 63; l2 > 0; l2--) {
+      const unsigned v = __shfl(mine, l2, 64);
+      if (l2 > lane) above += v;
+    }
+    const bool here = above < (unsigned)need && (unsigned)need <= above + mine;
+    if (here) {
+      unsigned acc = above;
+      int b = lane * per + per - 1;
+      for (; b > lane * per; b--) { if (acc + hist[b] >= (unsigned)need) break; acc += hist[b]; }
+      s_out[0] = b; s_out[1] = need - (int)acc;
+    }
+  }
+  __syncthreads();
+  bin = s_out[0]; need = s_out[1];
+  __syncthreads();
+}
+
+// pass 0, all CUs: class maximum -> order-preserving key, and the level's histogram of the top 11 key bits (per-block LDS
+// histogram, non-zero bins flushed with one atomic each: a scene whose scores share one coarse bin costs one atomic per block)
+constexpr int kKeyThreads = 256;
+__global__ void pp_zero_kernel(unsigned* p, int per_block) {        // (a kernel, not a memset node: replay-safe everywhere)
+  for (int i = threadIdx.x; i < per_block; i += blockDim.x) p[(size_t)blockIdx.x * per_block + i] = 0u;
+}
+__global__ void __launch_bounds__(kKeyThreads)
+pp_keys_kernel(const float* __restrict__ sig, int C, int N, SelParams P, unsigned* __restrict__ keys,
+               unsigned* __restrict__ hist1, int64_t* __restrict__ cand) {
+  __shared__ unsigned hist[2048];
+  int l = 0;
+  for (int i = 1; i < P.nlev; i++) if ((int)blockIdx.x >= P.blk0[i]) l = i;
+  const int base = P.off[l], n = P.off[l + 1] - base;
+  const int i = ((int)blockIdx.x - P.blk0[l]) * kKeyThreads + threadIdx.x;
+  if (P.sel_slot[l] < 0) {                                          // every point of this level is a candidate, grid order
+    if (i < n) cand[P.out_off[l] + i] = base + i;
+    return;
+  }
+  for (int h = threadIdx.x; h < 2048; h += kKeyThreads) hist[h] = 0;
+  __syncthreads();
+  if (i < n) {
+    float m = sig[base + i];
+    for (int c = 1; c < C; c++) m = max_nan(m, sig[(size_t)c * N + base + i]);
+    if (m != m) m = __uint_as_float(0x7fc00000u);                  // one NaN pattern: the key 0 stays reserved for padding
+    const unsigned key = ord_key(m);
+    keys[base + i] = key;
+    atomicAdd(&hist[key >> 21], 1u);
+  }
+  __syncthreads();
+  unsigned* gh = hist1 + (size_t)P.sel_slot[l] * 2048;
+  for (int h = threadIdx.x; h < 2048; h += kKeyThreads) if (hist[h]) atomicAdd(&gh[h], hist[h]);
+}
+
+// one workgroup per selected level: the keys stay in registers (thread t owns the contiguous keys [t*kpt, (t+1)*kpt)), two more
+// histogram passes pin the k-th key, two block scans place the survivors
+constexpr int kMaxKpt = 40;                                         // n <= 40 960 points per level
+__global__ void __launch_bounds__(kScanThreads)
+pp_select_kernel(SelParams P, const unsigned* __restrict__ keys, const unsigned* __restrict__ hist1,
+                 unsigned* __restrict__ selkey, int* __restrict__ selidx) {
+  __shared__ unsigned hist[2048];
+  __shared__ int s_out[2];
+  __shared__ int wsum[16];
+  int l = 0;
+  for (int i = 0; i < P.nlev; i++) if (P.sel_slot[i] == (int)blockIdx.x) l = i;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int base = P.off[l], n = P.off[l + 1] - base, k = P.k;
+  const int kpt = (n + kScanThreads - 1) / kScanThreads;
+  unsigned* sk = selkey + (size_t)blockIdx.x * k;
+  int* si = selidx + (size_t)blockIdx.x * k;
+  unsigned key[kMaxKpt];
+#pragma unroll
+  for (int j = 0; j < kMaxKpt; j++) {
+    const int i = tid * kpt + j;
+    key[j] = (j < kpt && i < n) ? keys[base + i] : 0u;              // 0 is below every real key (ord_key sets or flips the top bit)
+  }
+  for (int h = tid; h < 2048; h += kScanThreads) hist[h] = hist1[(size_t)blockIdx.x * 2048 + h];
+  __syncthreads();
+  int need = k, b1, b2, b3;
+  find_bin(hist, 2048, need, b1, s_out);
+  for (int h = tid; h < 2048; h += kScanThreads) hist[h] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kMaxKpt; j++)
+    if (key[j] != 0u && (int)(key[j] >> 21) == b1) atomicAdd(&hist[(key[j] >> 10) & 2047u], 1u);
+  __syncthreads();
+  find_bin(hist, 2048, need, b2, s_out);
+  for (int h = tid; h < 1024; h += kScanThreads) hist[h] = 0;
+  __syncthreads();
+  const unsigned hi22 = ((unsigned)b1 << 11) | (unsigned)b2;
+#pragma unroll
+  for (int j = 0; j < kMaxKpt; j++)
+    if (key[j] != 0u && (key[j] >> 10) == hi22) atomicAdd(&hist[key[j] & 1023u], 1u);
+  __syncthreads();
+  find_bin(hist, 1024, need, b3, s_out);
+  const unsigned T = (hi22 << 10) | (unsigned)b3;                   // the k-th largest key; the first `need` keys == T are kept
+
+  // exclusive block scan of a per-thread count (wave ballot-free: shuffles inside the wave, LDS across the 16 waves)
+  auto block_exclusive = [&](int v) {
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    __syncthreads();
+    return off + incl - v;
+  };
+  int n_eq = 0;
+#pragma unroll
+  for (int j = 0; j < kMaxKpt; j++) n_eq += key[j] == T;
+  int eq_rank = block_exclusive(n_eq);
+  int n_sel = 0;
+  unsigned long long selmask = 0;
+#pragma unroll
+  for (int j = 0; j < kMaxKpt; j++) {
+    const bool eq = key[j] == T;
+    const bool sel = key[j] > T || (eq && eq_rank < need);
+    eq_rank += eq;
+    n_sel += sel;
+    selmask |= sel ? (1ull << j) : 0ull;
+  }
+  int pos = block_exclusive(n_sel);
+#pragma unroll
+  for (int j = 0; j < kMaxKpt; j++)
+    if ((selmask >> j) & 1ull) {
+      if (pos < k) { sk[pos] = key[j]; si[pos] = tid * kpt + j; }
+      pos++;
+    }
+}
+
+// rank of each survivor among the k of its level: 64 survivors per workgroup, 16 lanes each over a sixteenth of the keys
+__global__ void __launch_bounds__(kScanThreads)
+pp_rank_kernel(SelParams P, const unsigned* __restrict__ selkey, const int* __restrict__ selidx, int64_t* __restrict__ cand) {
+  extern __shared__ unsigned char smem_rank[];
+  unsigned* lk = reinterpret_cast<unsigned*>(smem_rank);
+  int* li = reinterpret_cast<int*>(lk + P.k);
+  int l = 0;
+  for (int i = 0; i < P.nlev; i++) if (P.sel_slot[i] == (int)blockIdx.y) l = i;
+  const int k = P.k, tid = threadIdx.x;
+  const unsigned* sk = selkey + (size_t)blockIdx.y * k;
+  const int* si = selidx + (size_t)blockIdx.y * k;
+  for (int i = tid; i < k; i += kScanThreads) { lk[i] = sk[i]; li[i] = si[i]; }
+  __syncthreads();
+  const int j = blockIdx.x * 64 + (tid >> 4), part = tid & 15;
+  int cnt = 0;
+  if (j < k) {
+    const unsigned kj = lk[j];
+    const int ij = li[j];
+    for (int i = part; i < k; i += 16) {
+      const unsigned ki = lk[i];
+      cnt += (ki > kj) | ((ki == kj) & (li[i] < ij));
+    }
+  }
+  for (int o = 8; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (j < k && part == 0) cand[P.out_off[l] + cnt] = P.off[l] + li[j];
+}
+
 inline int done() { hipError_t e = hipGetLastError(); return e == hipSuccess ? ORP_OK : (int)e; }
 
 }  // namespace
@@ -205,6 +388,51 @@ inline int done() { hipError_t e = hipGetLastError(); return e == hipSuccess ? O
 extern "C" {
 
 size_t orp_pp_compact_scratch_bytes(int m0) { return 256 + sizeof(unsigned) * (size_t)(m0 > 0 ? m0 : 1); }
+
+size_t orp_pp_select_scratch_bytes(int n, int nms_pre, int nlevels) {
+  const size_t nn = n > 0 ? n : 1, kk = nms_pre > 0 ? nms_pre : 1, ll = nlevels > 0 ? nlevels : 1;
+  return 512 + sizeof(unsigned) * (nn + 64) + (sizeof(unsigned) + sizeof(int)) * kk * ll + sizeof(unsigned) * 2048 * ll;
+}
+
+int orp_pp_select(const float* sig_all, int num_classes, int n, const int* level_offsets_host, int nlevels, int nms_pre,
+                  int64_t* cand, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!sig_all || !level_offsets_host || !cand || !scratch || num_classes <= 0 || n <= 0 || nlevels <= 0 ||
+      nlevels > kMaxLevels || nms_pre <= 0 || nms_pre > 4096)
+    return ORP_EINVAL;
+  if (scratch_bytes < orp_pp_select_scratch_bytes(n, nms_pre, nlevels)) return ORP_EWORKSPACE;
+  SelParams P;
+  P.nlev = nlevels; P.k = nms_pre;
+  int out = 0, nsel = 0, blk = 0;
+  for (int i = 0; i < kMaxLevels; i++) {
+    P.off[i] = i < nlevels ? level_offsets_host[i] : n;
+    P.out_off[i] = out;
+    P.blk0[i] = i < nlevels ? blk : 0x7fffffff;
+    P.sel_slot[i] = -1;
+    if (i < nlevels) {
+      const int n_l = (i + 1 < nlevels ? level_offsets_host[i + 1] : n) - level_offsets_host[i];
+      if (n_l < 0) return ORP_EINVAL;
+      if (n_l > kMaxKpt * kScanThreads && n_l > nms_pre) return ORP_ETOOBIG;
+      if (n_l > nms_pre) P.sel_slot[i] = nsel++;
+      out += n_l > nms_pre ? nms_pre : n_l;
+      blk += (n_l + kKeyThreads - 1) / kKeyThreads;
+    }
+  }
+  P.off[nlevels] = n; P.off[kMaxLevels] = n; P.out_off[kMaxLevels] = out; P.blk0[kMaxLevels] = 0x7fffffff;
+  for (int i = nlevels; i < kMaxLevels; i++) P.out_off[i] = out;
+  unsigned* keys = reinterpret_cast<unsigned*>(scratch);
+  unsigned* selkey = keys + (((size_t)n + 63) & ~(size_t)63);
+  int* selidx = reinterpret_cast<int*>(selkey + (size_t)nms_pre * nlevels);
+  unsigned* hist1 = reinterpret_cast<unsigned*>(selidx + (size_t)nms_pre * nlevels);
+  hipStream_t st = (hipStream_t)stream;
+  if (nsel > 0) hipLaunchKernelGGL(pp_zero_kernel, dim3(nsel), dim3(kScanThreads), 0, st, hist1, 2048);
+  hipLaunchKernelGGL(pp_keys_kernel, dim3(blk), dim3(kKeyThreads), 0, st, sig_all, num_classes, n, P, keys, hist1, cand);
+  if (nsel > 0) {
+    hipLaunchKernelGGL(pp_select_kernel, dim3(nsel), dim3(kScanThreads), 0, st, P, keys, hist1, selkey, selidx);
+    hipLaunchKernelGGL(pp_rank_kernel, dim3((nms_pre + 63) / 64, nsel), dim3(kScanThreads),
+                       (sizeof(unsigned) + sizeof(int)) * (size_t)nms_pre, st, P, selkey, selidx, cand);
+  }
+  return done();
+}
 
 int orp_pp_gather(const float* pts_all, const int64_t* cand, int m0, int n, const int* level_offsets_host,
                   const int* level_widths_host, const float* level_strides_host, int nlevels, float* pts_xy,

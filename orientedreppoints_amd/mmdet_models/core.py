@@ -214,17 +214,20 @@ def fused_postprocess(cls_scores, points_preds, strides, cfg, num_points=9):
     pts_all = torch.cat([p.reshape(2 * num_points, -1) for p in points_preds], 1).contiguous()   # [18, N]
     sig = logits.sigmoid()
     nms_pre = cfg.get('nms_pre', -1)
-    cand = []
-    max_scores = None
-    for l, n_l in enumerate(sizes):
-        if nms_pre > 0 and n_l > nms_pre:
-            if max_scores is None:
-                max_scores = sig.max(dim=0)[0]
-            _, topk_inds = max_scores[int(offs[l]):int(offs[l + 1])].topk(nms_pre)
-            cand.append(topk_inds + int(offs[l]))
-        else:
-            cand.append(_arange_cached(int(offs[l]), int(offs[l + 1]), dev))
-    cand = torch.cat(cand)
+    if 0 < nms_pre <= 4096 and any(n_l > nms_pre for n_l in sizes) and len(sizes) <= 8 and max(sizes) <= 40960:
+        cand = select_candidates(sig, offs, nms_pre)
+    else:
+        cand = []
+        max_scores = None
+        for l, n_l in enumerate(sizes):
+            if nms_pre > 0 and n_l > nms_pre:
+                if max_scores is None:
+                    max_scores = sig.max(dim=0)[0]
+                _, topk_inds = max_scores[int(offs[l]):int(offs[l + 1])].topk(nms_pre)
+                cand.append(topk_inds + int(offs[l]))
+            else:
+                cand.append(_arange_cached(int(offs[l]), int(offs[l + 1]), dev))
+        cand = torch.cat(cand)
     m0 = cand.numel()
     f32 = dict(dtype=torch.float32, device=dev)
     pts_xy = torch.empty((m0, 18), **f32)
@@ -261,6 +264,26 @@ def fused_postprocess(cls_scores, points_preds, strides, cfg, num_points=9):
                                  _lib.ptr(boxes), _lib.ptr(rep), _lib.ptr(total), cap, m, _lib.ptr(packed), st),
                    "orp_pp_pack")
     return packed
+
+
+def select_candidates(sig, offs, nms_pre):
+    """`scores.max(dim=1)` + per-level `topk(nms_pre)` of get_bboxes_single (head :730-737) as one radix select + counting
+    rank (`orp_pp_select`): sig [C, N] sigmoid scores of all levels, offs = first point of each level (+ N).  Returns the
+    int64 candidate indices, level-major, descending class-maximum score inside a selected level."""
+    import ctypes
+    L = _lib.lib()
+    C, N = int(sig.size(0)), int(sig.size(1))
+    nlev = len(offs) - 1
+    sizes = [int(offs[i + 1] - offs[i]) for i in range(nlev)]
+    m0 = sum(min(n_l, nms_pre) for n_l in sizes)
+    cand = torch.empty((m0,), dtype=torch.int64, device=sig.device)
+    lo = (ctypes.c_int * nlev)(*[int(o) for o in offs[:-1]])
+    nbytes = L.orp_pp_select_scratch_bytes(N, nms_pre, nlev)
+    with torch.cuda.device(sig.device):
+        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=sig.device)
+        _lib.check(L.orp_pp_select(_lib.ptr(sig), C, N, lo, nlev, int(nms_pre), _lib.ptr(cand), _lib.ptr(scratch), nbytes,
+                                   _lib.stream_of(sig)), "orp_pp_select")
+    return cand
 
 
 _arange_cache = {}

@@ -282,3 +282,49 @@ def test_head_loss_vs_reference_python(dev, G, oracle, name):
         want[rows[:, 0], rows[:, 1]] = G[p + 'grad_%s_vals' % nm]
         assert np.max(np.abs(ga.transpose(0, 2, 1) - want)) <= 1e-4, nm
     assert n_tie < 0.1 * sum(len(G[p + 'qa_%d' % i]) for i in range(B))       # ties are the exception, not a loophole
+
+
+def test_candidate_selection_radix_select_equals_topk(dev):
+    """`orp_pp_select` (radix select + counting rank) == `scores.max(dim=1)` + per-level `topk(nms_pre)` of
+    get_bboxes_single (head :730-737): identical candidate lists on continuous scores; on heavily tied scores the set and
+    order of a stable descending sort (ties by ascending index), NaN scores first."""
+    import numpy as np
+    from orientedreppoints_amd.mmdet_models.core import select_candidates
+    sizes = [16384, 4096, 1024, 256, 64]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N, C, k = int(offs[-1]), 15, 2000
+    g = torch.Generator(device='cpu').manual_seed(5)
+    sig = torch.sigmoid(torch.randn(C, N, generator=g) * 2 - 3).to(dev)
+    cand = select_candidates(sig, offs, k)
+    mx = sig.max(dim=0)[0]
+    want = []
+    for l, n_l in enumerate(sizes):
+        seg = mx[int(offs[l]):int(offs[l + 1])]
+        want.append(seg.topk(k)[1] + int(offs[l]) if n_l > k else torch.arange(int(offs[l]), int(offs[l + 1]), device=dev))
+    assert torch.equal(cand, torch.cat(want))
+    # ties (scores quantised to 1/32) and NaNs: stable descending order, NaN highest
+    q = (torch.rand(C, N, generator=g) * 32).floor() / 32
+    q[3, 100] = float('nan'); q[0, 17000] = float('nan'); q[7, 5] = float('nan')
+    q = q.to(dev)
+    cand = select_candidates(q, offs, k).cpu().numpy()
+    mxq = q.cpu().numpy()
+    m = np.where(np.isnan(mxq).any(0), np.inf, np.nanmax(mxq, axis=0))          # NaN propagates through the class max, ranks first
+    pos = 0
+    for l, n_l in enumerate(sizes):
+        seg = m[int(offs[l]):int(offs[l + 1])]
+        if n_l > k:
+            order = np.lexsort((np.arange(n_l), -seg))[:k]
+            assert np.array_equal(cand[pos:pos + k], order + int(offs[l]))
+            pos += k
+        else:
+            assert np.array_equal(cand[pos:pos + n_l], np.arange(int(offs[l]), int(offs[l + 1])))
+            pos += n_l
+    assert pos == cand.size
+    # a level of 36 864 points (1536^2 patches) and k that is not a multiple of 64
+    sizes2 = [36864, 9216, 100]
+    offs2 = np.concatenate([[0], np.cumsum(sizes2)]).astype(np.int64)
+    sig2 = torch.rand(4, int(offs2[-1]), generator=g).to(dev)
+    c2 = select_candidates(sig2, offs2, 1999)
+    mx2 = sig2.max(dim=0)[0]
+    w2 = torch.cat([mx2[:36864].topk(1999)[1], mx2[36864:46080].topk(1999)[1] + 36864, torch.arange(46080, 46180, device=dev)])
+    assert torch.equal(c2, w2)
