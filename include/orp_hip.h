@@ -306,6 +306,19 @@ typedef struct { const float* input; const float* residual; float* output; float
 int orp_bias_act_multi(const orp_bias_level* levels_host, int nlevels, int batch, int channels, const float* bias,
                        const float* sub, int relu, void* stream);
 
+/* orp_conv1x1_multi: the head's 1x1 output convolutions (reppoints_pts_init_out / reppoints_cls_out /
+ *   reppoints_pts_refine_out, orientedreppoints_head.py:105-113 applied at :156-170) for ALL FPN levels in one launch,
+ *   with what follows them fused in the order the head applies it: y = relu?(W.x + bias (+ residual)), optionally
+ *   y2 = y - sub[k].  levels_host[i] = {input [B,Cin,H,W], residual [B,Cout,H,W] | NULL, output [B,Cout,H,W], output2 | NULL,
+ *   height, width}, NCHW fp32.  weight_packed: orp_conv1x1_packed_floats(Cin) floats from orp_conv1x1_pack_weight
+ *   ([Cout,Cin] -> [Cin][32]).  Requires orp_conv1x1_ok: Cin % 4 == 0, Cout <= 32.  fp32 FMA chain in channel order per
+ *   channel quarter, the four quarters added in a fixed order. */
+size_t orp_conv1x1_packed_floats(int c_in);
+int orp_conv1x1_ok(int c_in, int c_out);
+int orp_conv1x1_pack_weight(const float* weight, int c_out, int c_in, float* packed, void* stream);
+int orp_conv1x1_multi(const orp_bias_level* levels_host, int nlevels, int batch, int c_in, int c_out,
+                      const float* weight_packed, const float* bias, const float* sub, int relu, void* stream);
+
 /* orp_conv3x3_small_multi: 3x3 / stride 1 / pad 1 convolution (no bias) of the SMALL FPN levels -- the 32^2 / 16^2 / 8^2
  *   maps the head's seven 256->256 convolutions (orientedreppoints_head.py:91-132) also visit -- all levels in ONE
  *   launch: exact-fp32 MFMA implicit GEMM reading and writing NCHW [B,C,H,W] fp32 (input != output).  weight_packed: the

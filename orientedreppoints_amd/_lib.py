@@ -71,6 +71,10 @@ _SIGNATURES = {
     "orp_poly_nms_f64_workspace_bytes": (_sz, [_i]),
     "orp_poly_nms_f64": (_i, [_vp, _i, ctypes.c_double, _vp, _vp, _vp, _sz, _vp]),
     "orp_soft_rnms_host": (_i, [_vp, _i, _f, _i, _f, _f, _vp, _vp]),
+    "orp_conv1x1_packed_floats": (_sz, [_i]),
+    "orp_conv1x1_ok": (_i, [_i, _i]),
+    "orp_conv1x1_pack_weight": (_i, [_vp, _i, _i, _vp, _vp]),
+    "orp_conv1x1_multi": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "orp_pp_select_scratch_bytes": (_sz, [_i, _i, _i]),
     "orp_pp_select": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "orp_pp_gather": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),

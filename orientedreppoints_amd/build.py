@@ -32,6 +32,7 @@ SOURCES = [
     ("orp_eval.hip", ["-ffp-contract=off"]),
     ("orp_norm.hip", []),
     ("orp_conv_small.hip", []),
+    ("orp_conv1x1.hip", []),
     ("orp_dcn.hip", []),
     ("orp_dcn_half.hip", []),
     ("orp_dcn_bwd.hip", []),

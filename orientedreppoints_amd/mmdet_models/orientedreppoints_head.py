@@ -215,8 +215,14 @@ class OrientedRepPointsHead(nn.Module):
             from ..mmdet_ops.fused_norm import bias_act_multi, conv3x3_multi
             hid = bias_act_multi(conv3x3_multi(pts_feats, self.reppoints_pts_init_conv),
                                  self.reppoints_pts_init_conv.bias, relu=True)
-            inits, offsets = bias_act_multi([self._conv_nobias(self.reppoints_pts_init_out, h) for h in hid],
-                                            self.reppoints_pts_init_out.bias, sub=dcn_base_offset)
+            from ..mmdet_ops.fused_norm import conv1x1_multi, conv1x1_ok
+            one_by_one = all(conv1x1_ok(m, hid[0]) for m in (self.reppoints_pts_init_out, self.reppoints_cls_out,
+                                                              self.reppoints_pts_refine_out))
+            if one_by_one:                      # 1x1 output convolution + bias + `- dcn_base_offset`: one launch, all levels
+                inits, offsets = conv1x1_multi(hid, self.reppoints_pts_init_out, sub=dcn_base_offset)
+            else:
+                inits, offsets = bias_act_multi([self._conv_nobias(self.reppoints_pts_init_out, h) for h in hid],
+                                                self.reppoints_pts_init_out.bias, sub=dcn_base_offset)
         else:
             cls_feats, pts_feats, inits = [], [], []
             for x in feats:
@@ -226,7 +232,10 @@ class OrientedRepPointsHead(nn.Module):
             offsets = [init - dcn_base_offset for init in inits]
         # both DeformConvs take the same offsets: ONE launch for the two layers and all levels, ReLU fused in the epilogue
         dcn_cls, dcn_pts = self._dcn_pair(cls_feats, pts_feats, offsets)
-        if fused:
+        if fused and one_by_one:
+            cls_outs = conv1x1_multi(dcn_cls, self.reppoints_cls_out)
+            refines = conv1x1_multi(dcn_pts, self.reppoints_pts_refine_out, residuals=inits)
+        elif fused:
             cls_outs = bias_act_multi([self._conv_nobias(self.reppoints_cls_out, c) for c in dcn_cls],
                                       self.reppoints_cls_out.bias)
             refines = bias_act_multi([self._conv_nobias(self.reppoints_pts_refine_out, p) for p in dcn_pts],

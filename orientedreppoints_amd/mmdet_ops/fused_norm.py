@@ -130,6 +130,71 @@ def bias_act_multi(xs, bias, relu=False, residuals=None, sub=None):
     return (ys, zs) if sub is not None else ys
 
 
+_packed_1x1 = {}
+
+
+def _packed_1x1_weight(weight):
+    """[Cout,Cin,1,1] -> the [Cin][32] pack of orp_conv1x1_multi, cached per (storage, version) for inference."""
+    w = weight.detach()
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index)
+    hit = _packed_1x1.get(id(weight))
+    if hit is not None and hit[0] == key:
+        return _lib.keep_for_graph(hit[1])
+    cout, cin = w.size(0), w.size(1)
+    w2 = w.float().reshape(cout, cin).contiguous()
+    packed = torch.empty((_lib.lib().orp_conv1x1_packed_floats(cin),), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.lib().orp_conv1x1_pack_weight(_lib.ptr(w2), cout, cin, _lib.ptr(packed), _lib.stream_of(w2)),
+                   "orp_conv1x1_pack_weight")
+    if len(_packed_1x1) > 64:
+        _packed_1x1.clear()
+    _packed_1x1[id(weight)] = (key, packed)
+    return _lib.keep_for_graph(packed)
+
+
+def conv1x1_ok(conv, x):
+    w = conv.weight
+    return bool(x.is_cuda and x.dtype == torch.float32 and w.dim() == 4 and w.size(2) == 1 and w.size(3) == 1 and
+                tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (0, 0) and conv.groups == 1 and
+                _lib.lib().orp_conv1x1_ok(w.size(1), w.size(0)))
+
+
+def conv1x1_multi(xs, conv, relu=False, residuals=None, sub=None):
+    """ys[i] = relu?(conv(xs[i]) (+ residuals[i])) for a 1x1 nn.Conv2d with at most 32 output channels (bias included),
+    all FPN levels in ONE launch; with `sub` ([Cout]) also returns zs[i] = ys[i] - sub.  Inference only (no autograd).
+    Same epilogue order as the framework passes it replaces (bias add, residual add, ReLU, subtraction)."""
+    x0 = xs[0]
+    B, cin = x0.size(0), x0.size(1)
+    cout = conv.weight.size(0)
+    packed = _packed_1x1_weight(conv.weight)
+    levels = (_BiasLevel * len(xs))()
+    ys, zs, keep = [], [], []
+    for i, x in enumerate(xs):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.size(0) == B and x.size(1) == cin):
+            raise ValueError("conv1x1_multi expects fp32 CUDA [B,Cin,H,W] tensors with equal B and Cin")
+        x = x.detach().contiguous()
+        y = torch.empty((B, cout, x.size(2), x.size(3)), dtype=torch.float32, device=x.device)
+        r = None
+        if residuals is not None:
+            r = residuals[i].detach().contiguous()
+            if r.shape != y.shape or r.dtype != torch.float32:
+                raise ValueError("conv1x1_multi: residual must match the output")
+        z = torch.empty_like(y) if sub is not None else None
+        keep += [x, r]
+        ys.append(y); zs.append(z)
+        levels[i] = _BiasLevel(x.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(),
+                               z.data_ptr() if z is not None else None, x.size(2), x.size(3))
+    b = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+    s = sub.detach().float().reshape(-1).contiguous() if sub is not None else None
+    if s is not None and s.numel() != cout:
+        raise ValueError("conv1x1_multi: sub must have Cout elements")
+    with torch.cuda.device(x0.device):
+        rc = _lib.lib().orp_conv1x1_multi(levels, len(xs), B, cin, cout, _lib.ptr(packed), _lib.ptr(b), _lib.ptr(s),
+                                          1 if relu else 0, _lib.stream_of(x0))
+    _lib.check(rc, "orp_conv1x1_multi")
+    return (ys, zs) if sub is not None else ys
+
+
 SMALL_LEVEL_POSITIONS = 1024        # H*W up to which a level goes through conv3x3_multi's HIP kernel (32 x 32 at 1024^2)
 
 

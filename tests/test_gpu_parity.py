@@ -912,6 +912,37 @@ def test_head_training_forward_all_levels_as_one_dcn_node(dev):
         assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(b.abs().max()))
 
 
+def test_conv1x1_multi_vs_library_convolution(dev):
+    """orp_conv1x1_multi (the head's 1x1 output convolutions, all levels in one launch, bias / residual / ReLU / `- sub`
+    fused in the head's order) against F.conv2d + the separate passes: <= 1e-5 of the output scale (fp32 FMA chain vs the
+    library GEMM's accumulation order)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv1x1_multi, conv1x1_ok
+    torch.manual_seed(11)
+    sizes = [(37, 41), (16, 16), (8, 8), (3, 5), (1, 1)]
+    for cout, relu, use_res, use_sub in ((18, False, False, True), (15, False, False, False), (18, False, True, False),
+                                         (32, True, True, True), (7, True, False, False)):
+        conv = nn.Conv2d(256, cout, 1).to(dev)
+        xs = [torch.randn(2, 256, h, w, device=dev) for h, w in sizes]
+        res = [torch.randn(2, cout, h, w, device=dev) for h, w in sizes] if use_res else None
+        sub = torch.randn(1, cout, 1, 1, device=dev) if use_sub else None
+        assert conv1x1_ok(conv, xs[0])
+        out = conv1x1_multi(xs, conv, relu=relu, residuals=res, sub=sub)
+        ys, zs = out if use_sub else (out, None)
+        for i, x in enumerate(xs):
+            want = F.conv2d(x, conv.weight, conv.bias)
+            if use_res:
+                want = want + res[i]
+            if relu:
+                want = want.relu()
+            scale = max(1.0, float(want.abs().max()))
+            assert float((ys[i] - want).abs().max()) <= 1e-5 * scale
+            if use_sub:
+                assert float((zs[i] - (want - sub)).abs().max()) <= 1e-5 * scale
+    assert not conv1x1_ok(nn.Conv2d(256, 33, 1).to(dev), xs[0]) and not conv1x1_ok(nn.Conv2d(256, 8, 3).to(dev), xs[0])
+
+
 # ---- end to end: one training step of the detector ---------------------------------------------------------------------
 def test_detector_train_step_and_inference(dev):
     from orientedreppoints_amd.dota_configs import r50_model, train_cfg, test_cfg
