@@ -219,25 +219,24 @@ __device__ __forceinline__ unsigned ord_key(float v) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// wave 0: the highest bin b with count(bins > b) < need <= count(bins >= b); returns b, need -= count(bins > b)
-__device__ inline void find_bin(const unsigned* hist, int nbins, int& need, int& bin, int* s_out) {
-  const int lane = threadIdx.x & 63;
-  if (threadIdx.x < 64) {
-    const int per = nbins / 64;
-    unsigned mine = 0;
-    for (int j = 0; j < per; j++) mine += hist[lane * per + j];
-    unsigned above = 0;                                             // sum of the lanes above mine (they hold the higher bins)
-    for (int l2 = 63; l2 > 0; l2--) {
-      const unsigned v = __shfl(mine, l2, 64);
-      if (l2 > lane) above += v;
-    }
-    const bool here = above < (unsigned)need && (unsigned)need <= above + mine;
-    if (here) {
-      unsigned acc = above;
-      int b = lane * per + per - 1;
-      for (; b > lane * per; b--) { if (acc + hist[b] >= (unsigned)need) break; acc += hist[b]; }
-      s_out[0] = b; s_out[1] = need - (int)acc;
-    }
+// all 1024 threads: the highest bin b with count(bins > b) < need <= count(bins >= b); on return need -= count(bins > b).
+// Thread t owns bins 2t, 2t+1 (nbins = 2048) or bin t (nbins = 1024): suffix scan inside the wave, wave totals through LDS.
+__device__ inline void find_bin(const unsigned* hist, int nbins, int& need, int& bin, int* s_out, int* wtot) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int v0 = nbins == 2048 ? (int)hist[2 * t] : (int)hist[t];
+  const int v1 = nbins == 2048 ? (int)hist[2 * t + 1] : 0;
+  const int pair = v0 + v1;
+  int s = pair;                                                     // inclusive suffix sum over the lanes >= mine
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_down(s, o, 64); if (lane + o < 64) s += u; }
+  if (lane == 0) wtot[wave] = s;
+  __syncthreads();
+  int above = s - pair;
+  for (int w = wave + 1; w < 16; w++) above += wtot[w];
+  if (above < need && need <= above + pair) {
+    if (nbins == 2048) {
+      if (above + v1 >= need) { s_out[0] = 2 * t + 1; s_out[1] = need - above; }
+      else { s_out[0] = 2 * t; s_out[1] = need - above - v1; }
+    } else { s_out[0] = t; s_out[1] = need - above; }
   }
   __syncthreads();
   bin = s_out[0]; need = s_out[1];
@@ -277,53 +276,72 @@ pp_keys_kernel(const float* __restrict__ sig, int C, int N, SelParams P, unsigne
   for (int h = threadIdx.x; h < 2048; h += kKeyThreads) if (hist[h]) atomicAdd(&gh[h], hist[h]);
 }
 
-// one workgroup per selected level: the keys stay in registers (thread t owns the contiguous keys [t*kpt, (t+1)*kpt)), two more
+// one workgroup per selected level: the keys stay in registers (thread t owns the contiguous keys [t*KPT, (t+1)*KPT)), two more
 // histogram passes pin the k-th key, two block scans place the survivors
 constexpr int kMaxKpt = 40;                                         // n <= 40 960 points per level
+template <int KPT>
 __global__ void __launch_bounds__(kScanThreads)
-pp_select_kernel(SelParams P, const unsigned* __restrict__ keys, const unsigned* __restrict__ hist1,
+pp_select_kernel(SelParams P, int slot0, const unsigned* __restrict__ keys, const unsigned* __restrict__ hist1,
                  unsigned* __restrict__ selkey, int* __restrict__ selidx) {
   __shared__ unsigned hist[2048];
   __shared__ int s_out[2];
   __shared__ int wsum[16];
+  const int slot = slot0 + (int)blockIdx.x;
   int l = 0;
-  for (int i = 0; i < P.nlev; i++) if (P.sel_slot[i] == (int)blockIdx.x) l = i;
+  for (int i = 0; i < P.nlev; i++) if (P.sel_slot[i] == slot) l = i;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int base = P.off[l], n = P.off[l + 1] - base, k = P.k;
-  const int kpt = (n + kScanThreads - 1) / kScanThreads;
-  unsigned* sk = selkey + (size_t)blockIdx.x * k;
-  int* si = selidx + (size_t)blockIdx.x * k;
-  unsigned key[kMaxKpt];
+  unsigned* sk = selkey + (size_t)slot * k;
+  int* si = selidx + (size_t)slot * k;
+  unsigned key[KPT];                                               // 0 = padding: below every real key (ord_key sets or flips the top bit)
+  if ((KPT & 3) == 0 && (base & 3) == 0) {
 #pragma unroll
-  for (int j = 0; j < kMaxKpt; j++) {
-    const int i = tid * kpt + j;
-    key[j] = (j < kpt && i < n) ? keys[base + i] : 0u;              // 0 is below every real key (ord_key sets or flips the top bit)
+    for (int j = 0; j < KPT; j += 4) {
+      const int i = tid * KPT + j;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (i + 3 < n) v = *reinterpret_cast<const uint4*>(keys + base + i);
+      else {
+        if (i < n) v.x = keys[base + i];
+        if (i + 1 < n) v.y = keys[base + i + 1];
+        if (i + 2 < n) v.z = keys[base + i + 2];
+      }
+      key[j] = v.x; key[j + 1] = v.y; key[j + 2] = v.z; key[j + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < KPT; j++) { const int i = tid * KPT + j; key[j] = i < n ? keys[base + i] : 0u; }
   }
-  for (int h = tid; h < 2048; h += kScanThreads) hist[h] = hist1[(size_t)blockIdx.x * 2048 + h];
+  for (int h = tid; h < 2048; h += kScanThreads) hist[h] = hist1[(size_t)slot * 2048 + h];
   __syncthreads();
   int need = k, b1, b2, b3;
-  find_bin(hist, 2048, need, b1, s_out);
+  find_bin(hist, 2048, need, b1, s_out, wsum);
   for (int h = tid; h < 2048; h += kScanThreads) hist[h] = 0;
   __syncthreads();
+  {                                                                 // neighbouring points score alike: runs of one bin -> one atomic
+    int run_bin = -1, run = 0;
 #pragma unroll
-  for (int j = 0; j < kMaxKpt; j++)
-    if (key[j] != 0u && (int)(key[j] >> 21) == b1) atomicAdd(&hist[(key[j] >> 10) & 2047u], 1u);
+    for (int j = 0; j < KPT; j++) {
+      const int bn = (key[j] != 0u && (int)(key[j] >> 21) == b1) ? (int)((key[j] >> 10) & 2047u) : -1;
+      if (bn != run_bin) { if (run_bin >= 0) atomicAdd(&hist[run_bin], (unsigned)run); run_bin = bn; run = 0; }
+      run++;
+    }
+    if (run_bin >= 0) atomicAdd(&hist[run_bin], (unsigned)run);
+  }
   __syncthreads();
-  find_bin(hist, 2048, need, b2, s_out);
+  find_bin(hist, 2048, need, b2, s_out, wsum);
   for (int h = tid; h < 1024; h += kScanThreads) hist[h] = 0;
   __syncthreads();
   const unsigned hi22 = ((unsigned)b1 << 11) | (unsigned)b2;
 #pragma unroll
-  for (int j = 0; j < kMaxKpt; j++)
+  for (int j = 0; j < KPT; j++)
     if (key[j] != 0u && (key[j] >> 10) == hi22) atomicAdd(&hist[key[j] & 1023u], 1u);
   __syncthreads();
-  find_bin(hist, 1024, need, b3, s_out);
+  find_bin(hist, 1024, need, b3, s_out, wsum);
   const unsigned T = (hi22 << 10) | (unsigned)b3;                   // the k-th largest key; the first `need` keys == T are kept
 
-  // exclusive block scan of a per-thread count (wave ballot-free: shuffles inside the wave, LDS across the 16 waves)
-  auto block_exclusive = [&](int v) {
+  auto block_exclusive = [&](int v) {                               // exclusive scan of a per-thread count over the 1024 threads
     int incl = v;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     int off = 0;
@@ -333,12 +351,12 @@ pp_select_kernel(SelParams P, const unsigned* __restrict__ keys, const unsigned*
   };
   int n_eq = 0;
 #pragma unroll
-  for (int j = 0; j < kMaxKpt; j++) n_eq += key[j] == T;
+  for (int j = 0; j < KPT; j++) n_eq += key[j] == T;
   int eq_rank = block_exclusive(n_eq);
   int n_sel = 0;
   unsigned long long selmask = 0;
 #pragma unroll
-  for (int j = 0; j < kMaxKpt; j++) {
+  for (int j = 0; j < KPT; j++) {
     const bool eq = key[j] == T;
     const bool sel = key[j] > T || (eq && eq_rank < need);
     eq_rank += eq;
@@ -347,9 +365,9 @@ pp_select_kernel(SelParams P, const unsigned* __restrict__ keys, const unsigned*
   }
   int pos = block_exclusive(n_sel);
 #pragma unroll
-  for (int j = 0; j < kMaxKpt; j++)
+  for (int j = 0; j < KPT; j++)
     if ((selmask >> j) & 1ull) {
-      if (pos < k) { sk[pos] = key[j]; si[pos] = tid * kpt + j; }
+      if (pos < k) { sk[pos] = key[j]; si[pos] = tid * KPT + j; }
       pos++;
     }
 }
@@ -427,7 +445,19 @@ int orp_pp_select(const float* sig_all, int num_classes, int n, const int* level
   if (nsel > 0) hipLaunchKernelGGL(pp_zero_kernel, dim3(nsel), dim3(kScanThreads), 0, st, hist1, 2048);
   hipLaunchKernelGGL(pp_keys_kernel, dim3(blk), dim3(kKeyThreads), 0, st, sig_all, num_classes, n, P, keys, hist1, cand);
   if (nsel > 0) {
-    hipLaunchKernelGGL(pp_select_kernel, dim3(nsel), dim3(kScanThreads), 0, st, P, keys, hist1, selkey, selidx);
+    // the register array is sized at compile time: one launch with the largest selected level's keys-per-thread count
+    int kpt = 1;
+    for (int i = 0; i < nlevels; i++) {
+      if (P.sel_slot[i] < 0) continue;
+      const int n_l = (i + 1 < nlevels ? level_offsets_host[i + 1] : n) - level_offsets_host[i];
+      const int kk = (n_l + kScanThreads - 1) / kScanThreads;
+      if (kk > kpt) kpt = kk;
+    }
+    if (kpt <= 4) hipLaunchKernelGGL(pp_select_kernel<4>, dim3(nsel), dim3(kScanThreads), 0, st, P, 0, keys, hist1, selkey, selidx);
+    else if (kpt <= 8) hipLaunchKernelGGL(pp_select_kernel<8>, dim3(nsel), dim3(kScanThreads), 0, st, P, 0, keys, hist1, selkey, selidx);
+    else if (kpt <= 16) hipLaunchKernelGGL(pp_select_kernel<16>, dim3(nsel), dim3(kScanThreads), 0, st, P, 0, keys, hist1, selkey, selidx);
+    else if (kpt <= 24) hipLaunchKernelGGL(pp_select_kernel<24>, dim3(nsel), dim3(kScanThreads), 0, st, P, 0, keys, hist1, selkey, selidx);
+    else hipLaunchKernelGGL(pp_select_kernel<kMaxKpt>, dim3(nsel), dim3(kScanThreads), 0, st, P, 0, keys, hist1, selkey, selidx);
     hipLaunchKernelGGL(pp_rank_kernel, dim3((nms_pre + 63) / 64, nsel), dim3(kScanThreads),
                        (sizeof(unsigned) + sizeof(int)) * (size_t)nms_pre, st, P, selkey, selidx, cand);
   }
