@@ -341,17 +341,25 @@ dcn_fwd_mfma_kernel(const FwdParams P) {
 //   * blockIdx -> tile is XCD-aware: the 8 XCDs each take a contiguous slab of tiles, so a feature-map row is pulled
 //     into ONE XCD's L2 instead of all eight.
 constexpr int KC2 = 16;          // input channels per weight chunk
+// the two-layer MT = 3 instantiation needs 10 registers more than the 256 a wave can have at two waves per SIMD: four of
+// the twelve next-tap rows a wave parks per tap go to a private LDS slot (32 KB) instead of registers
+template <int MT, int NCONV> constexpr int mfma2_stage_rows() { return (MT == 3 && NCONV == 2) ? 4 : 0; }
 constexpr int kThreads2 = 512;
 
-template <int MT, bool OUT_NCHW, int NCONV>
+// C256: Cin = Cout = 256 as compile-time constants (the head): the strides become immediates, which is what keeps the
+// two-layer instantiation free of register spills (254 VGPRs + 52 B of scratch per lane otherwise: 17 MB of extra writes)
+template <int MT, bool OUT_NCHW, int NCONV, bool C256>
 __global__ void __launch_bounds__(kThreads2)
 dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
+  const int Cin = C256 ? 256 : P.Cin, Cout = C256 ? 256 : P.Cout;
   constexpr int BM2 = 32 * MT;
   constexpr int ROWS = BM2 / 8;                                              // A rows produced per wave per tap
+  constexpr int STAGE = mfma2_stage_rows<MT, NCONV>();                       // of them, parked in LDS instead of registers
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sA = reinterpret_cast<float*>(smem);                                // [BM2][ASTR]
   float4* sCw = reinterpret_cast<float4*>(sA + BM2 * ASTR);                  // [BM2 * taps] bilinear weights
   int4* sCi = reinterpret_cast<int4*>(sCw + BM2 * MAX_TAPS);                 // [BM2 * taps] pixel indices
+  float4* sStage = reinterpret_cast<float4*>(sCi + BM2 * MAX_TAPS);          // [8 waves][STAGE][64 lanes]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int taps = P.kh * P.kw;
@@ -418,7 +426,7 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   const float* bias = conv ? P.bias2 : P.bias;
   float* outp = conv ? L.out2 : L.out;
   if (conv) __syncthreads();                                // every wave is past its last read of the previous layer's A tile
-  const int ncb = P.Cin / CB;                        // 256-channel blocks per tap (Cin % 256 == 0 on this path)
+  const int ncb = Cin / CB;                        // 256-channel blocks per tap (Cin % 256 == 0 on this path)
   const int nphase = taps * ncb;
   constexpr int NCHUNK = CB / KC2;                   // 16 chunks per phase
 
@@ -430,10 +438,10 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
 #if ORP_DCN_DBG & 1
     g[0] = g[1] = g[2] = g[3] = make_float4(1.f, 1.f, 1.f, 1.f); return;
 #endif
-    g[0] = *reinterpret_cast<const float4*>(base + (size_t)ix.x * P.Cin);
-    g[1] = *reinterpret_cast<const float4*>(base + (size_t)ix.y * P.Cin);
-    g[2] = *reinterpret_cast<const float4*>(base + (size_t)ix.z * P.Cin);
-    g[3] = *reinterpret_cast<const float4*>(base + (size_t)ix.w * P.Cin);
+    g[0] = *reinterpret_cast<const float4*>(base + (size_t)ix.x * Cin);
+    g[1] = *reinterpret_cast<const float4*>(base + (size_t)ix.y * Cin);
+    g[2] = *reinterpret_cast<const float4*>(base + (size_t)ix.z * Cin);
+    g[3] = *reinterpret_cast<const float4*>(base + (size_t)ix.w * Cin);
   };
   auto combine = [&](int phase, int m, const float4 (&g)[4]) {
     const int tap = phase / ncb;
@@ -450,17 +458,17 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   // lanes 0-31 / 32-63 read two contiguous 512 B segments.  No shared weight buffer -> no per-chunk barrier.
   const int n_wave = nb * BN + wave * 32;                 // first output channel of this wave
   const int mrow = lane & 31, kh = lane >> 5;
-  const bool n_ok = (n_wave + mrow) < P.Cout;
+  const bool n_ok = (n_wave + mrow) < Cout;
   auto load_bq = [&](int phase, int j, float4 (&r)[2]) {
     const int tap = phase / ncb, cb = phase - tap * ncb;
-    const size_t c4 = (size_t)(tap * P.Cin + cb * CB + j * KC2 + 4 * kh) >> 2;
-    const float* base = w3 + (c4 * P.Cout + n_wave + mrow) * 4;
+    const size_t c4 = (size_t)(tap * Cin + cb * CB + j * KC2 + 4 * kh) >> 2;
+    const float* base = w3 + (c4 * Cout + n_wave + mrow) * 4;
 #if ORP_DCN_DBG & 2
     r[0] = r[1] = make_float4(1.f, 1.f, 1.f, 1.f); return;
 #endif
     if (n_ok) {
       r[0] = *reinterpret_cast<const float4*>(base);
-      r[1] = *reinterpret_cast<const float4*>(base + (size_t)8 * P.Cout);     // channels + 8 -> c4 + 2
+      r[1] = *reinterpret_cast<const float4*>(base + (size_t)8 * Cout);     // channels + 8 -> c4 + 2
     } else {
       r[0] = r[1] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -526,7 +534,11 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
           }
         }
       }
-      if (do_row) hold[j < ROWS ? j : 0] = combine(phase + 1, j * 8 + wave, g);
+      if (do_row) {
+        const float4 v = combine(phase + 1, j * 8 + wave, g);
+        if (j < STAGE) sStage[(wave * (STAGE ? STAGE : 1) + (j < STAGE ? j : 0)) * 64 + lane] = v;   // own slot: no sync needed
+        else hold[j < ROWS ? j : 0] = v;
+      }
       bq[0] = bn[0]; bq[1] = bn[1];
     }
     // two barriers per tap: every wave is past its last read of this tap's A tile -> overwrite it with the next tap's rows
@@ -534,13 +546,14 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
       __syncthreads();
 #pragma unroll
       for (int rr = 0; rr < ROWS; rr++)
-        *reinterpret_cast<float4*>(sA + (size_t)(rr * 8 + wave) * ASTR + lane * 4) = hold[rr];
+        *reinterpret_cast<float4*>(sA + (size_t)(rr * 8 + wave) * ASTR + lane * 4) =
+            rr < STAGE ? sStage[(wave * (STAGE ? STAGE : 1) + (rr < STAGE ? rr : 0)) * 64 + lane] : hold[rr];
       __syncthreads();
     }
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
-  if (n_wave >= P.Cout) continue;                          // idle wave: it still meets the other waves at every barrier above
+  if (n_wave >= Cout) continue;                          // idle wave: it still meets the other waves at every barrier above
   auto finish = [&](float v, int ch) { if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
 #pragma unroll
   for (int mt = 0; mt < MT; mt++) {
@@ -548,11 +561,11 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
       const long p = p0 + mt * 32 + (lane & 31);
       if (p < npos) {
         const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
-        float* ob = outp + (size_t)b * P.Cout * HoWo + hw;
+        float* ob = outp + (size_t)b * Cout * HoWo + hw;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int ch = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (n_wave + ch < P.Cout) ob[(size_t)(n_wave + ch) * HoWo] = finish(acc[mt][r], n_wave + ch);
+          if (n_wave + ch < Cout) ob[(size_t)(n_wave + ch) * HoWo] = finish(acc[mt][r], n_wave + ch);
         }
       }
     } else {
@@ -560,28 +573,34 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
       for (int r = 0; r < 16; r++) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const long p = p0 + mt * 32 + m;
-        if (p < npos && n_wave + (lane & 31) < P.Cout) outp[(size_t)p * P.Cout + n_wave + (lane & 31)] = finish(acc[mt][r], n_wave + (lane & 31));
+        if (p < npos && n_wave + (lane & 31) < Cout) outp[(size_t)p * Cout + n_wave + (lane & 31)] = finish(acc[mt][r], n_wave + (lane & 31));
       }
     }
   }
   }
 }
 
-template <int MT>
+template <int MT, int NCONV>
 size_t mfma2_smem() {
-  return sizeof(float) * ((size_t)32 * MT * ASTR) + (sizeof(float4) + sizeof(int4)) * 32 * MT * MAX_TAPS;
+  return sizeof(float) * ((size_t)32 * MT * ASTR) + (sizeof(float4) + sizeof(int4)) * 32 * MT * MAX_TAPS +
+         sizeof(float4) * 8 * 64 * mfma2_stage_rows<MT, NCONV>();
 }
 
-template <int MT, bool OUT_NCHW, int NCONV>
-hipError_t launch_mfma2_n(const FwdParams& P, int tiles, int nblk_n, hipStream_t st) {
-  const size_t smem = mfma2_smem<MT>();
+template <int MT, bool OUT_NCHW, int NCONV, bool C256>
+hipError_t launch_mfma2_nc(const FwdParams& P, int tiles, int nblk_n, hipStream_t st) {
+  const size_t smem = mfma2_smem<MT, NCONV>();
   // once per kernel instantiation (not per launch: the call is not allowed while a stream is being captured)
   struct Tag {};
-  hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_mfma2_kernel<MT, OUT_NCHW, NCONV>), smem);
+  hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_mfma2_kernel<MT, OUT_NCHW, NCONV, C256>), smem);
   if (e != hipSuccess) return e;
   const int per = (tiles + 7) >> 3;
-  hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<MT, OUT_NCHW, NCONV>), dim3(per * 8, nblk_n), dim3(kThreads2), smem, st, P, tiles);
+  hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<MT, OUT_NCHW, NCONV, C256>), dim3(per * 8, nblk_n), dim3(kThreads2), smem, st, P, tiles);
   return hipGetLastError();
+}
+template <int MT, bool OUT_NCHW, int NCONV>
+hipError_t launch_mfma2_n(const FwdParams& P, int tiles, int nblk_n, hipStream_t st) {
+  return (P.Cin == 256 && P.Cout == 256) ? launch_mfma2_nc<MT, OUT_NCHW, NCONV, true>(P, tiles, nblk_n, st)
+                                         : launch_mfma2_nc<MT, OUT_NCHW, NCONV, false>(P, tiles, nblk_n, st);
 }
 template <int MT, bool OUT_NCHW>
 hipError_t launch_mfma2(const FwdParams& P, int tiles, int nblk_n, hipStream_t st) {

@@ -12,7 +12,7 @@ if which in ('dcn', 'all'):
     torch.manual_seed(0)
     w = torch.randn(256, 256, 3, 3, device=dev) * 0.01
     w2 = torch.randn(256, 256, 3, 3, device=dev) * 0.01
-    xs = [torch.randn(1, 256, h, h, device=dev).contiguous(memory_format=torch.channels_last) for h in (128, 64, 32, 16, 8)]
+    xs = [torch.randn(1, 256, h, h, device=dev) for h in (128, 64, 32, 16, 8)]      # NCHW, as the towers hand them over
     xs2 = [torch.randn_like(x) for x in xs]
     offs = [torch.randn(1, 18, h, h, device=dev) * 2 for h in (128, 64, 32, 16, 8)]
     for _ in range(iters):
