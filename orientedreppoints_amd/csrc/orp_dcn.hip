@@ -30,6 +30,9 @@
 #include "orp_launch.hpp"
 #include "orp_prof.hpp"
 
+#ifndef ORP_DCN_WDIST
+#define ORP_DCN_WDIST 1    // weight prefetch distance (chunks) of the single-layer second-generation kernel: 1 or 2 (2: measured, no gain)
+#endif
 #ifndef ORP_DCN_DBG
 #define ORP_DCN_DBG 0      // dev aid, compile-time (timing only, wrong results): 1 = no A gather, 2 = no weight loads, 4 = no per-tap barriers / LDS refill, 8 = no MFMA
 #endif
@@ -419,13 +422,15 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   __syncthreads();
 
   // a pair launch runs its two layers one after the other on the SAME coefficient table (same offsets / masks)
+  // (NCONV == 1 with gridDim.z == 2: "pair as grid" -- the second layer is a second workgroup of the same tile)
 #pragma unroll 1
-  for (int conv = 0; conv < NCONV; conv++) {
+  for (int it = 0; it < NCONV; it++) {
+  const int conv = NCONV == 1 ? (int)blockIdx.z : it;
   const float* xin = conv ? L.x2 : L.x;
   const float* w3 = conv ? P.w3b : P.w3;
   const float* bias = conv ? P.bias2 : P.bias;
   float* outp = conv ? L.out2 : L.out;
-  if (conv) __syncthreads();                                // every wave is past its last read of the previous layer's A tile
+  if (it) __syncthreads();                                  // every wave is past its last read of the previous layer's A tile
   const int ncb = Cin / CB;                        // 256-channel blocks per tap (Cin % 256 == 0 on this path)
   const int nphase = taps * ncb;
   constexpr int NCHUNK = CB / KC2;                   // 16 chunks per phase
@@ -475,9 +480,18 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   };
 
   // ---- prologue: A tile of phase 0, weight fragments of chunk 0 ------------------------------------------------
-  float4 bq[2];
+  // the weight fragments are fetched WDIST chunks ahead of their use (the single-layer instantiation has the registers for
+  // two; measured round 2: 505 us vs 503 us per pair -- the weight latency is not what the matrix pipe waits for)
+  constexpr int WDIST = (NCONV == 1) ? ORP_DCN_WDIST : 1;
+  auto load_lin = [&](int phase, int j, float4 (&r)[2]) {            // chunk (phase, j) with j possibly >= NCHUNK
+    const int ph = phase + j / NCHUNK, jj = j % NCHUNK;
+    if (ph < nphase) load_bq(ph, jj, r);
+    else r[0] = r[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  float4 bq[2], bq1[2];
   {
     load_bq(0, 0, bq);
+    if (WDIST == 2) load_lin(0, 1, bq1);
     // four rows in flight per wave (16 outstanding 1 KB loads) so the first tap's gather latency is paid ROWS/4 times
 #pragma unroll 1
     for (int r0 = 0; r0 < ROWS; r0 += 4) {
@@ -504,10 +518,8 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
 #pragma unroll
     for (int j = 0; j < NCHUNK; j++) {
       // (1) issue the global loads of the next chunk's weight fragments and of one row of the next phase's A tile
-      const bool last_chunk = (j + 1 == NCHUNK);
       float4 bn[2];
-      if (!(last_chunk && !next_phase)) load_bq(last_chunk ? phase + 1 : phase, last_chunk ? 0 : j + 1, bn);
-      else { bn[0] = bn[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      load_lin(phase, j + WDIST, bn);
       float4 g[4];
       const bool do_row = next_phase && (j < ROWS);
       if (do_row) gather_issue(phase + 1, j * 8 + wave, g);
@@ -539,7 +551,8 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
         if (j < STAGE) sStage[(wave * (STAGE ? STAGE : 1) + (j < STAGE ? j : 0)) * 64 + lane] = v;   // own slot: no sync needed
         else hold[j < ROWS ? j : 0] = v;
       }
-      bq[0] = bn[0]; bq[1] = bn[1];
+      if (WDIST == 2) { bq[0] = bq1[0]; bq[1] = bq1[1]; bq1[0] = bn[0]; bq1[1] = bn[1]; }
+      else { bq[0] = bn[0]; bq[1] = bn[1]; }
     }
     // two barriers per tap: every wave is past its last read of this tap's A tile -> overwrite it with the next tap's rows
     if (next_phase && !(ORP_DCN_DBG & 4)) {
@@ -594,7 +607,8 @@ hipError_t launch_mfma2_nc(const FwdParams& P, int tiles, int nblk_n, hipStream_
   hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_mfma2_kernel<MT, OUT_NCHW, NCONV, C256>), smem);
   if (e != hipSuccess) return e;
   const int per = (tiles + 7) >> 3;
-  hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<MT, OUT_NCHW, NCONV, C256>), dim3(per * 8, nblk_n), dim3(kThreads2), smem, st, P, tiles);
+  hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<MT, OUT_NCHW, NCONV, C256>), dim3(per * 8, nblk_n, (NCONV == 1 && P.nconv == 2) ? 2 : 1),
+                     dim3(kThreads2), smem, st, P, tiles);
   return hipGetLastError();
 }
 template <int MT, bool OUT_NCHW, int NCONV>
@@ -604,7 +618,9 @@ hipError_t launch_mfma2_n(const FwdParams& P, int tiles, int nblk_n, hipStream_t
 }
 template <int MT, bool OUT_NCHW>
 hipError_t launch_mfma2(const FwdParams& P, int tiles, int nblk_n, hipStream_t st) {
-  return P.nconv == 2 ? launch_mfma2_n<MT, OUT_NCHW, 2>(P, tiles, nblk_n, st) : launch_mfma2_n<MT, OUT_NCHW, 1>(P, tiles, nblk_n, st);
+  static const bool pair_as_grid = getenv("ORP_DCN_PAIR_GRID") && atoi(getenv("ORP_DCN_PAIR_GRID")) == 1;   // dev aid
+  return (P.nconv == 2 && !pair_as_grid) ? launch_mfma2_n<MT, OUT_NCHW, 2>(P, tiles, nblk_n, st)
+                                         : launch_mfma2_n<MT, OUT_NCHW, 1>(P, tiles, nblk_n, st);
 }
 
 // ---- direct kernel: every configuration (groups, deformable groups, DCNv2 mask + bias), NCHW in / out -----------
