@@ -65,9 +65,18 @@ __device__ __forceinline__ float max_nan(float a, float b) { return (a != a || b
 // the boxes that own at least one detection (bboxes.max() of the expanded set) through one atomicMax per workgroup
 __global__ void __launch_bounds__(256)
 pp_flags_kernel(const float* __restrict__ sig_all, const int64_t* __restrict__ cand, int m0, int n, int num_cls,
-                const float* __restrict__ boxes, float thr, unsigned* __restrict__ bits, unsigned* __restrict__ max_ord) {
+                const float* __restrict__ boxes, float thr, unsigned* __restrict__ bits, unsigned* __restrict__ max_ord,
+                int cap, float* __restrict__ dets, int32_t* __restrict__ sel_cand, int32_t* __restrict__ sel_label) {
   __shared__ float red[4];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  // every detection row starts as padding (score -inf: sorts last, never evaluated); the compaction kernel behind this
+  // one overwrites the first `count` rows -- filling 8 K rows is parallel work, not something for its single workgroup
+  for (int r = j; r < cap; r += gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) dets[(size_t)r * 9 + k] = 0.f;
+    dets[(size_t)r * 9 + 8] = -INFINITY;
+    sel_cand[r] = 0; sel_label[r] = 0;
+  }
   float mx = -INFINITY;
   if (j < m0) {
     const int g = (int)cand[j];
@@ -111,7 +120,7 @@ __global__ void __launch_bounds__(kScanThreads)
 pp_compact_kernel(const float* __restrict__ sig_all, const int64_t* __restrict__ cand, int m0, int n,
                   const unsigned* __restrict__ bits, const unsigned* __restrict__ max_ord,
                   const float* __restrict__ boxes, int cap, float* __restrict__ dets, int32_t* __restrict__ sel_cand,
-                  int32_t* __restrict__ sel_label, int32_t* __restrict__ seg, int32_t* __restrict__ total_out) {
+                  int32_t* __restrict__ sel_label, int32_t* __restrict__ seg, int32_t* __restrict__ total_out, int fill_here) {
   __shared__ int wsum[kScanThreads / 64];
   const int tid = threadIdx.x;
   const float span = ord2f(*max_ord) + 1.0f;                 // max_coordinate + 1
@@ -144,7 +153,7 @@ pp_compact_kernel(const float* __restrict__ sig_all, const int64_t* __restrict__
     running += chunk_total;
   }
   const int count = running < cap ? running : cap;
-  for (int r = count + tid; r < cap; r += kScanThreads) {
+  if (fill_here) for (int r = count + tid; r < cap; r += kScanThreads) {      // (no candidates: the flags kernel did not run)
 #pragma unroll
     for (int k = 0; k < 8; k++) dets[(size_t)r * 9 + k] = 0.f;
     dets[(size_t)r * 9 + 8] = -INFINITY;
@@ -501,9 +510,9 @@ int orp_pp_compact(const float* sig_all, const int64_t* cand, int m0, int n, int
   if (e != hipSuccess) return (int)e;
   if (m0 > 0)
     hipLaunchKernelGGL(pp_flags_kernel, dim3((m0 + 255) / 256), dim3(256), 0, st, sig_all, cand, m0, n, num_classes, boxes,
-                       score_thr, bits, max_ord);
+                       score_thr, bits, max_ord, capacity, dets, sel_cand, sel_label);
   hipLaunchKernelGGL(pp_compact_kernel, dim3(1), dim3(kScanThreads), 0, st, sig_all, cand, m0, n, bits, max_ord, boxes,
-                     capacity, dets, sel_cand, sel_label, seg2, total);
+                     capacity, dets, sel_cand, sel_label, seg2, total, m0 > 0 ? 0 : 1);
   return done();
 }
 
