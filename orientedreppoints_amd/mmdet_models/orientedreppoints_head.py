@@ -208,7 +208,20 @@ class OrientedRepPointsHead(nn.Module):
         dcn_base_offset = self._base_offset_on(feats[0])
         fused = self._fused_towers_ok(feats)
         if fused:
-            cls_feats = self._tower_multi(self.cls_convs, feats)
+            import os
+            side = None
+            if os.environ.get('ORP_TOWER_STREAMS', '1') == '1':          # (0: single stream, for A/B timing)
+                # the two towers are independent chains: the classification tower runs on a second stream (a fork / join in
+                # a captured graph), so that its small-level kernels fill the CUs the other tower's leave idle
+                cur = torch.cuda.current_stream(feats[0].device)
+                if getattr(self, '_side_stream', None) is None:
+                    self._side_stream = torch.cuda.Stream(device=feats[0].device)
+                side = self._side_stream
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    cls_feats = self._tower_multi(self.cls_convs, feats)
+            else:
+                cls_feats = self._tower_multi(self.cls_convs, feats)
             pts_feats = self._tower_multi(self.reg_convs, feats)
             # bias-carrying convolutions: the convolution runs without its bias, ONE launch per layer then adds it for
             # all levels together with what follows (ReLU / `- dcn_base_offset` / `+ pts_out_init`), same op order
@@ -230,6 +243,10 @@ class OrientedRepPointsHead(nn.Module):
                 cls_feats.append(cls_feat); pts_feats.append(pts_feat); inits.append(pts_out_init)
             # (1-g)*p.detach() + g*p is p up to one rounding; without autograd the two extra passes are skipped
             offsets = [init - dcn_base_offset for init in inits]
+        if fused and side is not None:
+            torch.cuda.current_stream(feats[0].device).wait_stream(side)
+            for t in cls_feats:
+                t.record_stream(torch.cuda.current_stream(feats[0].device))
         # both DeformConvs take the same offsets: ONE launch for the two layers and all levels, ReLU fused in the epilogue
         dcn_cls, dcn_pts = self._dcn_pair(cls_feats, pts_feats, offsets)
         if fused and one_by_one:
