@@ -535,6 +535,8 @@ def main():
                     help='launcher / rank / timing plumbing only, stand-in step (the CPU test of the N > 1 path)')
     ap.add_argument('--batch', type=int, default=1, help='images per GPU per step (config 1: 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pipeline', type=int, default=4,
+                    help='captured graphs in flight in the throughput measurement (PipelinedInference); 1 = off')
     ap.add_argument('--graph', type=int, default=1,
                     help='1 (default): after the eager loop, time the same K steps as ONE hipGraph replay each (device '
                          'part captured once) and report that as `value`; 0: eager only')
@@ -600,6 +602,7 @@ def main():
     # ~240 launches per step leave the host.  This is the deployment path and the reported `value` when capture works;
     # the eager loop above stays in the JSON (`eager_ms_per_step`) and provides the live HIP-event kernel timings.
     graph_ms = None
+    pipe_ms = None
     eager_elapsed = elapsed
     if args.graph:
         ok = 1
@@ -635,6 +638,44 @@ def main():
                 g_elapsed = float(t.item())
             graph_ms = g_elapsed / args.steps * 1e3
             elapsed = g_elapsed
+        # ---- throughput mode: two captured graphs in flight (the tail of image i overlaps the backbone of image i + 1);
+        # every image runs the complete step, results are collected one submit later and all of them inside the bracket
+        if ok and args.pipeline > 1:
+            pok = 1
+            try:
+                from orientedreppoints_amd.mmdet_models import PipelinedInference
+                del gi
+                pi = PipelinedInference(model, img, metas, depth=args.pipeline)
+                got = [r for r in (pi.submit(img) for _ in range(args.warmup + args.pipeline)) if r is not None] + pi.flush()
+                if any(int(sum(sum(len(c) for c in r) for r in g)) != ndet for g in got):
+                    raise RuntimeError('pipelined replay returned a different detection count')
+            except Exception as e:   # noqa: BLE001
+                pok = 0
+                pipe_ms = 'failed: %s' % (str(e)[:200],)
+            if distributed:
+                flag = torch.tensor([pok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                pok = int(flag.item())
+            if pok:
+                torch.cuda.synchronize()
+                if distributed:
+                    dist.barrier()
+                tp = time.perf_counter()
+                n_res = 0
+                for _ in range(args.steps):
+                    n_res += pi.submit(img) is not None
+                n_res += len(pi.flush())
+                torch.cuda.synchronize()
+                if distributed:
+                    dist.barrier()
+                p_elapsed = time.perf_counter() - tp
+                assert n_res == args.steps
+                if distributed:
+                    t = torch.tensor([p_elapsed], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    p_elapsed = float(t.item())
+                pipe_ms = p_elapsed / args.steps * 1e3
+                elapsed = p_elapsed
 
     prof = {name: read_prof(slot) for name, slot in
             (('nms_mask', 0), ('nms_sweep', 1), ('nms_rank_prepare', 2), ('dcn_fwd', 3), ('minarearect', 4))}
@@ -745,9 +786,11 @@ def main():
         'detections_per_step': ndet,
         'rotated_iou_nms_us_per_img': nms_us, 'nms_boxes': M,
         'kernel_us': {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()},
-        'mode': 'hipgraph replay' if isinstance(graph_ms, float) else 'eager',
+        'mode': ('hipgraph replay, %d images in flight' % args.pipeline) if isinstance(pipe_ms, float) else
+                'hipgraph replay' if isinstance(graph_ms, float) else 'eager',
         'eager_ms_per_step': round(eager_elapsed / args.steps * 1e3, 4),
         'graph_replay_ms': graph_ms,
+        'pipelined_ms_per_step': pipe_ms,
         'roofline': roof, 'nms': nms, 'nms_batched_16_images': batched, 'per_op_us': per_op, 'cpu_baseline': cpu,
     }
     print(json.dumps(out))

@@ -7,4 +7,4 @@ from .registry import (BACKBONES, NECKS, HEADS, LOSSES, DETECTORS, BBOX_ASSIGNER
 from . import resnet, fpn, losses, assigners, orientedreppoints_head, detector  # noqa: F401
 from .orientedreppoints_head import OrientedRepPointsHead  # noqa: F401
 from .detector import OrientedRepPointsDetector  # noqa: F401
-from .graph_inference import GraphedInference  # noqa: F401
+from .graph_inference import GraphedInference, PipelinedInference  # noqa: F401

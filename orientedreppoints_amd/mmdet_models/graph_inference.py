@@ -92,3 +92,71 @@ class GraphedInference(object):
             with torch.no_grad():
                 return self.model.simple_test_batch(img, self.metas)
         return results
+
+
+class PipelinedInference(object):
+    """Throughput mode of `GraphedInference`: `depth` (default 2) captured graphs, each with its own input / output /
+    scratch, replayed on their own streams with the results fetched asynchronously into pinned host buffers.  `submit(img)`
+    queues an image and returns the results of the image submitted `depth` calls earlier (None while the pipe fills);
+    `flush()` returns what is still in flight, oldest first.  The tail of one image (decode, NMS: many small kernels
+    that leave most CUs idle) then overlaps the backbone of the next one, and the host never waits on the image it has
+    just queued.  Every image still runs the complete step and produces the same detections as `GraphedInference`."""
+
+    def __init__(self, model, img, img_metas, depth=2, warmup=3):
+        dev = img.device
+        self.model, self.metas, self.depth = model, list(img_metas), depth
+        self.num_classes = model.bbox_head.num_classes
+        # with several images in flight the two towers of ONE image need no second stream (measured: 225 vs 218 img/s)
+        head = model.bbox_head
+        prev = getattr(head, 'tower_streams', None)
+        head.tower_streams = False
+        try:
+            self.slots = [GraphedInference(model, img, img_metas, warmup) for _ in range(depth)]
+        finally:
+            head.tower_streams = prev
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self.events = [torch.cuda.Event() for _ in range(depth)]
+        self.host = [[torch.empty(p.shape, dtype=p.dtype, pin_memory=True) for p in s.packed] for s in self.slots]
+        self.pending = [None] * depth
+        self.count = 0
+
+    def _collect(self, k):
+        img = self.pending[k]
+        self.pending[k] = None
+        self.events[k].synchronize()
+        results = [rbbox2result_packed(h, self.num_classes) for h in self.host[k]]
+        if any(r is None for r in results):               # static capacity overflow: the reference-shaped path, synchronously
+            with torch.no_grad():
+                return self.model.simple_test_batch(img, self.metas)
+        return results
+
+    def submit(self, img):
+        k = self.count % self.depth
+        out = self._collect(k) if self.pending[k] is not None else None
+        slot, s = self.slots[k], self.streams[k]
+        if _param_fingerprint(slot._tensors) != slot._fingerprint:
+            head = self.model.bbox_head
+            prev, head.tower_streams = getattr(head, 'tower_streams', None), False
+            try:
+                slot._capture()
+            finally:
+                head.tower_streams = prev
+            self.host[k] = [torch.empty(p.shape, dtype=p.dtype, pin_memory=True) for p in slot.packed]
+        s.wait_stream(torch.cuda.current_stream(img.device))     # the image may have been produced on the caller's stream
+        with torch.cuda.stream(s):
+            slot.static_img.copy_(img, non_blocking=True)
+            slot.graph.replay()
+            for h, p in zip(self.host[k], slot.packed):
+                h.copy_(p, non_blocking=True)
+            self.events[k].record(s)
+        self.pending[k] = img
+        self.count += 1
+        return out
+
+    def flush(self):
+        outs = []
+        for j in range(self.depth):
+            k = (self.count + j) % self.depth
+            if self.pending[k] is not None:
+                outs.append(self._collect(k))
+        return outs

@@ -210,7 +210,8 @@ class OrientedRepPointsHead(nn.Module):
         if fused:
             import os
             side = None
-            if os.environ.get('ORP_TOWER_STREAMS', '1') == '1':          # (0: single stream, for A/B timing)
+            two = getattr(self, 'tower_streams', None)                # None: default on (ORP_TOWER_STREAMS=0: off, for A/B timing)
+            if two if two is not None else os.environ.get('ORP_TOWER_STREAMS', '1') == '1':
                 # the two towers are independent chains: the classification tower runs on a second stream (a fork / join in
                 # a captured graph), so that its small-level kernels fill the CUs the other tower's leave idle
                 cur = torch.cuda.current_stream(feats[0].device)

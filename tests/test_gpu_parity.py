@@ -1211,6 +1211,43 @@ def test_graphed_inference_equals_simple_test(dev):
                     assert np.allclose(a, b, rtol=1e-4, atol=1e-2)
 
 
+def test_pipelined_inference_returns_each_images_own_results_in_order(dev):
+    """mmdet_models.PipelinedInference (bench.py's throughput mode: several captured graphs in flight on their own streams,
+    results fetched asynchronously): a stream of DIFFERENT images must come back in order, each with exactly what
+    GraphedInference / simple_test_batch return for that image."""
+    from orientedreppoints_amd.dota_configs import r50_model, test_cfg
+    from orientedreppoints_amd.mmdet_models import ConfigDict, PipelinedInference, build_detector
+    torch.manual_seed(0)
+    model = build_detector(ConfigDict(r50_model), train_cfg=None, test_cfg=ConfigDict(test_cfg)).to(dev).eval()
+    head = model.bbox_head
+    with torch.no_grad():
+        head.reppoints_cls_out.weight.normal_(0, 0.05)
+        head.reppoints_cls_out.bias.fill_(-3.3)
+        head.reppoints_pts_init_out.bias.copy_(torch.tensor(
+            [[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 0], [0, 1], [1, -1], [1, 0], [1, 1]],
+            dtype=torch.float32, device=dev).reshape(-1) * 2.0)
+    metas = [dict(img_shape=(256, 256, 3), pad_shape=(256, 256, 3), scale_factor=1.0, flip=False)]
+    imgs = [torch.randn(1, 3, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(10 + i)) for i in range(7)]
+    with torch.no_grad():
+        want = [model.simple_test_batch(im, metas) for im in imgs]
+    assert len({sum(len(c) for r in w for c in r) for w in want}) > 1          # the images really differ
+    for depth in (2, 3):
+        pi = PipelinedInference(model, imgs[0], metas, depth=depth)
+        got = []
+        for i, im in enumerate(imgs):
+            r = pi.submit(im)
+            assert (r is None) == (i < depth)
+            if r is not None:
+                got.append(r)
+        got += pi.flush()
+        assert len(got) == len(imgs) and pi.flush() == []
+        for g, w in zip(got, want):
+            for gr, wr in zip(g, w):
+                assert [c.shape for c in gr] == [c.shape for c in wr]
+                for a, b in zip(gr, wr):
+                    assert np.allclose(a, b, rtol=1e-4, atol=1e-2)
+
+
 def test_graphed_inference_owns_its_memory_and_follows_weight_updates(dev):
     """A captured graph must survive everything an eager caller does afterwards in the same process: scratch growth (a
     20 k-box fp64 merge NMS, a 16 k-box rnms, the capacity-overflow fallback), cache eviction of the packed weights /
