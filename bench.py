@@ -13,9 +13,12 @@ HBM before the timed region.  Random-init weights and a synthetic image (no netw
 scores ~0.01 everywhere and predicts zero-size point sets, two biases are calibrated ONCE before timing so that the
 post-processing sees a realistic dense scene (see `calibrate_head`) -- the compute of every layer is unchanged.
 
-The K steps are timed twice: launched eagerly from Python (`eager_ms_per_step`; this loop also provides the live
-HIP-event kernel timings) and as ONE hipGraph replay per step (`mmdet_models.GraphedInference`: same kernels, same
-detections, ~240 launches leave the host) -- the replay is `value` when the capture works (`mode`), else the eager figure.
+The K steps are timed three times: launched eagerly from Python (`eager_ms_per_step`; this loop also provides the live
+HIP-event kernel timings), as ONE hipGraph replay per step with the host waiting for each result
+(`mmdet_models.GraphedInference`, `graph_replay_ms`: same kernels, same detections, ~220 launches leave the host), and in
+throughput mode (`mmdet_models.PipelinedInference`, `pipelined_ms_per_step`): `--pipeline` captured graphs in flight on
+their own streams, results fetched asynchronously and ALL collected inside the timed bracket -- `value` / `mode` report the
+last one that works.
 
 One JSON line on rank 0: metric/value = whole-job images/sec; plus `roofline` for the dominant hot-path kernel (the
 DeformConv implicit GEMM, timed live with HIP events inside liborp_hip.so over the timed region, MFMA-bound), `nms`

@@ -311,8 +311,8 @@ int orp_bias_act_multi(const orp_bias_level* levels_host, int nlevels, int batch
  *   with what follows them fused in the order the head applies it: y = relu?(W.x + bias (+ residual)), optionally
  *   y2 = y - sub[k].  levels_host[i] = {input [B,Cin,H,W], residual [B,Cout,H,W] | NULL, output [B,Cout,H,W], output2 | NULL,
  *   height, width}, NCHW fp32.  weight_packed: orp_conv1x1_packed_floats(Cin) floats from orp_conv1x1_pack_weight
- *   ([Cout,Cin] -> [Cin][32]).  Requires orp_conv1x1_ok: Cin % 4 == 0, Cout <= 32.  fp32 FMA chain in channel order per
- *   channel quarter, the four quarters added in a fixed order. */
+ *   ([Cout,Cin] -> [Cin][32]).  Requires orp_conv1x1_ok: Cin % 8 == 0, Cout <= 32.  fp32 FMA chain in channel order per
+ *   channel slice, the eight slices added in a fixed order. */
 size_t orp_conv1x1_packed_floats(int c_in);
 int orp_conv1x1_ok(int c_in, int c_out);
 int orp_conv1x1_pack_weight(const float* weight, int c_out, int c_in, float* packed, void* stream);
