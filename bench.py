@@ -785,7 +785,8 @@ def main():
                                % ('configs[1]' if (args.model, IMG, args.batch) == ('r50', 1024, 1) else
                                   ('configs[3] per-GPU load' if (args.model, args.batch) == ('r101', 2) else 'variant'),
                                   {'r50': 'R-50', 'r101': 'R-101'}[args.model], IMG, IMG, args.batch, TARGET_DETS),
-                   'global_batch': args.batch * world, 'parallelism': 'replicas x%d (image-parallel, no collective)' % world},
+                   'global_batch': args.batch * world, 'parallelism': 'replicas x%d (image-parallel, no collective)' % world,
+                   'images_in_flight_per_gpu': args.pipeline if isinstance(pipe_ms, float) else 1},
         'detections_per_step': ndet,
         'rotated_iou_nms_us_per_img': nms_us, 'nms_boxes': M,
         'kernel_us': {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()},
