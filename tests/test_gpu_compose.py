@@ -328,3 +328,40 @@ def test_candidate_selection_radix_select_equals_topk(dev):
     mx2 = sig2.max(dim=0)[0]
     w2 = torch.cat([mx2[:36864].topk(1999)[1], mx2[36864:46080].topk(1999)[1] + 36864, torch.arange(46080, 46180, device=dev)])
     assert torch.equal(c2, w2)
+
+
+def test_candidate_selection_edge_cases(dev):
+    """Radix select corner cases: every score equal (the first k indices), one distinct value at the cut, k = n - 1,
+    scores spanning many exponents incl. 0, denormals and exact 1.0, and a single class (no class maximum to take)."""
+    import numpy as np
+    from orientedreppoints_amd.mmdet_models.core import select_candidates
+
+    def expect(mx, offs, k):
+        out = []
+        for l in range(len(offs) - 1):
+            seg = mx[int(offs[l]):int(offs[l + 1])]
+            n_l = seg.size
+            out.append((np.lexsort((np.arange(n_l), -seg))[:k] if n_l > k else np.arange(n_l)) + int(offs[l]))
+        return np.concatenate(out)
+    rng = np.random.RandomState(3)
+    # all equal
+    offs = np.array([0, 5000, 5100], np.int64)
+    sig = torch.full((3, 5100), 0.25, device=dev)
+    assert np.array_equal(select_candidates(sig, offs, 2000).cpu().numpy(), expect(np.full(5100, 0.25), offs, 2000))
+    # k = n - 1, and a cut that falls inside a run of equal values
+    offs = np.array([0, 2001, 4500], np.int64)
+    v = rng.choice(np.array([0.1, 0.2, 0.3, 0.7], np.float32), size=4500)
+    sig = torch.from_numpy(v[None].copy()).to(dev)                     # one class
+    assert np.array_equal(select_candidates(sig, offs, 2000).cpu().numpy(), expect(v, offs, 2000))
+    # wide dynamic range
+    e = rng.uniform(-45, 0, size=9000)
+    v = (10.0 ** e).astype(np.float32)
+    v[:50] = 0.0
+    v[50:60] = 1.0
+    v[60:70] = np.float32(1e-45)
+    rng.shuffle(v)
+    offs = np.array([0, 9000], np.int64)
+    sig = torch.from_numpy(np.stack([v, v * 0.5])).to(dev)
+    assert np.array_equal(select_candidates(sig, offs, 2000).cpu().numpy(), expect(v, offs, 2000))
+    assert np.array_equal(select_candidates(sig, offs, 37).cpu().numpy(), expect(v, offs, 37))
+    assert np.array_equal(select_candidates(sig, offs, 4096).cpu().numpy(), expect(v, offs, 4096))
