@@ -164,6 +164,21 @@ int orp_dcn_forward_pair(const orp_dcn_level* levels_a, const orp_dcn_level* lev
                          const float* weight_b_packed, const float* bias_a, const float* bias_b, int relu, int kh, int kw,
                          int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout,
                          int out_layout, void* workspace, size_t workspace_bytes, void* stream);
+/* The head's complete refinement stage in one launch: both DeformConvs (256 -> 256, same offsets), ReLU, and the 1x1
+ * output convolution behind each (reppoints_cls_out: k_a = 15 channels; reppoints_pts_refine_out: k_b = 18, with
+ * `+ pts_out_init` as residual_b), orientedreppoints_head.py:164-170.  The 256-channel DeformConv outputs are never
+ * written (levels_a[i].output / levels_b[i].output are ignored).  heads->weight_*_packed: orp_dcn_head_packed_floats()
+ * floats from orp_dcn_pack_head_weight ([k,256] -> [256][20]); heads->levels[i]: NCHW outputs [B,k_a,Ho,Wo] / [B,k_b,Ho,Wo]
+ * and the optional residual of the second head.  k <= 20.  The partial sums of the eight waves are added in a fixed order. */
+typedef struct { float* output_a; float* output_b; const float* residual_b; } orp_dcn_head_level;
+typedef struct { const float* weight_a_packed; const float* bias_a; int k_a; const float* weight_b_packed; const float* bias_b;
+                 int k_b; const orp_dcn_head_level* levels; } orp_dcn_heads;
+size_t orp_dcn_head_packed_floats(void);
+int orp_dcn_pack_head_weight(const float* weight, int k, float* packed, void* stream);
+int orp_dcn_forward_pair_heads(const orp_dcn_level* levels_a, const orp_dcn_level* levels_b, int nlevels, int batch,
+                               const float* weight_a_packed, const float* weight_b_packed, const orp_dcn_heads* heads,
+                               int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                               int in_layout, void* workspace, size_t workspace_bytes, void* stream);
 /* fp16 / bf16 DeformConv forward on v_mfma_f32_32x32x16_{f16,bf16} (the reference dispatches its DCN kernels over float
  * AND half: deform_conv_cuda_kernel.cu:259,353,451,781,813 AT_DISPATCH_FLOATING_TYPES_AND_HALF; BASELINE configs[4]).
  * dtype: 1 = fp16, 2 = bf16 -- inputs, offsets, masks, bias, packed weights and outputs are all of that type; the bilinear

@@ -57,6 +57,9 @@ _SIGNATURES = {
     "orp_dcn_forward_multi": (_i, [_vp, _i, _i, _i, _i, _vp] + [_i] * 10 + [_vp, _sz, _vp]),
     "orp_dcn_forward_multi_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp]),
     "orp_dcn_forward_pair": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp]),
+    "orp_dcn_head_packed_floats": (_sz, []),
+    "orp_dcn_pack_head_weight": (_i, [_vp, _i, _vp, _vp]),
+    "orp_dcn_forward_pair_heads": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp, _sz, _vp]),
     "orp_dcn_half_path_ok": (_i, [_i, _i, _i, _i, _i, _i]),
     "orp_dcn_pack_weight_h": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "orp_dcn_forward_h_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),

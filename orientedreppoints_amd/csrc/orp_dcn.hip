@@ -57,6 +57,9 @@ struct LevelDesc {
   float* out;          // NCHW [B, Cout, Ho, Wo] or NHWC [B, Ho, Wo, Cout]
   const float* x2;     // second layer of a pair launch (same offsets / mask): its input ...
   float* out2;         // ... and output
+  float* hout;         // fused 1x1 head of the first layer: [B, head_k[0], Ho, Wo] (HEADS instantiation)
+  float* hout2;        // ... of the second layer
+  const float* hres2;  // residual added to the second head's output ([B, head_k[1], Ho, Wo]) or nullptr
   int H, W, Ho, Wo;
   int tile0;           // first tile of this level
 };
@@ -71,7 +74,11 @@ struct FwdParams {
   int nconv;           // 1, or 2: a second layer (w3b, bias2, LevelDesc::x2 / out2) over the same offsets in the same launch
   const float* w3b;
   const float* bias2;
+  const float* head_w[2];   // fused 1x1 heads: packed [256][KH] (zero padded), bias [k], output channels k <= KH
+  const float* head_b[2];
+  int head_k[2];
 };
+constexpr int KH = 20;           // packed output-channel count of a fused 1x1 head
 
 // ---- helpers -------------------------------------------------------------------------------------------------
 __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int cin, int taps, float* __restrict__ w2) {
@@ -84,6 +91,14 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
     const float v = w[((long)o * cin + c) * taps + tap];
     w2[i] = v;
     if ((cin & 3) == 0) w2[total + (((long)tap * (cin >> 2) + (c >> 2)) * cout + o) * 4 + (c & 3)] = v;
+  }
+}
+
+// head weight [k][256] -> [256][KH], zero padded
+__global__ void pack_head_kernel(const float* __restrict__ w, int k, float* __restrict__ packed) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 256 * KH; i += gridDim.x * blockDim.x) {
+    const int kk = i % KH, c = i / KH;
+    packed[i] = kk < k ? w[(size_t)kk * 256 + c] : 0.f;
   }
 }
 
@@ -351,7 +366,9 @@ constexpr int kThreads2 = 512;
 
 // C256: Cin = Cout = 256 as compile-time constants (the head): the strides become immediates, which is what keeps the
 // two-layer instantiation free of register spills (254 VGPRs + 52 B of scratch per lane otherwise: 17 MB of extra writes)
-template <int MT, bool OUT_NCHW, int NCONV, bool C256>
+// HEADS: the 1x1 convolution that follows each DeformConv + ReLU in the head (reppoints_cls_out / reppoints_pts_refine_out,
+// orientedreppoints_head.py:166-170) is applied in the epilogue -- the 256-channel DeformConv output never goes to HBM.
+template <int MT, bool OUT_NCHW, int NCONV, bool C256, bool HEADS = false>
 __global__ void __launch_bounds__(kThreads2)
 dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   const int Cin = C256 ? 256 : P.Cin, Cout = C256 ? 256 : P.Cout;
@@ -566,8 +583,60 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
-  if (n_wave >= Cout) continue;                          // idle wave: it still meets the other waves at every barrier above
   auto finish = [&](float v, int ch) { if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
+  if (HEADS) {
+    // out1[p, k] = sum_c relu(dcn[p, c]) * W1[k, c] + b1[k] (+ residual): every wave holds 32 of the 256 channels of its
+    // positions -> per-wave partial sums, added over the two half-waves (shuffle) and the eight waves (LDS, fixed order).
+    // The A tile is dead: its memory holds the head's weights and the partial sums.
+    float* sW = sA;                                        // [256][KH]
+    float* sRed = sA + 256 * KH;                           // [8 waves][BM2][KH]
+    const float* hw_ = P.head_w[conv];
+    const int K = P.head_k[conv];
+    __syncthreads();                                       // every wave is past its last read of the A tile
+    for (int i = tid; i < 256 * KH; i += kThreads2) sW[i] = hw_[i];
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+#pragma unroll 1
+      for (int q = 0; q < KH / 4; q++) {                     // four output channels at a time keeps the register need small
+        float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int ch = n_wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const float v = finish(acc[mt][r], ch);
+          const float4 w4 = *reinterpret_cast<const float4*>(sW + ch * KH + 4 * q);
+          part.x = __builtin_fmaf(v, w4.x, part.x);
+          part.y = __builtin_fmaf(v, w4.y, part.y);
+          part.z = __builtin_fmaf(v, w4.z, part.z);
+          part.w = __builtin_fmaf(v, w4.w, part.w);
+        }
+        part.x += __shfl_xor(part.x, 32, 64);
+        part.y += __shfl_xor(part.y, 32, 64);
+        part.z += __shfl_xor(part.z, 32, 64);
+        part.w += __shfl_xor(part.w, 32, 64);
+        if (lane < 32) *reinterpret_cast<float4*>(sRed + ((size_t)wave * BM2 + mt * 32 + lane) * KH + 4 * q) = part;
+      }
+    }
+    __syncthreads();
+    float* ho = conv ? L.hout2 : L.hout;
+    const float* hres = conv ? L.hres2 : nullptr;
+    const float* hb = P.head_b[conv];
+    for (int idx = tid; idx < BM2 * K; idx += kThreads2) {
+      const int k = idx / BM2, m = idx - k * BM2;
+      const long p = p0 + m;
+      if (p >= npos) continue;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; w++) v += sRed[((size_t)w * BM2 + m) * KH + k];
+      const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+      const size_t o = ((size_t)b * K + k) * HoWo + hw;
+      if (hb) v += hb[k];
+      if (hres) v += hres[o];
+      ho[o] = v;
+    }
+    continue;                                              // (the next layer's prologue is behind its own barrier)
+  }
+  if (n_wave >= Cout) continue;                          // idle wave: it still meets the other waves at every barrier above
 #pragma unroll
   for (int mt = 0; mt < MT; mt++) {
     if (OUT_NCHW) {
@@ -609,6 +678,16 @@ hipError_t launch_mfma2_nc(const FwdParams& P, int tiles, int nblk_n, hipStream_
   const int per = (tiles + 7) >> 3;
   hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<MT, OUT_NCHW, NCONV, C256>), dim3(per * 8, nblk_n, (NCONV == 1 && P.nconv == 2) ? 2 : 1),
                      dim3(kThreads2), smem, st, P, tiles);
+  return hipGetLastError();
+}
+template <int MT>
+hipError_t launch_mfma2_heads(const FwdParams& P, int tiles, hipStream_t st) {
+  const size_t smem = mfma2_smem<MT, 2>();
+  struct TagH { int unused; };
+  hipError_t e = orp::set_max_dynamic_lds_once<TagH>(reinterpret_cast<const void*>(&dcn_fwd_mfma2_kernel<MT, true, 2, true, true>), smem);
+  if (e != hipSuccess) return e;
+  const int per = (tiles + 7) >> 3;
+  hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<MT, true, 2, true, true>), dim3(per * 8, 1, 1), dim3(kThreads2), smem, st, P, tiles);
   return hipGetLastError();
 }
 template <int MT, bool OUT_NCHW, int NCONV>
@@ -720,8 +799,12 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
                             const float* weight_packed, const float* weight2_packed, const float* bias, const float* bias2,
                             int relu, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
                             int dil_w, int in_layout, int out_layout, void* workspace, size_t workspace_bytes,
-                            void* stream) {
+                            void* stream, const orp_dcn_heads* heads = nullptr) {
   const int nconv = levels2_host ? 2 : 1;
+  if (heads && (nconv != 2 || c_in != 256 || c_out != 256 || out_layout != 0 || !heads->weight_a_packed ||
+                !heads->weight_b_packed || !heads->levels || heads->k_a <= 0 || heads->k_a > KH || heads->k_b <= 0 ||
+                heads->k_b > KH))
+    return ORP_EINVAL;
   if (!levels_host || nlevels <= 0 || nlevels > MAX_LEVELS || batch <= 0 || !weight_packed) return ORP_EINVAL;
   if (nconv == 2 && !weight2_packed) return ORP_EINVAL;
   if (!orp_dcn_fast_path_ok(c_in, c_out, kh, kw, 1, 1)) return ORP_EINVAL;
@@ -751,6 +834,7 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
       if (best < 0 || cost < best) { best = cost; MT = mt; }
     }
     if (force_mt >= 1 && force_mt <= 3) MT = force_mt;
+    if (heads && MT < 2) MT = 2;
     if (force_mt == 0 && nconv == 1) { gen = 1; MT = 0; }
   }
   const int bm = MT > 0 ? 32 * MT : BM;
@@ -766,8 +850,9 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
   int tbx = 0, ntl = 0;
   for (int i = 0; i < nlevels; i++) {
     const orp_dcn_level& lv = levels_host[i];
-    if (!lv.input || !lv.offset || !lv.output || lv.height <= 0 || lv.width <= 0) return ORP_EINVAL;
-    if (nconv == 2 && (!levels2_host[i].input || !levels2_host[i].output || levels2_host[i].height != lv.height ||
+    if (!lv.input || !lv.offset || (!lv.output && !heads) || lv.height <= 0 || lv.width <= 0) return ORP_EINVAL;
+    if (heads && (!heads->levels[i].output_a || !heads->levels[i].output_b)) return ORP_EINVAL;
+    if (nconv == 2 && (!levels2_host[i].input || (!levels2_host[i].output && !heads) || levels2_host[i].height != lv.height ||
                        levels2_host[i].width != lv.width))
       return ORP_EINVAL;
     LevelDesc& D = P.lv[i];
@@ -779,6 +864,9 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
     D.off = lv.offset; D.out = lv.output;
     D.mask = masks_host ? masks_host[i] : nullptr;
     D.out2 = nconv == 2 ? levels2_host[i].output : lv.output;
+    D.hout = heads ? heads->levels[i].output_a : nullptr;
+    D.hout2 = heads ? heads->levels[i].output_b : nullptr;
+    D.hres2 = heads ? heads->levels[i].residual_b : nullptr;
     for (int cv = 0; cv < nconv; cv++) {
       const float* src = cv ? levels2_host[i].input : lv.input;
       if (in_layout == 0) {
@@ -807,6 +895,14 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
   OrpProfScope prof(ORP_PROF_DCN_FWD, st);
   const int nblk_n = (c_out + BN - 1) / BN;
   const bool nchw = out_layout == 0;
+  P.head_w[0] = heads ? heads->weight_a_packed : nullptr; P.head_w[1] = heads ? heads->weight_b_packed : nullptr;
+  P.head_b[0] = heads ? heads->bias_a : nullptr; P.head_b[1] = heads ? heads->bias_b : nullptr;
+  P.head_k[0] = heads ? heads->k_a : 0; P.head_k[1] = heads ? heads->k_b : 0;
+  if (heads) {                                                 // (MT >= 2: the partial sums need the A tile's LDS)
+    if (gen != 2) return ORP_EINVAL;
+    e = MT == 2 ? launch_mfma2_heads<2>(P, tiles, st) : launch_mfma2_heads<3>(P, tiles, st);
+    return e == hipSuccess ? ORP_OK : (int)e;
+  }
   if (gen == 2) {
     if (MT == 1) e = nchw ? launch_mfma2<1, true>(P, tiles, nblk_n, st) : launch_mfma2<1, false>(P, tiles, nblk_n, st);
     else if (MT == 2) e = nchw ? launch_mfma2<2, true>(P, tiles, nblk_n, st) : launch_mfma2<2, false>(P, tiles, nblk_n, st);
@@ -849,6 +945,25 @@ int orp_dcn_forward_pair(const orp_dcn_level* levels_a, const orp_dcn_level* lev
   return dcn_forward_impl(levels_a, levels_b, masks_host, nlevels, batch, c_in, c_out, weight_a_packed, weight_b_packed,
                           bias_a, bias_b, relu, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, in_layout,
                           out_layout, workspace, workspace_bytes, stream);
+}
+
+size_t orp_dcn_head_packed_floats(void) { return (size_t)256 * KH; }
+
+int orp_dcn_pack_head_weight(const float* weight, int k, float* packed, void* stream) {
+  if (!weight || !packed || k <= 0 || k > KH) return ORP_EINVAL;
+  hipLaunchKernelGGL(pack_head_kernel, dim3(20), dim3(256), 0, (hipStream_t)stream, weight, k, packed);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_dcn_forward_pair_heads(const orp_dcn_level* levels_a, const orp_dcn_level* levels_b, int nlevels, int batch,
+                               const float* weight_a_packed, const float* weight_b_packed, const orp_dcn_heads* heads,
+                               int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                               int in_layout, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!levels_b || !heads) return ORP_EINVAL;
+  return dcn_forward_impl(levels_a, levels_b, nullptr, nlevels, batch, 256, 256, weight_a_packed, weight_b_packed, nullptr,
+                          nullptr, 1, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, in_layout, 0, workspace,
+                          workspace_bytes, stream, heads);
 }
 
 int orp_dcn_forward_direct(const float* input, const float* offset, const float* mask, const float* weight,

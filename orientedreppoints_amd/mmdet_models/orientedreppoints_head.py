@@ -248,6 +248,18 @@ class OrientedRepPointsHead(nn.Module):
             torch.cuda.current_stream(feats[0].device).wait_stream(side)
             for t in cls_feats:
                 t.record_stream(torch.cuda.current_stream(feats[0].device))
+        if fused and one_by_one and getattr(self, 'fuse_output_convs', False):
+            # (off by default -- measured round 2: the fused epilogue adds ~45 us to the DeformConv launch, as much as the two
+            # bandwidth-bound 1x1 launches it replaces cost, and those overlap with other work in throughput mode)
+            from ..mmdet_ops.deform_conv import deform_conv_forward_pair_heads, pair_heads_ok
+            if pair_heads_ok(self.reppoints_cls_conv, self.reppoints_pts_refine_conv, self.reppoints_cls_out,
+                             self.reppoints_pts_refine_out, cls_feats[0]):
+                # the whole refinement stage in ONE launch: both DeformConvs, ReLU, both 1x1 output convolutions and
+                # `+ pts_out_init`; the 256-channel DeformConv outputs never reach HBM
+                cls_outs, refines = deform_conv_forward_pair_heads(
+                    cls_feats, pts_feats, offsets, self.reppoints_cls_conv, self.reppoints_pts_refine_conv,
+                    self.reppoints_cls_out, self.reppoints_pts_refine_out, residuals_b=inits)
+                return cls_outs, inits, refines, list(feats)
         # both DeformConvs take the same offsets: ONE launch for the two layers and all levels, ReLU fused in the epilogue
         dcn_cls, dcn_pts = self._dcn_pair(cls_feats, pts_feats, offsets)
         if fused and one_by_one:

@@ -263,6 +263,98 @@ def deform_conv_forward_pair(inputs_a, inputs_b, offsets, weight_a, weight_b, st
     return outs_a, outs_b
 
 
+class _DcnHeadLevel(ctypes.Structure):
+    _fields_ = [("output_a", ctypes.c_void_p), ("output_b", ctypes.c_void_p), ("residual_b", ctypes.c_void_p)]
+
+
+class _DcnHeads(ctypes.Structure):
+    _fields_ = [("weight_a_packed", ctypes.c_void_p), ("bias_a", ctypes.c_void_p), ("k_a", ctypes.c_int),
+                ("weight_b_packed", ctypes.c_void_p), ("bias_b", ctypes.c_void_p), ("k_b", ctypes.c_int),
+                ("levels", ctypes.POINTER(_DcnHeadLevel))]
+
+
+_packed_heads = {}
+
+
+def _packed_head_weight(weight):
+    """[k,256,1,1] -> the [256][20] pack of orp_dcn_forward_pair_heads, cached per (storage, version)."""
+    w = weight.detach()
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index)
+    hit = _packed_heads.get(id(weight))
+    if hit is not None and hit[0] == key:
+        return _lib.keep_for_graph(hit[1])
+    k = w.size(0)
+    w2 = w.float().reshape(k, 256).contiguous()
+    packed = torch.empty((_lib.lib().orp_dcn_head_packed_floats(),), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.lib().orp_dcn_pack_head_weight(_lib.ptr(w2), k, _lib.ptr(packed), _lib.stream_of(w2)),
+                   "orp_dcn_pack_head_weight")
+    if len(_packed_heads) > 64:
+        _packed_heads.clear()
+    _packed_heads[id(weight)] = (key, packed)
+    return _lib.keep_for_graph(packed)
+
+
+def pair_heads_ok(conv_a, conv_b, head_a, head_b, x):
+    """The head's refinement stage can run as ONE launch (`deform_conv_forward_pair_heads`)."""
+    def one_by_one(m):
+        w = m.weight
+        return (w.dim() == 4 and w.size(1) == 256 and w.size(2) == 1 and w.size(3) == 1 and w.size(0) <= 20 and
+                tuple(m.stride) == (1, 1) and tuple(m.padding) == (0, 0) and m.groups == 1)
+    return bool(x.is_cuda and x.dtype == torch.float32 and tuple(conv_a.weight.shape) == (256, 256, 3, 3) and
+                tuple(conv_b.weight.shape) == (256, 256, 3, 3) and conv_a.stride == conv_b.stride and
+                conv_a.padding == conv_b.padding and conv_a.dilation == conv_b.dilation and
+                conv_a.groups == conv_b.groups == 1 and conv_a.deformable_groups == conv_b.deformable_groups == 1 and
+                one_by_one(head_a) and one_by_one(head_b))
+
+
+def deform_conv_forward_pair_heads(inputs_a, inputs_b, offsets, conv_a, conv_b, head_a, head_b, residuals_b=None):
+    """relu(DeformConv_a(x_a)) -> head_a (1x1) and relu(DeformConv_b(x_b)) -> head_b (1x1) (+ residuals_b) for all levels
+    in ONE launch (`orp_dcn_forward_pair_heads`): the head's refinement stage, orientedreppoints_head.py:164-170.  The
+    256-channel DeformConv outputs are never materialised.  fp32, no autograd.  Returns (outs_a, outs_b)."""
+    L = _lib.lib()
+    stride, padding, dilation = _pair(conv_a.stride), _pair(conv_a.padding), _pair(conv_a.dilation)
+    x0 = inputs_a[0]
+    B = x0.size(0)
+    kh, kw = conv_a.weight.size(2), conv_a.weight.size(3)
+    ka, kb = head_a.weight.size(0), head_b.weight.size(0)
+    pa, pb = _packed_weight(conv_a.weight), _packed_weight(conv_b.weight)
+    ha, hb = _packed_head_weight(head_a.weight), _packed_head_weight(head_b.weight)
+    ba = head_a.bias.detach().float().contiguous() if head_a.bias is not None else None
+    bb = head_b.bias.detach().float().contiguous() if head_b.bias is not None else None
+    n = len(inputs_a)
+    lev_a, lev_b, hl = (_DcnLevel * n)(), (_DcnLevel * n)(), (_DcnHeadLevel * n)()
+    keep, outs_a, outs_b = [], [], []
+    for i in range(n):
+        xa, xb = inputs_a[i].detach().float().contiguous(), inputs_b[i].detach().float().contiguous()
+        off = offsets[i].detach().float().contiguous()
+        ho, wo = _out_hw(xa.size(2), xa.size(3), conv_a.weight, stride, padding, dilation)
+        if xa.shape != xb.shape or xa.size(1) != 256 or tuple(off.shape) != (B, 2 * kh * kw, ho, wo):
+            raise ValueError("deform_conv_forward_pair_heads: [B,256,H,W] inputs and [B,2*kh*kw,Ho,Wo] offsets expected")
+        oa = torch.empty((B, ka, ho, wo), dtype=torch.float32, device=xa.device)
+        ob = torch.empty((B, kb, ho, wo), dtype=torch.float32, device=xa.device)
+        r = None
+        if residuals_b is not None:
+            r = residuals_b[i].detach().float().contiguous()
+            if r.shape != ob.shape:
+                raise ValueError("deform_conv_forward_pair_heads: residual must match the second head's output")
+        keep += [xa, xb, off, r]
+        outs_a.append(oa); outs_b.append(ob)
+        lev_a[i] = _DcnLevel(xa.data_ptr(), off.data_ptr(), None, xa.size(2), xa.size(3))
+        lev_b[i] = _DcnLevel(xb.data_ptr(), off.data_ptr(), None, xb.size(2), xb.size(3))
+        hl[i] = _DcnHeadLevel(oa.data_ptr(), ob.data_ptr(), r.data_ptr() if r is not None else None)
+    heads = _DcnHeads(ha.data_ptr(), ba.data_ptr() if ba is not None else None, ka, hb.data_ptr(),
+                      bb.data_ptr() if bb is not None else None, kb, hl)
+    nbytes = 2 * L.orp_dcn_forward_workspace_bytes(lev_a, n, B, 256, 0)
+    ws = _lib.workspace(x0.device, nbytes)
+    with torch.cuda.device(x0.device):
+        rc = L.orp_dcn_forward_pair_heads(lev_a, lev_b, n, B, _lib.ptr(pa), _lib.ptr(pb), ctypes.byref(heads), kh, kw,
+                                          stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], 0,
+                                          _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
+    _lib.check(rc, "orp_dcn_forward_pair_heads")
+    return outs_a, outs_b
+
+
 def _forward_direct(input, offset, mask, weight, bias, stride, padding, dilation, groups, deformable_groups):
     x = input.detach().float().contiguous()
     off = offset.detach().float().contiguous()

@@ -912,6 +912,36 @@ def test_head_training_forward_all_levels_as_one_dcn_node(dev):
         assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(b.abs().max()))
 
 
+def test_dcn_pair_with_fused_1x1_heads_vs_separate_launches(dev):
+    """orp_dcn_forward_pair_heads: both DeformConvs + ReLU + the 1x1 output convolution behind each (+ `pts_out_init`
+    residual) in ONE launch, against the separate route (pair launch with ReLU, then F.conv2d): <= 1e-5 of the output
+    scale -- tiles that straddle images, levels smaller than a tile, offsets outside the map, MT = 2 and 3 tilings."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from orientedreppoints_amd.mmdet_ops import DeformConv, deform_conv_forward_pair
+    from orientedreppoints_amd.mmdet_ops.deform_conv import deform_conv_forward_pair_heads, pair_heads_ok
+    torch.manual_seed(21)
+    ca, cb = DeformConv(256, 256, 3, 1, 1).to(dev), DeformConv(256, 256, 3, 1, 1).to(dev)
+    ha, hb = nn.Conv2d(256, 15, 1).to(dev), nn.Conv2d(256, 18, 1).to(dev)
+    assert pair_heads_ok(ca, cb, ha, hb, torch.zeros(1, 256, 4, 4, device=dev))
+    assert not pair_heads_ok(ca, cb, nn.Conv2d(256, 21, 1).to(dev), hb, torch.zeros(1, 256, 4, 4, device=dev))
+    for B, sizes in ((2, [(21, 19), (8, 8), (3, 5), (1, 1)]), (1, [(64, 64), (32, 32), (16, 16)])):
+        xa = [torch.randn(B, 256, h, w, device=dev) for h, w in sizes]
+        xb = [torch.randn(B, 256, h, w, device=dev) for h, w in sizes]
+        offs = [torch.randn(B, 18, h, w, device=dev) * (4.0 if i == 1 else 1.5) for i, (h, w) in enumerate(sizes)]
+        res = [torch.randn(B, 18, h, w, device=dev) for h, w in sizes]
+        with torch.no_grad():
+            oa, ob = deform_conv_forward_pair_heads(xa, xb, offs, ca, cb, ha, hb, residuals_b=res)
+            da, db = deform_conv_forward_pair(xa, xb, offs, ca.weight, cb.weight, 1, 1, 1, relu=True)
+            for i in range(len(sizes)):
+                wa = F.conv2d(da[i], ha.weight, ha.bias)
+                wb = F.conv2d(db[i], hb.weight, hb.bias) + res[i]
+                assert float((oa[i] - wa).abs().max()) <= 1e-5 * max(1.0, float(wa.abs().max()))
+                assert float((ob[i] - wb).abs().max()) <= 1e-5 * max(1.0, float(wb.abs().max()))
+            o2a, o2b = deform_conv_forward_pair_heads(xa, xb, offs, ca, cb, ha, hb)          # no residual
+            assert float((o2b[0] + res[0] - ob[0]).abs().max()) <= 1e-5 * max(1.0, float(ob[0].abs().max()))
+
+
 def test_conv1x1_multi_vs_library_convolution(dev):
     """orp_conv1x1_multi (the head's 1x1 output convolutions, all levels in one launch, bias / residual / ReLU / `- sub`
     fused in the head's order) against F.conv2d + the separate passes: <= 1e-5 of the output scale (fp32 FMA chain vs the
