@@ -578,6 +578,9 @@ def main():
         with torch.no_grad():
             return model.simple_test_batch(img, metas)
 
+    # the eager loop (kernel timings, roofline) runs the launch sequence of the throughput mode's graphs: one stream, no
+    # tower fork -- the fork belongs to the one-image-at-a-time replay below
+    model.bbox_head.tower_streams = False
     for _ in range(args.warmup):
         res = step()
     ndet = int(sum(sum(len(c) for c in r) for r in res))
@@ -596,6 +599,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     _lib.lib().orp_profile_enable(0)
+    model.bbox_head.tower_streams = None                    # default (fork on) for the single-graph replay
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
