@@ -12,7 +12,8 @@ for d in dirs:
     for f in glob.glob(d + '/*/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            key = ('dcn_fwd_half' if 'dcn_fwd_half' in k else 'dcn_fwd_pair' if 'dcn_fwd_mfma2' in k else 'nms_mask' if 'nms_mask' in k
+            key = ('dcn_bwd_input' if 'dcn_bwd_input' in k else 'dcn_bwd_weight' if 'dcn_bwd_weight' in k else
+                   'dcn_fwd_half' if 'dcn_fwd_half' in k else 'dcn_fwd_pair' if 'dcn_fwd_mfma2' in k else 'nms_mask' if 'nms_mask' in k
                    else 'nms_sweep' if 'nms_sweep' in k else 'nms_rankprep' if 'nms_rankprep' in k else None)
             if key:
                 agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
@@ -27,6 +28,9 @@ for k, c in agg.items():
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in m and 'GRBM_GUI_ACTIVE' in m and m['GRBM_GUI_ACTIVE'] > 0:
         # MFMA busy is summed over 1024 SIMDs, GRBM_GUI_ACTIVE over 8 XCDs
         e['mfma_busy_frac'] = (m['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0) / (m['GRBM_GUI_ACTIVE'] / 8.0)
+    if k.startswith('dcn_bwd'):
+        e['batch'] = 2
+        e['img'] = 1024
     if k.startswith('dcn_fwd'):
         e['batch'] = 1
         e['img'] = 1024

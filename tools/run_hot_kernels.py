@@ -1,5 +1,5 @@
 """Launch the hot-path kernels a few times on the bench shapes (for rocprofv3 --pmc passes; development aid).
-usage: python tools/run_hot_kernels.py [dcn|nms|all] [iters]"""
+usage: python tools/run_hot_kernels.py [dcn|nms|bwd|all] [iters]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -26,5 +26,15 @@ if which in ('nms', 'all'):
     t = torch.from_numpy(d.astype(np.float32)).to(dev)
     for _ in range(iters):
         rnms_device(t, 0.4)
+if which in ('bwd', 'all'):
+    from orientedreppoints_amd.mmdet_ops import deform_conv_backward as bw
+    torch.manual_seed(1)
+    B = 2
+    xs = [torch.randn(B, 256, h, h, device=dev) for h in (128, 64, 32, 16, 8)]
+    offs = [torch.randn(B, 18, h, h, device=dev) * 2 for h in (128, 64, 32, 16, 8)]
+    gos = [torch.randn(B, 256, h, h, device=dev) for h in (128, 64, 32, 16, 8)]
+    w = torch.randn(256, 256, 3, 3, device=dev) * 0.01
+    for _ in range(iters):
+        bw.backward_mfma(xs, offs, w, gos, (1, 1), (1, 1), (1, 1))         # dense gradients, 2 x 21 824 positions
 torch.cuda.synchronize()
 print('done')
