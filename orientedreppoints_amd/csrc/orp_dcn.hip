@@ -30,6 +30,18 @@
 #include "orp_launch.hpp"
 #include "orp_prof.hpp"
 
+#ifndef ORP_DCN_IPF
+#define ORP_DCN_IPF 0      // gather pixel indices read from LDS one chunk ahead (measured: no gain on top of APF)
+#endif
+#ifndef ORP_DCN_APF_ALL
+#define ORP_DCN_APF_ALL 1  // ... also in the two-layer instantiation (254 VGPRs, no spill; 494 -> 482 us per pair launch)
+#endif
+#ifndef ORP_DCN_APF
+#define ORP_DCN_APF 1      // A-fragment LDS prefetch one k-step ahead in the single-layer second-generation kernel
+#endif
+#ifndef ORP_DCN_GDIST
+#define ORP_DCN_GDIST 1    // gather-to-combine distance (chunks) of the single-layer second-generation kernel: 1 or 2
+#endif
 #ifndef ORP_DCN_WDIST
 #define ORP_DCN_WDIST 1    // weight prefetch distance (chunks) of the single-layer second-generation kernel: 1 or 2 (2: measured, no gain)
 #endif
@@ -465,6 +477,14 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
     g[2] = *reinterpret_cast<const float4*>(base + (size_t)ix.z * Cin);
     g[3] = *reinterpret_cast<const float4*>(base + (size_t)ix.w * Cin);
   };
+  auto gather_issue_ix = [&](int phase, const int4 ix, float4 (&g)[4]) {      // ... with the pixel indices already in registers
+    const int tap = phase / ncb, cb = phase - tap * ncb;
+    const float* base = xin + cb * CB + lane * 4;
+    g[0] = *reinterpret_cast<const float4*>(base + (size_t)ix.x * Cin);
+    g[1] = *reinterpret_cast<const float4*>(base + (size_t)ix.y * Cin);
+    g[2] = *reinterpret_cast<const float4*>(base + (size_t)ix.z * Cin);
+    g[3] = *reinterpret_cast<const float4*>(base + (size_t)ix.w * Cin);
+  };
   auto combine = [&](int phase, int m, const float4 (&g)[4]) {
     const int tap = phase / ncb;
     const float4 wgt = sCw[m * taps + tap];
@@ -500,6 +520,11 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   // the weight fragments are fetched WDIST chunks ahead of their use (the single-layer instantiation has the registers for
   // two; measured round 2: 505 us vs 503 us per pair -- the weight latency is not what the matrix pipe waits for)
   constexpr int WDIST = (NCONV == 1) ? ORP_DCN_WDIST : 1;
+  // a gathered row is combined GDIST chunks after its loads were issued (the single-layer instantiation has the 16
+  // registers for a second row in flight; ROWS + GDIST - 1 <= NCHUNK)
+  constexpr int GDIST = (NCONV == 1 && STAGE == 0 && ROWS + 1 <= CB / KC2) ? ORP_DCN_GDIST : 1;
+  constexpr bool APF = (NCONV == 1 || ORP_DCN_APF_ALL) && ORP_DCN_APF;
+  constexpr bool IPF = APF && ORP_DCN_IPF;
   auto load_lin = [&](int phase, int j, float4 (&r)[2]) {            // chunk (phase, j) with j possibly >= NCHUNK
     const int ph = phase + j / NCHUNK, jj = j % NCHUNK;
     if (ph < nphase) load_bq(ph, jj, r);
@@ -532,16 +557,51 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   for (int phase = 0; phase < nphase; phase++) {
     const bool next_phase = phase + 1 < nphase;
     float4 hold[ROWS];
+    float4 gq[2][4];                                         // gathered rows in flight (GDIST = 2: two)
+    int4 ixn = make_int4(0, 0, 0, 0);                        // IPF: pixel indices of the row gathered in the next chunk
+    if (IPF && next_phase) ixn = sCi[wave * taps + (phase + 1) / ncb];
+    float4 apre[MT];                                         // APF: the A fragments of the next k-step
+    if (APF) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) apre[mt] = *reinterpret_cast<const float4*>(sA + (size_t)(mt * 32 + mrow) * ASTR + 4 * kh);
+    }
 #pragma unroll
     for (int j = 0; j < NCHUNK; j++) {
       // (1) issue the global loads of the next chunk's weight fragments and of one row of the next phase's A tile
       float4 bn[2];
       load_lin(phase, j + WDIST, bn);
-      float4 g[4];
+      float4 (&g)[4] = gq[GDIST == 2 ? (j & 1) : 0];
       const bool do_row = next_phase && (j < ROWS);
-      if (do_row) gather_issue(phase + 1, j * 8 + wave, g);
+      if (do_row) { if (IPF) gather_issue_ix(phase + 1, ixn, g); else gather_issue(phase + 1, j * 8 + wave, g); }
       // (2) MFMA over the current chunk
-      {
+      if (APF) {
+        // the A fragments of the NEXT k-step are read from LDS before the MFMAs of this one are issued (the wave's own
+        // LDS latency is then hidden behind its own matrix work; the tile only changes behind the tap's barriers, so the
+        // chain stops at the last k-step of a tap)
+        const float* arow = sA + (size_t)mrow * ASTR + j * KC2 + 4 * kh;
+#pragma unroll
+        for (int t = 0; t < KC2 / 8; t++) {
+          float4 a4[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++) a4[mt] = apre[mt];
+          const bool more = !(j + 1 == NCHUNK && t + 1 == KC2 / 8);
+          if (more) {
+            const float* nrow = (t + 1 < KC2 / 8) ? arow + 8 * (t + 1) : arow + KC2;      // next k-step: same chunk or chunk j + 1
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) apre[mt] = *reinterpret_cast<const float4*>(nrow + (size_t)mt * 32 * ASTR);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float b0 = (i == 0) ? bq[t].x : (i == 1) ? bq[t].y : (i == 2) ? bq[t].z : bq[t].w;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+              const float av = (i == 0) ? a4[mt].x : (i == 1) ? a4[mt].y : (i == 2) ? a4[mt].z : a4[mt].w;
+              if (OUT_NCHW) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, av, acc[mt], 0, 0, 0);
+              else          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[mt], 0, 0, 0);
+            }
+          }
+        }
+      } else {
         const float* arow = sA + (size_t)mrow * ASTR + j * KC2 + 4 * kh;
 #pragma unroll
         for (int t = 0; t < KC2 / 8; t++) {
@@ -563,10 +623,16 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
           }
         }
       }
-      if (do_row) {
-        const float4 v = combine(phase + 1, j * 8 + wave, g);
-        if (j < STAGE) sStage[(wave * (STAGE ? STAGE : 1) + (j < STAGE ? j : 0)) * 64 + lane] = v;   // own slot: no sync needed
-        else hold[j < ROWS ? j : 0] = v;
+      if (IPF && next_phase && j + 1 < ROWS)                 // pixel indices of the NEXT row: read now, needed one chunk later
+        ixn = sCi[((j + 1) * 8 + wave) * taps + (phase + 1) / ncb];
+      if (GDIST == 1) {
+        if (do_row) {
+          const float4 v = combine(phase + 1, j * 8 + wave, g);
+          if (j < STAGE) sStage[(wave * (STAGE ? STAGE : 1) + (j < STAGE ? j : 0)) * 64 + lane] = v;   // own slot: no sync needed
+          else hold[j < ROWS ? j : 0] = v;
+        }
+      } else if (next_phase && j >= 1 && j - 1 < ROWS) {      // GDIST = 2: the row gathered one chunk ago is due now
+        hold[j - 1 < ROWS ? j - 1 : 0] = combine(phase + 1, (j - 1) * 8 + wave, gq[(j - 1) & 1]);
       }
       if (WDIST == 2) { bq[0] = bq1[0]; bq[1] = bq1[1]; bq1[0] = bn[0]; bq1[1] = bn[1]; }
       else { bq[0] = bn[0]; bq[1] = bn[1]; }
