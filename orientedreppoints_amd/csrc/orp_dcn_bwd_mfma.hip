@@ -432,23 +432,33 @@ dcn_bwd_weight_kernel(const BwdParams P) {
       const bool have_next = chunk + 1 < c_end;
       const int nbuf = (it + 1) & 1;
       float4 holdc[4], holdg[4];
+      // operands of k-step j + 1 are read from LDS before the MFMAs of step j are issued (the wave's own LDS latency
+      // otherwise sits in front of every group of eight MFMAs)
+      float a0, a1, b0, b1, b2, b3;
+      {
+        const float* ga = sG + (size_t)kh * RS + (2 * wo) * 32 + mrow;
+        const float* cb = sC + (size_t)kh * RS + (4 * wc) * 32 + mrow;
+        a0 = ga[0]; a1 = ga[32]; b0 = cb[0]; b1 = cb[32]; b2 = cb[64]; b3 = cb[96];
+      }
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         float4 g[4];
         const bool do_row = have_next && j < 4;
         if (do_row) gather_issue(chunk + 1, nbuf, j * 8 + wave, g, holdg[j < 4 ? j : 0]);
-        const float* ga = sG + (size_t)(2 * j + kh) * RS + (2 * wo) * 32 + mrow;
-        const float* cb = sC + (size_t)(2 * j + kh) * RS + (4 * wc) * 32 + mrow;
-        const float a0 = ga[0], a1 = ga[32];
-        const float b0 = cb[0], b1 = cb[32], b2 = cb[64], b3 = cb[96];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);             // D[o][c]
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, acc[3], 0, 0, 0);
-        acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[4], 0, 0, 0);
-        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[5], 0, 0, 0);
-        acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[6], 0, 0, 0);
-        acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, acc[7], 0, 0, 0);
+        const float ca0 = a0, ca1 = a1, cb0 = b0, cb1 = b1, cb2 = b2, cb3 = b3;
+        if (j + 1 < 16) {
+          const float* ga = sG + (size_t)(2 * (j + 1) + kh) * RS + (2 * wo) * 32 + mrow;
+          const float* cb = sC + (size_t)(2 * (j + 1) + kh) * RS + (4 * wc) * 32 + mrow;
+          a0 = ga[0]; a1 = ga[32]; b0 = cb[0]; b1 = cb[32]; b2 = cb[64]; b3 = cb[96];
+        }
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0, cb0, acc[0], 0, 0, 0);             // D[o][c]
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0, cb1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0, cb2, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0, cb3, acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1, cb0, acc[4], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1, cb1, acc[5], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1, cb2, acc[6], 0, 0, 0);
+        acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1, cb3, acc[7], 0, 0, 0);
         if (do_row) holdc[j < 4 ? j : 0] = combine(nbuf, j * 8 + wave, g);
       }
       if (have_next) {
