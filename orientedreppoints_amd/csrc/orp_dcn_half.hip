@@ -250,11 +250,20 @@ dcn_fwd_half_kernel(const FwdH P, int total_tiles) {
     }
     // (2) the tap: one MFMA per (chunk, row block); the weight register of chunk j is refilled for the next tap at once
     const T* arow = sA + (size_t)mrow * ASTRH + 8 * kg;
+    // the A fragments of chunk j + 1 are read from LDS before the MFMAs of chunk j are issued: with 32-cycle MFMAs a
+    // chunk is only ~100 cycles of matrix work, less than the LDS round trip it would otherwise wait for
+    v8 apre[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) apre[mt] = *reinterpret_cast<const v8*>(arow + (size_t)mt * 32 * ASTRH);
 #pragma unroll
     for (int j = 0; j < NCHUNK; j++) {
       v8 a[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; mt++) a[mt] = *reinterpret_cast<const v8*>(arow + (size_t)mt * 32 * ASTRH + j * KCH);
+      for (int mt = 0; mt < MT; mt++) a[mt] = apre[mt];
+      if (j + 1 < NCHUNK) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) apre[mt] = *reinterpret_cast<const v8*>(arow + (size_t)mt * 32 * ASTRH + (j + 1) * KCH);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) {
         if (OUT_NCHW) acc[mt] = Elem<T>::mfma(bq[j], a[mt], acc[mt]);     // D[channel][position]
