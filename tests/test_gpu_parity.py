@@ -1276,6 +1276,29 @@ def test_pipelined_inference_returns_each_images_own_results_in_order(dev):
                 assert [c.shape for c in gr] == [c.shape for c in wr]
                 for a, b in zip(gr, wr):
                     assert np.allclose(a, b, rtol=1e-4, atol=1e-2)
+    # more (point, class) pairs above score_thr than the static capacity holds: every image falls back to the
+    # reference-shaped path and still returns its own results; two images per call
+    model.test_cfg['static_capacity'] = 64
+    try:
+        pi = PipelinedInference(model, imgs[0], metas, depth=2)
+        got = [r for r in (pi.submit(im) for im in imgs[:4]) if r is not None] + pi.flush()
+        for g, w in zip(got, want[:4]):
+            for gr, wr in zip(g, w):
+                assert [c.shape for c in gr] == [c.shape for c in wr]
+    finally:
+        model.test_cfg['static_capacity'] = 8192
+    metas2 = metas * 2
+    pair = [torch.cat([imgs[0], imgs[1]]), torch.cat([imgs[2], imgs[3]]), torch.cat([imgs[4], imgs[0]])]
+    with torch.no_grad():                                   # (the library picks other algorithms at N = 2: compare like with like)
+        want2 = [model.simple_test_batch(p, metas2) for p in pair]
+    pi = PipelinedInference(model, pair[0], metas2, depth=2)
+    got = [r for r in (pi.submit(p) for p in pair) if r is not None] + pi.flush()
+    for g, w in zip(got, want2):
+        assert len(g) == len(w) == 2
+        for gr, wr in zip(g, w):
+            assert [c.shape for c in gr] == [c.shape for c in wr]
+            for a, b in zip(gr, wr):
+                assert np.allclose(a, b, rtol=1e-4, atol=1e-2)
 
 
 def test_graphed_inference_owns_its_memory_and_follows_weight_updates(dev):
