@@ -257,7 +257,7 @@ __device__ __forceinline__ void mask_tile(TileLds& T, TermLds& X, const orp::Qua
   __syncthreads();
   if (tid < rpb && row_base + tid < n) {
     const u64 w = T.words[tid];
-    mask[(size_t)(s0 + row_base + tid) * mask_stride + c] = w;
+    mask[(size_t)(c) * mask_stride + (s0 + row_base + tid)] = w;
     if (w) {                                             // sparse side list of this segment for the LDS-resident sweep
       const int pos = atomicAdd(nz_count, 1);
       if (pos < kNzCap) nz_rc[pos] = ((unsigned)(row_base + tid) << 11) | (unsigned)c;
@@ -352,7 +352,7 @@ nms_mask_f64_kernel(const orp::QuadPrepT<double>* __restrict__ prep, int n, int 
       hit = !(iou <= thr);
     }
     const u64 bits = __ballot(hit);
-    if (lane == 0) mask[(size_t)r * mask_stride + c] = bits;
+    if (lane == 0) mask[(size_t)(c) * mask_stride + r] = bits;
   }
 }
 
@@ -434,7 +434,7 @@ __device__ __forceinline__ void sweep_small(unsigned char* smem, const u64* __re
   for (int i = tid; i < nnz; i += kSweepThreads) {
     const unsigned rc = my_rc[i];
     const unsigned row = rc >> 11, cc = rc & 2047u;
-    const u64 w = mask[(size_t)(s0 + (int)row) * mask_stride + cc];
+    const u64 w = mask[(size_t)(cc) * mask_stride + (s0 + (int)row)];
     const int pos = atomicAdd(&bend[row >> 6], 1);
     nzrc[pos] = rc; nzw[pos] = w;
     if (cc == (row >> 6)) diagw[row] = w;
@@ -568,7 +568,7 @@ nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order
       const unsigned rc = my_rc[i];
       const int pos = atomicAdd(&bend[rc >> 17], 1);
       nzrc[pos] = rc;
-      nzw[pos] = mask[(size_t)(s0 + (int)(rc >> 11)) * mask_stride + (rc & 2047u)];
+      nzw[pos] = mask[(size_t)((rc & 2047u)) * mask_stride + (s0 + (int)(rc >> 11))];
     }
     __syncthreads();
     // block 0's diagonal words
@@ -618,7 +618,7 @@ nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order
   // an empty word cannot suppress anything inside the block), which in practice is a handful per block.
   constexpr int kPre = 8;
   u64 d_next = 0ull;
-  if (!sparse && wave == 0) { const int row = lane; d_next = (row < n) ? mask[(size_t)(s0 + row) * mask_stride + 0] : 0ull; }
+  if (!sparse && wave == 0) { const int row = lane; d_next = (row < n) ? mask[(size_t)(0) * mask_stride + (s0 + row)] : 0ull; }
   for (int blk = 0; !sparse && blk < cb; blk++) {
     const int ncols = cb - (blk + 1);
     int slices = 1, rows_per_slice = 64;
@@ -636,12 +636,12 @@ nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order
     for (int u = 0; u < kPre; u++) {
       const int kk = k00 + u;
       const int row = blk * 64 + kk;
-      pre[u] = (has && u < rows_per_slice && kk < 64 && row < n) ? mask[(size_t)(s0 + row) * mask_stride + cidx0] : 0ull;
+      pre[u] = (has && u < rows_per_slice && kk < 64 && row < n) ? mask[(size_t)(cidx0) * mask_stride + (s0 + row)] : 0ull;
     }
     if (wave == 0) {
       const u64 d = d_next;
       const int nrow = (blk + 1) * 64 + lane;
-      d_next = (blk + 1 < cb && nrow < n) ? mask[(size_t)(s0 + nrow) * mask_stride + blk + 1] : 0ull;
+      d_next = (blk + 1 < cb && nrow < n) ? mask[(size_t)(blk + 1) * mask_stride + (s0 + nrow)] : 0ull;
       const u64 cur0 = removed[blk];
       unsigned clo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur0);
       unsigned chi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur0 >> 32));
@@ -671,10 +671,10 @@ nms_sweep_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ order
           for (int u = 0; u < kPre; u++)
             if (u < rows_per_slice && k0 + u < 64 && ((kept >> (k0 + u)) & 1ull)) acc |= pre[u];
           for (int kk = k0 + kPre; kk < k0 + rows_per_slice && kk < 64; kk++)
-            if ((kept >> kk) & 1ull) acc |= mask[(size_t)(s0 + blk * 64 + kk) * mask_stride + cidx];
+            if ((kept >> kk) & 1ull) acc |= mask[(size_t)(cidx) * mask_stride + (s0 + blk * 64 + kk)];
         } else {
           for (int kk = k0; kk < k0 + rows_per_slice && kk < 64; kk++)
-            if ((kept >> kk) & 1ull) acc |= mask[(size_t)(s0 + blk * 64 + kk) * mask_stride + cidx];
+            if ((kept >> kk) & 1ull) acc |= mask[(size_t)(cidx) * mask_stride + (s0 + blk * 64 + kk)];
         }
         if (acc) atomicOr(&removed[cidx], acc);
       }
@@ -837,8 +837,8 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
   static const int dbg = getenv("ORP_NMS_DBG") ? atoi(getenv("ORP_NMS_DBG")) : 0;   // dev aid (timing): 1 = skip phase B, 2 = skip classifier, 4/8/16 = see tile_drain_terms
   {
     OrpProfScope prof(ORP_PROF_NMS_MASK, st);
-    if (flavor == 0) hipLaunchKernelGGL(nms_mask_loop_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc);
-    else hipLaunchKernelGGL(nms_mask_loop_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, max_cb, thr, mask, dbg, nz_count, nz_rc);
+    if (flavor == 0) hipLaunchKernelGGL(nms_mask_loop_kernel<false>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, n_total, thr, mask, dbg, nz_count, nz_rc);
+    else hipLaunchKernelGGL(nms_mask_loop_kernel<true>, grid, dim3(kMaskThreads), 0, st, boxes, seg, R, n_total, thr, mask, dbg, nz_count, nz_rc);
   }
 
   // ---- stage 3: greedy sweep + compaction ------------------------------------------------------------------------------------
@@ -846,7 +846,7 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
   if (sweep_attr() != hipSuccess) return (int)sweep_attr();
   {
     OrpProfScope prof(ORP_PROF_NMS_SWEEP, st);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(nseg), dim3(kSweepThreads), smem, st, mask, order, seg, max_cb, order_out,
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(nseg), dim3(kSweepThreads), smem, st, mask, order, seg, n_total, order_out,
                        keep_out, num_keep, nz_count, nz_rc);
   }
   hipError_t e = hipGetLastError();
@@ -944,10 +944,10 @@ int orp_poly_nms_f64(const double* dets_sorted, int n, double iou_thr, int64_t* 
   { const long tiles = (long)cb * (cb + 1) / 2; long r = tiles * 64 / 8192; while (R * 2 <= r && R < 16) R *= 2; }
   const int rpb = R * (kMaskThreads / 64);
   hipLaunchKernelGGL(nms_mask_f64_kernel, dim3(max_cb, (n + rpb - 1) / rpb), dim3(kMaskThreads), 0, st, prep, n, R,
-                     max_cb, iou_thr, mask);
+                     n, iou_thr, mask);
   const size_t smem = sweep_smem_bytes(max_cb);
   if (sweep_attr() != hipSuccess) return (int)sweep_attr();
-  hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(kSweepThreads), smem, st, mask, order, seg, max_cb, 1, keep_out,
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(kSweepThreads), smem, st, mask, order, seg, n, 1, keep_out,
                      num_keep, (const int*)nullptr, (const unsigned*)nullptr);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
