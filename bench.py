@@ -761,6 +761,16 @@ def main():
                    hbm_frac=alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, pairs_per_launch=pairs,
                    gpairs_per_s=pairs / avg_s / 1e9,
                    note='bit-exact fp32 triangle-fan IoU: ALU-bound, 0.6 MB of traffic per launch')
+        # counters of HEAD's mask kernel from the committed rocprofv3 --pmc passes (2 000-box dense scene of the same shape)
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc.json'))).get('nms_mask', {})
+            c = pm.get('counters', {})
+            simd_cycles = c['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0          # GRBM is summed over the 8 XCDs; 1024 SIMDs
+            nms.update(traffic=pm.get('hbm_bytes_per_launch'), valu_busy_frac=c['SQ_ACTIVE_INST_VALU'] / simd_cycles,
+                       waves_per_simd=c['SQ_WAVE_CYCLES'] / simd_cycles,
+                       traffic_source='profiles/r02_pmc.json (rocprofv3 --pmc passes, collected separately)')
+        except Exception:   # noqa: BLE001
+            pass
     per_op = None
     if not args.no_cpu_baseline:
         try:
