@@ -766,8 +766,9 @@ def main():
             pm = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc.json'))).get('nms_mask', {})
             c = pm.get('counters', {})
             simd_cycles = c['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0          # GRBM is summed over the 8 XCDs; 1024 SIMDs
-            nms.update(traffic=pm.get('hbm_bytes_per_launch'), valu_busy_frac=c['SQ_ACTIVE_INST_VALU'] / simd_cycles,
-                       waves_per_simd=c['SQ_WAVE_CYCLES'] / simd_cycles,
+            # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md, "SQ PMC units")
+            nms.update(traffic=pm.get('hbm_bytes_per_launch'), valu_busy_frac=4.0 * c['SQ_ACTIVE_INST_VALU'] / simd_cycles,
+                       waves_per_simd=4.0 * c['SQ_WAVE_CYCLES'] / simd_cycles,
                        traffic_source='profiles/r02_pmc.json (rocprofv3 --pmc passes, collected separately)')
         except Exception:   # noqa: BLE001
             pass
