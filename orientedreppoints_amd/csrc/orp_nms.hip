@@ -270,8 +270,11 @@ __device__ __forceinline__ void mask_tile(TileLds& T, TermLds& X, const orp::Qua
 // an 8 K capacity holding 2 K boxes must not pay for 60 K empty workgroups).  A bounded grid of workgroups loops over the
 // UPPER-TRIANGULAR tiles of the actual count (enumerated in closed form; lower-triangular tiles are never read by the
 // sweep), which also balances the load: 117 -> 83 us at 2000 boxes against one workgroup per tile of the full grid.
+#ifndef ORP_MASK_WGS
+#define ORP_MASK_WGS 4
+#endif
 template <bool GUARD>
-__global__ void __launch_bounds__(kMaskThreads, 4)
+__global__ void __launch_bounds__(kMaskThreads, ORP_MASK_WGS)
 nms_mask_loop_kernel(const orp::QuadPrep* __restrict__ prep, const int32_t* __restrict__ seg_off, int rows_per_wave,
                      int mask_stride, float thr, u64* __restrict__ mask, int dbg, int* __restrict__ nz_count,
                      unsigned* __restrict__ nz_rc) {

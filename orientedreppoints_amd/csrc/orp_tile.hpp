@@ -11,7 +11,10 @@ namespace orp_tile {
 using orp::Pt;
 typedef unsigned long long u64;
 
-constexpr int kMaxTileRows = 64;
+#ifndef ORP_TILE_ROWS
+#define ORP_TILE_ROWS 64
+#endif
+constexpr int kMaxTileRows = ORP_TILE_ROWS;   // rows a tile may have (dev aid: 16 shrinks the LDS footprint for occupancy experiments)
 
 struct TileLds {
   float4 rowE[4][kMaxTileRows];      // oriented fan edges (ax, ay, bx, by) per edge, per tile row
