@@ -165,8 +165,8 @@ def workspace(device, nbytes):
     key = (idx, torch.cuda.current_stream(device).cuda_stream)
     w = _workspaces.get(key)
     if w is None or w.numel() < nbytes:
-        if len(_workspaces) > 32:                   # short-lived side streams: do not hoard their buffers
-            _workspaces.clear()
+        if key not in _workspaces and len(_workspaces) >= 32:   # short-lived side streams: drop the oldest buffer only
+            _workspaces.pop(next(iter(_workspaces)))           # (its block goes back to the allocator in stream order)
         w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = w
     return w

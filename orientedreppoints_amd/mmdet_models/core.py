@@ -46,10 +46,10 @@ class PointGenerator(object):
         key = (int(feat_h), int(feat_w), float(stride), str(device))
         cache = self.__dict__.setdefault('_grid_cache', {})
         if key not in cache:
-            if len(cache) > 32:
-                cache.clear()
+            if len(cache) >= 64:                               # value-keyed; drop the oldest entry only
+                cache.pop(next(iter(cache)))
             cache[key] = self._grid_points(featmap_size, stride, device)
-        return cache[key]
+        return _lib.keep_for_graph(cache[key])
 
     def _grid_points(self, featmap_size, stride, device):
         feat_h, feat_w = featmap_size
@@ -290,14 +290,16 @@ _arange_cache = {}
 
 
 def _arange_cached(a, b, dev):
+    """Index range of one FPN level (value-keyed, so a hit can never be a different range); a captured graph that
+    reads it keeps it alive itself (`keep_for_graph`), eviction drops the oldest entry only."""
     key = (a, b, dev)
     t = _arange_cache.get(key)
     if t is None:
         t = torch.arange(a, b, device=dev)
-        if len(_arange_cache) > 64:
-            _arange_cache.clear()
+        if len(_arange_cache) >= 256:
+            _arange_cache.pop(next(iter(_arange_cache)))
         _arange_cache[key] = t
-    return t
+    return _lib.keep_for_graph(t)
 
 
 def rbbox2result_packed(packed, num_classes):

@@ -17,7 +17,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair, _single
 
-from .. import _lib
+from .. import _lib, _packcache
 
 
 class _DcnLevel(ctypes.Structure):
@@ -25,38 +25,38 @@ class _DcnLevel(ctypes.Structure):
                 ("height", ctypes.c_int), ("width", ctypes.c_int)]
 
 
-_packed_cache = {}
+_packed_cache = _packcache.new_cache("dcn_weight_fp32")
 
 
-def _packed_weight(weight):
+def _packed_weight(weight, cache=True):
     """[Cout,Cin,kh,kw] -> [kh*kw,Cin,Cout] ++ [kh*kw,Cin/4,Cout,4] (both kernel generations).
 
-    Inference (no autograd) caches the pack per (storage, version).  With autograd enabled on a trainable weight the
-    pack is rebuilt on every call: an optimizer / EMA / `reset_parameters` writing through `.data` does not bump the
-    version counter, and a stale pack would make forward and backward disagree (the pack costs ~1 % of the conv)."""
+    `cache=True` (inference): the pack is cached on the live parameter object (_packcache.OwnerCache: weak reference +
+    identity check + storage / version state).  `cache=False` (the autograd Functions pass it when the weight takes a
+    gradient -- decided from `ctx.needs_input_grad`, because grad mode is always off inside Function.forward): the pack
+    is rebuilt on every call, so an optimizer / EMA / `reset_parameters` writing through `.data` (no version bump) can
+    never make forward and backward disagree (the pack costs ~1 % of the conv)."""
     w = weight.detach()
-    cacheable = not (torch.is_grad_enabled() and weight.requires_grad)
-    key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index)
-    hit = _packed_cache.get(id(weight)) if cacheable else None
-    if hit is not None and hit[0] == key:
-        return _lib.keep_for_graph(hit[1])
+    state = _packcache.tensor_state(w)
+    if cache:
+        hit = _packed_cache.get(weight, state)
+        if hit is not None:
+            return _lib.keep_for_graph(hit)
     w = w.float().contiguous()
     cout, cin, kh, kw = w.shape
     packed = torch.empty((_lib.lib().orp_dcn_packed_weight_floats(cout, cin, kh, kw),), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
         rc = _lib.lib().orp_dcn_pack_weight(_lib.ptr(w), cout, cin, kh, kw, _lib.ptr(packed), _lib.stream_of(w))
     _lib.check(rc, "orp_dcn_pack_weight")
-    if not cacheable:
+    if not cache:
         return packed
-    if len(_packed_cache) > 64:
-        _packed_cache.clear()
-    _packed_cache[id(weight)] = (key, packed)
-    return _lib.keep_for_graph(packed)
+    return _lib.keep_for_graph(_packed_cache.put(weight, state, packed))
 
 
 def invalidate_packed_weights():
-    """Drop every cached weight pack (call after writing parameters through `.data`, which bypasses the version key)."""
-    _packed_cache.clear()
+    """Drop EVERY cached weight pack and folded affine (fp32 / half DeformConv packs, head 1x1 packs, BatchNorm
+    affines): call after writing parameters through `.data`, which bypasses the version counters."""
+    _packcache.invalidate_all()
 
 
 def _out_hw(h, w, weight, stride, padding, dilation):
@@ -70,11 +70,13 @@ def fast_path_ok(weight, groups, deformable_groups):
     return bool(_lib.lib().orp_dcn_fast_path_ok(cin_g * groups, cout, kh, kw, groups, deformable_groups))
 
 
-def deform_conv_forward_multi(inputs, offsets, weight, stride, padding, dilation, masks=None, bias=None, relu=False):
+def deform_conv_forward_multi(inputs, offsets, weight, stride, padding, dilation, masks=None, bias=None, relu=False,
+                              cache_pack=True):
     """One DeformConv layer over a list of feature maps (same batch / channels) in ONE launch.  fp32, no autograd.
     masks (list of [B,kh*kw,Ho,Wo], DCNv2 modulation) / bias ([Cout]) / relu (fused max(., 0)) are optional."""
     if inputs[0].dtype in _HALF_CODES and weight.dtype == inputs[0].dtype and half_path_ok(weight, 1, 1):
-        return deform_conv_forward_multi_half(inputs, offsets, weight, stride, padding, dilation, masks, bias, relu)
+        return deform_conv_forward_multi_half(inputs, offsets, weight, stride, padding, dilation, masks, bias, relu,
+                                              cache_pack)
     L = _lib.lib()
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     x0 = inputs[0]
@@ -82,7 +84,7 @@ def deform_conv_forward_multi(inputs, offsets, weight, stride, padding, dilation
     cout, _, kh, kw = weight.shape
     nhwc = all(x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
                for x in inputs)
-    packed = _packed_weight(weight)
+    packed = _packed_weight(weight, cache_pack)
     xs, offs, outs = [], [], []
     levels = (_DcnLevel * len(inputs))()
     for i, (x, off) in enumerate(zip(inputs, offsets)):
@@ -120,17 +122,17 @@ def deform_conv_forward_multi(inputs, offsets, weight, stride, padding, dilation
 
 
 _HALF_CODES = {torch.float16: 1, torch.bfloat16: 2}
-_packed_cache_h = {}
+_packed_cache_h = _packcache.new_cache("dcn_weight_half")
 
 
-def _packed_weight_h(weight):
+def _packed_weight_h(weight, cache=True):
     """[Cout,Cin,kh,kw] fp16 / bf16 -> [tap][Cin/16][2][Cout][8] (orp_dcn_pack_weight_h), cached like the fp32 pack."""
     w = weight.detach()
-    cacheable = not (torch.is_grad_enabled() and weight.requires_grad)
-    key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index, w.dtype)
-    hit = _packed_cache_h.get(id(weight)) if cacheable else None
-    if hit is not None and hit[0] == key:
-        return _lib.keep_for_graph(hit[1])
+    state = _packcache.tensor_state(w)
+    if cache:
+        hit = _packed_cache_h.get(weight, state)
+        if hit is not None:
+            return _lib.keep_for_graph(hit)
     w = w.contiguous()
     cout, cin, kh, kw = w.shape
     packed = torch.empty((cout * cin * kh * kw,), dtype=w.dtype, device=w.device)
@@ -138,11 +140,9 @@ def _packed_weight_h(weight):
         rc = _lib.lib().orp_dcn_pack_weight_h(_lib.ptr(w), cout, cin, kh, kw, _lib.ptr(packed), _HALF_CODES[w.dtype],
                                               _lib.stream_of(w))
     _lib.check(rc, "orp_dcn_pack_weight_h")
-    if cacheable:
-        if len(_packed_cache_h) > 64:
-            _packed_cache_h.clear()
-        _packed_cache_h[id(weight)] = (key, packed)
-    return _lib.keep_for_graph(packed) if cacheable else packed
+    if not cache:
+        return packed
+    return _lib.keep_for_graph(_packed_cache_h.put(weight, state, packed))
 
 
 def half_path_ok(weight, groups, deformable_groups):
@@ -151,7 +151,8 @@ def half_path_ok(weight, groups, deformable_groups):
                                                                                deformable_groups))
 
 
-def deform_conv_forward_multi_half(inputs, offsets, weight, stride, padding, dilation, masks=None, bias=None, relu=False):
+def deform_conv_forward_multi_half(inputs, offsets, weight, stride, padding, dilation, masks=None, bias=None, relu=False,
+                                   cache_pack=True):
     """`deform_conv_forward_multi` for fp16 / bf16 tensors (the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF
     branch; BASELINE configs[4]): v_mfma_f32_32x32x16_{f16,bf16}, fp32 bilinear combine and accumulation, outputs in the
     input dtype.  All tensors (inputs, offsets, masks, bias, weight) must share that dtype."""
@@ -166,7 +167,7 @@ def deform_conv_forward_multi_half(inputs, offsets, weight, stride, padding, dil
         raise TypeError("deform_conv (half): weight dtype %s != input dtype %s" % (weight.dtype, dt))
     nhwc = all(x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
                for x in inputs)
-    packed = _packed_weight_h(weight)
+    packed = _packed_weight_h(weight, cache_pack)
 
     class _LevelH(ctypes.Structure):
         _fields_ = [("input", ctypes.c_void_p), ("offset", ctypes.c_void_p), ("output", ctypes.c_void_p),
@@ -208,7 +209,7 @@ def deform_conv_forward_multi_half(inputs, offsets, weight, stride, padding, dil
 
 
 def deform_conv_forward_pair(inputs_a, inputs_b, offsets, weight_a, weight_b, stride, padding, dilation, masks=None,
-                             bias_a=None, bias_b=None, relu=False):
+                             bias_a=None, bias_b=None, relu=False, cache_pack=True):
     """Two DeformConv layers with the SAME offsets (the head's cls / refine pair) over a list of feature maps in ONE
     launch (`orp_dcn_forward_pair`): the bilinear coefficient table of every tile is built once for both layers.
     fp32, no autograd.  Returns (outs_a, outs_b).  Falls back to two `deform_conv_forward_multi` launches when the
@@ -219,11 +220,13 @@ def deform_conv_forward_pair(inputs_a, inputs_b, offsets, weight_a, weight_b, st
     B, cin = x0.size(0), x0.size(1)
     cout, _, kh, kw = weight_a.shape
     if cin % 256 != 0 or tuple(weight_b.shape) != tuple(weight_a.shape):
-        return (deform_conv_forward_multi(inputs_a, offsets, weight_a, stride, padding, dilation, masks, bias_a, relu),
-                deform_conv_forward_multi(inputs_b, offsets, weight_b, stride, padding, dilation, masks, bias_b, relu))
+        return (deform_conv_forward_multi(inputs_a, offsets, weight_a, stride, padding, dilation, masks, bias_a, relu,
+                                          cache_pack),
+                deform_conv_forward_multi(inputs_b, offsets, weight_b, stride, padding, dilation, masks, bias_b, relu,
+                                          cache_pack))
     nhwc = all(x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
                for x in list(inputs_a) + list(inputs_b))
-    pa, pb = _packed_weight(weight_a), _packed_weight(weight_b)
+    pa, pb = _packed_weight(weight_a, cache_pack), _packed_weight(weight_b, cache_pack)
     n = len(inputs_a)
     lev_a, lev_b = (_DcnLevel * n)(), (_DcnLevel * n)()
     keep, outs_a, outs_b = [], [], []
@@ -273,26 +276,23 @@ class _DcnHeads(ctypes.Structure):
                 ("levels", ctypes.POINTER(_DcnHeadLevel))]
 
 
-_packed_heads = {}
+_packed_heads = _packcache.new_cache("dcn_head_1x1")
 
 
 def _packed_head_weight(weight):
-    """[k,256,1,1] -> the [256][20] pack of orp_dcn_forward_pair_heads, cached per (storage, version)."""
+    """[k,256,1,1] -> the [256][20] pack of orp_dcn_forward_pair_heads, cached on the live parameter (inference only)."""
     w = weight.detach()
-    key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index)
-    hit = _packed_heads.get(id(weight))
-    if hit is not None and hit[0] == key:
-        return _lib.keep_for_graph(hit[1])
+    state = _packcache.tensor_state(w)
+    hit = _packed_heads.get(weight, state)
+    if hit is not None:
+        return _lib.keep_for_graph(hit)
     k = w.size(0)
     w2 = w.float().reshape(k, 256).contiguous()
     packed = torch.empty((_lib.lib().orp_dcn_head_packed_floats(),), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
         _lib.check(_lib.lib().orp_dcn_pack_head_weight(_lib.ptr(w2), k, _lib.ptr(packed), _lib.stream_of(w2)),
                    "orp_dcn_pack_head_weight")
-    if len(_packed_heads) > 64:
-        _packed_heads.clear()
-    _packed_heads[id(weight)] = (key, packed)
-    return _lib.keep_for_graph(packed)
+    return _lib.keep_for_graph(_packed_heads.put(weight, state, packed))
 
 
 def pair_heads_ok(conv_a, conv_b, head_a, head_b, x):
@@ -394,7 +394,8 @@ class DeformConvFunction(Function):
         cur_im2col_step = min(ctx.im2col_step, input.shape[0])
         assert (input.shape[0] % cur_im2col_step) == 0, 'im2col step must divide batchsize'
         if fast_path_ok(weight, groups, deformable_groups):
-            out = deform_conv_forward_multi([input], [offset], weight, ctx.stride, ctx.padding, ctx.dilation)[0]
+            out = deform_conv_forward_multi([input], [offset], weight, ctx.stride, ctx.padding, ctx.dilation,
+                                            cache_pack=not ctx.needs_input_grad[2])[0]
         else:
             out = _forward_direct(input, offset, None, weight, None, ctx.stride, ctx.padding, ctx.dilation, groups,
                                   deformable_groups)
@@ -450,7 +451,7 @@ class ModulatedDeformConvFunction(Function):
         if fast_path_ok(weight, groups, deformable_groups):
             # DCNv2 on the MFMA implicit GEMM: the modulation scalar is folded into the bilinear weights of the tile
             out = deform_conv_forward_multi([input], [offset], weight, stride, padding, dilation, masks=[mask],
-                                            bias=bias)[0]
+                                            bias=bias, cache_pack=not ctx.needs_input_grad[3])[0]
         else:
             out = _forward_direct(input, offset, mask, weight, bias, _pair(stride), _pair(padding), _pair(dilation),
                                   groups, deformable_groups)
@@ -480,7 +481,8 @@ class DeformConvPairFunction(Function):
         ctx.stride, ctx.padding, ctx.dilation, ctx.n = _pair(stride), _pair(padding), _pair(dilation), n
         xa, xb, offs = list(tensors[:n]), list(tensors[n:2 * n]), list(tensors[2 * n:])
         ctx.save_for_backward(weight_a, weight_b, *tensors)
-        oa, ob = deform_conv_forward_pair(xa, xb, offs, weight_a, weight_b, ctx.stride, ctx.padding, ctx.dilation)
+        oa, ob = deform_conv_forward_pair(xa, xb, offs, weight_a, weight_b, ctx.stride, ctx.padding, ctx.dilation,
+                                          cache_pack=not (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]))
         return tuple(oa) + tuple(ob)
 
     @staticmethod

@@ -7,7 +7,7 @@ import ctypes
 
 import torch
 
-from .. import _lib
+from .. import _lib, _packcache
 
 
 class _NormLevel(ctypes.Structure):
@@ -53,26 +53,25 @@ def group_norm_act_multi(xs, gn, relu=True, inplace=True):
     return outs
 
 
-_affine_cache = {}
+_affine_cache = _packcache.new_cache("bn_affine")
 
 
 def _bn_affine(bn):
-    """eval-mode BatchNorm as (scale, shift): y = x*scale + shift; cached per parameter versions."""
-    key = (bn.weight._version if bn.weight is not None else -1, bn.bias._version if bn.bias is not None else -1,
-           bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.running_mean.device.index)
-    hit = _affine_cache.get(id(bn))
-    if hit is not None and hit[0] == key:
-        return _lib.keep_for_graph(hit[1]), _lib.keep_for_graph(hit[2])
-    with torch.no_grad():
-        rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
-        w = bn.weight.float() if bn.weight is not None else torch.ones_like(rstd)
-        b = bn.bias.float() if bn.bias is not None else torch.zeros_like(rstd)
-        scale = (w * rstd).contiguous()
-        shift = (b - bn.running_mean.float() * scale).contiguous()
-    if len(_affine_cache) > 512:
-        _affine_cache.clear()
-    _affine_cache[id(bn)] = (key, scale, shift)
-    return _lib.keep_for_graph(scale), _lib.keep_for_graph(shift)
+    """eval-mode BatchNorm as (scale, shift): y = x*scale + shift; cached on the live module (_packcache.OwnerCache:
+    weak reference + identity check), keyed by the storage / version state of its four tensors."""
+    def st(t):
+        return _packcache.tensor_state(t) if t is not None else None
+    state = (st(bn.weight), st(bn.bias), st(bn.running_mean), st(bn.running_var), float(bn.eps))
+    hit = _affine_cache.get(bn, state)
+    if hit is None:
+        with torch.no_grad():
+            rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+            w = bn.weight.float() if bn.weight is not None else torch.ones_like(rstd)
+            b = bn.bias.float() if bn.bias is not None else torch.zeros_like(rstd)
+            scale = (w * rstd).contiguous()
+            shift = (b - bn.running_mean.float() * scale).contiguous()
+        hit = _affine_cache.put(bn, state, (scale, shift))
+    return _lib.keep_for_graph(hit[0]), _lib.keep_for_graph(hit[1])
 
 
 def bn_act(x, bn, residual=None, relu=True):
@@ -130,26 +129,23 @@ def bias_act_multi(xs, bias, relu=False, residuals=None, sub=None):
     return (ys, zs) if sub is not None else ys
 
 
-_packed_1x1 = {}
+_packed_1x1 = _packcache.new_cache("conv1x1_weight")
 
 
 def _packed_1x1_weight(weight):
-    """[Cout,Cin,1,1] -> the [Cin][32] pack of orp_conv1x1_multi, cached per (storage, version) for inference."""
+    """[Cout,Cin,1,1] -> the [Cin][32] pack of orp_conv1x1_multi, cached on the live parameter (inference only)."""
     w = weight.detach()
-    key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index)
-    hit = _packed_1x1.get(id(weight))
-    if hit is not None and hit[0] == key:
-        return _lib.keep_for_graph(hit[1])
+    state = _packcache.tensor_state(w)
+    hit = _packed_1x1.get(weight, state)
+    if hit is not None:
+        return _lib.keep_for_graph(hit)
     cout, cin = w.size(0), w.size(1)
     w2 = w.float().reshape(cout, cin).contiguous()
     packed = torch.empty((_lib.lib().orp_conv1x1_packed_floats(cin),), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
         _lib.check(_lib.lib().orp_conv1x1_pack_weight(_lib.ptr(w2), cout, cin, _lib.ptr(packed), _lib.stream_of(w2)),
                    "orp_conv1x1_pack_weight")
-    if len(_packed_1x1) > 64:
-        _packed_1x1.clear()
-    _packed_1x1[id(weight)] = (key, packed)
-    return _lib.keep_for_graph(packed)
+    return _lib.keep_for_graph(_packed_1x1.put(weight, state, packed))
 
 
 def conv1x1_ok(conv, x):

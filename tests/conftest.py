@@ -23,3 +23,10 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_collection_modifyitems(config, items):
+    """ORP_TEST_ORDER=reverse runs the collected tests back to front (order-independence check of the GPU suite: no test
+    may depend on allocator / cache state left by an earlier one; logs under profiles/r03_gputest_*.log)."""
+    if os.environ.get("ORP_TEST_ORDER", "") == "reverse":
+        items.reverse()

@@ -1343,7 +1343,7 @@ def test_graphed_inference_owns_its_memory_and_follows_weight_updates(dev):
     cur = torch.cuda.current_stream(dev).cuda_stream
     grown = [k for k, v in _lib._workspaces.items() if k[1] == cur and before.get(k) != v.data_ptr()]
     assert grown or not before, "the eager scratch was expected to be replaced by a larger one"
-    DC._packed_cache.clear(); FN._affine_cache.clear()                                  # cache eviction
+    DC.invalidate_packed_weights()                                                       # cache eviction
     junk = [torch.full((1 << 22,), float('nan'), device=dev) for _ in range(8)]        # recycle freed blocks with NaNs
     del junk
     torch.cuda.synchronize()
