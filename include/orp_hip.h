@@ -205,7 +205,15 @@ int orp_dcn_forward_direct(const float* input, const float* offset, const float*
  *   input [B,256,H,W], offset [B,2*kh*kw,Ho,Wo], grad_output [B,256,Ho,Wo] ->
  *   grad_input [B,256,H,W], grad_offset [B,2*kh*kw,Ho,Wo] (both OVERWRITTEN; written when need_input_grads != 0),
  *   grad_weight [256,256,kh,kw] (OVERWRITTEN; NULL = not wanted) = sum over levels and images, added in a fixed order.
+ * need_input_grads: 0 = grad_weight only; ORP_DCN_BWD_INPUT (1) = grad_input / grad_offset without atomics: every
+ *   8 x 8-pixel region of grad_input is accumulated by ONE workgroup in LDS in a fixed order (bitwise reproducible, each
+ *   byte of grad_input written once); ORP_DCN_BWD_INPUT | ORP_DCN_BWD_SPARSE (3) = the caller expects grad_output to be
+ *   zero almost everywhere (a detection head's regression branch: gradient at the positive points only): the few live
+ *   rows are scattered with fp32 atomics instead, which skips the fixed cost of the region pass (same values to 1e-4;
+ *   summation order not fixed, as in the reference's deformable_col2im).
  * weight is the layer's [256,256,kh,kw] tensor.  workspace: orp_dcn_backward_workspace_bytes() bytes. */
+#define ORP_DCN_BWD_INPUT 1
+#define ORP_DCN_BWD_SPARSE 2
 typedef struct { const float* input; const float* offset; const float* grad_output; float* grad_input; float* grad_offset;
                  int height; int width; } orp_dcn_bwd_level;
 int orp_dcn_backward_mfma_ok(int c_in, int c_out, int kh, int kw, int groups, int deformable_groups);

@@ -9,10 +9,18 @@
 //   kernel A  (grad_input, grad_offset)   per tile of MT*32 positions and per kernel tap t:
 //       G_t[p, c] = sum_o  go[p, o] * W[o, c, t]                      (v_mfma_f32_32x32x2_f32, K = 256 output channels)
 //     the grad_out tile stays in LDS for all nine taps, wave w owns input channels [32w, 32w+32) and streams its W^T
-//     fragments L2 -> registers; the accumulator of a tap is consumed in place: four bilinear-weighted atomic adds into
-//     grad_input (NHWC: one half-wave = one 128-byte row segment) and the two coordinate derivatives
+//     fragments L2 -> registers; the accumulator of a tap is consumed in place: the two coordinate derivatives
 //     (get_coordinate_weight, deform_conv_cuda_kernel.cu:145-188), reduced over the 32 lanes with DPP and over the 8 waves
-//     in LDS.
+//     in a fixed order through LDS, and the row G_t[p, :] is stored (1 KB, coalesced) for kernel A2.
+//   kernel A2 (grad_input, round 3: NO atomics)   one workgroup owns an 8 x 8-pixel region of grad_input for all 256
+//     channels as a 64 KB LDS accumulator.  A pre-pass files every (position, tap) sample under the <= 4 regions its
+//     bilinear footprint touches (fixed slots + a STABLE device radix sort by region: every region's list is in ascending
+//     sample order); the region's workgroup (thread = channel, so no two threads ever touch the same accumulator) walks
+//     its list, adds  weight x G  for the corners inside the region with plain LDS read-modify-writes, and writes its 64
+//     pixels once, coalesced.  Every pixel is written by exactly one workgroup (no zero fill, no atomics), the summation
+//     order is fixed: bitwise reproducible.  Round 2 scattered with 4 x 9 x 256 fp32 atomics per position: 402 M
+//     lane-atomics per launch left the L2 as 1.555 GB of single transactions (profiles/r02_pmc.json) for 45 MB of
+//     gradient, 1.43 ms; that path is still selectable (ORP_DCN_BWD_ATOMIC=1, dev aid) for comparison.
 //   kernel B  (grad_weight)   workgroup (split s, tap t):
 //       gW_t[o, c] = sum_p  go[p, o] * col_t[p, c],    col_t[p, c] = bilinear(x[:, c], p + t + offset)
 //     K = positions, walked in 32-position chunks: the col tile is gathered exactly like the forward's A tile (coalesced
@@ -32,6 +40,7 @@
 // (313 G lane-atomics/s, agent and workgroup scope alike) -- but ds_add_f32 ran at the same ~310 G lanes/s on this part,
 // and the 112 KB of rows cut the occupancy from three workgroups per CU to one: 2.56 ms vs 1.40 ms without.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -39,8 +48,11 @@
 #include "orp_launch.hpp"
 #include "orp_prof.hpp"
 
+#ifndef ORP_BWD_SPLITACC
+#define ORP_BWD_SPLITACC 1   // kernel A: even / odd k-steps accumulate into two independent tiles (two MFMA dependency chains per wave)
+#endif
 #ifndef ORP_BWD_DBG
-#define ORP_BWD_DBG 0      // dev aid, compile-time (timing only, wrong results): 1 = no grad_input atomics, 2 = no x loads / derivative reduction
+#define ORP_BWD_DBG 0      // dev aid, compile-time (timing only, wrong results): 1 = no grad_input atomics, 2 = no x loads / derivative reduction, 4 = no G store, 8 = no epilogue at all
 #endif
 
 namespace {
@@ -63,6 +75,7 @@ struct BLevel {
   int H, W, Ho, Wo;
   int tile0;           // kernel A: first tile of this level
   int chunk0;          // kernel B: first 32-position chunk of this level
+  int reg0, RH, RW;    // kernel A2: first 8 x 8-pixel region of this level, regions per image column / row
 };
 struct BwdParams {
   BLevel lv[MAXL];
@@ -72,6 +85,13 @@ struct BwdParams {
   float* partial;      // [nsplit][tap][o][c]
   int nsplit, total_chunks;
   const int* active;   // [total_chunks] chunk indices with a non-zero grad_out row, ascending; active[total_chunks] = count
+  float* G;            // kernel A -> A2: G[(position * taps + tap)][256], positions numbered chunk0 * 32 + p (NULL: atomics)
+  const int* flags;    // [total_chunks] chunk holds a non-zero grad_out row
+  int nregions;
+  unsigned* keys;      // [4 * total_chunks * 32 * taps] region of slot (sample, k); nregions = unused slot
+  unsigned* vals;      //   the sample index of the slot
+  int* rcount;         // [nregions + 1] first sorted slot of region r (region_bounds_kernel)
+  const unsigned* sorted_vals;
 };
 
 inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -202,7 +222,7 @@ __device__ inline float half_wave_sum(float v) {
 // ---- kernel A: grad_input + grad_offset ---------------------------------------------------------------------------
 // One tile = one 32-position chunk (MT = 1: three workgroups per CU hide the epilogue's load / atomic latency; two
 // sub-tiles per workgroup measured 5 % slower).
-template <int MT>
+template <int MT, bool STORE_G>
 __global__ void __launch_bounds__(kThreads)
 dcn_bwd_input_kernel(const BwdParams P) {
   constexpr int BM2 = 32 * MT;
@@ -211,8 +231,8 @@ dcn_bwd_input_kernel(const BwdParams P) {
   float* sG = reinterpret_cast<float*>(smem);                       // [BM2][ASTR] grad_out rows
   int4* sCi = reinterpret_cast<int4*>(sG + BM2 * ASTR);             // [BM2 * taps]
   float2* sCl = reinterpret_cast<float2*>(sCi + BM2 * MAXT);        // [BM2 * taps] (lh, lw)
-  float* sGO = reinterpret_cast<float*>(sCl + BM2 * MAXT);          // [BM2][taps][2] grad_offset of the tile
-  int* sNZ = reinterpret_cast<int*>(sGO + BM2 * MAXT * 2);          // [BM2] row has a non-zero grad_out value
+  float* sGO = reinterpret_cast<float*>(sCl + BM2 * MAXT);          // [8 waves][BM2][taps][2] grad_offset partials of the tile
+  int* sNZ = reinterpret_cast<int*>(sGO + 8 * BM2 * MAXT * 2);      // [BM2] row has a non-zero grad_out value
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int taps = P.kh * P.kw;
@@ -238,8 +258,8 @@ dcn_bwd_input_kernel(const BwdParams P) {
     float2 fr = make_float2(0.f, 0.f);
     if (p0 + m < npos) sample_point(P, L, p0 + m, tap, taps, HoWo, ix, fr);
     sCi[e] = ix; sCl[e] = fr;
-    sGO[2 * e] = 0.f; sGO[2 * e + 1] = 0.f;
   }
+  for (int e = tid; e < 8 * BM2 * MAXT * 2; e += kThreads) sGO[e] = 0.f;
   for (int r = wave; r < BM2; r += 8) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p0 + r < npos) v = *reinterpret_cast<const float4*>(L.go + (size_t)(p0 + r) * CH + lane * 4);
@@ -264,6 +284,11 @@ dcn_bwd_input_kernel(const BwdParams P) {
     floatx16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) acc[mt] = floatx16{0};
+#if ORP_BWD_SPLITACC
+    floatx16 acc_odd[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc_odd[mt] = floatx16{0};
+#endif
 #pragma unroll
     for (int j = 0; j < CH / 16; j++) {
       float4 bn[2];
@@ -282,12 +307,20 @@ dcn_bwd_input_kernel(const BwdParams P) {
 #pragma unroll
           for (int mt = 0; mt < MT; mt++) {
             const float av = (i == 0) ? a4[mt].x : (i == 1) ? a4[mt].y : (i == 2) ? a4[mt].z : a4[mt].w;
+#if ORP_BWD_SPLITACC
+            if (i & 1) acc_odd[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc_odd[mt], 0, 0, 0);
+            else
+#endif
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[mt], 0, 0, 0);       // D[position][channel]
           }
         }
       }
       bq[0] = bn[0]; bq[1] = bn[1];
     }
+#if ORP_BWD_SPLITACC
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] += acc_odd[mt];
+#endif
     // ---- consume G_t: scatter into grad_input, coordinate derivatives into the tile's grad_offset ---------------
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
@@ -295,7 +328,10 @@ dcn_bwd_input_kernel(const BwdParams P) {
       for (int r = 0; r < 16; r++) {
         const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         const int e = m * taps + tap;
-        const bool live = sNZ[m] != 0;                              // a zero grad_out row gives G = 0: nothing to add
+        const bool live = (ORP_BWD_DBG & 8) ? false : (sNZ[m] != 0);   // a zero grad_out row gives G = 0: nothing to add
+        if (STORE_G && !(ORP_BWD_DBG & 4)) {                        // the row of (position, tap) for kernel A2 (zeros included)
+          if (p0 + m < npos) P.G[((size_t)((long)tile * BM2 + m) * taps + tap) * CH + c] = acc[mt][r];
+        }
         if (__ballot(live) == 0) continue;
         const int4 ix = live ? sCi[e] : make_int4(-1, -1, -1, -1);
         const float2 fr = sCl[e];
@@ -310,16 +346,19 @@ dcn_bwd_input_kernel(const BwdParams P) {
         const float v3 = ix.z >= 0 ? L.x[o3] : 0.f, v4 = ix.w >= 0 ? L.x[o4] : 0.f;
 #endif
 #if !(ORP_BWD_DBG & 1)
-        if (ix.x >= 0) atomicAdd(L.gx + o1, uh * uw * g);
-        if (ix.y >= 0) atomicAdd(L.gx + o2, uh * lw * g);
-        if (ix.z >= 0) atomicAdd(L.gx + o3, lh * uw * g);
-        if (ix.w >= 0) atomicAdd(L.gx + o4, lh * lw * g);
+        if (!STORE_G) {
+          if (ix.x >= 0) atomicAdd(L.gx + o1, uh * uw * g);
+          if (ix.y >= 0) atomicAdd(L.gx + o2, uh * lw * g);
+          if (ix.z >= 0) atomicAdd(L.gx + o3, lh * uw * g);
+          if (ix.w >= 0) atomicAdd(L.gx + o4, lh * lw * g);
+        }
 #endif
         float dh = g * (-uw * v1 - lw * v2 + uw * v3 + lw * v4);
         float dw = g * (-uh * v1 + uh * v2 - lh * v3 + lh * v4);
         dh = half_wave_sum(dh);
         dw = half_wave_sum(dw);
-        if (mrow == 31) { atomicAdd(sGO + 2 * e, dh); atomicAdd(sGO + 2 * e + 1, dw); }
+        // this wave's 32-channel partial of (position, tap): one writer per slot, summed over the waves in order below
+        if (mrow == 31) { sGO[(wave * BM2 * MAXT + e) * 2] = dh; sGO[(wave * BM2 * MAXT + e) * 2 + 1] = dw; }
       }
     }
   }
@@ -330,15 +369,168 @@ dcn_bwd_input_kernel(const BwdParams P) {
     const long p = p0 + m;
     if (p < npos) {
       const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
-      L.goff[((size_t)b * 2 * taps + plane) * HoWo + hw] = sGO[m * 2 * taps + plane];
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; w++) v += sGO[(w * BM2 * MAXT) * 2 + m * 2 * taps + plane];   // fixed order: reproducible
+      L.goff[((size_t)b * 2 * taps + plane) * HoWo + hw] = v;
     }
   }
 }
 
 template <int MT>
 size_t input_smem() {
-  return sizeof(float) * (size_t)32 * MT * ASTR + (sizeof(int4) + sizeof(float2) + 2 * sizeof(float)) * 32 * MT * MAXT +
+  return sizeof(float) * (size_t)32 * MT * ASTR + (sizeof(int4) + sizeof(float2) + 8 * 2 * sizeof(float)) * 32 * MT * MAXT +
          sizeof(int) * 32 * MT;
+}
+
+// ---- kernel A2: grad_input without atomics ------------------------------------------------------------------------------
+// region of the pixel with linear index q = (b * H + h) * W + w of level L
+__device__ inline int region_of_pixel(const BLevel& L, int q) {
+  const int w = q % L.W, bh = q / L.W;
+  const int h = bh % L.H, b = bh / L.H;
+  return L.reg0 + (b * L.RH + (h >> 3)) * L.RW + (w >> 3);
+}
+__device__ inline int level_of_chunk(const BwdParams& P, int chunk) {
+  int lvl = 0;
+#pragma unroll 1
+  for (int i = 1; i < P.nlev; i++) if (chunk >= P.lv[i].chunk0) lvl = i;
+  return lvl;
+}
+
+// one thread per (position, tap) sample e = (chunk * 32 + m) * taps + tap: slots 4e .. 4e+3 receive the distinct regions
+// the sample's four corners fall into (unused slots: key = nregions, sorted to the end)
+__global__ void bin_samples_kernel(const BwdParams P) {
+  const int taps = P.kh * P.kw;
+  const long E = (long)P.total_chunks * 32 * taps;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const long pg = e / taps;
+  const int tap = (int)(e - pg * taps);
+  const int chunk = (int)(pg >> 5);
+  unsigned k[4] = {(unsigned)P.nregions, (unsigned)P.nregions, (unsigned)P.nregions, (unsigned)P.nregions};
+  const BLevel& L = P.lv[level_of_chunk(P, chunk)];
+  const int HoWo = L.Ho * L.Wo;
+  const long p = pg - (long)L.chunk0 * 32;
+  if (P.flags[chunk] == 0) {
+    // kernel A skips this chunk: its grad_offset is zero (written here instead of one memset per level)
+    if (p < (long)P.B * HoWo) {
+      const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+      float* o = L.goff + ((size_t)b * 2 * taps + 2 * tap) * HoWo + hw;
+      o[0] = 0.f; o[HoWo] = 0.f;
+    }
+  } else {
+    if (p < (long)P.B * HoWo) {
+      int4 ix; float2 fr;
+      sample_point(P, L, p, tap, taps, HoWo, ix, fr);
+      const int r0 = ix.x >= 0 ? region_of_pixel(L, ix.x) : -1, r1 = ix.y >= 0 ? region_of_pixel(L, ix.y) : -1;
+      const int r2 = ix.z >= 0 ? region_of_pixel(L, ix.z) : -1, r3 = ix.w >= 0 ? region_of_pixel(L, ix.w) : -1;
+      int n = 0;
+      if (r0 >= 0) k[n++] = (unsigned)r0;
+      if (r1 >= 0 && r1 != r0) k[n++] = (unsigned)r1;
+      if (r2 >= 0 && r2 != r0 && r2 != r1) k[n++] = (unsigned)r2;
+      if (r3 >= 0 && r3 != r0 && r3 != r1 && r3 != r2) k[n++] = (unsigned)r3;
+    }
+  }
+  *reinterpret_cast<uint4*>(P.keys + 4 * e) = make_uint4(k[0], k[1], k[2], k[3]);
+  *reinterpret_cast<uint4*>(P.vals + 4 * e) = make_uint4((unsigned)e, (unsigned)e, (unsigned)e, (unsigned)e);
+}
+
+// first[r] = index of the first sorted slot with key >= r, for r in [0, nregions]: region r's list is
+// [first[r], first[r + 1]).  Every boundary between two different keys fills the entries in between (empty regions too).
+__global__ void region_bounds_kernel(const unsigned* __restrict__ keys_sorted, long nslots, int nregions, int* __restrict__ first) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nslots) return;
+  const long k = (long)keys_sorted[i];
+  const long kprev = i > 0 ? (long)keys_sorted[i - 1] : -1;
+  for (long r = kprev + 1; r <= k && r <= nregions; r++) first[r] = (int)i;
+  if (i == nslots - 1) for (long r = k + 1; r <= nregions; r++) first[r] = (int)nslots;
+}
+
+// One workgroup (256 threads, thread = channel) per 8 x 8-pixel region.  LDS: acc[64][256] | sample meta of 64 list entries.
+constexpr int kScatterThreads = 256;
+constexpr int kAccRows = 65;                                         // 64 pixels + one dummy row for corners of other regions
+constexpr size_t scatter_smem() { return sizeof(float) * kAccRows * CH; }
+__global__ void __launch_bounds__(kScatterThreads)
+dcn_bwd_scatter_kernel(const BwdParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* acc = reinterpret_cast<float*>(smem);                       // [65][256]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int taps = P.kh * P.kw;
+  // regions are visited in XCD-contiguous blocks (workgroup b runs on XCD b % 8): neighbouring regions share G rows
+  int reg;
+  {
+    const int per = (P.nregions + 7) >> 3;
+    reg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || reg >= P.nregions) return;
+  }
+  int lvl = 0;
+#pragma unroll 1
+  for (int i = 1; i < P.nlev; i++) if (reg >= P.lv[i].reg0) lvl = i;
+  const BLevel L = P.lv[lvl];
+  const int rl = reg - L.reg0;
+  const int rw = rl % L.RW, rbh = rl / L.RW;
+  const int rh = rbh % L.RH, rb = rbh / L.RH;
+  // Thread c only ever touches acc[.][c], and every wave keeps its own copy of the list entries' geometry in registers
+  // (lane t <-> entry s0 + t, handed to the other lanes by v_readlane): no barrier, no atomics, no shared metadata.
+  const int c = tid;
+  float* mine = acc + c;
+#pragma unroll 5
+  for (int l = 0; l < kAccRows; l++) mine[l * CH] = 0.f;
+  const int l0 = P.rcount[reg], l1 = P.rcount[reg + 1];
+  const int HoWo = L.Ho * L.Wo;
+  constexpr int U = 8;                                               // list entries per step (G rows in flight per thread)
+  for (int s0 = l0; s0 < l1; s0 += 64) {
+    int o0 = 64 * CH, o1 = 64 * CH, o2 = 64 * CH, o3 = 64 * CH;      // accumulator row offsets (floats); 64 = the dummy row
+    float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+    unsigned e = 0;                                                  // entries past the list: row 0 of G x weight 0 into the dummy row
+    if (s0 + lane < l1) {
+      e = P.sorted_vals[s0 + lane];
+      const long pg = (long)(e / (unsigned)taps);
+      const int tap = (int)(e - (unsigned)pg * (unsigned)taps);
+      const long p = pg - (long)L.chunk0 * 32;                       // the sample belongs to this region's level
+      int4 ix; float2 fr;
+      sample_point(P, L, p, tap, taps, HoWo, ix, fr);
+      const float lh = fr.x, lw = fr.y, uh = 1.f - lh, uw = 1.f - lw;
+      auto local = [&](int q) {                                      // pixel -> row of this region, 64 = another region's / outside
+        if (q < 0) return 64;
+        const int w = q % L.W, bh = q / L.W;
+        const int h = bh % L.H, b = bh / L.H;
+        return (b == rb && (h >> 3) == rh && (w >> 3) == rw) ? ((h & 7) * 8 + (w & 7)) : 64;
+      };
+      const int i0 = local(ix.x), i1 = local(ix.y), i2 = local(ix.z), i3 = local(ix.w);
+      o0 = i0 * CH; o1 = i1 * CH; o2 = i2 * CH; o3 = i3 * CH;
+      w0 = i0 < 64 ? uh * uw : 0.f; w1 = i1 < 64 ? uh * lw : 0.f; w2 = i2 < 64 ? lh * uw : 0.f; w3 = i3 < 64 ? lh * lw : 0.f;
+    }
+    const int nb = (l1 - s0) < 64 ? (l1 - s0) : 64;
+#pragma unroll 1
+    for (int j0 = 0; j0 < nb; j0 += U) {
+      float g[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)                                    // j0 + u < 64 always (U divides 64)
+        g[u] = P.G[(size_t)(unsigned)__builtin_amdgcn_readlane((int)e, j0 + u) * CH + c];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int q0 = __builtin_amdgcn_readlane(o0, j0 + u), q1 = __builtin_amdgcn_readlane(o1, j0 + u);
+        const int q2 = __builtin_amdgcn_readlane(o2, j0 + u), q3 = __builtin_amdgcn_readlane(o3, j0 + u);
+        const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w0), j0 + u));
+        const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w1), j0 + u));
+        const float x2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w2), j0 + u));
+        const float x3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w3), j0 + u));
+        // the four corners of a sample are four different pixels (or the dummy row): read all, then write all; the next
+        // sample's reads follow these writes in program order and the LDS executes a wave's accesses in order
+        const float a0 = mine[q0], a1 = mine[q1], a2 = mine[q2], a3 = mine[q3];
+        mine[q0] = a0 + x0 * g[u];
+        mine[q1] = a1 + x1 * g[u];
+        mine[q2] = a2 + x2 * g[u];
+        mine[q3] = a3 + x3 * g[u];
+      }
+    }
+  }
+  // every pixel of the region is written exactly once (zeros included): no memset, no atomics
+  for (int l = 0; l < 64; l++) {
+    const int h = rh * 8 + (l >> 3), w = rw * 8 + (l & 7);
+    if (h < L.H && w < L.W) L.gx[((size_t)(rb * L.H + h) * L.W + w) * CH + c] = mine[l * CH];
+  }
 }
 
 // ---- kernel B: grad_weight partial sums ---------------------------------------------------------------------------------
@@ -504,8 +696,10 @@ int device_cus() {
 struct Plan {
   size_t x_off[MAXL], go_off[MAXL], gx_off[MAXL];
   size_t gx_begin, gx_bytes, wT_off, partial_off, flags_off, list_off, total;
-  int Ho[MAXL], Wo[MAXL];
-  int total_chunks, nsplit;
+  size_t G_off, keys_in_off, keys_out_off, vals_in_off, vals_out_off, rcount_off, cub_off, cub_bytes;
+  int Ho[MAXL], Wo[MAXL], reg0[MAXL], RH[MAXL], RW[MAXL];
+  int total_chunks, nsplit, nregions, key_bits;
+  long nslots;
 };
 int make_plan(const orp_dcn_bwd_level* lv, int nlevels, int batch, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
               int dw, int cus, Plan& pl) {
@@ -530,6 +724,29 @@ int make_plan(const orp_dcn_bwd_level* lv, int nlevels, int batch, int kh, int k
   pl.partial_off = cur; cur += align256(sizeof(float) * (size_t)ns * kh * kw * CH * CH);
   pl.flags_off = cur; cur += align256(sizeof(int) * (size_t)pl.total_chunks);
   pl.list_off = cur; cur += align256(sizeof(int) * ((size_t)pl.total_chunks + 1));
+  // kernel A2: regions, the G rows, the (region, sample) slots and the radix sort's scratch
+  pl.nregions = 0;
+  for (int i = 0; i < nlevels; i++) {
+    pl.RH[i] = (lv[i].height + 7) / 8; pl.RW[i] = (lv[i].width + 7) / 8;
+    pl.reg0[i] = pl.nregions; pl.nregions += batch * pl.RH[i] * pl.RW[i];
+  }
+  pl.key_bits = 1;
+  while ((1L << pl.key_bits) <= (long)pl.nregions) pl.key_bits++;   // keys 0 .. nregions (nregions = unused slot)
+  const long E = (long)pl.total_chunks * 32 * kh * kw;
+  if (4 * E >= (1L << 31)) return ORP_ETOOBIG;
+  pl.nslots = 4 * E;
+  pl.G_off = cur; cur += align256(sizeof(float) * (size_t)E * CH);
+  pl.keys_in_off = cur; cur += align256(sizeof(unsigned) * (size_t)pl.nslots);
+  pl.keys_out_off = cur; cur += align256(sizeof(unsigned) * (size_t)pl.nslots);
+  pl.vals_in_off = cur; cur += align256(sizeof(unsigned) * (size_t)pl.nslots);
+  pl.vals_out_off = cur; cur += align256(sizeof(unsigned) * (size_t)pl.nslots);
+  pl.rcount_off = cur; cur += align256(sizeof(int) * ((size_t)pl.nregions + 1));
+  size_t cub = 0;
+  if (hipcub::DeviceRadixSort::SortPairs((void*)nullptr, cub, (const unsigned*)nullptr, (unsigned*)nullptr,
+                                         (const unsigned*)nullptr, (unsigned*)nullptr, (int)pl.nslots, 0, pl.key_bits,
+                                         (hipStream_t)0) != hipSuccess) return ORP_EINVAL;
+  pl.cub_bytes = cub;
+  pl.cub_off = cur; cur += align256(cub);
   pl.total = cur + 256;
   return ORP_OK;
 }
@@ -573,6 +790,7 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
   P.wT = reinterpret_cast<float*>(ws + pl.wT_off);
   P.partial = reinterpret_cast<float*>(ws + pl.partial_off);
   P.nsplit = pl.nsplit; P.total_chunks = pl.total_chunks;
+  P.G = nullptr; P.flags = nullptr; P.nregions = 0; P.keys = nullptr; P.vals = nullptr; P.rcount = nullptr; P.sorted_vals = nullptr;
   int* flags = reinterpret_cast<int*>(ws + pl.flags_off);
   P.active = reinterpret_cast<int*>(ws + pl.list_off);
   TransposeSet TI, TO;
@@ -588,6 +806,7 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
     D.gx = reinterpret_cast<float*>(ws + pl.gx_off[i]);
     D.off = lv.offset; D.goff = lv.grad_offset;
     D.tile0 = tiles; D.chunk0 = chunks;
+    D.reg0 = pl.reg0[i]; D.RH = pl.RH[i]; D.RW = pl.RW[i];
     const long npos = (long)batch * D.Ho * D.Wo;
     tiles += (int)((npos + 32 * MT - 1) / (32 * MT));
     chunks += (int)((npos + 31) / 32);
@@ -601,7 +820,7 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
     TO.in[i] = D.gx; TO.out[i] = lv.grad_input; TO.R[i] = HW; TO.S[i] = CH; TO.t0[i] = tout; TO.chunk0[i] = -1;
     tout += ((HW + 31) / 32) * (CH / 32);
   }
-  for (int i = nlevels; i < MAXL; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; P.lv[i].chunk0 = 0x7fffffff; }
+  for (int i = nlevels; i < MAXL; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; P.lv[i].chunk0 = 0x7fffffff; P.lv[i].reg0 = 0x7fffffff; }
   TI.n = ti; TO.n = nlevels;
   for (int i = ti; i <= 2 * MAXL; i++) TI.t0[i] = tin;
   for (int i = nlevels; i <= 2 * MAXL; i++) TO.t0[i] = tout;
@@ -618,19 +837,50 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
   if (e != hipSuccess) return (int)e;
 
   if (need_input_grads) {
-    e = hipMemsetAsync(ws + pl.gx_begin, 0, pl.gx_bytes, st);
-    if (e != hipSuccess) return (int)e;
+    static const int force = getenv("ORP_DCN_BWD_ATOMIC") ? atoi(getenv("ORP_DCN_BWD_ATOMIC")) : -1;   // dev aid: 1 / 0 force a path
+    const bool use_atomics = force >= 0 ? force != 0 : (need_input_grads & ORP_DCN_BWD_SPARSE) != 0;
     hipLaunchKernelGGL(pack_wT_kernel, dim3(1024), dim3(256), 0, st, weight, taps, const_cast<float*>(P.wT));
-    // grad_offset of the chunks that are skipped is zero
-    for (int i = 0; i < nlevels; i++) {
-      e = hipMemsetAsync(levels_host[i].grad_offset, 0, sizeof(float) * (size_t)batch * 2 * taps * pl.Ho[i] * pl.Wo[i], st);
-      if (e != hipSuccess) return (int)e;
-    }
     const int per = (tiles + 7) >> 3;
-    struct T1 { int unused; };
-    e = orp::set_max_dynamic_lds_once<T1>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT>), input_smem<MT>());
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dcn_bwd_input_kernel<MT>, dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
+    P.flags = flags;
+    P.nregions = pl.nregions;
+    P.keys = reinterpret_cast<unsigned*>(ws + pl.keys_in_off);
+    P.vals = reinterpret_cast<unsigned*>(ws + pl.vals_in_off);
+    P.rcount = reinterpret_cast<int*>(ws + pl.rcount_off);
+    P.sorted_vals = reinterpret_cast<unsigned*>(ws + pl.vals_out_off);
+    if (use_atomics) {
+      P.G = nullptr;
+      e = hipMemsetAsync(ws + pl.gx_begin, 0, pl.gx_bytes, st);
+      if (e != hipSuccess) return (int)e;
+      for (int i = 0; i < nlevels; i++) {                            // grad_offset of the chunks that are skipped is zero
+        e = hipMemsetAsync(levels_host[i].grad_offset, 0, sizeof(float) * (size_t)batch * 2 * taps * pl.Ho[i] * pl.Wo[i], st);
+        if (e != hipSuccess) return (int)e;
+      }
+      struct T1 { int unused; };
+      e = orp::set_max_dynamic_lds_once<T1>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT, false>), input_smem<MT>());
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL((dcn_bwd_input_kernel<MT, false>), dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
+    } else {
+      P.G = reinterpret_cast<float*>(ws + pl.G_off);
+      // (region, sample) slots -> stable sort by region: every region's list in ascending sample order
+      const long E = pl.nslots / 4;
+      hipLaunchKernelGGL(bin_samples_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, P);
+      size_t cub_bytes = pl.cub_bytes;
+      e = hipcub::DeviceRadixSort::SortPairs(ws + pl.cub_off, cub_bytes, P.keys, reinterpret_cast<unsigned*>(ws + pl.keys_out_off),
+                                             P.vals, reinterpret_cast<unsigned*>(ws + pl.vals_out_off), (int)pl.nslots, 0,
+                                             pl.key_bits, st);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(region_bounds_kernel, dim3((unsigned)((pl.nslots + 255) / 256)), dim3(256), 0, st,
+                         reinterpret_cast<const unsigned*>(ws + pl.keys_out_off), pl.nslots, pl.nregions, P.rcount);
+      struct T2 { int unused; };
+      e = orp::set_max_dynamic_lds_once<T2>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT, true>), input_smem<MT>());
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL((dcn_bwd_input_kernel<MT, true>), dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
+      struct T3 { int unused; };
+      e = orp::set_max_dynamic_lds_once<T3>(reinterpret_cast<const void*>(&dcn_bwd_scatter_kernel), scatter_smem());
+      if (e != hipSuccess) return (int)e;
+      const int rper = (pl.nregions + 7) >> 3;
+      hipLaunchKernelGGL(dcn_bwd_scatter_kernel, dim3(rper * 8), dim3(kScatterThreads), scatter_smem(), st, P);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(transpose_set_kernel, dim3(tout, batch), dim3(256), 0, st, TO);

@@ -11,14 +11,31 @@ namespace orp_tile {
 using orp::Pt;
 typedef unsigned long long u64;
 
+// Development aid (-DORP_NMS_PHASE_PROF): shader-clock cycles of thread 0 per phase, summed over all tiles of a launch.
+// Slots 0..6 belong to the including kernel file, 8 = B1, 9 = B2, 10 = B3, 11 = chunks, 12 = B2 iterations.
+#ifdef ORP_NMS_PHASE_PROF
+// One row of 16 counters per workgroup (plain read-modify-write by thread 0: no atomics, the measurement must not queue
+// behind itself); the host sums the rows.
+constexpr int kPhaseRows = 4096;
+static __device__ unsigned long long g_phase_cycles[kPhaseRows * 16];
+#define ORP_PHASE_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define ORP_PHASE_ADD(slot, t0, t1) do { if (threadIdx.x == 0) orp_tile::g_phase_cycles[(blockIdx.x % orp_tile::kPhaseRows) * 16 + (slot)] += (unsigned long long)((t1) - (t0)); } while (0)
+#else
+#define ORP_PHASE_T(var)
+#define ORP_PHASE_ADD(slot, t0, t1)
+#endif
+
 #ifndef ORP_TILE_ROWS
 #define ORP_TILE_ROWS 64
 #endif
 constexpr int kMaxTileRows = ORP_TILE_ROWS;   // rows a tile may have (dev aid: 16 shrinks the LDS footprint for occupancy experiments)
 
 struct TileLds {
-  float4 rowE[4][kMaxTileRows];      // oriented fan edges (ax, ay, bx, by) per edge, per tile row
-  float4 colE[4][64];
+  // oriented fan edges (ax, ay, bx, by) per edge, per tile row / column.  One float4 of padding per edge plane: phase
+  // B2 assigns consecutive lanes to the terms of ONE pair, i.e. the same row / column and different edges -- with planes
+  // 1024 B apart (a multiple of the 256-B bank period) those four 16-byte reads fell on the same banks
+  float4 rowE[4][kMaxTileRows + 1];
+  float4 colE[4][64 + 1];
   int rowS[kMaxTileRows];            // 4 signs packed 2 bits each (0 -> 0, +1 -> 1, -1 -> 2) | force_slow << 8
   int colS[64];
   float rowArea[kMaxTileRows];
@@ -26,6 +43,10 @@ struct TileLds {
   u64 words[kMaxTileRows];
   unsigned short queue[kMaxTileRows * 64];
   int qcount;
+  // phase A of the NMS mask kernel reads its (wave-uniform) row from here instead of scalar global loads: the quad's
+  // vertices in polygon order (x0..x3 | y0..y3), and the row's mask of unresolved columns until the wave files them
+  float4 rowV[2][kMaxTileRows];
+  u64 pend[kMaxTileRows];
 };
 
 __device__ __forceinline__ int pack_signs(const orp::QuadPrep& p) {
@@ -81,6 +102,7 @@ __device__ __forceinline__ void tile_drain_terms(const TileLds& T, TermLds& X, i
       __syncthreads();
     }
     // ---- B1 ----------------------------------------------------------------------------------------------------
+    ORP_PHASE_T(tb0);
     const bool live = (tid < kChunkPairs) && (q0 + tid) < nq;
     const int item = live ? T.queue[q0 + tid] : 0;
     const int rl = item >> 6, cl = item & 63;
@@ -134,6 +156,7 @@ __device__ __forceinline__ void tile_drain_terms(const TileLds& T, TermLds& X, i
       }
     }
     __syncthreads();
+    ORP_PHASE_T(tb1);
     // ---- B2 ----------------------------------------------------------------------------------------------------
     const int total = (dbg & 4) ? 0 : X.tcount;
     for (int e = tid; e < total; e += kDrainThreads) {
@@ -159,6 +182,7 @@ __device__ __forceinline__ void tile_drain_terms(const TileLds& T, TermLds& X, i
       X.tq[e] = __float_as_int(v);
     }
     __syncthreads();
+    ORP_PHASE_T(tb2);
     // ---- B3 ----------------------------------------------------------------------------------------------------
     if (live && alive != 0u && !(dbg & 16)) {
       float inter = 0.f;
@@ -169,6 +193,11 @@ __device__ __forceinline__ void tile_drain_terms(const TileLds& T, TermLds& X, i
       else iou = inter / uni;
       sink(rl, cl, iou);
     }
+#ifdef ORP_NMS_PHASE_PROF
+    { ORP_PHASE_T(tb3);
+      ORP_PHASE_ADD(8, tb0, tb1); ORP_PHASE_ADD(9, tb1, tb2); ORP_PHASE_ADD(10, tb2, tb3); ORP_PHASE_ADD(11, 0ull, 1ull);
+      ORP_PHASE_ADD(12, 0ull, (unsigned long long)((total + kDrainThreads - 1) / kDrainThreads)); }
+#endif
   }
 }
 

@@ -191,8 +191,10 @@ class OrientedRepPointsHead(nn.Module):
             cls_feats.append(cls_feat); pts_feats.append(pts_feat); inits.append(pts_out_init)
             offsets.append(grad_mul - dcn_base_offset)
         a, b = self.reppoints_cls_conv, self.reppoints_pts_refine_conv
+        # the classification branch's gradient is dense (focal loss at every point), the refinement branch's only lives at
+        # the positive points: its DeformConv backward takes the sparse route
         dcn_cls, dcn_pts = deform_conv_pair(cls_feats, pts_feats, offsets, a.weight, b.weight, a.stride, a.padding,
-                                            a.dilation)
+                                            a.dilation, sparse_grad=(False, True))
         cls_outs = [self.reppoints_cls_out(torch.relu(c)) for c in dcn_cls]
         refines = [self.reppoints_pts_refine_out(torch.relu(p)) + init.detach() for p, init in zip(dcn_pts, inits)]
         return cls_outs, inits, refines, list(feats)

@@ -478,7 +478,10 @@ class DeformConvPairFunction(Function):
 
     @staticmethod
     def forward(ctx, stride, padding, dilation, n, weight_a, weight_b, *tensors):
-        ctx.stride, ctx.padding, ctx.dilation, ctx.n = _pair(stride), _pair(padding), _pair(dilation), n
+        ctx.stride, ctx.padding, ctx.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        # n may carry the callers' expectation about the two layers' output gradients (deform_conv_pair's sparse_grad)
+        n, ctx.sparse_a, ctx.sparse_b = (n if isinstance(n, tuple) else (n, False, False))
+        ctx.n = n
         xa, xb, offs = list(tensors[:n]), list(tensors[n:2 * n]), list(tensors[2 * n:])
         ctx.save_for_backward(weight_a, weight_b, *tensors)
         oa, ob = deform_conv_forward_pair(xa, xb, offs, weight_a, weight_b, ctx.stride, ctx.padding, ctx.dilation,
@@ -495,11 +498,11 @@ class DeformConvPairFunction(Function):
         xa, xb, offs = list(tensors[:n]), list(tensors[n:2 * n]), list(tensors[2 * n:])
         need_in = any(ctx.needs_input_grad[6:])
         res = []
-        for w, xs, gs, wi in ((weight_a, xa, grads[:n], 4), (weight_b, xb, grads[n:], 5)):
+        for w, xs, gs, wi, sparse in ((weight_a, xa, grads[:n], 4, ctx.sparse_a), (weight_b, xb, grads[n:], 5, ctx.sparse_b)):
             gs = [g if g is not None else torch.zeros((x.size(0), w.size(0)) + tuple(o.shape[2:]), device=x.device)
                   for g, x, o in zip(gs, xs, offs)]
             res.append(bw.backward_mfma(xs, offs, w, gs, ctx.stride, ctx.padding, ctx.dilation, need_input=need_in,
-                                        need_weight=ctx.needs_input_grad[wi]))
+                                        need_weight=ctx.needs_input_grad[wi], sparse_grad=sparse))
         (gia, goa, gwa), (gib, gob, gwb) = res
         goff = [a + b for a, b in zip(goa, gob)] if need_in else [None] * n
         if not need_in:
@@ -507,10 +510,14 @@ class DeformConvPairFunction(Function):
         return (None, None, None, None, gwa, gwb) + tuple(gia) + tuple(gib) + tuple(goff)
 
 
-def deform_conv_pair(inputs_a, inputs_b, offsets, weight_a, weight_b, stride=1, padding=0, dilation=1):
-    """Autograd-capable pair launch over a list of levels (training path of the head): (outs_a, outs_b)."""
+def deform_conv_pair(inputs_a, inputs_b, offsets, weight_a, weight_b, stride=1, padding=0, dilation=1,
+                     sparse_grad=(False, False)):
+    """Autograd-capable pair launch over a list of levels (training path of the head): (outs_a, outs_b).
+    sparse_grad[i]: layer i's output gradient is expected to be zero almost everywhere (the head's point-refinement
+    branch only receives gradient at positive points) -> its backward scatters with atomics (ORP_DCN_BWD_SPARSE)."""
     n = len(inputs_a)
-    outs = DeformConvPairFunction.apply(stride, padding, dilation, n, weight_a, weight_b, *inputs_a, *inputs_b, *offsets)
+    outs = DeformConvPairFunction.apply(stride, padding, dilation, (n, bool(sparse_grad[0]), bool(sparse_grad[1])),
+                                        weight_a, weight_b, *inputs_a, *inputs_b, *offsets)
     return list(outs[:n]), list(outs[n:])
 
 

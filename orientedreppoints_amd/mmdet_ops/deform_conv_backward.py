@@ -27,9 +27,12 @@ def mfma_ok(weight, groups, deformable_groups):
     return bool(_lib.lib().orp_dcn_backward_mfma_ok(cin_g * groups, cout, kh, kw, groups, deformable_groups))
 
 
-def backward_mfma(inputs, offsets, weight, grad_outputs, stride, padding, dilation, need_input=True, need_weight=True):
+def backward_mfma(inputs, offsets, weight, grad_outputs, stride, padding, dilation, need_input=True, need_weight=True,
+                  sparse_grad=False):
     """All levels of ONE DeformConv layer in one call: lists of NCHW inputs / offsets / grad_outputs ->
-    (grad_inputs, grad_offsets, grad_weight); grad_weight is summed over the levels in a fixed order."""
+    (grad_inputs, grad_offsets, grad_weight); grad_weight is summed over the levels in a fixed order.
+    sparse_grad: the caller expects grad_outputs to be zero almost everywhere (ORP_DCN_BWD_SPARSE, include/orp_hip.h):
+    grad_input is then scattered with atomics instead of the (bitwise reproducible) region pass."""
     L = _lib.lib()
     w = weight.detach().float().contiguous()
     cout, cin, kh, kw = w.shape
@@ -52,7 +55,7 @@ def backward_mfma(inputs, offsets, weight, grad_outputs, stride, padding, dilati
         raise ValueError("orp_dcn_backward_workspace_bytes: invalid geometry")
     with torch.cuda.device(w.device):
         ws = _lib.workspace(w.device, nbytes)
-        rc = L.orp_dcn_backward_multi(levels, n, B, cin, cout, _lib.ptr(w), _lib.ptr(gw), 1 if need_input else 0, kh, kw,
+        rc = L.orp_dcn_backward_multi(levels, n, B, cin, cout, _lib.ptr(w), _lib.ptr(gw), (1 | (2 if sparse_grad else 0)) if need_input else 0, kh, kw,
                                       stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
                                       _lib.ptr(ws), nbytes, _lib.stream_of(w))
     _lib.check(rc, "orp_dcn_backward_multi")

@@ -13,8 +13,9 @@ def prof(slot):
     tot = ctypes.c_double(0); cnt = ctypes.c_int(0)
     _lib.lib().orp_profile_read(slot, ctypes.cast(ctypes.byref(tot), ctypes.c_void_p), ctypes.cast(ctypes.byref(cnt), ctypes.c_void_p), 1)
     return tot.value / max(cnt.value, 1) * 1e3
+ncls = int(os.environ.get('ORP_DECOMP_CLASSES', '15'))
 for n in (2000, 5344):
-    d, _ = S.gen_dense_scene(n, 1, clustered=True)
+    d, _ = S.gen_dense_scene(n, 1, num_classes=ncls, clustered=True)
     t = torch.from_numpy(d.astype(np.float32)).to(dev)
     for _ in range(3): rnms_device(t, 0.4)
     torch.cuda.synchronize()

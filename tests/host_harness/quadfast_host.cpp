@@ -115,4 +115,25 @@ void host_quadgeneric_matrix(const float* a, int n, const float* b, int k, int g
                                      : orp::quad_iou<float, false>(P, Q, a + 8 * (size_t)i, b + 8 * (size_t)j);
 }
 
+// per-pair census of the NMS mask kernel's phases for boxes a[n] (already in visiting order): out[i*n+j] (j > i) =
+// 0 the classifier resolves the pair (phase A), 1 + number of fan terms the per-term screen leaves alive otherwise
+// (1 = emptied by the screen, 17 = forced generic).  Development aid (tests/checks/nms_tile_census.py).
+void host_pair_census(const float* a, int n, unsigned char* out) {
+  orp::QuadPrep* ra = new orp::QuadPrep[n > 0 ? n : 1];
+  for (int i = 0; i < n; i++) orp::quad_prepare(a + 8 * (size_t)i, ra[i]);
+  for (int j = 0; j < n; j++) {
+    const orp::FarCol fc = orp::far_col(ra[j]);
+    for (int i = 0; i < j; i++) {
+      const orp::QuadPrep* r = &ra[i];
+      unsigned char v;
+      if ((r->force_slow | ra[j].force_slow) != 0) v = 17;
+      else if (orp::pair_is_far<float>(r->vx, r->vy, r->mabs, fc)) v = 0;
+      else v = (unsigned char)(1 + __builtin_popcount(orp::pair_term_alive_mask<float>(
+               r->ax, r->ay, r->bx, r->by, r->s, r->mabs, ra[j].ax, ra[j].ay, ra[j].bx, ra[j].by, ra[j].s, ra[j].mabs)));
+      out[(size_t)i * n + j] = v;
+    }
+  }
+  delete[] ra;
+}
+
 }  // extern "C"

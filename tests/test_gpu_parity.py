@@ -865,6 +865,38 @@ def test_dcn_backward_mfma_vs_oracle(dev, oracle):
         assert _rel_err(a, b) <= 1e-4
 
 
+def test_dcn_backward_input_without_atomics_is_bitwise_reproducible(dev, oracle):
+    """grad_input / grad_offset of orp_dcn_backward_multi come from the region-owner formulation (kernel A2 of
+    csrc/orp_dcn_bwd_mfma.hip: no atomics, fixed summation order): three calls return the SAME BITS, the values match the
+    oracle's column formulation to 1e-4 of scale, on maps whose sizes are not multiples of the 8 x 8 regions, with
+    offsets that throw samples across region / image borders and far outside the map, and with B = 3."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv_backward as bw
+    shapes = [(19, 21), (8, 8), (5, 13)]
+    cases = [_dcn_case(60 + i, 3, 256, h, w, 256, std_off=(1.5, 9.0, 30.0)[i]) for i, (h, w) in enumerate(shapes)]
+    w = cases[0][2]
+    gos = [np.random.RandomState(70 + i).normal(size=(3, 256, h, ww)).astype(np.float32) for i, (h, ww) in enumerate(shapes)]
+    gos[1][1] = 0.0                                                       # one image without gradient
+    runs = []
+    for _ in range(3):
+        gis, goffs, _ = bw.backward_mfma([_t(c[0], dev) for c in cases], [_t(c[1], dev) for c in cases], _t(w, dev),
+                                         [_t(g, dev) for g in gos], (1, 1), (1, 1), (1, 1), need_weight=False)
+        runs.append(([g.clone() for g in gis], [g.clone() for g in goffs]))
+        junk = torch.full((1 << 24,), float("nan"), device=dev); del junk   # recycle the workspace neighbourhood
+    for gis, goffs in runs[1:]:
+        for a, b in zip(gis + goffs, runs[0][0] + runs[0][1]):
+            assert torch.equal(a, b), "grad_input / grad_offset bits differ between identical calls"
+    for c, g, gi, goff in zip(cases, gos, runs[0][0], runs[0][1]):
+        wi, woff, _ = oracle.dcn_backward(c[0], c[1], w, g)
+        assert _rel_err(gi.cpu().numpy(), wi) <= 1e-4
+        assert _rel_err(goff.cpu().numpy(), woff) <= 1e-4
+        assert np.isfinite(gi.cpu().numpy()).all()
+    # ORP_DCN_BWD_SPARSE (the head's refinement branch): same values from the atomic scatter
+    gis, goffs, _ = bw.backward_mfma([_t(c[0], dev) for c in cases], [_t(c[1], dev) for c in cases], _t(w, dev),
+                                     [_t(g, dev) for g in gos], (1, 1), (1, 1), (1, 1), need_weight=False, sparse_grad=True)
+    for a, b in zip(gis + goffs, runs[0][0] + runs[0][1]):
+        assert _rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4
+
+
 def test_head_training_forward_all_levels_as_one_dcn_node(dev):
     """Training forward of the head with both DeformConvs of all levels as ONE autograd node (pair launch forward, MFMA
     backward over all levels) == the per-level forward_single route on the column-formulation backward: outputs equal,
