@@ -49,10 +49,10 @@
 #include "orp_prof.hpp"
 
 #ifndef ORP_BWD_SPLITACC
-#define ORP_BWD_SPLITACC 1   // kernel A: even / odd k-steps accumulate into two independent tiles (two MFMA dependency chains per wave)
+#define ORP_BWD_SPLITACC 0   // kernel A: even / odd k-steps into two independent accumulator tiles (measured: 792 vs 791 us, +16 VGPRs: off)
 #endif
 #ifndef ORP_BWD_DBG
-#define ORP_BWD_DBG 0      // dev aid, compile-time (timing only, wrong results): 1 = no grad_input atomics, 2 = no x loads / derivative reduction, 4 = no G store, 8 = no epilogue at all
+#define ORP_BWD_DBG 0      // dev aid, compile-time (timing only, wrong results): 1 = no grad_input atomics, 2 = no x loads / derivative reduction, 4 = no G store, 8 = no epilogue at all, 16 = scatter kernel without G row reads, 32 = scatter kernel without accumulator updates
 #endif
 
 namespace {
@@ -450,12 +450,51 @@ __global__ void region_bounds_kernel(const unsigned* __restrict__ keys_sorted, l
 constexpr int kScatterThreads = 256;
 constexpr int kAccRows = 65;                                         // 64 pixels + one dummy row for corners of other regions
 constexpr size_t scatter_smem() { return sizeof(float) * kAccRows * CH; }
+// One descriptor per list entry, built once per call right after the sort: the G row and, per corner, the accumulator row
+// offset (in floats; 64 * CH = the dummy row) and the bilinear weight (0 for the dummy).  The region's waves then read
+// their list with one coalesced 48-byte load per lane and no arithmetic (sample_point and the pixel -> region-row
+// mapping cost ~10 integer divisions per entry; with them inside the region kernel its empty shell took 145 us).
+struct __attribute__((aligned(16))) SampleDesc { int q[4]; float w[4]; unsigned row; int pad0, pad1, pad2; };
+
+__global__ void build_desc_kernel(const BwdParams P, const unsigned* __restrict__ keys_sorted, SampleDesc* __restrict__ desc) {
+  const int taps = P.kh * P.kw;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)P.rcount[P.nregions]) return;                       // slots past the last region's list are unused
+  const int reg = (int)keys_sorted[i];
+  const unsigned e = P.sorted_vals[i];
+  int lvl = 0;
+#pragma unroll 1
+  for (int k = 1; k < P.nlev; k++) if (reg >= P.lv[k].reg0) lvl = k;
+  const BLevel& L = P.lv[lvl];
+  const int rl = reg - L.reg0;
+  const int rw = rl % L.RW, rbh = rl / L.RW;
+  const int rh = rbh % L.RH, rb = rbh / L.RH;
+  const long pg = (long)(e / (unsigned)taps);
+  const int tap = (int)(e - (unsigned)pg * (unsigned)taps);
+  const long p = pg - (long)L.chunk0 * 32;                           // the sample belongs to this region's level
+  int4 ix; float2 fr;
+  sample_point(P, L, p, tap, taps, L.Ho * L.Wo, ix, fr);
+  const float lh = fr.x, lw = fr.y, uh = 1.f - lh, uw = 1.f - lw;
+  auto local = [&](int q) {                                          // pixel -> row of this region, 64 = another region's / outside
+    if (q < 0) return 64;
+    const int w = q % L.W, bh = q / L.W;
+    const int h = bh % L.H, b = bh / L.H;
+    return (b == rb && (h >> 3) == rh && (w >> 3) == rw) ? ((h & 7) * 8 + (w & 7)) : 64;
+  };
+  const int i0 = local(ix.x), i1 = local(ix.y), i2 = local(ix.z), i3 = local(ix.w);
+  SampleDesc d;
+  d.row = e; d.pad0 = d.pad1 = d.pad2 = 0;
+  d.q[0] = i0 * CH; d.q[1] = i1 * CH; d.q[2] = i2 * CH; d.q[3] = i3 * CH;
+  d.w[0] = i0 < 64 ? uh * uw : 0.f; d.w[1] = i1 < 64 ? uh * lw : 0.f;
+  d.w[2] = i2 < 64 ? lh * uw : 0.f; d.w[3] = i3 < 64 ? lh * lw : 0.f;
+  desc[i] = d;
+}
+
 __global__ void __launch_bounds__(kScatterThreads)
-dcn_bwd_scatter_kernel(const BwdParams P) {
+dcn_bwd_scatter_kernel(const BwdParams P, const SampleDesc* __restrict__ desc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* acc = reinterpret_cast<float*>(smem);                       // [65][256]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int taps = P.kh * P.kw;
   // regions are visited in XCD-contiguous blocks (workgroup b runs on XCD b % 8): neighbouring regions share G rows
   int reg;
   {
@@ -470,44 +509,44 @@ dcn_bwd_scatter_kernel(const BwdParams P) {
   const int rl = reg - L.reg0;
   const int rw = rl % L.RW, rbh = rl / L.RW;
   const int rh = rbh % L.RH, rb = rbh / L.RH;
-  // Thread c only ever touches acc[.][c], and every wave keeps its own copy of the list entries' geometry in registers
-  // (lane t <-> entry s0 + t, handed to the other lanes by v_readlane): no barrier, no atomics, no shared metadata.
+  // Thread c only ever touches acc[.][c], and every wave keeps its own copy of 64 list entries in registers (lane t <->
+  // entry s0 + t, handed to the other lanes by v_readlane): no barrier, no atomics, no shared metadata.
   const int c = tid;
   float* mine = acc + c;
+  const int l0 = P.rcount[reg], l1 = P.rcount[reg + 1];
+  SampleDesc nxt;                                                    // the next 64 entries are in flight during a block
+  auto fetch = [&](int s0) {
+    SampleDesc d;
+    d.q[0] = d.q[1] = d.q[2] = d.q[3] = 64 * CH; d.w[0] = d.w[1] = d.w[2] = d.w[3] = 0.f; d.row = 0;   // past the list: G row 0 x 0 into the dummy row
+    if (s0 + lane < l1) d = desc[s0 + lane];
+    return d;
+  };
+  nxt = fetch(l0);
 #pragma unroll 5
   for (int l = 0; l < kAccRows; l++) mine[l * CH] = 0.f;
-  const int l0 = P.rcount[reg], l1 = P.rcount[reg + 1];
-  const int HoWo = L.Ho * L.Wo;
-  constexpr int U = 8;                                               // list entries per step (G rows in flight per thread)
+  constexpr int U = 16;                                              // list entries per step (2 x U G rows in flight per thread)
+  const float* Gc = P.G + c;
+#if ORP_BWD_DBG & 32
+  float dbg_sum = 0.f;
+#endif
   for (int s0 = l0; s0 < l1; s0 += 64) {
-    int o0 = 64 * CH, o1 = 64 * CH, o2 = 64 * CH, o3 = 64 * CH;      // accumulator row offsets (floats); 64 = the dummy row
-    float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
-    unsigned e = 0;                                                  // entries past the list: row 0 of G x weight 0 into the dummy row
-    if (s0 + lane < l1) {
-      e = P.sorted_vals[s0 + lane];
-      const long pg = (long)(e / (unsigned)taps);
-      const int tap = (int)(e - (unsigned)pg * (unsigned)taps);
-      const long p = pg - (long)L.chunk0 * 32;                       // the sample belongs to this region's level
-      int4 ix; float2 fr;
-      sample_point(P, L, p, tap, taps, HoWo, ix, fr);
-      const float lh = fr.x, lw = fr.y, uh = 1.f - lh, uw = 1.f - lw;
-      auto local = [&](int q) {                                      // pixel -> row of this region, 64 = another region's / outside
-        if (q < 0) return 64;
-        const int w = q % L.W, bh = q / L.W;
-        const int h = bh % L.H, b = bh / L.H;
-        return (b == rb && (h >> 3) == rh && (w >> 3) == rw) ? ((h & 7) * 8 + (w & 7)) : 64;
-      };
-      const int i0 = local(ix.x), i1 = local(ix.y), i2 = local(ix.z), i3 = local(ix.w);
-      o0 = i0 * CH; o1 = i1 * CH; o2 = i2 * CH; o3 = i3 * CH;
-      w0 = i0 < 64 ? uh * uw : 0.f; w1 = i1 < 64 ? uh * lw : 0.f; w2 = i2 < 64 ? lh * uw : 0.f; w3 = i3 < 64 ? lh * lw : 0.f;
-    }
+    const SampleDesc cur = nxt;
+    if (s0 + 64 < l1) nxt = fetch(s0 + 64);
+    const int o0 = cur.q[0], o1 = cur.q[1], o2 = cur.q[2], o3 = cur.q[3];
+    const float w0 = cur.w[0], w1 = cur.w[1], w2 = cur.w[2], w3 = cur.w[3];
+    const unsigned e = cur.row;
     const int nb = (l1 - s0) < 64 ? (l1 - s0) : 64;
+    // G rows of step j0 + U are in flight while the read-modify-writes of step j0 run (double buffer)
+    float g[U], gn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) g[u] = (ORP_BWD_DBG & 16) ? 1.f : Gc[(size_t)(unsigned)__builtin_amdgcn_readlane((int)e, u) * CH];
 #pragma unroll 1
     for (int j0 = 0; j0 < nb; j0 += U) {
-      float g[U];
+      const bool more = j0 + U < nb;                                 // uniform; j0 + U + u < 64 then
+      if (more) {
 #pragma unroll
-      for (int u = 0; u < U; u++)                                    // j0 + u < 64 always (U divides 64)
-        g[u] = P.G[(size_t)(unsigned)__builtin_amdgcn_readlane((int)e, j0 + u) * CH + c];
+        for (int u = 0; u < U; u++) gn[u] = (ORP_BWD_DBG & 16) ? 1.f : Gc[(size_t)(unsigned)__builtin_amdgcn_readlane((int)e, j0 + U + u) * CH];
+      }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int q0 = __builtin_amdgcn_readlane(o0, j0 + u), q1 = __builtin_amdgcn_readlane(o1, j0 + u);
@@ -518,14 +557,25 @@ dcn_bwd_scatter_kernel(const BwdParams P) {
         const float x3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w3), j0 + u));
         // the four corners of a sample are four different pixels (or the dummy row): read all, then write all; the next
         // sample's reads follow these writes in program order and the LDS executes a wave's accesses in order
+#if ORP_BWD_DBG & 32
+        dbg_sum += x0 * g[u] + x1 * g[u] + x2 * g[u] + x3 * g[u] + (float)(q0 + q1 + q2 + q3);
+#else
         const float a0 = mine[q0], a1 = mine[q1], a2 = mine[q2], a3 = mine[q3];
         mine[q0] = a0 + x0 * g[u];
         mine[q1] = a1 + x1 * g[u];
         mine[q2] = a2 + x2 * g[u];
         mine[q3] = a3 + x3 * g[u];
+#endif
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; u++) g[u] = gn[u];
       }
     }
   }
+#if ORP_BWD_DBG & 32
+  mine[0] = dbg_sum;
+#endif
   // every pixel of the region is written exactly once (zeros included): no memset, no atomics
   for (int l = 0; l < 64; l++) {
     const int h = rh * 8 + (l >> 3), w = rw * 8 + (l & 7);
@@ -696,7 +746,7 @@ int device_cus() {
 struct Plan {
   size_t x_off[MAXL], go_off[MAXL], gx_off[MAXL];
   size_t gx_begin, gx_bytes, wT_off, partial_off, flags_off, list_off, total;
-  size_t G_off, keys_in_off, keys_out_off, vals_in_off, vals_out_off, rcount_off, cub_off, cub_bytes;
+  size_t G_off, keys_in_off, keys_out_off, vals_in_off, vals_out_off, rcount_off, desc_off, cub_off, cub_bytes;
   int Ho[MAXL], Wo[MAXL], reg0[MAXL], RH[MAXL], RW[MAXL];
   int total_chunks, nsplit, nregions, key_bits;
   long nslots;
@@ -741,6 +791,7 @@ int make_plan(const orp_dcn_bwd_level* lv, int nlevels, int batch, int kh, int k
   pl.vals_in_off = cur; cur += align256(sizeof(unsigned) * (size_t)pl.nslots);
   pl.vals_out_off = cur; cur += align256(sizeof(unsigned) * (size_t)pl.nslots);
   pl.rcount_off = cur; cur += align256(sizeof(int) * ((size_t)pl.nregions + 1));
+  pl.desc_off = cur; cur += align256(sizeof(SampleDesc) * (size_t)pl.nslots);
   size_t cub = 0;
   if (hipcub::DeviceRadixSort::SortPairs((void*)nullptr, cub, (const unsigned*)nullptr, (unsigned*)nullptr,
                                          (const unsigned*)nullptr, (unsigned*)nullptr, (int)pl.nslots, 0, pl.key_bits,
@@ -879,7 +930,10 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
       e = orp::set_max_dynamic_lds_once<T3>(reinterpret_cast<const void*>(&dcn_bwd_scatter_kernel), scatter_smem());
       if (e != hipSuccess) return (int)e;
       const int rper = (pl.nregions + 7) >> 3;
-      hipLaunchKernelGGL(dcn_bwd_scatter_kernel, dim3(rper * 8), dim3(kScatterThreads), scatter_smem(), st, P);
+      SampleDesc* desc = reinterpret_cast<SampleDesc*>(ws + pl.desc_off);
+      hipLaunchKernelGGL(build_desc_kernel, dim3((unsigned)((pl.nslots + 255) / 256)), dim3(256), 0, st, P,
+                         reinterpret_cast<const unsigned*>(ws + pl.keys_out_off), desc);
+      hipLaunchKernelGGL(dcn_bwd_scatter_kernel, dim3(rper * 8), dim3(kScatterThreads), scatter_smem(), st, P, desc);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
