@@ -275,6 +275,41 @@ int orp_apaa_feature_dissimilarity(const float* const* feats_host, const int* he
 int orp_apaa_select(const float* quality, const int64_t* pos_gt_inds, const int32_t* pos_level, int p, int num_gt,
                     int num_level, int per_level_topk, double top_ratio, uint8_t* keep, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Batched glue of the training path (csrc/orp_train.hip): what the reference does with per-image / per-level Python
+ * loops of small tensor operations between its compiled operators.  Level tensors are described by HOST arrays of
+ * orp_level_desc { data [B,C,H,W] fp32 on the device, grad (same shape; only for the backward entry), H, W, point stride };
+ * a location is addressed as  b * N + i  with i running over the levels in order (fine -> coarse), row-major inside a
+ * level -- the order of PointGenerator.grid_points / levels_to_images.
+ * orp_pointset_target: init_ / refine_pointset_target_single + unmap + images_to_levels
+ *   (mmdet/core/bbox/pointset_target.py:61-121,171-230) for all images in ONE launch.  gt_inds [batch*n] int64 from the
+ *   assigner (-1 ignore, 0 negative, i+1 = gt i of the image), valid [batch*n] uint8 or NULL (invalid locations get the
+ *   reference's unmap fill 0), gt_boxes [K_total,8] / gt_labels [K_total] int64 (NULL: label 1) of all images
+ *   concatenated, gt_offset [batch+1] int32, proposals [batch*n, dim] or NULL.  Outputs at full-N positions:
+ *   labels int64, label_weights (pos_weight <= 0 -> 1), rbbox_gt [.,8], pos_proposals [., dim] (NULL = not wanted),
+ *   proposal_weights, gt_inds_out int64, counts [batch,2] int32 = positives / negatives per image (NULL = not wanted).
+ * orp_points_from_offsets: every location's 9-point set from the [B,18,H,W] offset maps -> out [batch, N, 18].
+ *   mode 0 = offset_to_pts (orientedreppoints_head.py:204-222): (x, y) pairs, x = pred[2k+1] * stride + cx;
+ *   mode 1 = the refine-stage proposals of loss() (:378-381): element j = centre[j & 1] + pred[j] * stride (no swap).
+ * orp_gather_levels: out [p, C] = the C channels at location index[p] (mode 0), or the image-space point set of
+ *   offset_to_pts at that location (mode 1, C = 18).  orp_gather_levels_backward: the level gradients (zero-filled
+ *   here) receive grad_out at the selected locations (distinct locations: plain stores, deterministic).
+ * orp_outline_samples: sampling_points (:250-292): corners [p,8] -> out [p, 4*n, 2], n points per edge at the
+ *   caller's ratios [n] (device; the reference's torch.linspace(0, 1, n)), edges 1->2->3->4->1.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct { const float* data; float* grad; int height; int width; float stride; } orp_level_desc;
+int orp_pointset_target(const int64_t* gt_inds, const uint8_t* valid, int batch, int n, const float* gt_boxes,
+                        const int64_t* gt_labels, const int32_t* gt_offset, const float* proposals, int dim,
+                        float pos_weight, int64_t* labels, float* label_weights, float* rbbox_gt, float* pos_proposals,
+                        float* proposal_weights, int64_t* gt_inds_out, int32_t* counts, void* stream);
+int orp_points_from_offsets(const orp_level_desc* levels_host, int nlevels, int batch, int channels, int mode, float* out,
+                            void* stream);
+int orp_gather_levels(const orp_level_desc* levels_host, int nlevels, int batch, int channels, const int64_t* index, int p,
+                      int mode, float* out, void* stream);
+int orp_gather_levels_backward(const orp_level_desc* levels_host, int nlevels, int batch, int channels, const int64_t* index,
+                               int p, int mode, const float* grad_out, void* stream);
+int orp_outline_samples(const float* corners, int p, int n, const float* ratios, float* out, void* stream);
+
 /* fp64 greedy polygon NMS -- the merge step of the DOTA evaluation workflow (DOTA_devkit/ResultMerge.py:18-41
  * py_cpu_nms_poly over polyiou.cpp:108-128 iou_poly), SURVEY 8f rank 2.  dets_sorted [n,9] DOUBLE on device, already
  * in visiting order (the caller applies numpy's `scores.argsort()[::-1]` exactly as the reference does); a box

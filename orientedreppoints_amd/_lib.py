@@ -48,6 +48,11 @@ _SIGNATURES = {
     "orp_max_iou_assign": (_i, [_vp, _i, _i, _f, _f, _f, _f, _i, _vp, _vp, _vp, _sz, _vp]),
     "orp_apaa_feature_dissimilarity": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "orp_apaa_select": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_double, _vp, _vp]),
+    "orp_pointset_target": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "orp_points_from_offsets": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "orp_gather_levels": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "orp_gather_levels_backward": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "orp_outline_samples": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "orp_profile_enable": (_i, [_i]),
     "orp_profile_read": (_i, [_i, _vp, _vp, _i]),
     "orp_dcn_fast_path_ok": (_i, [_i, _i, _i, _i, _i, _i]),

@@ -30,6 +30,7 @@ SOURCES = [
     ("orp_postproc.hip", ["-ffp-contract=off"]),
     ("orp_soft_rnms.hip", ["-ffp-contract=off"]),
     ("orp_eval.hip", ["-ffp-contract=off"]),
+    ("orp_train.hip", ["-ffp-contract=off"]),
     ("orp_norm.hip", []),
     ("orp_conv_small.hip", []),
     ("orp_conv1x1.hip", []),
