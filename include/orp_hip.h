@@ -353,6 +353,21 @@ int orp_groupnorm_act_multi(const orp_norm_level* levels_host, int nlevels, int 
 int orp_groupnorm_act_multi_ex(const orp_norm_level* levels, const float* const* gammas_host,
                                const float* const* betas_host, int nlevels, int batch, int channels, int groups,
                                float eps, int relu, void* workspace, size_t workspace_bytes, void* stream);
+/* training: the same launch pair, additionally storing (mean, rstd) of every (image, group) in
+ * stats [sum over tensors of batch * groups][2] (tensor i's rows follow tensor i-1's), and the backward:
+ *   grad_inputs[i] = d loss / d x_i given grad_outputs[i] = d loss / d y_i (dy masked where y <= 0 when relu),
+ *   dgammas / dbetas [C] of every DISTINCT parameter set (tensors sharing a gamma pointer are summed; pass the same
+ *   dgamma / dbeta pointers for them), all sums in a fixed order.  levels_host[i].input = x_i (the forward's input),
+ *   .output = y_i (the forward's output: its sign is the ReLU mask).  workspace: orp_groupnorm_backward_workspace_bytes(). */
+int orp_groupnorm_act_multi_train(const orp_norm_level* levels, const float* const* gammas_host,
+                                  const float* const* betas_host, int nlevels, int batch, int channels, int groups,
+                                  float eps, int relu, float* stats, void* workspace, size_t workspace_bytes, void* stream);
+size_t orp_groupnorm_backward_workspace_bytes(const orp_norm_level* levels_host, int nlevels, int batch, int channels, int groups);
+int orp_groupnorm_act_multi_backward(const orp_norm_level* levels, const float* const* grad_outputs_host,
+                                     float* const* grad_inputs_host, const float* const* gammas_host,
+                                     const float* const* betas_host, float* const* dgammas_host, float* const* dbetas_host,
+                                     int nlevels, int batch, int channels, int groups, int relu, const float* stats,
+                                     void* workspace, size_t workspace_bytes, void* stream);
 int orp_affine_act(const float* x, const float* residual, const float* scale, const float* shift, float* y, int batch,
                    int channels, int hw, int relu, void* stream);
 

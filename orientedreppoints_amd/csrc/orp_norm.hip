@@ -41,6 +41,11 @@ struct GnParams {
   int nlev, B, C, G;
   float eps; int relu;
   float2* partial;        // [total_chunks] (mean, M2)
+  float2* stats;          // training: [sum_levels B * G] (mean, rstd) per (image, group), level i at chunk0 / cpg; or NULL
+  // backward (orp_groupnorm_act_multi_backward)
+  const float* dy[kGnMaxLevels];
+  float* dx[kGnMaxLevels];
+  float4* bpart;          // [total_chunks][C / G] (sum dy', sum dy' xhat) per channel of the chunk's group, chunk-local
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -136,6 +141,7 @@ gn_apply_kernel(const GnParams P) {
   }
   const float var = block_sum(m2, red) / (float)g.span;
   const float rstd = rsqrtf(var + P.eps);
+  if (P.stats && g.k == 0 && threadIdx.x == 0) P.stats[(size_t)g.lvl * P.B * P.G + g.bg] = make_float2(mean, rstd);
 
   const int cg = P.C / P.G;
   const int grp = g.bg % P.G;
@@ -253,6 +259,98 @@ bias_act_multi_kernel(const BiasParams P) {
   }
 }
 
+// ---- GroupNorm (+ ReLU) backward, all levels in one launch pair -------------------------------------------------------------
+// y = relu?(xhat * gamma_c + beta_c), xhat = (x - mean_g) * rstd_g.  With dy' = dy * [y > 0]:
+//   dgamma_c = sum_{b,hw} dy' xhat,  dbeta_c = sum_{b,hw} dy'
+//   dx = rstd_g * (dy' gamma_c - (A + xhat * Bq) / span),  A = sum_g dy' gamma_c,  Bq = sum_g dy' gamma_c xhat
+// pass 1 (one workgroup per 4096-float chunk, as the forward): per channel of the chunk's group the chunk-local sums
+//         (sum dy', sum dy' xhat) -> bpart[chunk][cg]; pass 2: every workgroup adds its group's partials in chunk order
+//         (fixed order: reproducible), forms A and Bq and writes dx for its chunk; pass 3: dgamma / dbeta per parameter
+//         set by a fixed-order sum over tensors, images and chunks.
+__global__ void __launch_bounds__(kThreads)
+gn_bwd_partial_kernel(const GnParams P) {
+  __shared__ float red[4];
+  const ChunkGeom g = locate(P, blockIdx.x);
+  const GnLevel& L = P.lv[g.lvl];
+  const int cg = P.C / P.G, grp = g.bg % P.G;
+  const float2 st = P.stats[(size_t)g.lvl * P.B * P.G + g.bg];
+  const float mean = st.x, rstd = st.y;
+  const float* x = L.x + (size_t)g.bg * g.span + g.n0;
+  const float* y = L.y + (size_t)g.bg * g.span + g.n0;             // the forward's output: the ReLU mask is read, not recomputed
+  const float* dy = P.dy[g.lvl] + (size_t)g.bg * g.span + g.n0;
+  // the chunk's elements e in [0, n): channel (g.n0 + e) / hw of the group; accumulate per channel (<= cg of them)
+  const int c_first = g.n0 / L.hw, c_last = (g.n0 + g.n - 1) / L.hw;
+  for (int cl = c_first; cl <= c_last; cl++) {
+    const int e0 = max(cl * L.hw - g.n0, 0), e1 = min((cl + 1) * L.hw - g.n0, g.n);
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = e0 + threadIdx.x; e < e1; e += kThreads) {
+      const float xv = x[e];
+      float d = dy[e];
+      if (P.relu && !(y[e] > 0.f)) d = 0.f;
+      s1 += d; s2 += d * ((xv - mean) * rstd);
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) P.bpart[(size_t)blockIdx.x * cg + cl] = make_float4(s1, s2, 0.f, 0.f);
+  }
+  // channels of the group this chunk does not touch: zero entries (every slot is read by pass 2 / 3)
+  for (int cl = threadIdx.x; cl < cg; cl += kThreads)
+    if (cl < c_first || cl > c_last) P.bpart[(size_t)blockIdx.x * cg + cl] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(kThreads)
+gn_bwd_apply_kernel(const GnParams P) {
+  __shared__ float red[4];
+  const ChunkGeom g = locate(P, blockIdx.x);
+  const GnLevel& L = P.lv[g.lvl];
+  const int cg = P.C / P.G, grp = g.bg % P.G;
+  const float2 st = P.stats[(size_t)g.lvl * P.B * P.G + g.bg];
+  const float mean = st.x, rstd = st.y;
+  // the group's partials: thread t takes entries t, t + 256, ... (chunk-major, channel-minor), then a fixed reduction tree
+  float pa = 0.f, pb = 0.f;
+  {
+    const float4* part = P.bpart + ((size_t)L.chunk0 + (size_t)g.bg * L.cpg) * cg;
+    for (int i = threadIdx.x; i < L.cpg * cg; i += kThreads) {
+      const float4 p = part[i];
+      const float gm = L.gamma[grp * cg + i % cg];
+      pa += gm * p.x; pb += gm * p.y;
+    }
+  }
+  const float inv = 1.f / (float)g.span;
+  const float A = block_sum(pa, red) * inv;
+  const float Bq = block_sum(pb, red) * inv;
+  const float* x = L.x + (size_t)g.bg * g.span + g.n0;
+  const float* y = L.y + (size_t)g.bg * g.span + g.n0;
+  const float* dy = P.dy[g.lvl] + (size_t)g.bg * g.span + g.n0;
+  float* dx = P.dx[g.lvl] + (size_t)g.bg * g.span + g.n0;
+  for (int e = threadIdx.x; e < g.n; e += kThreads) {
+    const int c = grp * cg + (g.n0 + e) / L.hw;
+    const float gm = L.gamma[c];
+    const float xv = x[e];
+    float d = dy[e];
+    if (P.relu && !(y[e] > 0.f)) d = 0.f;
+    const float xh = (xv - mean) * rstd;
+    dx[e] = rstd * (d * gm - A - xh * Bq);
+  }
+}
+
+// dgamma / dbeta of ONE parameter set: the tensors whose gamma pointer equals `gamma`, fixed order (tensor, image, chunk)
+__global__ void gn_bwd_param_kernel(const GnParams P, const float* gamma, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= P.C) return;
+  const int cg = P.C / P.G, grp = c / cg, cl = c - grp * cg;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < P.nlev; i++) {
+    const GnLevel& L = P.lv[i];
+    if (L.gamma != gamma) continue;
+    for (int b = 0; b < P.B; b++) {
+      const float4* part = P.bpart + ((size_t)L.chunk0 + (size_t)(b * P.G + grp) * L.cpg) * cg;
+      for (int k = 0; k < L.cpg; k++) { const float4 p = part[(size_t)k * cg + cl]; s1 += p.x; s2 += p.y; }
+    }
+  }
+  dbeta[c] = s1; dgamma[c] = s2;
+}
+
 int fill(const orp_norm_level* levels, int nlevels, int batch, int channels, int groups, GnParams& P) {
   if (!levels || nlevels <= 0 || nlevels > kGnMaxLevels || batch <= 0 || channels <= 0 || groups <= 0 ||
       channels % groups)
@@ -299,9 +397,76 @@ int orp_groupnorm_act_multi_ex(const orp_norm_level* levels, const float* const*
   }
   P.eps = eps; P.relu = relu;
   P.partial = reinterpret_cast<float2*>(workspace);
+  P.stats = nullptr;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_groupnorm_act_multi_train(const orp_norm_level* levels, const float* const* gammas_host,
+                                  const float* const* betas_host, int nlevels, int batch, int channels, int groups,
+                                  float eps, int relu, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
+  GnParams P;
+  const int chunks = fill(levels, nlevels, batch, channels, groups, P);
+  if (chunks == -2) return ORP_ETOOBIG;
+  if (chunks <= 0 || !gammas_host || !betas_host || !stats) return ORP_EINVAL;
+  if (!workspace || workspace_bytes < sizeof(float2) * (size_t)chunks) return ORP_EWORKSPACE;
+  for (int i = 0; i < nlevels; i++) {
+    if (!gammas_host[i] || !betas_host[i]) return ORP_EINVAL;
+    P.lv[i].gamma = gammas_host[i]; P.lv[i].beta = betas_host[i];
+  }
+  P.eps = eps; P.relu = relu;
+  P.partial = reinterpret_cast<float2*>(workspace);
+  P.stats = reinterpret_cast<float2*>(stats);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+size_t orp_groupnorm_backward_workspace_bytes(const orp_norm_level* levels, int nlevels, int batch, int channels, int groups) {
+  GnParams P;
+  const int chunks = fill(levels, nlevels, batch, channels, groups, P);
+  return chunks > 0 ? sizeof(float4) * (size_t)chunks * (size_t)(channels / groups) + 256 : 256;
+}
+
+int orp_groupnorm_act_multi_backward(const orp_norm_level* levels, const float* const* grad_outputs_host,
+                                     float* const* grad_inputs_host, const float* const* gammas_host,
+                                     const float* const* betas_host, float* const* dgammas_host, float* const* dbetas_host,
+                                     int nlevels, int batch, int channels, int groups, int relu, const float* stats,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  GnParams P;
+  const int chunks = fill(levels, nlevels, batch, channels, groups, P);
+  if (chunks == -2) return ORP_ETOOBIG;
+  if (chunks <= 0 || !grad_outputs_host || !grad_inputs_host || !gammas_host || !betas_host || !dgammas_host ||
+      !dbetas_host || !stats)
+    return ORP_EINVAL;
+  const int cg = channels / groups;
+  if (!workspace || workspace_bytes < sizeof(float4) * (size_t)chunks * cg) return ORP_EWORKSPACE;
+  for (int i = 0; i < nlevels; i++) {
+    if (!gammas_host[i] || !betas_host[i] || !grad_outputs_host[i] || !grad_inputs_host[i]) return ORP_EINVAL;
+    P.lv[i].gamma = gammas_host[i]; P.lv[i].beta = betas_host[i];
+    P.dy[i] = grad_outputs_host[i]; P.dx[i] = grad_inputs_host[i];
+  }
+  for (int i = nlevels; i < kGnMaxLevels; i++) { P.dy[i] = nullptr; P.dx[i] = nullptr; }
+  P.eps = 0.f; P.relu = relu;
+  P.partial = nullptr;
+  P.stats = reinterpret_cast<float2*>(const_cast<float*>(stats));
+  P.bpart = reinterpret_cast<float4*>(workspace);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
+  // one launch per distinct parameter set (the tensors sharing a GroupNorm module)
+  for (int i = 0; i < nlevels; i++) {
+    bool first = true;
+    for (int j = 0; j < i; j++) if (gammas_host[j] == gammas_host[i]) first = false;
+    if (!first || !dgammas_host[i] || !dbetas_host[i]) continue;
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, P, gammas_host[i], dgammas_host[i],
+                       dbetas_host[i]);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }

@@ -53,7 +53,7 @@ class FPN(nn.Module):
         """Inference on the GPU with GroupNorm'ed, activation-free ConvModules (the DOTA configs): the lateral / output
         normalisations of all levels run as ONE launch pair each, the small output levels on the HIP convolution."""
         x = inputs[0]
-        if torch.is_grad_enabled() or not (x.is_cuda and x.dtype == torch.float32):
+        if not (x.is_cuda and x.dtype == torch.float32):
             return False
         used = len(self.lateral_convs)
         mods = list(self.lateral_convs) + list(self.fpn_convs[:used])
@@ -64,7 +64,13 @@ class FPN(nn.Module):
         assert len(inputs) == len(self.in_channels)
         used = len(self.lateral_convs)
         fused = self._fused_ok(inputs)
-        if fused:
+        train = fused and torch.is_grad_enabled()     # autograd: the same launch pairs as one node per normalisation layer
+        if train:
+            from ..mmdet_ops.fused_norm import group_norm_act_train
+            laterals = group_norm_act_train([lc.conv(inputs[i + self.start_level])
+                                             for i, lc in enumerate(self.lateral_convs)],
+                                            [lc.norm for lc in self.lateral_convs], relu=False)
+        elif fused:
             from ..mmdet_ops.fused_norm import conv3x3_multi, group_norm_act_multi
             laterals = group_norm_act_multi([lc.conv(inputs[i + self.start_level])
                                              for i, lc in enumerate(self.lateral_convs)],
@@ -74,7 +80,10 @@ class FPN(nn.Module):
         for i in range(used - 1, 0, -1):
             laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
                                                               mode='nearest')
-        if fused:
+        if train:
+            outs = group_norm_act_train([self.fpn_convs[i].conv(laterals[i]) for i in range(used)],
+                                        [fc.norm for fc in self.fpn_convs[:used]], relu=False)
+        elif fused:
             outs = group_norm_act_multi(conv3x3_multi(laterals, [fc.conv for fc in self.fpn_convs[:used]]),
                                         [fc.norm for fc in self.fpn_convs[:used]], relu=False, inplace=True)
         else:

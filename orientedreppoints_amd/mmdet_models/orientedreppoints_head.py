@@ -179,14 +179,31 @@ class OrientedRepPointsHead(nn.Module):
         pts_out_refine = pts_out_refine + pts_out_init.detach()
         return cls_out, pts_out_init, pts_out_refine, x
 
+    def _tower_train(self, convs, feats):
+        """One tower over all levels, layer by layer, with autograd: the library convolution per level, then GroupNorm +
+        ReLU of all levels as ONE autograd node (one launch pair forward, three launches backward instead of ~8 per
+        level; mmdet_ops/fused_norm.py group_norm_act_train)."""
+        from ..mmdet_ops.fused_norm import group_norm_act_train
+        cur = list(feats)
+        for m in convs:
+            cur = group_norm_act_train([m.conv(x) for x in cur], m.norm, relu=True)
+        return cur
+
     def forward_train_multi(self, feats):
         """Training forward with the two DeformConvs of ALL levels as one autograd node (one pair launch forward, the MFMA
         backward over all levels at once); per level the same operations as forward_single, in the same order."""
         from ..mmdet_ops.deform_conv import deform_conv_pair
         dcn_base_offset = self._base_offset_on(feats[0])
         cls_feats, pts_feats, inits, offsets = [], [], [], []
-        for x in feats:
-            cls_feat, pts_feat, pts_out_init = self._towers(x)
+        fused_gn = self._fused_towers_ok(feats)
+        if fused_gn:
+            cls_all, pts_all = self._tower_train(self.cls_convs, feats), self._tower_train(self.reg_convs, feats)
+        for i, x in enumerate(feats):
+            if fused_gn:
+                cls_feat, pts_feat = cls_all[i], pts_all[i]
+                pts_out_init = self.reppoints_pts_init_out(self.relu(self.reppoints_pts_init_conv(pts_feat)))
+            else:
+                cls_feat, pts_feat, pts_out_init = self._towers(x)
             grad_mul = (1 - self.gradient_mul) * pts_out_init.detach() + self.gradient_mul * pts_out_init
             cls_feats.append(cls_feat); pts_feats.append(pts_feat); inits.append(pts_out_init)
             offsets.append(grad_mul - dcn_base_offset)

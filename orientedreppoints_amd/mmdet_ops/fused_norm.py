@@ -1,8 +1,9 @@
-"""Fused normalisation + activation passes for inference (include/orp_hip.h `orp_groupnorm_act_multi`,
-`orp_affine_act`, `orp_bias_act_multi`): the GroupNorm+ReLU of the dense-head ConvModules for all FPN levels in one
-launch pair, the eval-mode BatchNorm (+ residual) + ReLU of the ResNet bottlenecks as one pass, and the bias / ReLU /
-residual / base-offset passes around the head's output convolutions for all levels in one launch.  No autograd: callers use them only
-under torch.no_grad(); with gradients enabled the stock PyTorch modules run."""
+"""Fused normalisation + activation passes (include/orp_hip.h `orp_groupnorm_act_multi`, `orp_affine_act`,
+`orp_bias_act_multi`): the GroupNorm+ReLU of the dense-head ConvModules for all FPN levels in one launch pair, the
+eval-mode BatchNorm (+ residual) + ReLU of the ResNet bottlenecks as one pass, and the bias / ReLU / residual / base-offset
+passes around the head's output convolutions for all levels in one launch.  Those are inference-only (callers use them
+under torch.no_grad()).  Training: `group_norm_act_train` is the autograd-capable GroupNorm(+ReLU) over a list of tensors
+(one launch pair forward, one pair + a parameter reduction backward, `orp_groupnorm_act_multi_train / _backward`)."""
 import ctypes
 
 import torch
@@ -240,3 +241,97 @@ def conv3x3_multi(xs, conv):
             rc = L.orp_conv3x3_small_multi_ex(levels, wts, len(small), B, cin, cout, _lib.stream_of(x0))
         _lib.check(rc, "orp_conv3x3_small_multi_ex")
     return outs
+
+
+class _GroupNormActTrain(torch.autograd.Function):
+    """ys[i] = relu?(GroupNorm(xs[i])) for n tensors (the FPN levels of one tower layer) with autograd: forward = the
+    inference launch pair + stored (mean, rstd); backward = two launches for every grad_input + one per distinct module
+    for (dgamma, dbeta), all sums in a fixed order.  Inputs: n, groups, eps, relu, owner (tensor i uses parameter set
+    owner[i]), then the n tensors, then the distinct gammas, then the distinct betas."""
+
+    @staticmethod
+    def forward(ctx, n, groups, eps, relu, owner, *tensors):
+        L = _lib.lib()
+        xs = [t.detach().contiguous() for t in tensors[:n]]
+        m = (len(tensors) - n) // 2
+        gammas = [t.detach().float().contiguous() for t in tensors[n:n + m]]
+        betas = [t.detach().float().contiguous() for t in tensors[n + m:]]
+        x0 = xs[0]
+        B, C = x0.size(0), x0.size(1)
+        levels = (_NormLevel * n)()
+        gam = (ctypes.c_void_p * n)()
+        bet = (ctypes.c_void_p * n)()
+        ys = []
+        for i, x in enumerate(xs):
+            if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.size(0) == B and x.size(1) == C):
+                raise ValueError("group_norm_act_train expects fp32 CUDA [B,C,H,W] tensors with equal B and C")
+            y = torch.empty_like(x)
+            ys.append(y)
+            levels[i] = _NormLevel(x.data_ptr(), y.data_ptr(), x.size(2), x.size(3))
+            gam[i], bet[i] = gammas[owner[i]].data_ptr(), betas[owner[i]].data_ptr()
+        stats = torch.empty((n * B * groups, 2), dtype=torch.float32, device=x0.device)
+        nbytes = L.orp_groupnorm_workspace_bytes(levels, n, B, C, groups)
+        ws = _lib.workspace(x0.device, nbytes)
+        with torch.cuda.device(x0.device):
+            rc = L.orp_groupnorm_act_multi_train(levels, gam, bet, n, B, C, groups, float(eps), 1 if relu else 0,
+                                                 _lib.ptr(stats), _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
+        _lib.check(rc, "orp_groupnorm_act_multi_train")
+        ctx.save_for_backward(stats, *xs, *gammas, *betas, *ys)      # ys: the ReLU mask (the next layer keeps them alive anyway)
+        ctx.meta = (n, m, groups, bool(relu), tuple(owner))
+        return tuple(ys)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        L = _lib.lib()
+        n, m, groups, relu, owner = ctx.meta
+        saved = ctx.saved_tensors
+        stats, xs, gammas, betas = saved[0], saved[1:1 + n], saved[1 + n:1 + n + m], saved[1 + n + m:1 + n + 2 * m]
+        ys = saved[1 + n + 2 * m:]
+        x0 = xs[0]
+        B, C = x0.size(0), x0.size(1)
+        levels = (_NormLevel * n)()
+        dys = (ctypes.c_void_p * n)()
+        dxs = (ctypes.c_void_p * n)()
+        gam = (ctypes.c_void_p * n)()
+        bet = (ctypes.c_void_p * n)()
+        dg = (ctypes.c_void_p * n)()
+        db = (ctypes.c_void_p * n)()
+        keep, gxs = [], []
+        dgam = [torch.empty_like(g) for g in gammas]
+        dbet = [torch.empty_like(b) for b in betas]
+        for i, x in enumerate(xs):
+            g = grads[i]
+            g = torch.zeros_like(x) if g is None else g.detach().float().contiguous()
+            gx = torch.empty_like(x)
+            keep.append(g); gxs.append(gx)
+            levels[i] = _NormLevel(x.data_ptr(), ys[i].data_ptr(), x.size(2), x.size(3))
+            dys[i], dxs[i] = g.data_ptr(), gx.data_ptr()
+            gam[i], bet[i] = gammas[owner[i]].data_ptr(), betas[owner[i]].data_ptr()
+            dg[i], db[i] = dgam[owner[i]].data_ptr(), dbet[owner[i]].data_ptr()
+        nbytes = L.orp_groupnorm_backward_workspace_bytes(levels, n, B, C, groups)
+        ws = _lib.workspace(x0.device, nbytes)
+        with torch.cuda.device(x0.device):
+            rc = L.orp_groupnorm_act_multi_backward(levels, dys, dxs, gam, bet, dg, db, n, B, C, groups, 1 if relu else 0,
+                                                    _lib.ptr(stats), _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
+        _lib.check(rc, "orp_groupnorm_act_multi_backward")
+        return (None, None, None, None, None) + tuple(gxs) + tuple(dgam) + tuple(dbet)
+
+
+def group_norm_act_train(xs, gn, relu=True):
+    """[relu?(GroupNorm(x)) for x in xs] with autograd, ONE launch pair forward for all tensors (up to 16).  gn: one
+    nn.GroupNorm for all of them or a list with one module per tensor (equal num_groups / eps; modules may repeat)."""
+    gns = list(gn) if isinstance(gn, (list, tuple)) else [gn] * len(xs)
+    if len(gns) != len(xs) or any(g.num_groups != gns[0].num_groups or g.eps != gns[0].eps for g in gns):
+        raise ValueError("group_norm_act_train: one GroupNorm per tensor, equal num_groups / eps")
+    distinct, owner = [], []
+    for g in gns:
+        for k, d in enumerate(distinct):
+            if d is g:
+                owner.append(k)
+                break
+        else:
+            owner.append(len(distinct)); distinct.append(g)
+    outs = _GroupNormActTrain.apply(len(xs), gns[0].num_groups, gns[0].eps, bool(relu), tuple(owner), *xs,
+                                    *[d.weight for d in distinct], *[d.bias for d in distinct])
+    return list(outs)

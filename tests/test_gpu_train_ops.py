@@ -144,3 +144,42 @@ def test_pointset_target_api_wrappers(dev):
         if b == 0 and pos.numel():
             assert torch.equal(ref[0][0][pos], labels[0][ref[6][0] - 1])
     assert ref[5][1].numel() == 0
+
+
+@pytest.mark.parametrize("relu,C,sizes", [(True, 64, [(40, 40), (16, 16), (7, 9), (2, 2)]), (False, 64, [(40, 40), (16, 16), (7, 9), (2, 2)]),
+                                          (True, 256, [(24, 24), (12, 12), (6, 6), (3, 3)]),      # groups spanning two chunks
+                                          (True, 256, [(70, 70), (5, 5), (5, 5), (1, 1)])])
+def test_group_norm_act_train_forward_backward_vs_torch(dev, relu, C, sizes):
+    """The autograd GroupNorm(+ReLU) over a list of tensors (orp_groupnorm_act_multi_train / _backward): outputs, grad_input,
+    dgamma and dbeta against torch.nn.GroupNorm (+ relu) per tensor; a module shared by several tensors gets the summed
+    parameter gradients; two identical calls give identical bits."""
+    import torch.nn as nn
+    from orientedreppoints_amd.mmdet_ops.fused_norm import group_norm_act_train
+    torch.manual_seed(0)
+    B, G = 2, 32
+    shared, own = nn.GroupNorm(G, C).to(dev), nn.GroupNorm(G, C).to(dev)
+    with torch.no_grad():
+        for m in (shared, own):
+            m.weight.normal_(1.0, 0.3); m.bias.normal_(0, 0.3)
+    mods = [shared, shared, own, shared]
+    xs = [(torch.randn(B, C, h, w, device=dev) * 2 + 0.5).requires_grad_(True) for h, w in sizes]
+    wts = [torch.randn(B, C, h, w, device=dev) for h, w in sizes]
+
+    def run(fn):
+        for t in xs + [shared.weight, shared.bias, own.weight, own.bias]:
+            t.grad = None
+        ys = fn()
+        sum((y * w).sum() for y, w in zip(ys, wts)).backward()
+        return [y.detach().clone() for y in ys], [x.grad.clone() for x in xs], \
+            [p.grad.clone() for p in (shared.weight, shared.bias, own.weight, own.bias)]
+    mine = run(lambda: group_norm_act_train(xs, mods, relu=relu))
+    again = run(lambda: group_norm_act_train(xs, mods, relu=relu))
+    ref = run(lambda: [torch.relu(m(x)) if relu else m(x) for m, x in zip(mods, xs)])
+    for a, b in zip(mine[0] + mine[1] + mine[2], again[0] + again[1] + again[2]):
+        assert torch.equal(a, b)
+    for a, b in zip(mine[0], ref[0]):
+        assert float((a - b).abs().max()) <= 2e-5
+    for a, b in zip(mine[1], ref[1]):
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+    for a, b in zip(mine[2], ref[2]):
+        assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
