@@ -56,7 +56,10 @@ def calibrate_head(model, img, target=TARGET_DETS):
     """Make the random-init head emit a realistic post-processing load without touching any layer's compute:
       * reppoints_pts_init_out.bias <- a 3x3 grid (in feature-grid units, (y,x) order) whose extent varies per channel
         through the existing random weights (std raised to 0.05) -> decoded boxes have non-zero size / orientation;
-      * reppoints_cls_out.bias      <- shifted so that exactly ~`target` (point, class) scores exceed score_thr.
+      * reppoints_cls_out.bias      <- shifted PER CLASS so that each of the 15 classes contributes ~target / 15 of the
+        (point, class) scores above score_thr: the timed NMS then sees the class-offset coordinates of multiclass_rnms
+        (bbox_nms.py:156-158) the fp32 IoU arithmetic has to reproduce, and the per-class CPU baseline is 15-way.
+        (Round 2 shifted one common bias: all ~2 000 detections fell into one class.)
     """
     head = model.bbox_head
     with torch.no_grad():
@@ -68,11 +71,35 @@ def calibrate_head(model, img, target=TARGET_DETS):
         head.reppoints_cls_out.weight.normal_(0, 0.05)
         feats = model.extract_feat(img)
         cls_outs, _, _, _ = head(feats)
-        logits = torch.cat([c.permute(0, 2, 3, 1).reshape(-1) for c in cls_outs])
-        k = min(target, logits.numel() - 1)
-        kth = torch.topk(logits, k).values[-1]
+        C = cls_outs[0].size(1)
+        logits = torch.cat([c.permute(1, 0, 2, 3).reshape(C, -1) for c in cls_outs], 1)       # [C, B*N]
         thr_logit = float(np.log(TEST_CFG['score_thr'] / (1 - TEST_CFG['score_thr'])))
-        head.reppoints_cls_out.bias.add_(thr_logit - kth + 1e-4)
+        per_class = [target // C + (1 if c < target % C else 0) for c in range(C)]
+        for c in range(C):
+            k = max(1, min(per_class[c], logits.size(1) - 1))
+            kth = torch.topk(logits[c], k).values[-1]
+            head.reppoints_cls_out.bias[c] += thr_logit - kth + 1e-4
+
+
+PMC_FILE = 'profiles/r03_pmc.json'
+
+
+def load_pmc():
+    """(counters dict, provenance note) of the committed rocprofv3 --pmc passes -- or ({}, why not) when the passes were
+    collected on a different build of liborp_hip.so than the one that runs now (`orp_version` carries a hash of the
+    kernel sources): stale counters are not reported."""
+    path = os.path.join(ROOT, PMC_FILE)
+    if not os.path.exists(path):
+        return {}, '%s not present' % PMC_FILE
+    try:
+        pmc = json.load(open(path))
+    except Exception as e:   # noqa: BLE001
+        return {}, '%s unreadable: %s' % (PMC_FILE, e)
+    have = _lib.lib().orp_version().decode()
+    want = pmc.get('_build', {}).get('orp_version')
+    if want != have:
+        return {}, '%s was collected on build "%s", this run uses "%s": traffic not reported' % (PMC_FILE, want, have)
+    return pmc, '%s (rocprofv3 --pmc passes on this build, collected separately)' % PMC_FILE
 
 
 def read_prof(slot):
@@ -694,6 +721,10 @@ def main():
     total_imgs = args.batch * args.steps * world
     value = total_imgs / elapsed
     ms_per_step = elapsed / args.steps * 1e3
+    # one image at a time per GPU (a replay is submitted only after the previous result has been read): comparable with a
+    # latency-style baseline and with round 1's `value`; `value` itself is the throughput mode when that ran
+    value_serial = (total_imgs / (graph_ms * 1e-3 * args.steps)) if isinstance(graph_ms, float) else \
+        total_imgs / eager_elapsed
 
     # ---- stage timings on rank 0 (outside the timed region): rotated-IoU+NMS us/img -------------------------
     cap = nms_inputs_of_one_image(model, img[:1], metas[:1])
@@ -729,16 +760,11 @@ def main():
         alg_bytes = 4.0 * (layers * (npos * cin + 9 * cin * cout + npos * cout) + npos * 18)
         achieved = flops / avg_s / 1e12
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, 'profiles', 'r02_pmc.json')
-        if os.path.exists(pmc_path):
-            try:
-                pmc = json.load(open(pmc_path))
-                d = pmc.get('dcn_fwd_pair', {})
-                if args.batch == d.get('batch') and IMG == d.get('img', 1024):
-                    traffic = d['hbm_bytes_per_launch']
-                    traffic_src = 'profiles/r02_pmc.json (rocprofv3 --pmc pass of this kernel, collected separately)'
-            except Exception:
-                traffic = None
+        pmc, pmc_note = load_pmc()
+        d = pmc.get('dcn_fwd_pair', {}) if pmc else {}
+        if d and args.batch == d.get('batch') and IMG == d.get('img', 1024):
+            traffic = d.get('hbm_bytes_per_launch')
+        traffic_src = pmc_note
         roof = dict(kernel='dcn_fwd_mfma2_kernel<3, nchw, 2 layers>', bound='mfma', achieved=achieved,
                     peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=traffic,
                     traffic_source=traffic_src, avg_launch_us=avg_s * 1e6, launches=dcn_n, layers_per_launch=layers,
@@ -763,13 +789,15 @@ def main():
                    note='bit-exact fp32 triangle-fan IoU: ALU-bound, 0.6 MB of traffic per launch')
         # counters of HEAD's mask kernel from the committed rocprofv3 --pmc passes (2 000-box dense scene of the same shape)
         try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc.json'))).get('nms_mask', {})
+            pmc, pmc_note = load_pmc()
+            pm = pmc.get('nms_mask', {})
             c = pm.get('counters', {})
             simd_cycles = c['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0          # GRBM is summed over the 8 XCDs; 1024 SIMDs
             # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md, "SQ PMC units")
             nms.update(traffic=pm.get('hbm_bytes_per_launch'), valu_busy_frac=4.0 * c['SQ_ACTIVE_INST_VALU'] / simd_cycles,
                        waves_per_simd=4.0 * c['SQ_WAVE_CYCLES'] / simd_cycles,
-                       traffic_source='profiles/r02_pmc.json (rocprofv3 --pmc passes, collected separately)')
+                       lds_bank_conflict_frac=(c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'])
+                       if c.get('SQ_LDS_IDX_ACTIVE') else None, traffic_source=pmc_note)
         except Exception:   # noqa: BLE001
             pass
     per_op = None
@@ -791,7 +819,8 @@ def main():
             batched = 'failed: %s' % (str(e)[:200],)
 
     out = {
-        'metric': 'images/sec (%dx%d DOTA, %s FPN)' % (IMG, IMG, {'r50': 'R-50', 'r101': 'R-101'}[args.model]), 'value': value, 'unit': 'images/s', 'n_gpus': world,
+        'metric': 'images/sec (%dx%d DOTA, %s FPN)' % (IMG, IMG, {'r50': 'R-50', 'r101': 'R-101'}[args.model]), 'value': value,
+        'value_serial': value_serial, 'unit': 'images/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: OrientedRepPoints %s FPN inference, %dx%d patch, 15 classes, '
@@ -802,7 +831,8 @@ def main():
                                   {'r50': 'R-50', 'r101': 'R-101'}[args.model], IMG, IMG, args.batch, TARGET_DETS),
                    'global_batch': args.batch * world, 'parallelism': 'replicas x%d (image-parallel, no collective)' % world,
                    'images_in_flight_per_gpu': args.pipeline if isinstance(pipe_ms, float) else 1},
-        'detections_per_step': ndet,
+        'detections_per_step': ndet, 'nms_classes_present': int(len(set(cap['labels'].tolist()))) if cap.get('labels') is not None else None,
+        'library_build': _lib.lib().orp_version().decode(),
         'rotated_iou_nms_us_per_img': nms_us, 'nms_boxes': M,
         'kernel_us': {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()},
         'mode': ('hipgraph replay, %d images in flight' % args.pipeline) if isinstance(pipe_ms, float) else

@@ -50,9 +50,29 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+VERSION_SOURCE = "orp_overlaps.hip"      # defines orp_version(): rebuilt whenever any kernel source changes
+
+
+def build_id():
+    """12 hex digits over every kernel source / header (what `orp_version` reports after "abi1"): profiles/*_pmc.json
+    record it, bench.py refuses to quote counters collected on another build."""
+    import hashlib
+    h = hashlib.sha1()
+    names = sorted([s for s, _ in SOURCES] + [x for x in HEADERS])
+    for n in names:
+        path = os.path.join(CSRC, n)
+        if os.path.exists(path):
+            h.update(n.encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def _compile(src, extra):
     obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if src == VERSION_SOURCE:
+        deps += [os.path.join(CSRC, s) for s, _ in SOURCES]
+        extra = extra + ['-DORP_BUILD_ID="%s"' % build_id()]
     if _stale(obj, deps):
         cmd = [HIPCC] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         subprocess.check_call(cmd, cwd=CSRC)

@@ -272,7 +272,7 @@ gn_bwd_partial_kernel(const GnParams P) {
   __shared__ float red[4];
   const ChunkGeom g = locate(P, blockIdx.x);
   const GnLevel& L = P.lv[g.lvl];
-  const int cg = P.C / P.G, grp = g.bg % P.G;
+  const int cg = P.C / P.G;
   const float2 st = P.stats[(size_t)g.lvl * P.B * P.G + g.bg];
   const float mean = st.x, rstd = st.y;
   const float* x = L.x + (size_t)g.bg * g.span + g.n0;

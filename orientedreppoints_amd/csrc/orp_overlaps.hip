@@ -194,5 +194,8 @@ done:
 #undef ORP_CHK
 }
 
-const char* orp_version(void) { return "orp_hip gfx950 abi1"; }
+#ifndef ORP_BUILD_ID
+#define ORP_BUILD_ID "dev"
+#endif
+const char* orp_version(void) { return "orp_hip gfx950 abi1 " ORP_BUILD_ID; }
 }

@@ -3,8 +3,10 @@
 tools/pmc_pass.sh on tools/run_hot_kernels.py) into profiles/<name>_pmc.json + a readable summary.
 HBM bytes per launch = 2 * FETCH_SIZE (gfx950: the counter tallies 128-B requests of wide reads at 64 B, see
 /opt/skills/guides/MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KiB, averaged over the launches of the pass.
+The library build the passes ran on (`orp_version`, written by tools/pmc_all.sh next to the passes) is stored under "_build":
+bench.py only quotes these counters when the running library reports the same build.
 usage: tools/make_pmc_json.py profiles/r01 gpurun_out/pmc_a gpurun_out/pmc_b ..."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 
 dst, dirs = sys.argv[1], sys.argv[2:]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -12,7 +14,8 @@ for d in dirs:
     for f in glob.glob(d + '/*/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            key = ('dcn_bwd_input' if 'dcn_bwd_input' in k else 'dcn_bwd_weight' if 'dcn_bwd_weight' in k else
+            key = ('dcn_bwd_scatter' if 'dcn_bwd_scatter' in k else
+                   'dcn_bwd_input' if 'dcn_bwd_input' in k else 'dcn_bwd_weight' if 'dcn_bwd_weight' in k else
                    'dcn_fwd_half' if 'dcn_fwd_half' in k else 'dcn_fwd_pair' if 'dcn_fwd_mfma2' in k else 'nms_mask' if 'nms_mask' in k
                    else 'nms_sweep' if 'nms_sweep' in k else 'nms_rankprep' if 'nms_rankprep' in k else None)
             if key:
@@ -35,9 +38,14 @@ for k, c in agg.items():
         e['batch'] = 1
         e['img'] = 1024
     out[k] = e
+vers = sorted({open(f).read().strip() for d in dirs for f in glob.glob(os.path.join(os.path.dirname(d.rstrip('/')) or '.', 'pmc_version.txt'))})
+out['_build'] = dict(orp_version=vers[0] if len(vers) == 1 else None, note='library build of the passes (tools/pmc_all.sh)')
 json.dump(out, open(dst + '_pmc.json', 'w'), indent=1, sort_keys=True)
 with open(dst + '_pmc.txt', 'w') as f:
+    f.write('build: %s\n' % out['_build']['orp_version'])
     for k, e in sorted(out.items()):
+        if k.startswith('_'):
+            continue
         f.write('%s  launches %d\n' % (k, e['launches']))
         for n, v in sorted(e['counters'].items()):
             f.write('    %-28s %.4g\n' % (n, v))
