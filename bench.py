@@ -452,7 +452,34 @@ def main_dry(args):
 
     def step():
         return (x @ x).sum()
+    if args.mode == 'train':
+        # the exchange of `--mode train` (dist_utils.train_step + the overlapped bucketed all-reduce) around a stand-in
+        # model whose second head only rank 0 uses: the ranks' autograd graphs differ, as with images without positives
+        from orientedreppoints_amd import dist_utils as D
+
+        class Standin(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.body = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1))
+                self.a, self.b = torch.nn.Conv2d(8, 2, 1), torch.nn.Conv2d(8, 2, 1)
+
+            def forward(self, img, use_b):
+                f = self.body(img)
+                return {'loss_cls': self.a(f).pow(2).mean() + (self.b(f).abs().mean() if use_b else 0.0)}
+        torch.manual_seed(0)
+        net = Standin().to(dev)
+        opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
+        hook = D.DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2), overlap=True, bucket_size_mb=0.001)
+        data = dict(img=torch.randn(2, 3, 16, 16, device=dev), use_b=(rank == 0))
+
+        def step():                                           # noqa: F811
+            return D.train_step(net, opt, data, hook)
     elapsed = timed_steps(step, args, dev, dist, world)
+    if args.mode == 'train' and dist is not None:             # every rank holds the same parameters after the steps
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(flat, ref), 'ranks diverged in the dry training exchange'
     n = world
     if dist is not None:
         t = torch.ones(1, device=dev)

@@ -72,7 +72,9 @@ class OverlappedGradientReducer(object):
       async_op=True (RCCL's own stream: it overlaps the rest of backward);
     * buckets are ALWAYS issued in index order and `finish()` issues whatever is left (parameters that took no part in
       this iteration on this rank contribute zeros), so every rank issues the same sequence of collectives even when
-      their autograd graphs differ (an image without positives)."""
+      their autograd graphs differ (an image without positives);
+    * every bucket carries one "took part" flag per parameter behind its gradients, reduced by the same collective: a
+      parameter no rank produced a gradient for is found without an extra collective (one small host read in finish())."""
 
     def __init__(self, params, bucket_cap_mb=32):
         self.params = [p for p in params if p.requires_grad]
@@ -91,17 +93,21 @@ class OverlappedGradientReducer(object):
             key = k
         if cur:
             self._close(cur)
-        self._bucket_of = {}
+        self._bucket_of, self._offset = {}, {}
         for bi, b in enumerate(self.buckets):
-            for p in b['params']:
+            off = 0
+            for k, p in enumerate(b['params']):
                 self._bucket_of[id(p)] = bi
+                self._offset[id(p)] = (off, k)                 # element offset of the gradient view, flag slot
+                off += p.numel()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._next = 0
         self.zero_grad()
 
     def _close(self, plist):
-        flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
-        self.buckets.append(dict(flat=flat, params=list(plist), pending=0, ready=False, handle=None))
+        n = sum(p.numel() for p in plist)
+        flat = torch.zeros(n + len(plist), dtype=plist[0].dtype, device=plist[0].device)     # gradients | one flag per parameter
+        self.buckets.append(dict(flat=flat, nel=n, params=list(plist), pending=0, ready=False, handle=None))
 
     def zero_grad(self):
         """Zero the flat buffers and (re)attach the gradient views; call instead of optimizer.zero_grad()."""
@@ -118,6 +124,9 @@ class OverlappedGradientReducer(object):
     def _launch_ready(self):
         while self._next < len(self.buckets) and self.buckets[self._next]['ready']:
             b = self.buckets[self._next]
+            # flags of the parameters that produced a gradient on this rank (world: > 0 after the averaged sum = some rank)
+            b['flat'][b['nel']:] = torch.tensor([float(self.world) if id(p) in self._used else 0.0 for p in b['params']],
+                                                dtype=b['flat'].dtype).to(b['flat'].device, non_blocking=True)
             if self.world > 1:
                 b['flat'].div_(self.world)
                 b['handle'] = dist.all_reduce(b['flat'], async_op=True)
@@ -125,7 +134,7 @@ class OverlappedGradientReducer(object):
 
     def _on_grad(self, p):
         b = self.buckets[self._bucket_of[id(p)]]
-        if p.grad.data_ptr() != b['flat'].data_ptr() + self._offset_bytes(b, p):    # autograd replaced the view: copy back
+        if p.grad.data_ptr() != b['flat'].data_ptr() + self._offset[id(p)][0] * p.element_size():   # autograd replaced the view: copy back
             self._reattach(b, p)
         self._used.add(id(p))
         b['pending'] -= 1
@@ -133,17 +142,8 @@ class OverlappedGradientReducer(object):
             b['ready'] = True
             self._launch_ready()
 
-    @staticmethod
-    def _offset_bytes(b, p):
-        off = 0
-        for q in b['params']:
-            if q is p:
-                return off * p.element_size()
-            off += q.numel()
-        raise KeyError
-
     def _reattach(self, b, p):
-        off = self._offset_bytes(b, p) // p.element_size()
+        off = self._offset[id(p)][0]
         view = b['flat'][off:off + p.numel()].view_as(p)
         view.copy_(p.grad)
         p.grad = view
@@ -158,13 +158,14 @@ class OverlappedGradientReducer(object):
                 b['handle'].wait()
                 b['handle'] = None
         # a parameter no rank produced a gradient for keeps grad = None, as after a plain backward (the optimizer then
-        # skips it: no momentum / weight-decay step); one small MAX all-reduce of the "used" bitmap decides
-        used = torch.tensor([1.0 if id(p) in self._used else 0.0 for p in self.params], device=self.params[0].device)
-        if self.world > 1:
-            dist.all_reduce(used, op=dist.ReduceOp.MAX)
-        for p, u in zip(self.params, used.tolist()):
-            if u == 0.0:
-                p.grad = None
+        # skips it: no momentum / weight-decay step): the flags travelled with the buckets, one host read of all of them
+        flags = torch.cat([b['flat'][b['nel']:].float() for b in self.buckets]).tolist()
+        k = 0
+        for b in self.buckets:
+            for p in b['params']:
+                if flags[k] == 0.0:
+                    p.grad = None
+                k += 1
 
     def remove(self):
         for h in self._hooks:
