@@ -214,8 +214,8 @@ int orp_dcn_forward_direct(const float* input, const float* offset, const float*
  * weight is the layer's [256,256,kh,kw] tensor.  workspace: orp_dcn_backward_workspace_bytes() bytes. */
 #define ORP_DCN_BWD_INPUT 1
 #define ORP_DCN_BWD_SPARSE 2
-typedef struct { const float* input; const float* offset; const float* grad_output; float* grad_input; float* grad_offset;
-                 int height; int width; } orp_dcn_bwd_level;
+typedef struct { const void* input; const float* offset; const void* grad_output; void* grad_input; float* grad_offset;
+                 int height; int width; } orp_dcn_bwd_level;   /* input / grad_output / grad_input: fp32, or io_dtype of the _ex entry */
 int orp_dcn_backward_mfma_ok(int c_in, int c_out, int kh, int kw, int groups, int deformable_groups);
 size_t orp_dcn_backward_workspace_bytes(const orp_dcn_bwd_level* levels_host, int nlevels, int batch, int kh, int kw,
                                         int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w);
@@ -223,6 +223,18 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
                            const float* weight, float* grad_weight, int need_input_grads, int kh, int kw, int stride_h,
                            int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* The same with DCNv2 modulation and half-precision tensors (modulated_deform_conv_cuda_backward,
+ * deform_conv_cuda.cpp:592-685; AT_DISPATCH_FLOATING_TYPES_AND_HALF, deform_conv_cuda_kernel.cu:353,451,781,813):
+ *   masks_host[i] [B,kh*kw,Ho,Wo] fp32 (NULL array = DCNv1): the sample of (position, tap) is scaled by its mask value in
+ *     grad_weight's columns, grad_input's scatter and grad_offset; grad_masks_host[i] receives d loss / d mask
+ *     (= G . sampled value, summed over the channels in a fixed order);
+ *   io_dtype 0 / 1 / 2 = input, grad_output and grad_input are fp32 / fp16 / bf16 (converted inside the layout passes the
+ *     call runs anyway); offsets, masks, weight and the remaining gradients stay fp32, the arithmetic is fp32 MFMA. */
+int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float* const* masks_host,
+                              float* const* grad_masks_host, int io_dtype, int nlevels, int batch, int c_in, int c_out,
+                              const float* weight, float* grad_weight, int need_input_grads, int kh, int kw, int stride_h,
+                              int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* Deformable convolution backward, column formulation (deform_conv_cuda.cpp:262-488, kernels
  * deform_conv_cuda_kernel.cu:190-465 and the modulated twins :570-867).  NCHW fp32.

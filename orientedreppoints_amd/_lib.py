@@ -76,6 +76,7 @@ _SIGNATURES = {
     "orp_dcn_backward_mfma_ok": (_i, [_i] * 6),
     "orp_dcn_backward_workspace_bytes": (_sz, [_vp] + [_i] * 10),
     "orp_dcn_backward_multi": (_i, [_vp, _i, _i, _i, _i, _vp, _vp] + [_i] * 9 + [_vp, _sz, _vp]),
+    "orp_dcn_backward_multi_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp] + [_i] * 9 + [_vp, _sz, _vp]),
     "orp_poly_nms_f64_workspace_bytes": (_sz, [_i]),
     "orp_poly_nms_f64": (_i, [_vp, _i, ctypes.c_double, _vp, _vp, _vp, _sz, _vp]),
     "orp_soft_rnms_host": (_i, [_vp, _i, _f, _i, _f, _f, _vp, _vp]),

@@ -72,6 +72,8 @@ struct BLevel {
   const float* off;    // NCHW [B, 2*taps, Ho, Wo]
   float* gx;           // NHWC [B, H, W, 256], zeroed
   float* goff;         // NCHW [B, 2*taps, Ho, Wo]
+  const float* mask;   // DCNv2: NCHW [B, taps, Ho, Wo] modulation, or nullptr (DCNv1)
+  float* gmask;        // DCNv2: its gradient
   int H, W, Ho, Wo;
   int tile0;           // kernel A: first tile of this level
   int chunk0;          // kernel B: first 32-position chunk of this level
@@ -99,8 +101,9 @@ inline int out_dim(int in, int pad, int dil, int k, int stride) { return (in + 2
 
 // ---- batched [B][R][S] -> [B][S][R] for up to 16 tensors in one launch -------------------------------------------
 struct TransposeSet {
-  const float* in[2 * MAXL];
-  float* out[2 * MAXL];
+  const void* in[2 * MAXL];
+  void* out[2 * MAXL];
+  int in_code, out_code;         // element type of the inputs / outputs: 0 fp32, 1 fp16, 2 bf16 (the other side is fp32)
   int R[2 * MAXL], S[2 * MAXL];
   int t0[2 * MAXL + 1];
   int chunk0[2 * MAXL];          // >= 0: tensor i is a grad_out [256][HoWo]; flags[chunk0 + (b*S + s) / 32] = 1 where non-zero
@@ -117,18 +120,29 @@ __global__ void transpose_set_kernel(const TransposeSet T) {
   const int t = (int)blockIdx.x - T.t0[i];
   const int r0 = (t / ts_n) * 32, s0 = (t % ts_n) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const float* src = T.in[i] + (size_t)blockIdx.y * R * S;
-  float* dst = T.out[i] + (size_t)blockIdx.y * R * S;
+  const size_t plane = (size_t)blockIdx.y * R * S;
   for (int k = ty; k < 32; k += 8) {
     const int r = r0 + k, s = s0 + tx;
-    tile[k][tx] = (r < R && s < S) ? src[(size_t)r * S + s] : 0.f;
+    float v = 0.f;
+    if (r < R && s < S) {
+      const size_t at = plane + (size_t)r * S + s;
+      v = T.in_code == 0 ? reinterpret_cast<const float*>(T.in[i])[at]
+        : T.in_code == 1 ? (float)reinterpret_cast<const _Float16*>(T.in[i])[at]
+                         : (float)reinterpret_cast<const __bf16*>(T.in[i])[at];
+    }
+    tile[k][tx] = v;
   }
   __syncthreads();
   const int c0 = T.chunk0[i];
   for (int k = ty; k < 32; k += 8) {
     const int s = s0 + k, r = r0 + tx;
     const float v = tile[tx][k];
-    if (s < S && r < R) dst[(size_t)s * R + r] = v;
+    if (s < S && r < R) {
+      const size_t at = plane + (size_t)s * R + r;
+      if (T.out_code == 0) reinterpret_cast<float*>(T.out[i])[at] = v;
+      else if (T.out_code == 1) reinterpret_cast<_Float16*>(T.out[i])[at] = (_Float16)v;
+      else reinterpret_cast<__bf16*>(T.out[i])[at] = (__bf16)v;
+    }
     if (c0 >= 0) {                                                  // lanes 0-31 / 32-63 of a wave = 32 channels of ONE position
       const unsigned long long nz = __ballot(v != 0.f);
       const bool mine = (threadIdx.x & 32) ? (nz >> 32) != 0 : (nz & 0xffffffffull) != 0;
@@ -205,6 +219,13 @@ __device__ inline void sample_point(const BwdParams& P, const BLevel& L, long p,
   }
 }
 
+// DCNv2 modulation scalar of (position p of level L, tap); 1 for DCNv1
+__device__ inline float sample_mask(const BLevel& L, long p, int tap, int taps, int HoWo) {
+  if (!L.mask) return 1.f;
+  const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+  return L.mask[((size_t)b * taps + tap) * HoWo + hw];
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ inline float dpp_add(float v) {
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
@@ -230,9 +251,9 @@ dcn_bwd_input_kernel(const BwdParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sG = reinterpret_cast<float*>(smem);                       // [BM2][ASTR] grad_out rows
   int4* sCi = reinterpret_cast<int4*>(sG + BM2 * ASTR);             // [BM2 * taps]
-  float2* sCl = reinterpret_cast<float2*>(sCi + BM2 * MAXT);        // [BM2 * taps] (lh, lw)
-  float* sGO = reinterpret_cast<float*>(sCl + BM2 * MAXT);          // [8 waves][BM2][taps][2] grad_offset partials of the tile
-  int* sNZ = reinterpret_cast<int*>(sGO + 8 * BM2 * MAXT * 2);      // [BM2] row has a non-zero grad_out value
+  float4* sCl = reinterpret_cast<float4*>(sCi + BM2 * MAXT);        // [BM2 * taps] (lh, lw, modulation, -)
+  float* sGO = reinterpret_cast<float*>(sCl + BM2 * MAXT);          // [8 waves][BM2][taps][3] grad_offset (+ grad_mask) partials
+  int* sNZ = reinterpret_cast<int*>(sGO + 8 * BM2 * MAXT * 3);      // [BM2] row has a non-zero grad_out value
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int taps = P.kh * P.kw;
@@ -256,10 +277,11 @@ dcn_bwd_input_kernel(const BwdParams P) {
     const int m = e / taps, tap = e - m * taps;
     int4 ix = make_int4(-1, -1, -1, -1);
     float2 fr = make_float2(0.f, 0.f);
-    if (p0 + m < npos) sample_point(P, L, p0 + m, tap, taps, HoWo, ix, fr);
-    sCi[e] = ix; sCl[e] = fr;
+    float mm = 1.f;
+    if (p0 + m < npos) { sample_point(P, L, p0 + m, tap, taps, HoWo, ix, fr); mm = sample_mask(L, p0 + m, tap, taps, HoWo); }
+    sCi[e] = ix; sCl[e] = make_float4(fr.x, fr.y, mm, 0.f);
   }
-  for (int e = tid; e < 8 * BM2 * MAXT * 2; e += kThreads) sGO[e] = 0.f;
+  for (int e = tid; e < 8 * BM2 * MAXT * 3; e += kThreads) sGO[e] = 0.f;
   for (int r = wave; r < BM2; r += 8) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p0 + r < npos) v = *reinterpret_cast<const float4*>(L.go + (size_t)(p0 + r) * CH + lane * 4);
@@ -334,9 +356,9 @@ dcn_bwd_input_kernel(const BwdParams P) {
         }
         if (__ballot(live) == 0) continue;
         const int4 ix = live ? sCi[e] : make_int4(-1, -1, -1, -1);
-        const float2 fr = sCl[e];
+        const float4 fr = sCl[e];
         const float g = acc[mt][r];
-        const float lh = fr.x, lw = fr.y, uh = 1.f - lh, uw = 1.f - lw;
+        const float lh = fr.x, lw = fr.y, uh = 1.f - lh, uw = 1.f - lw, mm = fr.z;
         const size_t o1 = (size_t)(ix.x < 0 ? 0 : ix.x) * CH + c, o2 = (size_t)(ix.y < 0 ? 0 : ix.y) * CH + c;
         const size_t o3 = (size_t)(ix.z < 0 ? 0 : ix.z) * CH + c, o4 = (size_t)(ix.w < 0 ? 0 : ix.w) * CH + c;
 #if ORP_BWD_DBG & 2
@@ -347,18 +369,27 @@ dcn_bwd_input_kernel(const BwdParams P) {
 #endif
 #if !(ORP_BWD_DBG & 1)
         if (!STORE_G) {
-          if (ix.x >= 0) atomicAdd(L.gx + o1, uh * uw * g);
-          if (ix.y >= 0) atomicAdd(L.gx + o2, uh * lw * g);
-          if (ix.z >= 0) atomicAdd(L.gx + o3, lh * uw * g);
-          if (ix.w >= 0) atomicAdd(L.gx + o4, lh * lw * g);
+          const float gm = g * mm;
+          if (ix.x >= 0) atomicAdd(L.gx + o1, uh * uw * gm);
+          if (ix.y >= 0) atomicAdd(L.gx + o2, uh * lw * gm);
+          if (ix.z >= 0) atomicAdd(L.gx + o3, lh * uw * gm);
+          if (ix.w >= 0) atomicAdd(L.gx + o4, lh * lw * gm);
         }
 #endif
-        float dh = g * (-uw * v1 - lw * v2 + uw * v3 + lw * v4);
-        float dw = g * (-uh * v1 + uh * v2 - lh * v3 + lh * v4);
+        float dh = g * mm * (-uw * v1 - lw * v2 + uw * v3 + lw * v4);
+        float dw = g * mm * (-uh * v1 + uh * v2 - lh * v3 + lh * v4);
         dh = half_wave_sum(dh);
         dw = half_wave_sum(dw);
+        float dm = 0.f;
+        if (L.gmask) {                                               // DCNv2: d loss / d modulation = G . sampled value
+          dm = g * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4);
+          dm = half_wave_sum(dm);
+        }
         // this wave's 32-channel partial of (position, tap): one writer per slot, summed over the waves in order below
-        if (mrow == 31) { sGO[(wave * BM2 * MAXT + e) * 2] = dh; sGO[(wave * BM2 * MAXT + e) * 2 + 1] = dw; }
+        if (mrow == 31) {
+          float* slot = sGO + (size_t)(wave * BM2 * MAXT + e) * 3;
+          slot[0] = dh; slot[1] = dw; slot[2] = dm;
+        }
       }
     }
   }
@@ -369,17 +400,31 @@ dcn_bwd_input_kernel(const BwdParams P) {
     const long p = p0 + m;
     if (p < npos) {
       const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+      const int tap = plane >> 1, comp = plane & 1;
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; w++) v += sGO[(w * BM2 * MAXT) * 2 + m * 2 * taps + plane];   // fixed order: reproducible
+      for (int w = 0; w < 8; w++) v += sGO[(size_t)(w * BM2 * MAXT + m * taps + tap) * 3 + comp];   // fixed order: reproducible
       L.goff[((size_t)b * 2 * taps + plane) * HoWo + hw] = v;
+    }
+  }
+  if (L.gmask) {
+    for (int e2 = tid; e2 < BM2 * taps; e2 += kThreads) {
+      const int tap = e2 / BM2, m = e2 - tap * BM2;
+      const long p = p0 + m;
+      if (p < npos) {
+        const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) v += sGO[(size_t)(w * BM2 * MAXT + m * taps + tap) * 3 + 2];
+        L.gmask[((size_t)b * taps + tap) * HoWo + hw] = v;
+      }
     }
   }
 }
 
 template <int MT>
 size_t input_smem() {
-  return sizeof(float) * (size_t)32 * MT * ASTR + (sizeof(int4) + sizeof(float2) + 8 * 2 * sizeof(float)) * 32 * MT * MAXT +
+  return sizeof(float) * (size_t)32 * MT * ASTR + (sizeof(int4) + sizeof(float4) + 8 * 3 * sizeof(float)) * 32 * MT * MAXT +
          sizeof(int) * 32 * MT;
 }
 
@@ -417,6 +462,7 @@ __global__ void bin_samples_kernel(const BwdParams P) {
       const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
       float* o = L.goff + ((size_t)b * 2 * taps + 2 * tap) * HoWo + hw;
       o[0] = 0.f; o[HoWo] = 0.f;
+      if (L.gmask) L.gmask[((size_t)b * taps + tap) * HoWo + hw] = 0.f;
     }
   } else {
     if (p < (long)P.B * HoWo) {
@@ -474,6 +520,7 @@ __global__ void build_desc_kernel(const BwdParams P, const unsigned* __restrict_
   const long p = pg - (long)L.chunk0 * 32;                           // the sample belongs to this region's level
   int4 ix; float2 fr;
   sample_point(P, L, p, tap, taps, L.Ho * L.Wo, ix, fr);
+  const float mm = sample_mask(L, p, tap, taps, L.Ho * L.Wo);        // DCNv2: the sample's modulation scales its scatter
   const float lh = fr.x, lw = fr.y, uh = 1.f - lh, uw = 1.f - lw;
   auto local = [&](int q) {                                          // pixel -> row of this region, 64 = another region's / outside
     if (q < 0) return 64;
@@ -485,8 +532,8 @@ __global__ void build_desc_kernel(const BwdParams P, const unsigned* __restrict_
   SampleDesc d;
   d.row = e; d.pad0 = d.pad1 = d.pad2 = 0;
   d.q[0] = i0 * CH; d.q[1] = i1 * CH; d.q[2] = i2 * CH; d.q[3] = i3 * CH;
-  d.w[0] = i0 < 64 ? uh * uw : 0.f; d.w[1] = i1 < 64 ? uh * lw : 0.f;
-  d.w[2] = i2 < 64 ? lh * uw : 0.f; d.w[3] = i3 < 64 ? lh * lw : 0.f;
+  d.w[0] = i0 < 64 ? uh * uw * mm : 0.f; d.w[1] = i1 < 64 ? uh * lw * mm : 0.f;
+  d.w[2] = i2 < 64 ? lh * uw * mm : 0.f; d.w[3] = i3 < 64 ? lh * lw * mm : 0.f;
   desc[i] = d;
 }
 
@@ -617,9 +664,10 @@ dcn_bwd_weight_kernel(const BwdParams P) {
     if (p < (long)P.B * HoWo) {
       int4 ix; float2 fr;
       sample_point(P, L, p, tap, taps, HoWo, ix, fr);
+      const float mm = sample_mask(L, p, tap, taps, HoWo);           // DCNv2: the column is the modulated sample
       const float lh = fr.x, lw = fr.y, uh = 1.f - lh, uw = 1.f - lw;
-      w.x = ix.x >= 0 ? uh * uw : 0.f; w.y = ix.y >= 0 ? uh * lw : 0.f;
-      w.z = ix.z >= 0 ? lh * uw : 0.f; w.w = ix.w >= 0 ? lh * lw : 0.f;
+      w.x = ix.x >= 0 ? uh * uw * mm : 0.f; w.y = ix.y >= 0 ? uh * lw * mm : 0.f;
+      w.z = ix.z >= 0 ? lh * uw * mm : 0.f; w.w = ix.w >= 0 ? lh * lw * mm : 0.f;
       ixc = make_int4(ix.x < 0 ? 0 : ix.x, ix.y < 0 ? 0 : ix.y, ix.z < 0 ? 0 : ix.z, ix.w < 0 ? 0 : ix.w);
       row = p;
     }
@@ -823,8 +871,19 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
                            const float* weight, float* grad_weight, int need_input_grads, int kh, int kw, int stride_h,
                            int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, void* workspace,
                            size_t workspace_bytes, void* stream) {
+  return orp_dcn_backward_multi_ex(levels_host, nullptr, nullptr, 0, nlevels, batch, c_in, c_out, weight, grad_weight,
+                                   need_input_grads, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, workspace,
+                                   workspace_bytes, stream);
+}
+
+int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float* const* masks_host,
+                              float* const* grad_masks_host, int io_dtype, int nlevels, int batch, int c_in, int c_out,
+                              const float* weight, float* grad_weight, int need_input_grads, int kh, int kw, int stride_h,
+                              int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   if (!levels_host || nlevels <= 0 || nlevels > MAXL || batch <= 0 || !weight || !workspace) return ORP_EINVAL;
   if (!orp_dcn_backward_mfma_ok(c_in, c_out, kh, kw, 1, 1)) return ORP_EINVAL;
+  if (io_dtype < 0 || io_dtype > 2 || (need_input_grads && masks_host && !grad_masks_host)) return ORP_EINVAL;
   if (!grad_weight && !need_input_grads) return ORP_OK;
   hipStream_t st = (hipStream_t)stream;
   Plan pl;
@@ -856,6 +915,10 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
     D.go = reinterpret_cast<float*>(ws + pl.go_off[i]);
     D.gx = reinterpret_cast<float*>(ws + pl.gx_off[i]);
     D.off = lv.offset; D.goff = lv.grad_offset;
+    D.mask = masks_host ? masks_host[i] : nullptr;
+    D.gmask = (masks_host && grad_masks_host && need_input_grads) ? grad_masks_host[i] : nullptr;
+    if (masks_host && !D.mask) return ORP_EINVAL;
+    if (masks_host && need_input_grads && !D.gmask) return ORP_EINVAL;
     D.tile0 = tiles; D.chunk0 = chunks;
     D.reg0 = pl.reg0[i]; D.RH = pl.RH[i]; D.RW = pl.RW[i];
     const long npos = (long)batch * D.Ho * D.Wo;
@@ -878,6 +941,8 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
   for (int i = ti; i < 2 * MAXL; i++) { TI.in[i] = TI.in[0]; TI.out[i] = TI.out[0]; TI.R[i] = TI.S[i] = 0; TI.chunk0[i] = -1; }
   for (int i = nlevels; i < 2 * MAXL; i++) { TO.in[i] = TO.in[0]; TO.out[i] = TO.out[0]; TO.R[i] = TO.S[i] = 0; TO.chunk0[i] = -1; }
   TI.flags = flags; TO.flags = flags;
+  TI.in_code = io_dtype; TI.out_code = 0;                   // x / grad_out arrive in the I/O type, the workspace is fp32
+  TO.in_code = 0; TO.out_code = io_dtype;                   // grad_input leaves in the I/O type
 
   OrpProfScope prof(ORP_PROF_DCN_BWD, st);
   hipError_t e = hipMemsetAsync(flags, 0, sizeof(int) * (size_t)pl.total_chunks, st);
@@ -905,6 +970,10 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
       for (int i = 0; i < nlevels; i++) {                            // grad_offset of the chunks that are skipped is zero
         e = hipMemsetAsync(levels_host[i].grad_offset, 0, sizeof(float) * (size_t)batch * 2 * taps * pl.Ho[i] * pl.Wo[i], st);
         if (e != hipSuccess) return (int)e;
+        if (P.lv[i].gmask) {
+          e = hipMemsetAsync(P.lv[i].gmask, 0, sizeof(float) * (size_t)batch * taps * pl.Ho[i] * pl.Wo[i], st);
+          if (e != hipSuccess) return (int)e;
+        }
       }
       struct T1 { int unused; };
       e = orp::set_max_dynamic_lds_once<T1>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT, false>), input_smem<MT>());

@@ -27,27 +27,46 @@ def mfma_ok(weight, groups, deformable_groups):
     return bool(_lib.lib().orp_dcn_backward_mfma_ok(cin_g * groups, cout, kh, kw, groups, deformable_groups))
 
 
+_IO_CODES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
 def backward_mfma(inputs, offsets, weight, grad_outputs, stride, padding, dilation, need_input=True, need_weight=True,
-                  sparse_grad=False):
+                  sparse_grad=False, masks=None):
     """All levels of ONE DeformConv layer in one call: lists of NCHW inputs / offsets / grad_outputs ->
-    (grad_inputs, grad_offsets, grad_weight); grad_weight is summed over the levels in a fixed order.
+    (grad_inputs, grad_offsets, grad_weight) -- with `masks` (DCNv2 modulation, one [B,kh*kw,Ho,Wo] per level)
+    (grad_inputs, grad_offsets, grad_weight, grad_masks); grad_weight is summed over the levels in a fixed order.
+    fp16 / bf16 inputs (the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF branch): inputs, grad_outputs and grad_inputs
+    travel in that type and are converted inside the layout passes of the call; the arithmetic is fp32 MFMA, the small
+    tensors (offsets, masks, weight and their gradients) are converted here.
     sparse_grad: the caller expects grad_outputs to be zero almost everywhere (ORP_DCN_BWD_SPARSE, include/orp_hip.h):
     grad_input is then scattered with atomics instead of the (bitwise reproducible) region pass."""
     L = _lib.lib()
+    dt = inputs[0].dtype
+    if dt not in _IO_CODES:
+        raise TypeError("backward_mfma: fp32 / fp16 / bf16 tensors only")
     w = weight.detach().float().contiguous()
     cout, cin, kh, kw = w.shape
     B = inputs[0].size(0)
     n = len(inputs)
     levels = (_BwdLevel * n)()
-    keep, gis, gos = [], [], []
+    mptr = (ctypes.c_void_p * n)() if masks is not None else None
+    gmptr = (ctypes.c_void_p * n)() if masks is not None else None
+    keep, gis, gos, gms = [], [], [], []
     for i, (x, off, go) in enumerate(zip(inputs, offsets, grad_outputs)):
-        x, off, go = x.detach().float().contiguous(), off.detach().float().contiguous(), go.detach().float().contiguous()
+        x, go = x.detach().to(dt).contiguous(), go.detach().to(dt).contiguous()
+        off = off.detach().float().contiguous()
         gi = torch.empty_like(x) if need_input else None
         goff = torch.empty_like(off) if need_input else None
         keep.append((x, off, go))
         gis.append(gi)
         gos.append(goff)
         levels[i] = _BwdLevel(_lib.ptr(x), _lib.ptr(off), _lib.ptr(go), _lib.ptr(gi), _lib.ptr(goff), x.size(2), x.size(3))
+        if masks is not None:
+            m = masks[i].detach().float().contiguous()
+            gm = torch.empty_like(m) if need_input else None
+            keep.append(m); gms.append(gm)
+            mptr[i] = m.data_ptr()
+            gmptr[i] = gm.data_ptr() if gm is not None else None
     gw = torch.empty_like(w) if need_weight else None
     nbytes = L.orp_dcn_backward_workspace_bytes(levels, n, B, kh, kw, stride[0], stride[1], padding[0], padding[1],
                                                 dilation[0], dilation[1])
@@ -55,11 +74,16 @@ def backward_mfma(inputs, offsets, weight, grad_outputs, stride, padding, dilati
         raise ValueError("orp_dcn_backward_workspace_bytes: invalid geometry")
     with torch.cuda.device(w.device):
         ws = _lib.workspace(w.device, nbytes)
-        rc = L.orp_dcn_backward_multi(levels, n, B, cin, cout, _lib.ptr(w), _lib.ptr(gw), (1 | (2 if sparse_grad else 0)) if need_input else 0, kh, kw,
-                                      stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
-                                      _lib.ptr(ws), nbytes, _lib.stream_of(w))
-    _lib.check(rc, "orp_dcn_backward_multi")
-    return gis, gos, gw
+        rc = L.orp_dcn_backward_multi_ex(levels, mptr, gmptr, _IO_CODES[dt], n, B, cin, cout, _lib.ptr(w), _lib.ptr(gw),
+                                         (1 | (2 if sparse_grad else 0)) if need_input else 0, kh, kw,
+                                         stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                                         _lib.ptr(ws), nbytes, _lib.stream_of(w))
+    _lib.check(rc, "orp_dcn_backward_multi_ex")
+    if dt != torch.float32:                                        # the small gradients follow their tensors' type
+        gos = [g.to(offsets[i].dtype) if g is not None else None for i, g in enumerate(gos)]
+        gms = [g.to(masks[i].dtype) if g is not None else None for i, g in enumerate(gms)]
+        gw = gw.to(weight.dtype) if gw is not None else None
+    return (gis, gos, gw, gms) if masks is not None else (gis, gos, gw)
 
 
 def _geo(input, weight, stride, padding, dilation):
@@ -130,20 +154,23 @@ def backward_input(input, offset, weight, grad_output, stride, padding, dilation
     if mfma_ok(weight, groups, deformable_groups):
         gi, go, _ = backward_mfma([input], [offset], weight, [grad_output], stride, padding, dilation, True, False)
         return gi[0], go[0]
+    dt, dto = input.dtype, offset.dtype
     input, offset, weight, grad_output = _prep(input, offset, weight, grad_output)
     if groups == 1 and deformable_groups == 1:
-        return _backward_input_nhwc(input, offset, weight, grad_output, stride, padding, dilation)
-    gcol = _grad_columns(weight, grad_output, groups)
-    gi, go, _ = _col2im(gcol, input, offset, None, weight, stride, padding, dilation, deformable_groups)
-    return gi, go
+        gi, go = _backward_input_nhwc(input, offset, weight, grad_output, stride, padding, dilation)
+    else:
+        gcol = _grad_columns(weight, grad_output, groups)
+        gi, go, _ = _col2im(gcol, input, offset, None, weight, stride, padding, dilation, deformable_groups)
+    return gi.to(dt), go.to(dto)
 
 
 def backward_parameters(input, offset, weight, grad_output, stride, padding, dilation, groups, deformable_groups):
     if mfma_ok(weight, groups, deformable_groups):
         return backward_mfma([input], [offset], weight, [grad_output], stride, padding, dilation, False, True)[2]
+    dt = weight.dtype
     input, offset, weight, grad_output = _prep(input, offset, weight, grad_output)
     col = _im2col(input, offset, None, weight, stride, padding, dilation, deformable_groups)
-    return _grad_weight(col, weight, grad_output, groups)
+    return _grad_weight(col, weight, grad_output, groups).to(dt)
 
 
 def _grad_weight(col, weight, grad_output, groups):
@@ -155,10 +182,20 @@ def _grad_weight(col, weight, grad_output, groups):
 
 def modulated_backward(input, offset, mask, weight, grad_output, stride, padding, dilation, groups, deformable_groups,
                        with_bias):
+    if mfma_ok(weight, groups, deformable_groups):
+        # DCNv2 on the MFMA implicit GEMMs (orp_dcn_backward_multi_ex): the modulation rides in the sample weights
+        gis, gos, gw, gms = backward_mfma([input], [offset], weight, [grad_output], stride, padding, dilation, True, True,
+                                          masks=[mask])
+        gb = grad_output.float().sum(dim=(0, 2, 3)).to(grad_output.dtype) if with_bias else None
+        return gis[0], gos[0], gms[0], gw, gb
+    dt = input.dtype
     input, offset, mask, weight, grad_output = _prep(input, offset, mask, weight, grad_output)
     gcol = _grad_columns(weight, grad_output, groups)
     gi, go, gm = _col2im(gcol, input, offset, mask, weight, stride, padding, dilation, deformable_groups)
     col = _im2col(input, offset, mask, weight, stride, padding, dilation, deformable_groups)
     gw = _grad_weight(col, weight, grad_output, groups)
     gb = grad_output.sum(dim=(0, 2, 3)) if with_bias else None
+    if dt != torch.float32:
+        gi, go, gm, gw = gi.to(dt), go.to(dt), gm.to(dt), gw.to(dt)
+        gb = gb.to(dt) if gb is not None else None
     return gi, go, gm, gw, gb

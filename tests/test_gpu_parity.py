@@ -897,6 +897,69 @@ def test_dcn_backward_input_without_atomics_is_bitwise_reproducible(dev, oracle)
         assert _rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4
 
 
+def test_dcn_v2_backward_on_mfma_path_vs_column_formulation(dev, oracle):
+    """modulated_deform_conv backward at the head's 256 -> 256 channels through orp_dcn_backward_multi_ex (the modulation
+    scalar rides in the sample weights of both MFMA GEMMs; grad_mask = G . sampled value) against the column formulation
+    (HIP sampling kernels + library GEMMs, itself pinned to the oracle's im2col in test_dcn_backward): every gradient
+    within 1e-4 of its scale; the DCNv1 part of the same call against the oracle's backward with the mask folded in."""
+    from orientedreppoints_amd.mmdet_ops import modulated_deform_conv, deform_conv_backward as bw
+    rng = np.random.RandomState(21)
+    x, off, w = _dcn_case(81, 2, 256, 11, 13, 256, std_off=2.5)
+    m = rng.uniform(0.1, 1.0, size=(2, 9, 11, 13)).astype(np.float32)
+    b = rng.normal(size=(256,)).astype(np.float32)
+    go = rng.normal(size=(2, 256, 11, 13)).astype(np.float32)
+    grads = {}
+    for use in (True, False):
+        bw.USE_MFMA = use
+        try:
+            ts = [_t(a, dev).requires_grad_(True) for a in (x, off, m, w, b)]
+            y = modulated_deform_conv(ts[0], ts[1], ts[2], ts[3], ts[4], 1, 1, 1, 1, 1)
+            y.backward(_t(go, dev))
+            grads[use] = [t.grad.cpu().numpy() for t in ts]
+        finally:
+            bw.USE_MFMA = True
+    for name, a, c in zip(("input", "offset", "mask", "weight", "bias"), grads[True], grads[False]):
+        assert _rel_err(a, c) <= 1e-4, name
+    # mask == 1 reduces to DCNv1: the oracle's backward
+    ones = np.ones_like(m)
+    ts = [_t(a, dev).requires_grad_(True) for a in (x, off, ones, w)]
+    modulated_deform_conv(ts[0], ts[1], ts[2], ts[3], None, 1, 1, 1, 1, 1).backward(_t(go, dev))
+    wi, woff, wgw = oracle.dcn_backward(x, off, w, go)
+    for a, c in zip((ts[0].grad, ts[1].grad, ts[3].grad), (wi, woff, wgw)):
+        assert _rel_err(a.cpu().numpy(), c) <= 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [("float16", 4e-3), ("bfloat16", 3e-2)])
+def test_dcn_backward_half_precision_vs_fp32_oracle(dev, oracle, dtype, tol):
+    """fp16 / bf16 DeformConv backward (the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF branch of deformable_col2im /
+    col2im_coord / im2col, deform_conv_cuda_kernel.cu:353,451): tensors in half, arithmetic fp32 MFMA, gradients returned in
+    the tensors' type -- against the fp32 oracle evaluated on the SAME rounded inputs: |delta| <= tol of each gradient's scale
+    (tol = the type's rounding of the returned gradient plus of the forward's own output tolerance), DCNv1 and DCNv2."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv, modulated_deform_conv
+    dt = getattr(torch, dtype)
+    rng = np.random.RandomState(31)
+    x, off, w = _dcn_case(91, 2, 256, 9, 10, 256, std_off=2.0)
+    go = rng.normal(size=(2, 256, 9, 10)).astype(np.float32)
+    rnd = lambda a: _t(a, dev).to(dt)                                   # noqa: E731
+    tx, toff, tw = (rnd(a).requires_grad_(True) for a in (x, off, w))
+    tgo = rnd(go)
+    deform_conv(tx, toff, tw, 1, 1, 1, 1, 1, 64).backward(tgo)
+    assert tx.grad.dtype == dt and toff.grad.dtype == dt and tw.grad.dtype == dt
+    f = lambda t: t.detach().float().cpu().numpy()                      # noqa: E731
+    wi, woff, wgw = oracle.dcn_backward(f(tx), f(toff), f(tw), f(tgo))
+    for name, a, c in (("input", tx.grad, wi), ("offset", toff.grad, woff), ("weight", tw.grad, wgw)):
+        assert _rel_err(f(a), c) <= tol, name
+    # DCNv2 in half: against the fp32 run of the same op on the rounded tensors
+    m = rng.uniform(0.1, 1.0, size=(2, 9, 9, 10)).astype(np.float32)
+    hs = [rnd(a).requires_grad_(True) for a in (x, off, m, w)]
+    modulated_deform_conv(hs[0], hs[1], hs[2], hs[3], None, 1, 1, 1, 1, 1).backward(tgo)
+    fs = [t.detach().float().requires_grad_(True) for t in hs]
+    modulated_deform_conv(fs[0], fs[1], fs[2], fs[3], None, 1, 1, 1, 1, 1).backward(tgo.float())
+    for name, a, c in zip(("input", "offset", "mask", "weight"), hs, fs):
+        assert a.grad.dtype == dt
+        assert _rel_err(f(a.grad), f(c.grad)) <= tol, name
+
+
 def test_head_training_forward_all_levels_as_one_dcn_node(dev):
     """Training forward of the head with both DeformConvs of all levels as ONE autograd node (pair launch forward, MFMA
     backward over all levels) == the per-level forward_single route on the column-formulation backward: outputs equal,
