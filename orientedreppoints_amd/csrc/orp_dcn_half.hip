@@ -13,6 +13,13 @@
 //     next tap's A rows (12 rows x 4 neighbours, 96 VGPRs in flight), the weight fragment of chunk j is reloaded for
 //     the next tap right after chunk j has used it (in-place register ring, prefetch distance = one whole tap), and the
 //     gathered rows are combined and written to the single LDS A tile between two barriers at the end of the tap.
+// Round 3: a wave gathers with 16-byte loads (one neighbour of TWO rows per instruction) and combines with packed arithmetic
+// (v_pk_fma_f16; bf16 widened to v_pk_fma_f32): 74 -> 55 us per layer at 1024^2 (21 824 positions).  Decomposition with the
+// ORP_DCNH_DBG switches: without the gathers 42.7 us, without the per-tap weight loads 48.9 us, without both 34.1 us -- of
+// which the matrix work is 11.5 us at the instruction rate; the rest of that floor is the A tile's LDS reads (every one
+// of the 8 waves reads the whole tile: 128 B/clk/CU at full matrix rate, half the LDS's peak), so the next step is a wave
+// tile of 64 output channels (half the LDS reads per MFMA), not more prefetch.  Measured without gain: a second A buffer
+// with one barrier per tap (55.4 us), the NCHW output staged through LDS into 16-byte stores (56.3 us).
 // Tolerance (tests): |out - fp32 oracle on the same rounded inputs| <= 2e-3 (fp16) / 1.6e-2 (bf16) of the output scale.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -22,6 +29,10 @@
 #include "../../include/orp_hip.h"
 #include "orp_launch.hpp"
 #include "orp_prof.hpp"
+
+#ifndef ORP_DCNH_DBG
+#define ORP_DCNH_DBG 0     // dev aid, compile-time (timing only, wrong results): 1 = no gathers, 2 = no per-tap weight loads, 4 = no MFMA, 8 = no combine
+#endif
 
 namespace {
 
@@ -36,16 +47,49 @@ constexpr int ASTRH = CBH + 8;    // padded A row stride in ELEMENTS (132 dwords
 constexpr int KCH = 16;           // input channels per MFMA
 constexpr int kThreadsH = 512;    // 8 waves: wave w owns output channels [32w, 32w+32)
 
-// element type traits: storage <-> float, MFMA
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// element type traits: storage <-> float, MFMA, and the bilinear combine of 8 channels (one 16-byte piece of a row per
+// neighbour).  fp16 combines with packed half arithmetic (v_pk_mul_f16 / v_pk_fma_f16: two channels per instruction, 16
+// instructions per 8 channels -- the reference's own half kernels also multiply and add in half); bf16 has no packed ALU
+// form on gfx950: its pairs are widened with one shift / mask each and combined with v_pk_fma_f32, then rounded once.
 template <typename T> struct Elem;
 template <> struct Elem<_Float16> {
   typedef half8 v8;
+  static __device__ __forceinline__ uint4 combine8(const uint4 (&g)[4], float4 w) {
+    const half2v w0 = {(_Float16)w.x, (_Float16)w.x}, w1 = {(_Float16)w.y, (_Float16)w.y};
+    const half2v w2 = {(_Float16)w.z, (_Float16)w.z}, w3 = {(_Float16)w.w, (_Float16)w.w};
+    union U { uint4 u; half2v h[4]; } a, b, c, d, o;
+    a.u = g[0]; b.u = g[1]; c.u = g[2]; d.u = g[3];
+#pragma unroll
+    for (int q = 0; q < 4; q++) o.h[q] = w3 * d.h[q] + (w2 * c.h[q] + (w1 * b.h[q] + w0 * a.h[q]));
+    return o.u;
+  }
   static __device__ __forceinline__ float to_f(_Float16 x) { return (float)x; }
   static __device__ __forceinline__ _Float16 from_f(float x) { return (_Float16)x; }
   static __device__ __forceinline__ floatx16 mfma(v8 a, v8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct Elem<__bf16> {
   typedef bf8 v8;
+  static __device__ __forceinline__ uint4 combine8(const uint4 (&g)[4], float4 w) {
+    const float2v w0 = {w.x, w.x}, w1 = {w.y, w.y}, w2 = {w.z, w.z}, w3 = {w.w, w.w};
+    const unsigned* a = reinterpret_cast<const unsigned*>(&g[0]);
+    const unsigned* b = reinterpret_cast<const unsigned*>(&g[1]);
+    const unsigned* c = reinterpret_cast<const unsigned*>(&g[2]);
+    const unsigned* d = reinterpret_cast<const unsigned*>(&g[3]);
+    auto widen = [](unsigned u) { float2v r = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; return r; };
+    uint4 o;
+    unsigned* op = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float2v v = w3 * widen(d[q]) + (w2 * widen(c[q]) + (w1 * widen(b[q]) + w0 * widen(a[q])));
+      union { __bf16 h[2]; unsigned u; } r;
+      r.h[0] = (__bf16)v.x; r.h[1] = (__bf16)v.y;                        // one rounding to bf16
+      op[q] = r.u;
+    }
+    return o;
+  }
   static __device__ __forceinline__ float to_f(__bf16 x) { return (float)x; }
   static __device__ __forceinline__ __bf16 from_f(float x) { return (__bf16)x; }
   static __device__ __forceinline__ floatx16 mfma(v8 a, v8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
@@ -188,28 +232,25 @@ dcn_fwd_half_kernel(const FwdH P, int total_tiles) {
 
   const int ncb = P.Cin / CBH;                       // 256-channel blocks per tap
   const int nphase = taps * ncb;
-  // one A row = 256 channels = 64 lanes x 4 elements (8 B): four coalesced 512 B neighbour rows
-  auto gather_issue = [&](int phase, int m, uint2 (&g)[4]) {
+  // one A row = 256 channels = 32 lanes x 8 elements (16 B): a wave fetches the same neighbour of TWO rows per
+  // instruction (lanes 0-31 row 2q, lanes 32-63 row 2q + 1), each a coalesced 512 B piece -- 16-byte accesses move twice
+  // the bytes per L1 cycle of the 8-byte ones this kernel used before
+  const int half_id = lane >> 5, l8 = (lane & 31) * 8;
+  auto gather_issue = [&](int phase, int m2, uint4 (&g)[4]) {          // m2: even row of the pair
     const int tap = phase / ncb, cb = phase - tap * ncb;
-    const int4 ix = sCi[m * taps + tap];
-    const T* base = xin + cb * CBH + lane * 4;
-    g[0] = *reinterpret_cast<const uint2*>(base + (size_t)ix.x * P.Cin);
-    g[1] = *reinterpret_cast<const uint2*>(base + (size_t)ix.y * P.Cin);
-    g[2] = *reinterpret_cast<const uint2*>(base + (size_t)ix.z * P.Cin);
-    g[3] = *reinterpret_cast<const uint2*>(base + (size_t)ix.w * P.Cin);
+    const int4 ix = sCi[(m2 + half_id) * taps + tap];
+    const T* base = xin + cb * CBH + l8;
+    if (ORP_DCNH_DBG & 1) { g[0] = g[1] = g[2] = g[3] = make_uint4(ix.x, ix.y, ix.z, ix.w); return; }
+    g[0] = *reinterpret_cast<const uint4*>(base + (size_t)ix.x * P.Cin);
+    g[1] = *reinterpret_cast<const uint4*>(base + (size_t)ix.y * P.Cin);
+    g[2] = *reinterpret_cast<const uint4*>(base + (size_t)ix.z * P.Cin);
+    g[3] = *reinterpret_cast<const uint4*>(base + (size_t)ix.w * P.Cin);
   };
-  auto combine_store = [&](int phase, int m, const uint2 (&g)[4]) {
+  auto combine_store = [&](int phase, int m2, const uint4 (&g)[4]) {
     const int tap = phase / ncb;
-    const float4 wgt = sCw[m * taps + tap];
-    union { uint2 u; T h[4]; } n0, n1, n2, n3, o;
-    n0.u = g[0]; n1.u = g[1]; n2.u = g[2]; n3.u = g[3];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const float v = __builtin_fmaf(wgt.w, Elem<T>::to_f(n3.h[q]), __builtin_fmaf(wgt.z, Elem<T>::to_f(n2.h[q]),
-                      __builtin_fmaf(wgt.y, Elem<T>::to_f(n1.h[q]), wgt.x * Elem<T>::to_f(n0.h[q]))));
-      o.h[q] = Elem<T>::from_f(v);                          // ONE rounding to the storage type
-    }
-    *reinterpret_cast<uint2*>(sA + (size_t)m * ASTRH + lane * 4) = o.u;
+    const int m = m2 + half_id;
+    if (ORP_DCNH_DBG & 8) { *reinterpret_cast<uint4*>(sA + (size_t)m * ASTRH + l8) = g[0]; return; }
+    *reinterpret_cast<uint4*>(sA + (size_t)m * ASTRH + l8) = Elem<T>::combine8(g, sCw[m * taps + tap]);
   };
   // weight fragment of (phase, chunk j): lane (n = lane & 31, kg = lane >> 5) -> 8 k-values, one 16 B load
   const int n_wave = nb * 256 + wave * 32;
@@ -226,12 +267,13 @@ dcn_fwd_half_kernel(const FwdH P, int total_tiles) {
   v8 bq[NCHUNK];
 #pragma unroll
   for (int j = 0; j < NCHUNK; j++) bq[j] = load_b(0, j);
+  // wave w produces the row pairs (2 * (q * 8 + w), +1), q = 0 .. ROWS / 2 - 1
   {
-    uint2 g[ROWS][4];
+    uint4 g[ROWS / 2][4];
 #pragma unroll
-    for (int r = 0; r < ROWS; r++) gather_issue(0, r * 8 + wave, g[r]);
+    for (int r = 0; r < ROWS / 2; r++) gather_issue(0, 2 * (r * 8 + wave), g[r]);
 #pragma unroll
-    for (int r = 0; r < ROWS; r++) combine_store(0, r * 8 + wave, g[r]);
+    for (int r = 0; r < ROWS / 2; r++) combine_store(0, 2 * (r * 8 + wave), g[r]);
   }
   __syncthreads();
 
@@ -243,10 +285,10 @@ dcn_fwd_half_kernel(const FwdH P, int total_tiles) {
   for (int phase = 0; phase < nphase; phase++) {
     const bool next_phase = phase + 1 < nphase;
     // (1) every gather of the NEXT tap's A rows goes out now: a whole tap of MFMA work to land
-    uint2 g[ROWS][4];
+    uint4 g[ROWS / 2][4];
     if (next_phase) {
 #pragma unroll
-      for (int r = 0; r < ROWS; r++) gather_issue(phase + 1, r * 8 + wave, g[r]);
+      for (int r = 0; r < ROWS / 2; r++) gather_issue(phase + 1, 2 * (r * 8 + wave), g[r]);
     }
     // (2) the tap: one MFMA per (chunk, row block); the weight register of chunk j is refilled for the next tap at once
     const T* arow = sA + (size_t)mrow * ASTRH + 8 * kg;
@@ -266,25 +308,28 @@ dcn_fwd_half_kernel(const FwdH P, int total_tiles) {
       }
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) {
+        if (ORP_DCNH_DBG & 4) { acc[mt][0] += (float)a[mt][0] * (float)bq[j][0]; continue; }
         if (OUT_NCHW) acc[mt] = Elem<T>::mfma(bq[j], a[mt], acc[mt]);     // D[channel][position]
         else          acc[mt] = Elem<T>::mfma(a[mt], bq[j], acc[mt]);     // D[position][channel]
       }
-      if (next_phase) bq[j] = load_b(phase + 1, j);
+      if (next_phase && !(ORP_DCNH_DBG & 2)) bq[j] = load_b(phase + 1, j);
     }
     // (3) two barriers per tap: every wave is past its last read of the A tile -> overwrite it with the next tap's rows
+    //     (a second A buffer with ONE barrier per tap was measured in round 3: 55.4 vs 54.9 us -- the barriers are not what
+    //     the tap waits for -- and is not kept: it doubles the tile's LDS)
     if (next_phase) {
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < ROWS; r++) combine_store(phase + 1, r * 8 + wave, g[r]);
+      for (int r = 0; r < ROWS / 2; r++) combine_store(phase + 1, 2 * (r * 8 + wave), g[r]);
       __syncthreads();
     }
   }
 
   // ---- epilogue: fp32 accumulators (+ bias, ReLU) rounded once to the storage type -------------------------------------------
-  if (!live) return;
   const T* biasp = reinterpret_cast<const T*>(P.bias);
   T* outp = reinterpret_cast<T*>(L.out);
   auto finish = [&](float v, int ch) { if (biasp) v += Elem<T>::to_f(biasp[ch]); return Elem<T>::from_f(P.relu ? fmaxf(v, 0.f) : v); };
+  if (!live) return;
 #pragma unroll
   for (int mt = 0; mt < MT; mt++) {
     if (OUT_NCHW) {
