@@ -515,7 +515,9 @@ def main_train(args):
     opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-4, momentum=0.9,
                           weight_decay=1e-4)
     # N > 1: bucketed all-reduce overlapped with backward (32 MB buckets over RCCL / xGMI)
-    hook = D.DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2), overlap=True)
+    amp_dtype = dict(f32=None, fp16=torch.float16, bf16=torch.bfloat16)[args.dtype]
+    scaler = torch.amp.GradScaler('cuda') if args.dtype == 'fp16' else None
+    hook = D.DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2), overlap=True, scaler=scaler)
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
     data = dict(
         img=torch.randn(batch, 3, IMG, IMG, generator=g).to(dev),
@@ -526,7 +528,7 @@ def main_train(args):
 
     def step():
         # parse_losses all-reduces + .item()s the logged scalars every iteration as the reference's batch_processor does
-        return D.train_step(model, opt, data, hook)
+        return D.train_step(model, opt, data, hook, autocast_dtype=amp_dtype)
 
     for _ in range(args.warmup):
         log_vars = step()
@@ -565,7 +567,8 @@ def main_train(args):
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32',
+        'dtype': {'f32': 'f32', 'fp16': 'fp16 autocast (hot-path operators f32, GradScaler)',
+                  'bf16': 'bf16 autocast (hot-path operators f32)'}[args.dtype],
         'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[2]: train step, %d img/GPU x %d gts, %dx%d, 15 classes'
                                % (batch, args.gts, IMG, IMG),
@@ -604,6 +607,9 @@ def main():
                     help="test (default): the headline inference step; train: one SGD iteration of BASELINE configs[2] "
                          "(2 img/GPU, APAA on), gradients all-reduced over RCCL for N > 1")
     ap.add_argument('--gts', type=int, default=64, help='--mode train: ground-truth polygons per image')
+    ap.add_argument('--dtype', choices=('f32', 'fp16', 'bf16'), default='f32',
+                    help='--mode train only: f32 (default, the reference\'s arithmetic) or torch.autocast in fp16 (with a '
+                         'GradScaler) / bf16: library convolutions in half, hot-path operators on fp32-cast inputs')
     args = ap.parse_args()
     global IMG
     IMG = args.size

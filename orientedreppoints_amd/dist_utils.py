@@ -177,13 +177,14 @@ class DistOptimizerHook(object):
     """zero_grad -> backward -> (all-reduce unless the model is DDP-wrapped) -> clip -> step.
     overlap=True: the all-reduce runs bucket by bucket during backward (OverlappedGradientReducer)."""
 
-    def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1, ddp_wrapped=False, overlap=False):
+    def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1, ddp_wrapped=False, overlap=False, scaler=None):
         self.grad_clip = grad_clip
         self.coalesce = coalesce
         self.bucket_size_mb = bucket_size_mb
         self.ddp_wrapped = ddp_wrapped
         self.overlap = overlap
         self._reducer = None
+        self.scaler = scaler          # torch.amp.GradScaler for fp16 autocast training (the reference's Fp16OptimizerHook role), or None
 
     def clip_grads(self, params):
         return clip_grad.clip_grad_norm_(filter(lambda p: p.requires_grad and p.grad is not None, params),
@@ -196,19 +197,26 @@ class DistOptimizerHook(object):
                 self._reducer = OverlappedGradientReducer(model.parameters(),
                                                           self.bucket_size_mb if self.bucket_size_mb > 0 else 32)
             self._reducer.zero_grad()
-            loss.backward()
+            (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
             self._reducer.finish()
-            if self.grad_clip is not None:
-                self.clip_grads(list(model.parameters()))
-            optimizer.step()
+            self._clip_and_step(model, optimizer)
             return
         optimizer.zero_grad()
-        loss.backward()
+        (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
         if world > 1 and not self.ddp_wrapped:
             allreduce_grads(model.parameters(), self.coalesce, self.bucket_size_mb)
+        self._clip_and_step(model, optimizer)
+
+    def _clip_and_step(self, model, optimizer):
+        if self.scaler is not None:
+            self.scaler.unscale_(optimizer)               # clip on the true gradients; inf / nan steps are skipped by the scaler
         if self.grad_clip is not None:
             self.clip_grads(list(model.parameters()))
-        optimizer.step()
+        if self.scaler is not None:
+            self.scaler.step(optimizer)
+            self.scaler.update()
+        else:
+            optimizer.step()
 
 
 def parse_losses(losses):
@@ -244,9 +252,16 @@ def shard_indices(num_samples, rank, world_size, seed=0, epoch=0, samples_per_gp
     return perm[rank * per:(rank + 1) * per]
 
 
-def train_step(model, optimizer, data, hook):
-    """One iteration: forward_train -> parse_losses -> DistOptimizerHook (mmdet/apis/train.py:59-82)."""
-    losses = model(**data)
+def train_step(model, optimizer, data, hook, autocast_dtype=None):
+    """One iteration: forward_train -> parse_losses -> DistOptimizerHook (mmdet/apis/train.py:59-82).  autocast_dtype
+    (torch.float16 / torch.bfloat16): the forward runs under torch.autocast -- library convolutions in that type, the
+    hot-path operators keep fp32 arithmetic on fp32-cast inputs (custom_fwd), the loss is formed in fp32."""
+    if autocast_dtype is not None:
+        with torch.autocast(device_type='cuda', dtype=autocast_dtype):
+            losses = model(**data)
+        losses = {k: ([x.float() for x in v] if isinstance(v, (list, tuple)) else v.float()) for k, v in losses.items()}
+    else:
+        losses = model(**data)
     loss, log_vars = parse_losses(losses)
     hook.after_train_iter(model, optimizer, loss)
     return log_vars

@@ -68,6 +68,7 @@ class GIoULossFuction(Function):
     one, exactly as the reference does (iou_loss.py:96-100)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: fp32 inputs, autocast off inside
     def forward(ctx, pred, target, weight=None, reduction=None, avg_factor=None, loss_weight=1.0):
         ctx.save_for_backward(pred)
         convex_gious, grad = convex_giou(pred, target)

@@ -115,6 +115,7 @@ class _SegmentGIoULoss(Function):
     component > 1 replaced by 1e-6 first (iou_loss.py:87-89)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: fp32 inputs, autocast off inside
     def forward(ctx, pred, target, weight, seg, nseg, denom, loss_weight):
         if pred.size(0) == 0:                                         # no row at all: zero loss, empty gradient
             ctx.save_for_backward(torch.zeros_like(pred))

@@ -477,6 +477,7 @@ class DeformConvPairFunction(Function):
     n inputs of layer a, n inputs of layer b, n offsets.  Returns the 2n outputs."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: fp32 inputs, autocast off inside
     def forward(ctx, stride, padding, dilation, n, weight_a, weight_b, *tensors):
         ctx.stride, ctx.padding, ctx.dilation = _pair(stride), _pair(padding), _pair(dilation)
         # n may carry the callers' expectation about the two layers' output gradients (deform_conv_pair's sparse_grad)

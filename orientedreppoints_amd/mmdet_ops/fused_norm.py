@@ -250,6 +250,7 @@ class _GroupNormActTrain(torch.autograd.Function):
     owner[i]), then the n tensors, then the distinct gammas, then the distinct betas."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: fp32 inputs, autocast off inside
     def forward(ctx, n, groups, eps, relu, owner, *tensors):
         L = _lib.lib()
         xs = [t.detach().contiguous() for t in tensors[:n]]

@@ -53,6 +53,7 @@ sigmoid_focal_loss_cuda = _FocalExt()
 class SigmoidFocalLossFunction(Function):
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: fp32 inputs, autocast off inside
     def forward(ctx, input, target, gamma=2.0, alpha=0.25):
         ctx.save_for_backward(input, target)
         num_classes = input.shape[1]

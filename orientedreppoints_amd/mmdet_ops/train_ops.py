@@ -45,6 +45,7 @@ def points_from_offsets(levels, strides, mode=0):
 class _GatherLevels(Function):
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: fp32 inputs, autocast off inside
     def forward(ctx, index, strides, mode, *levels):
         lv = [t.detach().float().contiguous() for t in levels]
         tab, B, C, N = _level_table(lv, strides)
