@@ -415,6 +415,16 @@ int orp_conv3x3_small_multi(const orp_norm_level* levels_host, int nlevels, int 
 /* per-tensor weights (both towers' small levels in one launch): weights_packed_host[i] belongs to levels_host[i] */
 int orp_conv3x3_small_multi_ex(const orp_norm_level* levels_host, const float* const* weights_packed_host, int nlevels,
                                int batch, int c_in, int c_out, void* stream);
+/* ... with a stride per level (1 or 2; pad 1): levels_host[i].height / width are the INPUT sizes, the output of level i is
+ * [B, c_out, (H - 1) / s + 1, (W - 1) / s + 1].  Stride 2 = the FPN's extra levels P6 / P7 (mmdet/models/necks/fpn.py:160-174;
+ * ConvModule(stride=2) -> F.conv2d).  With a workspace (orp_conv3x3_small_workspace_bytes; NULL = none) launches with
+ * few positions also split K over the grid: partial images summed in slice order by a second launch -- fixed summation
+ * order, bitwise reproducible (the library's split-K kernel for these shapes accumulates with atomics and is not). */
+size_t orp_conv3x3_small_workspace_bytes(const orp_norm_level* levels_host, const int* strides_host, int nlevels, int batch,
+                                         int c_out);
+int orp_conv3x3_small_multi_strided(const orp_norm_level* levels_host, const float* const* weights_packed_host,
+                                    const int* strides_host, int nlevels, int batch, int c_in, int c_out, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Fused test-time post-processing around the rotated NMS: replaces the tensor-op chains of

@@ -102,6 +102,8 @@ _SIGNATURES = {
     "orp_conv3x3_small_ok": (_i, [_i, _i]),
     "orp_conv3x3_small_multi": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "orp_conv3x3_small_multi_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "orp_conv3x3_small_workspace_bytes": (ctypes.c_size_t, [_vp, _vp, _i, _i, _i]),
+    "orp_conv3x3_small_multi_strided": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
 }
 
 _lib = None

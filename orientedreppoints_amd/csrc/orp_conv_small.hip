@@ -1,4 +1,4 @@
-// orp_conv_small.hip -- 3x3 stride-1 pad-1 convolution of the SMALL FPN levels, all of them in one launch (gfx950).
+// orp_conv_small.hip -- 3x3 pad-1 convolution (stride 1 or 2) of the SMALL FPN levels, all of them in one launch (gfx950).
 //
 // The dense head runs seven 256->256 3x3 convolutions over every FPN level (orientedreppoints_head.py:91-132: three
 // cls tower + three reg tower ConvModules and reppoints_pts_init_conv).  On the 128^2 / 64^2 levels the library's
@@ -12,6 +12,10 @@
 //   4 k-steps, no LDS; three chunk pairs of global loads in flight), then the partial tiles are summed through
 //   LDS in a fixed order, so the result is deterministic.
 // No bias / activation here: GroupNorm+ReLU (orp_groupnorm_act_multi) or the bias pass (orp_bias_act_multi) follow.
+// Stride 2 (orp_conv3x3_small_multi_strided): the FPN's extra output levels (mmdet/models/necks/fpn.py:160-174, P6 / P7 =
+// stride-2 convolutions of 32^2 / 16^2 maps).  The library's pick for these two shapes on this part is a split-K
+// implicit GEMM that accumulates with atomics: 2e-6 run-to-run differences in P6 / P7, i.e. detections that come and go
+// at the score threshold; the fixed-order sum here makes the whole inference step bitwise reproducible.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,12 +33,16 @@ constexpr int kTileN = 64;                    // output channels per workgroup (
 struct ConvLevel {
   const float* x; float* y;
   const float* w3;                            // this tensor's weights, [tap][Cin/4][Cout][4]
-  int H, W;
+  int H, W;                                   // input height / width
+  int Ho, Wo, stride;                         // output height / width; 1 or 2
   int tile0;                                  // first position tile of this level
+  float* part;                                // ksplit > 1: this level's slice of the first partial image
 };
 struct ConvParams {
   ConvLevel lv[kMaxLevels];
   int nlev, B, Cin, Cout;
+  int ksplit;                                 // grid-level split of K (blockIdx.z): partial images, summed in fixed order
+  size_t part_stride;                         // floats between the partial images of consecutive K slices
 };
 
 // one K chunk = 8 input channels of one tap = four v_mfma_f32_32x32x2_f32 steps per accumulator
@@ -51,18 +59,18 @@ conv3x3_small_kernel(const ConvParams P) {
 #pragma unroll
   for (int i = 1; i < kMaxLevels; i++) l = (i < P.nlev && (int)blockIdx.x >= P.lv[i].tile0) ? i : l;
   const ConvLevel L = P.lv[l];
-  const int HW = L.H * L.W;
-  const long npos = (long)P.B * HW;
+  const int HW = L.H * L.W, HWo = L.Ho * L.Wo;
+  const long npos = (long)P.B * HWo;
   const long p = (long)((int)blockIdx.x - L.tile0) * kTileM + m;
   const bool valid = p < npos;
-  const int b = valid ? (int)(p / HW) : 0;
-  const int hw = valid ? (int)(p - (long)b * HW) : 0;
-  const int h = hw / L.W, w = hw - h * L.W;
+  const int b = valid ? (int)(p / HWo) : 0;
+  const int hw = valid ? (int)(p - (long)b * HWo) : 0;
+  const int h = (hw / L.Wo) * L.stride, w = (hw - (hw / L.Wo) * L.Wo) * L.stride;     // input coordinates of the centre tap
   // K = (tap, channel chunk) linearised: chunk g = tap * cpt + t.  This wave owns chunks [g0, g0 + G); with
   // G = 9 * cpt / kWaves <= 1.125 * cpt the range touches at most two taps (boundary gb).
   const int cpt = P.Cin >> 3;                           // chunks per tap
-  const int G = (kTaps * cpt) / kWaves;
-  const int g0 = wave * G;
+  const int G = (kTaps * cpt) / (kWaves * P.ksplit);
+  const int g0 = ((int)blockIdx.z * kWaves + wave) * G;
   const int tap0 = g0 / cpt, gb = (tap0 + 1) * cpt;     // chunks >= gb belong to tap0 + 1
   const int tap1 = tap0 + 1 < kTaps ? tap0 + 1 : tap0;
   const int hh0 = h + tap0 / 3 - 1, ww0 = w + tap0 % 3 - 1, hh1 = h + tap1 / 3 - 1, ww1 = w + tap1 % 3 - 1;
@@ -140,13 +148,36 @@ conv3x3_small_kernel(const ConvParams P) {
       for (int q = 0; q < 4; q++) {
         const long pq = (long)((int)blockIdx.x - L.tile0) * kTileM + ((l0 + q) & 31);
         if (pq < npos) {
-          const int bq = (int)(pq / HW);
-          const int hq = (int)(pq - (long)bq * HW);
-          L.y[((size_t)bq * P.Cout + ch) * HW + hq] = vals[q];
+          const int bq = (int)(pq / HWo);
+          const int hq = (int)(pq - (long)bq * HWo);
+          float* dst = P.ksplit > 1 ? L.part + (size_t)blockIdx.z * P.part_stride : L.y;
+          dst[((size_t)bq * P.Cout + ch) * HWo + hq] = vals[q];
         }
       }
     }
   }
+}
+
+// y[i] = part[0][i] + part[1][i] + ... in this order
+__global__ void conv_small_reduce_kernel(const float* __restrict__ part, size_t part_stride, int ksplit, float* __restrict__ y,
+                                         long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = part[i];
+    for (int z = 1; z < ksplit; z++) v += part[(size_t)z * part_stride + i];
+    y[i] = v;
+  }
+}
+
+// grid-level K split: as many slices as keep the launch near one workgroup per CU, with an even number of chunks per wave
+inline int pick_ksplit(int tiles, int nblk, int c_in) {
+  int best = 1;
+  for (int s = 2; s <= 16; s *= 2) {
+    const int per_wave = (kTaps * (c_in >> 3)) / (8 * s);
+    if ((kTaps * (c_in >> 3)) % (8 * s) || (per_wave & 1) || per_wave < 4) break;
+    if ((long)tiles * nblk * s > 320) break;
+    best = s;
+  }
+  return best;
 }
 
 }  // namespace
@@ -156,29 +187,74 @@ extern "C" {
 // Cin % 128: every wave's K slice (an eighth of 9 * Cin / 8 chunks) is a whole number of chunk PAIRS
 int orp_conv3x3_small_ok(int c_in, int c_out) { return (c_in >= 128 && c_in % 128 == 0 && c_out >= 64 && c_out % 64 == 0) ? 1 : 0; }
 
-int orp_conv3x3_small_multi_ex(const orp_norm_level* levels_host, const float* const* weights_packed_host, int nlevels,
-                               int batch, int c_in, int c_out, void* stream) {
+static int conv3x3_small_launch(const orp_norm_level* levels_host, const float* const* weights_packed_host,
+                               const int* strides_host, int nlevels, int batch, int c_in, int c_out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   if (!levels_host || nlevels <= 0 || nlevels > kMaxLevels || batch <= 0 || !weights_packed_host) return ORP_EINVAL;
   if (!orp_conv3x3_small_ok(c_in, c_out)) return ORP_EINVAL;
   ConvParams P;
   P.nlev = nlevels; P.B = batch; P.Cin = c_in; P.Cout = c_out;
   int tiles = 0;
+  size_t out_floats = 0;
   for (int i = 0; i < nlevels; i++) {
     const orp_norm_level& lv = levels_host[i];
-    if (!lv.input || !lv.output || lv.height <= 0 || lv.width <= 0 || lv.input == lv.output || !weights_packed_host[i])
+    const int st = strides_host ? strides_host[i] : 1;
+    if (!lv.input || !lv.output || lv.height <= 0 || lv.width <= 0 || lv.input == lv.output || !weights_packed_host[i] ||
+        (st != 1 && st != 2))
       return ORP_EINVAL;
     if ((long)batch * lv.height * lv.width >= (1L << 30)) return ORP_ETOOBIG;
     ConvLevel& L = P.lv[i];
     L.x = lv.input; L.y = lv.output; L.H = lv.height; L.W = lv.width; L.tile0 = tiles;
+    L.stride = st; L.Ho = (lv.height - 1) / st + 1; L.Wo = (lv.width - 1) / st + 1;      // (H + 2 - 3) / s + 1
     L.w3 = weights_packed_host[i] + (size_t)9 * c_in * c_out;        // second half of orp_dcn_pack_weight's output
-    tiles += (int)(((long)batch * lv.height * lv.width + kTileM - 1) / kTileM);
+    L.part = reinterpret_cast<float*>(workspace) + out_floats;
+    out_floats += (size_t)batch * c_out * L.Ho * L.Wo;
+    tiles += (int)(((long)batch * L.Ho * L.Wo + kTileM - 1) / kTileM);
   }
   for (int i = nlevels; i < kMaxLevels; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; }
+  // few positions (the FPN's extra levels: 256 / 64 of them, K = 9 x 2048 for the first): split K over the grid as well,
+  // partial images in the workspace, summed in slice order by a second launch -- parallelism without atomics
+  int ks = workspace ? pick_ksplit(tiles, c_out / kTileN, c_in) : 1;
+  while (ks > 1 && workspace_bytes < sizeof(float) * out_floats * ks) ks >>= 1;
+  P.ksplit = ks; P.part_stride = out_floats;
   // eight waves = two per SIMD (sixteen, with Cin % 256, measured slower: 43 us vs 34 us at the 1024^2 shapes)
   constexpr size_t smem = sizeof(float) * 8 * kTileM * kTileN;                     // 64 KB of partial tiles
-  hipLaunchKernelGGL(conv3x3_small_kernel<8>, dim3(tiles, c_out / kTileN), dim3(8 * 64), smem, (hipStream_t)stream, P);
+  hipLaunchKernelGGL(conv3x3_small_kernel<8>, dim3(tiles, c_out / kTileN, ks), dim3(8 * 64), smem, (hipStream_t)stream, P);
+  if (ks > 1) {
+    for (int i = 0; i < nlevels; i++) {
+      const long n = (long)batch * c_out * P.lv[i].Ho * P.lv[i].Wo;
+      long blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+      hipLaunchKernelGGL(conv_small_reduce_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, P.lv[i].part,
+                         P.part_stride, ks, P.lv[i].y, n);
+    }
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_conv3x3_small_multi_ex(const orp_norm_level* levels_host, const float* const* weights_packed_host, int nlevels,
+                               int batch, int c_in, int c_out, void* stream) {
+  return conv3x3_small_launch(levels_host, weights_packed_host, nullptr, nlevels, batch, c_in, c_out, nullptr, 0, stream);
+}
+
+size_t orp_conv3x3_small_workspace_bytes(const orp_norm_level* levels_host, const int* strides_host, int nlevels, int batch,
+                                         int c_out) {
+  if (!levels_host || nlevels <= 0) return 0;
+  size_t out_floats = 0;
+  for (int i = 0; i < nlevels; i++) {
+    const int st = strides_host ? strides_host[i] : 1;
+    if (st != 1 && st != 2) return 0;
+    out_floats += (size_t)batch * c_out * ((levels_host[i].height - 1) / st + 1) * ((levels_host[i].width - 1) / st + 1);
+  }
+  return sizeof(float) * out_floats * 16;                 // up to 16 K slices
+}
+
+int orp_conv3x3_small_multi_strided(const orp_norm_level* levels_host, const float* const* weights_packed_host,
+                                    const int* strides_host, int nlevels, int batch, int c_in, int c_out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  if (!strides_host) return ORP_EINVAL;
+  return conv3x3_small_launch(levels_host, weights_packed_host, strides_host, nlevels, batch, c_in, c_out, workspace,
+                              workspace_bytes, stream);
 }
 
 int orp_conv3x3_small_multi(const orp_norm_level* levels_host, int nlevels, int batch, int c_in, int c_out,

@@ -48,6 +48,9 @@
 #ifndef ORP_DCN_WDIST
 #define ORP_DCN_WDIST 1    // weight prefetch distance (chunks) of the single-layer second-generation kernel: 1 or 2 (2: measured, no gain)
 #endif
+#ifndef ORP_DCN_KS_DBG
+#define ORP_DCN_KS_DBG 0   // dev aid for the tap-granular split (timing only unless 2): 1 = no hand-over of the cut tiles at all, 2 = hand-over with agent-scope fences instead of scoped accesses, 4 = coefficient table built once only
+#endif
 #ifndef ORP_DCN_DBG
 #define ORP_DCN_DBG 0      // dev aid, compile-time (timing only, wrong results): 1 = no A gather, 2 = no weight loads, 4 = no per-tap barriers / LDS refill, 8 = no MFMA
 #endif
@@ -92,8 +95,13 @@ struct FwdParams {
   const float* head_w[2];   // fused 1x1 heads: packed [256][KH] (zero padded), bias [k], output channels k <= KH
   const float* head_b[2];
   int head_k[2];
+  // tap-granular split of the launch's (tile, layer, tap) sequence over ks_nwg workgroups (KSPLIT instantiation)
+  float* ks_scratch;        // [ks_nwg] accumulator images of the cut (tile, layer) pairs, register layout [MT][8][16][64]
+  int* ks_flags;            // [ks_nwg] 0 -> 1 when the image of slot i is complete (zeroed before every launch)
+  int ks_nwg, ks_total;     // workgroups (all layers), tiles * taps
 };
 constexpr int KH = 20;           // packed output-channel count of a fused 1x1 head
+inline size_t align256_(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // ---- helpers -------------------------------------------------------------------------------------------------
 __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int cin, int taps, float* __restrict__ w2) {
@@ -383,7 +391,7 @@ constexpr int kThreads2 = 512;
 // two-layer instantiation free of register spills (254 VGPRs + 52 B of scratch per lane otherwise: 17 MB of extra writes)
 // HEADS: the 1x1 convolution that follows each DeformConv + ReLU in the head (reppoints_cls_out / reppoints_pts_refine_out,
 // orientedreppoints_head.py:166-170) is applied in the epilogue -- the 256-channel DeformConv output never goes to HBM.
-template <int MT, bool OUT_NCHW, int NCONV, bool C256, bool HEADS = false>
+template <int MT, bool OUT_NCHW, int NCONV, bool C256, bool HEADS = false, bool KSPLIT = false>
 __global__ void __launch_bounds__(kThreads2)
 dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   const int Cin = C256 ? 256 : P.Cin, Cout = C256 ? 256 : P.Cout;
@@ -398,21 +406,57 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int taps = P.kh * P.kw;
-  // XCD-aware remap: hardware places block b on XCD b % 8; give XCD x the contiguous tiles [x*per, (x+1)*per)
-  int tile;
-  {
+  // XCD-aware remap: hardware places block b on XCD b % 8; give XCD x a contiguous slab of the work
+  //   plain:  workgroup = tile, XCD x takes the tiles [x*per, (x+1)*per)
+  //   KSPLIT: a layer is the linear sequence of its (tile, tap) steps, cut into equal ranges: a workgroup walks
+  //           [seq, seq_end), i.e. the tail of one tile, whole tiles, and the head of another.  228 tiles x 9 taps over
+  //           128 workgroups: 16.03 tap steps each instead of 18 on 228 CUs and none on 28.  In a pair launch XCDs 0-3 take
+  //           the first layer and XCDs 4-7 the second: an XCD's 4 MB L2 then only ever holds ONE layer's 2.36 MB of packed
+  //           weights (workgroups at different points of a (tile, layer, tap) sequence over both layers need all 4.7 MB at
+  //           once and thrash it: measured, no gain over whole tiles) and each layer's weights are fetched by 4 L2s, not 8.
+  int tile = 0, wg = 0, seq = 0, seq_end = NCONV * taps, ks_conv = 0;
+  if (KSPLIT) {
+    const int b = blockIdx.x, xcd = b & 7, per = P.ks_nwg >> 3;
+    int idx, wpl;
+    if (NCONV == 2) { ks_conv = xcd >> 2; idx = (xcd & 3) * per + (b >> 3); wpl = P.ks_nwg >> 1; }
+    else { idx = xcd * per + (b >> 3); wpl = P.ks_nwg; }
+    wg = ks_conv * wpl + idx;
+    seq = (int)(((long)idx * P.ks_total) / wpl);
+    seq_end = (int)(((long)(idx + 1) * P.ks_total) / wpl);
+  } else {
     const int b = blockIdx.x, per = (total_tiles + 7) >> 3;
     tile = (b & 7) * per + (b >> 3);
     if (tile >= total_tiles) return;                                         // whole workgroup leaves together
   }
+  const int nb = blockIdx.y;
+  LevelDesc L = P.lv[0];
+  int HoWo = 0, cur_tile = -1;
+  long npos = 0, p0 = 0;
+  bool first_seg = true;
+
+  // a pair launch runs its two layers one after the other on the SAME coefficient table (same offsets / masks)
+  // (NCONV == 1 with gridDim.z == 2: "pair as grid" -- the second layer is a second workgroup of the same tile)
+#pragma unroll 1
+  while (seq < seq_end) {
+  int conv, t0, t1;
+  if (KSPLIT) {
+    tile = seq / taps;
+    conv = ks_conv; t0 = seq - tile * taps;
+    t1 = min(taps, t0 + (seq_end - seq));
+  } else {
+    conv = NCONV == 1 ? (int)blockIdx.z : seq / taps; t0 = 0; t1 = taps;
+  }
+  if (!first_seg) __syncthreads();                          // every wave is past its last read of the previous segment's A tile / table
+  first_seg = false;
+  if (tile != cur_tile && !((ORP_DCN_KS_DBG & 4) && cur_tile >= 0)) {
+  cur_tile = tile;
   int lvl = 0;
 #pragma unroll 1
   for (int i = 1; i < P.nlev; i++) if (tile >= P.lv[i].tile0) lvl = i;
-  const LevelDesc L = P.lv[lvl];
-  const int HoWo = L.Ho * L.Wo;
-  const long npos = (long)P.B * HoWo;
-  const long p0 = (long)(tile - L.tile0) * BM2;
-  const int nb = blockIdx.y;
+  L = P.lv[lvl];
+  HoWo = L.Ho * L.Wo;
+  npos = (long)P.B * HoWo;
+  p0 = (long)(tile - L.tile0) * BM2;
 
   for (int e = tid; e < BM2 * taps; e += kThreads2) {
     const int m = e / taps, tap = e - m * taps;
@@ -452,19 +496,15 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
     sCw[e] = w; sCi[e] = ix;
   }
   __syncthreads();
+  }   // coefficient table of `tile`
 
-  // a pair launch runs its two layers one after the other on the SAME coefficient table (same offsets / masks)
-  // (NCONV == 1 with gridDim.z == 2: "pair as grid" -- the second layer is a second workgroup of the same tile)
-#pragma unroll 1
-  for (int it = 0; it < NCONV; it++) {
-  const int conv = NCONV == 1 ? (int)blockIdx.z : it;
   const float* xin = conv ? L.x2 : L.x;
   const float* w3 = conv ? P.w3b : P.w3;
   const float* bias = conv ? P.bias2 : P.bias;
   float* outp = conv ? L.out2 : L.out;
-  if (it) __syncthreads();                                  // every wave is past its last read of the previous layer's A tile
   const int ncb = Cin / CB;                        // 256-channel blocks per tap (Cin % 256 == 0 on this path)
   const int nphase = taps * ncb;
+  const int ph0 = t0 * ncb, ph1 = t1 * ncb;        // this segment's phases
   constexpr int NCHUNK = CB / KC2;                   // 16 chunks per phase
 
   // one A row = 256 channels = 64 lanes x float4: four coalesced 1 KB neighbour rows, combined with wave-uniform weights
@@ -535,18 +575,18 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   };
   float4 bq[2], bq1[2];
   {
-    load_bq(0, 0, bq);
-    if (WDIST == 2) load_lin(0, 1, bq1);
+    load_bq(ph0, 0, bq);
+    if (WDIST == 2) load_lin(ph0, 1, bq1);
     // four rows in flight per wave (16 outstanding 1 KB loads) so the first tap's gather latency is paid ROWS/4 times
 #pragma unroll 1
     for (int r0 = 0; r0 < ROWS; r0 += 4) {
       float4 g[4][4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) gather_issue(0, (r0 + u) * 8 + wave, g[u]);
+      for (int u = 0; u < 4; u++) gather_issue(ph0, (r0 + u) * 8 + wave, g[u]);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int m = (r0 + u) * 8 + wave;
-        *reinterpret_cast<float4*>(sA + (size_t)m * ASTR + lane * 4) = combine(0, m, g[u]);
+        *reinterpret_cast<float4*>(sA + (size_t)m * ASTR + lane * 4) = combine(ph0, m, g[u]);
       }
     }
   }
@@ -557,8 +597,8 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   for (int mt = 0; mt < MT; mt++) acc[mt] = floatx16{0};
 
 #pragma unroll 1
-  for (int phase = 0; phase < nphase; phase++) {
-    const bool next_phase = phase + 1 < nphase;
+  for (int phase = ph0; phase < ph1; phase++) {
+    const bool next_phase = phase + 1 < ph1;
     float4 hold[ROWS];
     float4 gq[2][4];                                         // gathered rows in flight (GDIST = 2: two)
     int4 ixn = make_int4(0, 0, 0, 0);                        // IPF: pixel indices of the row gathered in the next chunk
@@ -656,6 +696,68 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
   auto finish = [&](float v, int ch) { if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
+  bool store_out = true;
+  if (KSPLIT && !(t0 == 0 && t1 == taps)) {
+    // a cut tile: the TAIL part (taps [k, 9)) is the first segment of workgroup wg and is finished early in its
+    // life; the HEAD part (taps [0, k)) is the last segment of workgroup wg - 1 (same layer).  The tail's accumulators go to scratch
+    // slot wg - 1 in register layout; the head's owner waits for them at its very end (they are nearly always there),
+    // adds them -- head + tail, the same order whoever arrives first: reproducible -- and finishes the tile.  Workgroups
+    // are dispatched in order and a tail never waits, so the wait cannot deadlock.
+    const bool tail = t0 > 0;
+    const int slot = tail ? wg - 1 : wg;
+    float* sc = P.ks_scratch + (size_t)slot * (MT * 8 * 16 * 64) + (size_t)wave * 16 * 64 + lane;
+    int* flag = P.ks_flags + slot;
+#if ORP_DCN_KS_DBG & 1
+    if (tail) store_out = false;
+#elif ORP_DCN_KS_DBG & 2
+    if (tail) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) sc[(size_t)(mt * 8 * 16 + r) * 64] = acc[mt][r];
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      store_out = false;
+    } else {
+      if (tid == 0) {
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(4);
+      }
+      __syncthreads();
+      __threadfence();
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[mt][r] += sc[(size_t)(mt * 8 * 16 + r) * 64];
+    }
+#else
+    // Every access to the scratch image and its flag is an agent-scope atomic (write-through / cache-bypassing per
+    // INSTRUCTION): an agent-scope fence instead would write back and invalidate the whole L2 of the XCD -- the packed
+    // weights every other workgroup streams from it (measured: 575 us with fences vs 520 us without the split).
+    if (tail) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          __hip_atomic_store(sc + (size_t)(mt * 8 * 16 + r) * 64, acc[mt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // this wave's stores have left (s_waitcnt vmcnt(0)) ...
+      __syncthreads();                                          // ... and so have every other wave's
+      if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      store_out = false;
+    } else {
+      if (tid == 0) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(4);
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          acc[mt][r] += __hip_atomic_load(sc + (size_t)(mt * 8 * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
+  }
   if (HEADS) {
     // out1[p, k] = sum_c relu(dcn[p, c]) * W1[k, c] + b1[k] (+ residual): every wave holds 32 of the 256 channels of its
     // positions -> per-wave partial sums, added over the two half-waves (shuffle) and the eight waves (LDS, fixed order).
@@ -706,9 +808,10 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
       if (hres) v += hres[o];
       ho[o] = v;
     }
-    continue;                                              // (the next layer's prologue is behind its own barrier)
+    store_out = false;                                     // (the next layer's prologue is behind its own barrier)
   }
-  if (n_wave >= Cout) continue;                          // idle wave: it still meets the other waves at every barrier above
+  if (n_wave >= Cout) store_out = false;                 // idle wave: it still meets the other waves at every barrier above
+  if (store_out) {
 #pragma unroll
   for (int mt = 0; mt < MT; mt++) {
     if (OUT_NCHW) {
@@ -731,6 +834,8 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
       }
     }
   }
+  }
+  seq += t1 - t0;
   }
 }
 
@@ -762,6 +867,28 @@ hipError_t launch_mfma2_heads(const FwdParams& P, int tiles, hipStream_t st) {
   hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<MT, true, 2, true, true>), dim3(per * 8, 1, 1), dim3(kThreads2), smem, st, P, tiles);
   return hipGetLastError();
 }
+// tap-granular split (MT = 3, Cin = Cout = 256): ks_nwg workgroups, one per CU
+template <bool OUT_NCHW, int NCONV>
+hipError_t launch_mfma2_ksplit(const FwdParams& P, int tiles, hipStream_t st) {
+  const size_t smem = mfma2_smem<3, NCONV>();
+  struct TagK {};
+  hipError_t e = orp::set_max_dynamic_lds_once<TagK>(reinterpret_cast<const void*>(&dcn_fwd_mfma2_kernel<3, OUT_NCHW, NCONV, true, false, true>), smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((dcn_fwd_mfma2_kernel<3, OUT_NCHW, NCONV, true, false, true>), dim3(P.ks_nwg, 1, 1), dim3(kThreads2), smem, st, P, tiles);
+  return hipGetLastError();
+}
+constexpr size_t kKsSlotBytes = sizeof(float) * 3 * 8 * 16 * 64;       // one accumulator image (MT = 3)
+inline int ks_workgroups() {                                            // one workgroup per CU, a multiple of the 8 XCDs
+  static const int n = [] {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    const int cu = prop.multiProcessorCount & ~7;
+    return cu >= 8 ? (cu > 1024 ? 1024 : cu) : 8;
+  }();
+  return n;
+}
+inline size_t ks_bytes() { return align256_((size_t)ks_workgroups() * kKsSlotBytes) + align256_(sizeof(int) * 1024); }
+
 template <int MT, bool OUT_NCHW, int NCONV>
 hipError_t launch_mfma2_n(const FwdParams& P, int tiles, int nblk_n, hipStream_t st) {
   return (P.Cin == 256 && P.Cout == 256) ? launch_mfma2_nc<MT, OUT_NCHW, NCONV, true>(P, tiles, nblk_n, st)
@@ -849,10 +976,11 @@ int orp_dcn_fast_path_ok(int c_in, int c_out, int kh, int kw, int groups, int de
 
 size_t orp_dcn_forward_workspace_bytes(const orp_dcn_level* levels_host, int nlevels, int batch, int c_in,
                                        int in_layout) {
-  if (in_layout == 1 || !levels_host) return 256;
+  // (+ the scratch of the tap-granular split: accumulator images of the cut tiles and their flags)
+  if (in_layout == 1 || !levels_host) return 256 + ks_bytes();
   size_t tot = 0;
   for (int i = 0; i < nlevels; i++) tot += align256(sizeof(float) * (size_t)batch * c_in * levels_host[i].height * levels_host[i].width);
-  return tot + 256;
+  return tot + 256 + ks_bytes();
 }
 
 int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int batch, int c_in, int c_out,
@@ -883,9 +1011,10 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
   if ((in_layout != 0 && in_layout != 1) || (out_layout != 0 && out_layout != 1)) return ORP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const size_t w3_off = (size_t)kh * kw * c_in * c_out;
-  if (in_layout == 0 && workspace_bytes < (size_t)nconv * orp_dcn_forward_workspace_bytes(levels_host, nlevels, batch, c_in, 0))
+  if (in_layout == 0 && workspace_bytes < (size_t)nconv * (orp_dcn_forward_workspace_bytes(levels_host, nlevels, batch, c_in, 0) - ks_bytes()))
     return ORP_EWORKSPACE;
   char* wsp = reinterpret_cast<char*>(workspace);
+  char* const ws_end = wsp + workspace_bytes;
   // kernel generation: 2 (MT*32-position tiles, 256-channel phases, one or two layers per launch) when Cin is a multiple
   // of 256, else 1.  ORP_DCN_MT: dev aid.
   static const int force_mt = getenv("ORP_DCN_MT") ? atoi(getenv("ORP_DCN_MT")) : -1;   // 0 = first-generation kernel
@@ -916,6 +1045,7 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
   P.kh = kh; P.kw = kw; P.sh = stride_h; P.sw = stride_w; P.ph = pad_h; P.pw = pad_w; P.dh = dil_h; P.dw = dil_w;
   P.w2 = weight_packed; P.w3 = weight_packed + w3_off; P.bias = bias; P.relu = relu ? 1 : 0;
   P.nconv = nconv;
+  P.ks_scratch = nullptr; P.ks_flags = nullptr; P.ks_nwg = 0; P.ks_total = 0;
   P.w3b = weight2_packed ? weight2_packed + w3_off : P.w3;
   P.bias2 = bias2;
   TransposeLevels TL;
@@ -963,6 +1093,26 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
     for (int i = ntl; i < 2 * MAX_LEVELS; i++) { TL.in[i] = TL.in[0]; TL.out[i] = TL.out[0]; TL.hw[i] = 0; }
     hipLaunchKernelGGL(nchw_to_nhwc_multi_kernel, dim3(tbx, (c_in + 31) / 32, batch), dim3(256), 0, st, TL, c_in);
   }
+  // tap-granular split: when whole tiles leave the CUs unevenly loaded (228 tiles on 256 CUs: 18 tap steps on the busy
+  // ones, 16.03 on average).  ORP_DCN_KSPLIT=0 / 1: dev aid (off / whenever possible)
+  static const int ks_env = getenv("ORP_DCN_KSPLIT") ? atoi(getenv("ORP_DCN_KSPLIT")) : -1;
+  bool use_ks = false;
+  if (gen == 2 && MT == 3 && !heads && c_in == 256 && c_out == 256 && ks_env != 0 && workspace &&
+      !(getenv("ORP_DCN_PAIR_GRID") && atoi(getenv("ORP_DCN_PAIR_GRID")) == 1)) {
+    const int nwg = ks_workgroups(), taps = kh * kw, wpl = nwg / nconv;        // workgroups per layer
+    const long total = (long)tiles * taps;                                        // tap steps of one layer
+    const long per_old = (long)((tiles + nwg - 1) / nwg) * nconv * taps;          // ... of the busiest CU with whole tiles
+    wsp = reinterpret_cast<char*>(align256_(reinterpret_cast<size_t>(wsp)));
+    if (wsp + ks_bytes() <= ws_end && total / wpl >= taps && total < (1L << 30) &&
+        (ks_env == 1 || total * 105 <= per_old * wpl * 100)) {
+      P.ks_scratch = reinterpret_cast<float*>(wsp);
+      P.ks_flags = reinterpret_cast<int*>(wsp + align256_((size_t)nwg * kKsSlotBytes));
+      P.ks_nwg = nwg; P.ks_total = (int)total;
+      const hipError_t me = hipMemsetAsync(P.ks_flags, 0, sizeof(int) * nwg, st);
+      if (me != hipSuccess) return (int)me;
+      use_ks = true;
+    }
+  }
   hipError_t e;
   OrpProfScope prof(ORP_PROF_DCN_FWD, st);
   const int nblk_n = (c_out + BN - 1) / BN;
@@ -973,6 +1123,11 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
   if (heads) {                                                 // (MT >= 2: the partial sums need the A tile's LDS)
     if (gen != 2) return ORP_EINVAL;
     e = MT == 2 ? launch_mfma2_heads<2>(P, tiles, st) : launch_mfma2_heads<3>(P, tiles, st);
+    return e == hipSuccess ? ORP_OK : (int)e;
+  }
+  if (use_ks) {
+    e = nconv == 2 ? (nchw ? launch_mfma2_ksplit<true, 2>(P, tiles, st) : launch_mfma2_ksplit<false, 2>(P, tiles, st))
+                   : (nchw ? launch_mfma2_ksplit<true, 1>(P, tiles, st) : launch_mfma2_ksplit<false, 1>(P, tiles, st));
     return e == hipSuccess ? ORP_OK : (int)e;
   }
   if (gen == 2) {

@@ -93,13 +93,26 @@ class FPN(nn.Module):
                 for i in range(self.num_outs - used):
                     outs.append(F.max_pool2d(outs[-1], 1, stride=2))
             else:
+                extra = self._extra_fused if (fused and not train) else (lambda m, x: m(x))
                 if self.extra_convs_on_inputs:
-                    outs.append(self.fpn_convs[used](inputs[self.backbone_end_level - 1]))
+                    outs.append(extra(self.fpn_convs[used], inputs[self.backbone_end_level - 1]))
                 else:
-                    outs.append(self.fpn_convs[used](outs[-1]))
+                    outs.append(extra(self.fpn_convs[used], outs[-1]))
                 for i in range(used + 1, self.num_outs):
                     if self.relu_before_extra_convs:
-                        outs.append(self.fpn_convs[i](F.relu(outs[-1])))
+                        outs.append(extra(self.fpn_convs[i], F.relu(outs[-1])))
                     else:
-                        outs.append(self.fpn_convs[i](outs[-1]))
+                        outs.append(extra(self.fpn_convs[i], outs[-1]))
         return tuple(outs)
+
+    @staticmethod
+    def _extra_fused(m, x):
+        """One extra level (stride-2 ConvModule, GroupNorm, no activation) at inference: the fixed-order HIP convolution
+        when the map is small (the library's split-K kernel for these shapes sums with atomics: P6 / P7 would differ
+        by ~2e-6 from run to run and detections near score_thr would come and go), then the fused GroupNorm."""
+        from ..mmdet_ops.fused_norm import conv3x3_multi, group_norm_act_multi
+        c = m.conv
+        if not (m.with_norm and isinstance(m.norm, nn.GroupNorm) and not m.with_activation and c.bias is None and
+                tuple(c.kernel_size) == (3, 3)):
+            return m(x)
+        return group_norm_act_multi(conv3x3_multi([x], c, split_k=True), [m.norm], relu=False, inplace=True)[0]

@@ -195,10 +195,11 @@ def conv1x1_multi(xs, conv, relu=False, residuals=None, sub=None):
 SMALL_LEVEL_POSITIONS = 1024        # H*W up to which a level goes through conv3x3_multi's HIP kernel (32 x 32 at 1024^2)
 
 
-def conv3x3_multi(xs, conv):
-    """[conv(x) without bias for x in xs] for 3x3 / stride 1 / pad 1 / groups 1 nn.Conv2d modules, inference only; conv:
-    one module for all tensors or a list with one module per tensor (equal channel counts).  The small levels
-    (H*W <= SMALL_LEVEL_POSITIONS) share ONE launch of the exact-fp32 MFMA kernel `orp_conv3x3_small_multi_ex` (the
+def conv3x3_multi(xs, conv, split_k=False):
+    """[conv(x) without bias for x in xs] for 3x3 / stride 1 or 2 / pad 1 / groups 1 nn.Conv2d modules, inference only
+    (split_k: launches with few positions also split K over the grid, fixed-order sum of the partial images);
+    conv: one module for all tensors or a list with one module per tensor (equal channel counts).  The small levels
+    (H*W <= SMALL_LEVEL_POSITIONS) share ONE launch of the exact-fp32 MFMA kernel `orp_conv3x3_small_multi_strided` (the
     framework would issue an im2col + GEMM pair per level), the big levels stay on the library (Winograd)."""
     import torch.nn.functional as F
     from .deform_conv import _packed_weight
@@ -209,8 +210,8 @@ def conv3x3_multi(xs, conv):
 
     def eligible(c):
         w = c.weight
-        return (tuple(w.shape) == (cout, cin, 3, 3) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (1, 1) and
-                tuple(c.dilation) == (1, 1) and c.groups == 1 and w.dtype == torch.float32)
+        return (tuple(w.shape) == (cout, cin, 3, 3) and tuple(c.stride) in ((1, 1), (2, 2)) and tuple(c.padding) == (1, 1)
+                and tuple(c.dilation) == (1, 1) and c.groups == 1 and w.dtype == torch.float32)
     ok = bool(L.orp_conv3x3_small_ok(cin, cout)) and all(eligible(c) for c in {id(c): c for c in convs}.values())
     outs = [None] * len(xs)
     small = []
@@ -224,10 +225,13 @@ def conv3x3_multi(xs, conv):
         B = xs[small[0]].size(0)
         levels = (_NormLevel * len(small))()
         wts = (ctypes.c_void_p * len(small))()
+        strides = (ctypes.c_int * len(small))()
         keep, seen = [], {}
         for k, i in enumerate(small):
             x = xs[i].detach().contiguous()
-            y = torch.empty((B, cout, x.size(2), x.size(3)), dtype=torch.float32, device=x.device)
+            st = int(convs[i].stride[0])
+            y = torch.empty((B, cout, (x.size(2) - 1) // st + 1, (x.size(3) - 1) // st + 1), dtype=torch.float32,
+                            device=x.device)
             wp = seen.get(id(convs[i]))
             if wp is None:                                 # once per distinct module
                 packed = _packed_weight(convs[i].weight)
@@ -236,10 +240,14 @@ def conv3x3_multi(xs, conv):
             keep.append(x); outs[i] = y
             levels[k] = _NormLevel(x.data_ptr(), y.data_ptr(), x.size(2), x.size(3))
             wts[k] = wp
+            strides[k] = st
         x0 = xs[small[0]]
+        nbytes = L.orp_conv3x3_small_workspace_bytes(levels, strides, len(small), B, cout) if split_k else 0
+        ws = _lib.workspace(x0.device, nbytes) if nbytes else None
         with torch.cuda.device(x0.device):
-            rc = L.orp_conv3x3_small_multi_ex(levels, wts, len(small), B, cin, cout, _lib.stream_of(x0))
-        _lib.check(rc, "orp_conv3x3_small_multi_ex")
+            rc = L.orp_conv3x3_small_multi_strided(levels, wts, strides, len(small), B, cin, cout, _lib.ptr(ws),
+                                                   ws.numel() if ws is not None else 0, _lib.stream_of(x0))
+        _lib.check(rc, "orp_conv3x3_small_multi_strided")
     return outs
 
 

@@ -449,6 +449,34 @@ def test_dcn_pair_at_1536_patch_shapes_vs_torch_reference(dev, oracle):
             assert float((got - want).abs().max()) <= 1e-4 * scale, lvl
 
 
+@pytest.mark.parametrize("B,channels_last,relu", [(1, False, True), (1, True, False), (2, False, False)])
+def test_dcn_pair_tap_split_launch_at_1024_shapes(dev, B, channels_last, relu):
+    """The configs[1] / configs[2] launches themselves: all five levels of 1024^2 image(s), both head DeformConvs in one
+    launch.  228 (456) tiles do not divide over 256 CUs, so the launch is the tap-granular split: workgroups walk equal
+    ranges of the (tile, layer, tap) sequence and a cut tile is finished by the owner of its head part (head + tail
+    partial sums).  Checker: the plain PyTorch fp32 DeformConv (pinned to the oracle in the 1536 test); the result must
+    also be bitwise reproducible launch to launch (the partial sums are always added in the same order)."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv_forward_pair
+    torch.manual_seed(6 + B)
+    sizes = (128, 64, 32, 16, 8)
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    fa = [torch.randn(B, 256, n, n, device=dev).contiguous(memory_format=fmt) for n in sizes]
+    fb = [torch.randn(B, 256, n, n, device=dev).contiguous(memory_format=fmt) for n in sizes]
+    of = [torch.randn(B, 18, n, n, device=dev) * 2 for n in sizes]
+    w1, w2 = torch.randn(256, 256, 3, 3, device=dev) * 0.02, torch.randn(256, 256, 3, 3, device=dev) * 0.02
+    pa, pb = deform_conv_forward_pair(fa, fb, of, w1, w2, 1, 1, 1, relu=relu)
+    for lvl in range(5):
+        for got, x, w in ((pa[lvl], fa[lvl], w1), (pb[lvl], fb[lvl], w2)):
+            want = _dcn_torch_reference(x.contiguous(), of[lvl], w)
+            if relu:
+                want = want.clamp(min=0)
+            assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()), lvl
+    for _ in range(3):
+        qa, qb = deform_conv_forward_pair(fa, fb, of, w1, w2, 1, 1, 1, relu=relu)
+        for x, y in zip(pa + pb, qa + qb):
+            assert torch.equal(x, y)
+
+
 def test_postprocess_at_1536_patch_shapes(dev, oracle):
     """configs[4] shapes through decode -> multiclass rotated NMS: 6 720 candidates.  The fused static kernels, the static
     tensor-op path and the reference-shaped dynamic path agree; min-area-rect of every candidate and the rnms keep set
@@ -1211,6 +1239,68 @@ def test_small_level_conv3x3_vs_torch(dev, B, cin, cout, sizes):
         assert float((g_.double() - w_).abs().max()) <= 1e-4 * max(1.0, float(w_.abs().max()))
 
 
+@pytest.mark.parametrize("B,cin,cout,sizes,split_k", [(1, 2048, 256, [(32, 32)], True), (1, 256, 256, [(16, 16)], True),
+                                                      (2, 256, 256, [(31, 17), (8, 8), (1, 1), (2, 5)], True),
+                                                      (1, 256, 128, [(16, 16), (9, 9)], False)])
+def test_small_level_conv3x3_stride2_vs_torch(dev, B, cin, cout, sizes, split_k):
+    """The FPN's extra levels (3x3, stride 2, pad 1: P6 from the 2048-channel C5, P7 from P6) on the fixed-order HIP
+    convolution, with the grid-level K split and its fixed-order sum of partial images: against F.conv2d in fp64, every
+    border position, odd sizes; and bitwise reproducible launch to launch (what the library's kernel for these shapes
+    is not)."""
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv3x3_multi
+    torch.manual_seed(4)
+    conv = torch.nn.Conv2d(cin, cout, 3, stride=2, padding=1, bias=False).to(dev)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.02)
+    xs = [torch.randn(B, cin, h, w, device=dev) for h, w in sizes]
+    with torch.no_grad():
+        got = conv3x3_multi(xs, conv, split_k=split_k)
+        want = [torch.nn.functional.conv2d(x.double(), conv.weight.double(), None, stride=2, padding=1) for x in xs]
+        for g_, w_ in zip(got, want):
+            assert g_.shape == w_.shape
+            assert float((g_.double() - w_).abs().max()) <= 1e-4 * max(1.0, float(w_.abs().max()))
+        for _ in range(3):
+            for a, b in zip(conv3x3_multi(xs, conv, split_k=split_k), got):
+                assert torch.equal(a, b)
+
+
+def test_inference_step_is_bitwise_reproducible(dev):
+    """Backbone -> neck -> head -> decode / NMS of the same image twice: identical bits.  Every HIP kernel of the path sums
+    in a fixed order; the library kernels the detector keeps (Winograd / implicit-GEMM convolutions) are deterministic
+    for its shapes, except the split-K pick for the FPN's two extra levels, which therefore run on the HIP convolution."""
+    from orientedreppoints_amd.dota_configs import r50_model, test_cfg
+    from orientedreppoints_amd.mmdet_models import ConfigDict, build_detector
+    torch.manual_seed(0)
+    model = build_detector(ConfigDict(r50_model), train_cfg=None, test_cfg=ConfigDict(test_cfg)).to(dev).eval()
+    head = model.bbox_head
+    with torch.no_grad():
+        head.reppoints_cls_out.weight.normal_(0, 0.05)
+        head.reppoints_cls_out.bias.fill_(-3.0)
+        head.reppoints_pts_init_out.bias.copy_(torch.tensor(
+            [[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 0], [0, 1], [1, -1], [1, 0], [1, 1]],
+            dtype=torch.float32, device=dev).reshape(-1) * 2.0)
+    img = torch.randn(1, 3, 1024, 1024, device=dev)
+    metas = [dict(img_shape=(1024, 1024, 3), pad_shape=(1024, 1024, 3), scale_factor=1.0, flip=False)]
+    with torch.no_grad():
+        feats0 = model.extract_feat(img)
+        ref_feats = [f.clone() for f in feats0]
+        ref = model.simple_test(img, metas)
+        assert sum(len(c) for c in ref) > 100
+        for _ in range(3):
+            for a, b in zip(model.extract_feat(img), ref_feats):
+                assert torch.equal(a, b)
+            for a, b in zip(model.simple_test(img, metas), ref):
+                assert a.shape == b.shape and np.array_equal(a, b)
+    # the extra levels equal the stock modules' (library convolution + framework GroupNorm) to rounding
+    with torch.no_grad():
+        c = model.backbone(img)
+        fused = model.neck(c)
+        with torch.enable_grad():
+            stock = model.neck([t.detach() for t in c])          # autograd on: the unfused module path
+        for a, b in zip(fused, stock):
+            assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
+
+
 def test_multi_launch_ops_with_per_tensor_parameters(dev):
     """group_norm_act_multi / conv3x3_multi with one module PER TENSOR (the *_ex entry points): each tensor must get
     its own affine parameters / weights."""
@@ -1354,6 +1444,64 @@ def test_graphed_inference_equals_simple_test(dev):
                 assert [c.shape for c in gr] == [c.shape for c in wr]
                 for a, b in zip(gr, wr):
                     assert np.allclose(a, b, rtol=1e-4, atol=1e-2)
+
+
+def test_aug_test_is_one_nms_over_the_union_of_the_views(dev):
+    """Detector.aug_test (reference orientedreppoints_detector.py:111-144): (a) two copies of the same view suppress each
+    other -> exactly simple_test's boxes; (b) original + mirrored + half-size views: the result equals ONE multiclass
+    rotated NMS over the mapped-back candidates, the mapping restated here in numpy; (c) rescale=False multiplies by the
+    first view's scale factor."""
+    from orientedreppoints_amd.dota_configs import r50_model, test_cfg
+    from orientedreppoints_amd.mmdet_models import ConfigDict, build_detector
+    from orientedreppoints_amd.mmdet_models.core import multiclass_rnms, rbbox2result
+    torch.manual_seed(0)
+    model = build_detector(ConfigDict(r50_model), train_cfg=None, test_cfg=ConfigDict(test_cfg)).to(dev).eval()
+    head = model.bbox_head
+    with torch.no_grad():
+        head.reppoints_cls_out.weight.normal_(0, 0.05)
+        head.reppoints_cls_out.bias.fill_(-3.3)
+        head.reppoints_pts_init_out.bias.copy_(torch.tensor(
+            [[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 0], [0, 1], [1, -1], [1, 0], [1, 1]],
+            dtype=torch.float32, device=dev).reshape(-1) * 2.0)
+    img = torch.randn(1, 3, 256, 256, device=dev)
+    meta = dict(img_shape=(256, 256, 3), pad_shape=(256, 256, 3), scale_factor=1.0, flip=False)
+    with torch.no_grad():
+        single = model.simple_test(img, [meta], rescale=True)
+        twice = model(img=[img, img], img_meta=[[meta], [meta]], return_loss=False, rescale=True)
+    assert sum(len(c) for c in single) > 20
+    for a, b in zip(twice, single):
+        assert a.shape[1] == 9 and a.shape[0] == b.shape[0]
+        assert np.allclose(a, b[:, -9:], rtol=1e-5, atol=1e-4)   # simple_test rows are [reppoints | corners | score]
+    views = [(img, meta),
+             (img.flip(-1), dict(meta, flip=True)),
+             (torch.nn.functional.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False),
+              dict(img_shape=(128, 128, 3), pad_shape=(128, 128, 3), scale_factor=0.5, flip=False))]
+    imgs, metas = [v[0] for v in views], [[v[1]] for v in views]
+    with torch.no_grad():
+        got = model.aug_test(imgs, metas, rescale=True)
+        cand = []
+        for im, m in zip(imgs, metas):
+            outs = head(model.extract_feat(im))
+            b, sc = head.get_bboxes(*(tuple(outs) + (m, model.test_cfg, False, False)))[0]
+            b = b.cpu().numpy()
+            if m[0]['flip']:
+                b = b.copy()
+                b[:, 0::2] = np.float32(m[0]['img_shape'][1]) - b[:, 0::2] - np.float32(1)
+            cand.append((b / np.float32(m[0]['scale_factor']), sc.cpu().numpy()))
+        boxes = torch.from_numpy(np.concatenate([c[0] for c in cand])).to(dev)
+        scores = torch.from_numpy(np.concatenate([c[1] for c in cand])).to(dev)
+        det, lab = multiclass_rnms(boxes, scores, model.test_cfg.score_thr, model.test_cfg.nms, model.test_cfg.max_per_img)
+        want = rbbox2result(det, lab, head.num_classes)
+        half_first = model.aug_test(imgs[::-1], metas[::-1], rescale=False)
+        full_first = model.aug_test(imgs[::-1], metas[::-1], rescale=True)
+    assert sum(len(c) for c in want) > sum(len(c) for c in single)        # the extra views really add detections
+    # (the library's convolution kernels for the 128^2 view's tiny maps are not bitwise reproducible: two forwards of the
+    # same view agree to an ulp or two, hence allclose and not array_equal)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and np.allclose(a, b, rtol=1e-5, atol=1e-4)
+    for a, b in zip(half_first, full_first):
+        assert a.shape == b.shape and np.allclose(a[:, :8], b[:, :8] * np.float32(0.5), rtol=1e-5, atol=1e-4)
+        assert np.allclose(a[:, 8], b[:, 8], rtol=1e-5, atol=1e-6)
 
 
 def test_pipelined_inference_returns_each_images_own_results_in_order(dev):
