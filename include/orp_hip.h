@@ -322,6 +322,23 @@ int orp_gather_levels_backward(const orp_level_desc* levels_host, int nlevels, i
                                int p, int mode, const float* grad_out, void* stream);
 int orp_outline_samples(const float* corners, int p, int n, const float* ratios, float* out, void* stream);
 
+/* Segment losses of the head's loss(): rows = the positive point sets of a stage, seg[row] = its segment (FPN level of the
+ * init stage, or 0), nseg <= 16.  Replaces the tensor-op composition around GIoULoss (iou_loss.py:69-129, reduction mean per
+ * level, orientedreppoints_head.py:294-318) and SpatialBorderLoss (spatial_border_loss.py:8-92) -- ~25 framework launches each.
+ * orp_border_rows: over the points of a row that lie OUTSIDE its gt quad (pointsJf == 0) and only for weight > 0:
+ *   row_sum = sum 0.2 |p - centre|, row_cnt = their number, gdir [p,18] = d(0.2 |p - centre|)/dp (0 elsewhere).
+ * orp_giou_rows: contrib = (1 - giou) * weight; gsave [p,18] = -(grad, or 1e-6 in rows with any component > 1)
+ *   * weight / max(denom[seg], 1) * loss_weight -- the gradient the reference returns from backward().
+ * orp_segment_finish (one workgroup, fixed summation order): mode 0: loss[s] = sum_s(row_val) / max(denom[s], 1) *
+ *   loss_weight; mode 1: loss[s] = loss_weight * (sum_s(row_val) / max(sum_s(row_cnt), 1)) / (denom[s] + 1e-6) and
+ *   scale[s] = loss_weight / max(sum_s(row_cnt), 1) / (denom[s] + 1e-6). */
+int orp_border_rows(const float* pts18, const float* gt8, const float* weight, int p, float* row_sum, float* row_cnt,
+                    float* gdir, void* stream);
+int orp_giou_rows(const float* gious, const float* grad18, const float* weight, const int64_t* seg, const float* denom, int p,
+                  float loss_weight, float* contrib, float* gsave, void* stream);
+int orp_segment_finish(const float* row_val, const float* row_cnt, const int64_t* seg, int p, int nseg, const float* denom,
+                       float loss_weight, int mode, float* loss, float* scale, void* stream);
+
 /* fp64 greedy polygon NMS -- the merge step of the DOTA evaluation workflow (DOTA_devkit/ResultMerge.py:18-41
  * py_cpu_nms_poly over polyiou.cpp:108-128 iou_poly), SURVEY 8f rank 2.  dets_sorted [n,9] DOUBLE on device, already
  * in visiting order (the caller applies numpy's `scores.argsort()[::-1]` exactly as the reference does); a box

@@ -102,6 +102,9 @@ _SIGNATURES = {
     "orp_conv3x3_small_ok": (_i, [_i, _i]),
     "orp_conv3x3_small_multi": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "orp_conv3x3_small_multi_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "orp_border_rows": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "orp_giou_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
+    "orp_segment_finish": (_i, [_vp, _vp, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp]),
     "orp_conv3x3_small_workspace_bytes": (ctypes.c_size_t, [_vp, _vp, _i, _i, _i]),
     "orp_conv3x3_small_multi_strided": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
 }

@@ -2,6 +2,9 @@
 //   pointsJf          mmdet/ops/point_justify/src/points_justify_kernel.cu:25-119
 //   ChamferDistance2D mmdet/ops/chamfer_2d/src/chamfer_2d.cu:12-182
 //   sigmoid focal     mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_cuda.cu:23-167
+//   segment losses    the per-level / per-stage GIoU and SpatialBorder losses of the head's loss() (orientedreppoints_head.py
+//                     :294-318,474-520 over iou_loss.py:69-129 and spatial_border_loss.py:8-92) as a rows kernel + ONE
+//                     fixed-order segment reduction each (the framework composition is ~25 tiny launches per loss)
 // All are HBM-bound element-wise / tiny-reduction kernels: grid-stride, coalesced, no host synchronisation.
 #include <hip/hip_runtime.h>
 #include <float.h>
@@ -148,10 +151,122 @@ __global__ void focal_bwd_kernel(const float* __restrict__ logits, const int64_t
   }
 }
 
+
+// ---- segment losses ---------------------------------------------------------------------------------------------------
+// border: per row (a positive point set and its gt quad), over the points OUTSIDE the quad (pointsJf == 0; rows with
+// weight <= 0 do not count): sum of 0.2 * |p - centre|, their number, and d(0.2 |p - c|)/dp for the backward pass.
+__global__ void border_rows_kernel(const float* __restrict__ pts18, const float* __restrict__ gt8,
+                                   const float* __restrict__ weight, int P, float* __restrict__ row_sum,
+                                   float* __restrict__ row_cnt, float* __restrict__ gdir) {
+  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < P; row += gridDim.x * blockDim.x) {
+    float q[8];
+    const float4* qp = reinterpret_cast<const float4*>(gt8 + (size_t)row * 8);
+    const float4 a = qp[0], b = qp[1];
+    q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    const float cx = (q[0] + q[4]) / 2.0f, cy = (q[1] + q[5]) / 2.0f;
+    const bool counts = weight[row] > 0.f;
+    float sum = 0.f, cnt = 0.f;
+    for (int t = 0; t < 9; t++) {
+      const float px = pts18[(size_t)row * 18 + 2 * t], py = pts18[(size_t)row * 18 + 2 * t + 1];
+      float gx = 0.f, gy = 0.f;
+      if (counts && point_in_quad(px, py, q) == 0.f) {
+        const float dx = px - cx, dy = py - cy;
+        const float r = sqrtf(dx * dx + dy * dy);
+        sum += 0.2f * r; cnt += 1.f;
+        gx = 0.2f * dx / r; gy = 0.2f * dy / r;
+      }
+      gdir[(size_t)row * 18 + 2 * t] = gx; gdir[(size_t)row * 18 + 2 * t + 1] = gy;
+    }
+    row_sum[row] = sum; row_cnt[row] = cnt;
+  }
+}
+
+// GIoU: contrib = (1 - giou) w; the gradient the reference takes out of the forward kernel, rows with any component > 1
+// replaced by 1e-6 (iou_loss.py:87-89), scaled by -w / max(denom[seg], 1) * loss_weight
+__global__ void giou_rows_kernel(const float* __restrict__ gious, const float* __restrict__ grad18,
+                                 const float* __restrict__ weight, const int64_t* __restrict__ seg,
+                                 const float* __restrict__ denom, int P, float loss_weight, float* __restrict__ contrib,
+                                 float* __restrict__ gsave) {
+  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < P; row += gridDim.x * blockDim.x) {
+    const float w = weight[row];
+    const float d = fmaxf(denom[seg[row]], 1.0f);
+    contrib[row] = (1.0f - gious[row]) * w;
+    float g[18];
+    bool unvalid = false;
+    for (int j = 0; j < 18; j++) { g[j] = grad18[(size_t)row * 18 + j]; unvalid = unvalid || g[j] > 1.0f; }
+    const float t = w / d;
+    for (int j = 0; j < 18; j++) gsave[(size_t)row * 18 + j] = ((-(unvalid ? 1e-6f : g[j])) * t) * loss_weight;
+  }
+}
+
+// one workgroup: per-segment sums of row values (and counts) in a FIXED order (thread i takes rows i, i + 1024, ...;
+// then a tree over the threads), and the loss formulas:
+//   mode 0  loss[s] = sum[s] / max(denom[s], 1) * loss_weight
+//   mode 1  loss[s] = loss_weight * (sum[s] / max(cnt[s], 1)) / (denom[s] + 1e-6),  scale[s] = d loss[s] / d (a row value)
+constexpr int kMaxSeg = 16;
+constexpr int kSegThreads = 1024;
+__global__ void __launch_bounds__(kSegThreads)
+segment_finish_kernel(const float* __restrict__ row_val, const float* __restrict__ row_cnt, const int64_t* __restrict__ seg,
+                      int P, int nseg, const float* __restrict__ denom, float loss_weight, int mode,
+                      float* __restrict__ loss, float* __restrict__ scale) {
+  __shared__ float red[kSegThreads];
+  __shared__ float tot[2][kMaxSeg];
+  const int tid = threadIdx.x;
+  for (int s = 0; s < nseg; s++) {
+    for (int which = 0; which < (mode == 1 ? 2 : 1); which++) {
+      const float* src = which ? row_cnt : row_val;
+      float v = 0.f;
+      for (int i = tid; i < P; i += kSegThreads) if ((int)seg[i] == s) v += src[i];
+      red[tid] = v;
+      __syncthreads();
+      for (int off = kSegThreads / 2; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+      }
+      if (tid == 0) tot[which][s] = red[0];
+      __syncthreads();
+    }
+  }
+  if (tid < nseg) {
+    if (mode == 0) {
+      loss[tid] = tot[0][tid] / fmaxf(denom[tid], 1.0f) * loss_weight;
+    } else {
+      const float n = fmaxf(tot[1][tid], 1.0f), dd = denom[tid] + 1e-6f;
+      loss[tid] = loss_weight * (tot[0][tid] / n) / dd;
+      if (scale) scale[tid] = loss_weight / n / dd;
+    }
+  }
+}
+
 inline int done() { hipError_t e = hipGetLastError(); return e == hipSuccess ? ORP_OK : (int)e; }
 }  // namespace
 
 extern "C" {
+int orp_border_rows(const float* pts18, const float* gt8, const float* weight, int p, float* row_sum, float* row_cnt,
+                    float* gdir, void* stream) {
+  if (p < 0 || (p > 0 && (!pts18 || !gt8 || !weight || !row_sum || !row_cnt || !gdir))) return ORP_EINVAL;
+  if (p == 0) return ORP_OK;
+  hipLaunchKernelGGL(border_rows_kernel, dim3(grid_for(p)), dim3(kThreads), 0, (hipStream_t)stream, pts18, gt8, weight, p,
+                     row_sum, row_cnt, gdir);
+  return done();
+}
+int orp_giou_rows(const float* gious, const float* grad18, const float* weight, const int64_t* seg, const float* denom, int p,
+                  float loss_weight, float* contrib, float* gsave, void* stream) {
+  if (p < 0 || (p > 0 && (!gious || !grad18 || !weight || !seg || !denom || !contrib || !gsave))) return ORP_EINVAL;
+  if (p == 0) return ORP_OK;
+  hipLaunchKernelGGL(giou_rows_kernel, dim3(grid_for(p)), dim3(kThreads), 0, (hipStream_t)stream, gious, grad18, weight, seg,
+                     denom, p, loss_weight, contrib, gsave);
+  return done();
+}
+int orp_segment_finish(const float* row_val, const float* row_cnt, const int64_t* seg, int p, int nseg, const float* denom,
+                       float loss_weight, int mode, float* loss, float* scale, void* stream) {
+  if (p < 0 || nseg <= 0 || nseg > kMaxSeg || !denom || !loss || (mode != 0 && mode != 1) ||
+      (p > 0 && (!row_val || !seg || (mode == 1 && !row_cnt))))
+    return ORP_EINVAL;
+  hipLaunchKernelGGL(segment_finish_kernel, dim3(1), dim3(kSegThreads), 0, (hipStream_t)stream, row_val, row_cnt, seg, p, nseg,
+                     denom, loss_weight, mode, loss, scale);
+  return done();
+}
 int orp_points_justify(const float* points, int m, const float* polygons, int k, float* out, void* stream) {
   if (m < 0 || k < 0 || ((m > 0 && k > 0) && (!points || !polygons || !out))) return ORP_EINVAL;
   if (m == 0 || k == 0) return ORP_OK;

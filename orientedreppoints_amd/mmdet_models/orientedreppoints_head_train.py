@@ -21,14 +21,11 @@ The per-image / per-level functions of the reference (`offset_to_pts`, `sampling
 """
 import numpy as np
 import torch
-from torch.autograd import Function
-from torch.autograd.function import once_differentiable
 
 from ..mmdet_ops import apaa, train_ops
 from ..mmdet_ops.chamfer_distance import ChamferDistance2D
 from ..mmdet_ops.iou_wrapper import convex_giou
 from ..mmdet_ops.minarea_rect import minaerarect
-from ..mmdet_ops.point_justify import points_in_quad_aligned
 from .pointset_target import gt_tables, images_to_levels, pointset_targets
 
 
@@ -108,51 +105,12 @@ def sampling_points(corners, points_num):
 
 
 # ---- losses over segments (levels of the init stage / the kept positives of the refine stage) ----------------------------
-class _SegmentGIoULoss(Function):
-    """loss[s] = loss_weight * sum_{i in s} w_i (1 - GIoU_i) / denom[s]  for the rows' segments s (GIoULoss with
-    reduction 'mean' applied per segment, iou_loss.py:69-129).  As in the reference the gradient comes out of the forward
-    kernel and the incoming gradient is ignored: d/d pred_i = -grad_i w_i / denom[seg_i] * loss_weight, rows with any
-    component > 1 replaced by 1e-6 first (iou_loss.py:87-89)."""
-
-    @staticmethod
-    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: fp32 inputs, autocast off inside
-    def forward(ctx, pred, target, weight, seg, nseg, denom, loss_weight):
-        if pred.size(0) == 0:                                         # no row at all: zero loss, empty gradient
-            ctx.save_for_backward(torch.zeros_like(pred))
-            return pred.new_zeros((nseg,))
-        gious, grad = convex_giou(pred, target)
-        w = weight.to(gious.dtype)
-        d = denom.to(gious.dtype).clamp(min=1.0)
-        loss = torch.zeros((nseg,), dtype=gious.dtype, device=gious.device).index_add_(0, seg, (1 - gious) * w) / d
-        unvalid = (grad > 1).sum(1) > 0
-        grad = torch.where(unvalid[:, None], torch.full_like(grad, 1e-6), grad)
-        ctx.save_for_backward(-grad * (w / d[seg])[:, None] * loss_weight)
-        return loss * loss_weight
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, grad_out=None):
-        return ctx.saved_tensors[0], None, None, None, None, None, None
+# mmdet_ops/train_ops.py: rows kernel + one fixed-order segment reduction each (csrc/orp_pointwise.hip)
+_SegmentGIoULoss = train_ops._SegmentGIoULoss
 
 
 def _segment_border_loss(pts, gt, weight, seg, nseg, denom, loss_weight):
-    """SpatialBorderLoss per segment (spatial_border_loss.py:8-92): for the points of rows with weight > 0 that lie
-    outside their gt quad, 0.2 * distance to the quad centre, summed, divided by the number of such points and by
-    denom[s] + 1e-6.  Differentiable w.r.t. pts through plain tensor operations."""
-    P = pts.size(0)
-    out = pts.new_zeros((nseg,))
-    if P == 0:
-        return out
-    inside = points_in_quad_aligned(pts.detach(), gt)                                # [P, 9]: 1 inside, 0 outside / border
-    outside = (inside == 0) & (weight > 0)[:, None]
-    p9 = pts.reshape(P, 9, 2)
-    centre = torch.stack([(gt[:, 0] + gt[:, 4]) / 2.0, (gt[:, 1] + gt[:, 5]) / 2.0], 1)[:, None, :]
-    d2 = ((p9 - centre) ** 2).sum(-1)
-    dist = 0.2 * torch.where(outside, d2, torch.ones_like(d2)).sqrt()               # no sqrt'(0) at points that do not count
-    dist = torch.where(outside, dist, torch.zeros_like(dist))
-    s_sum = out.index_add(0, seg, dist.sum(1))
-    n_out = out.index_add(0, seg, outside.sum(1).to(out.dtype))
-    return loss_weight * (s_sum / n_out.clamp(min=1.0)) / (denom.to(out.dtype) + 1e-6)
+    return train_ops.segment_border_loss(pts, gt, weight, seg, nseg, denom, loss_weight)
 
 
 def init_loss_single(head, pts_pred_init, rbox_gt_init, rbox_weights_init, stride):

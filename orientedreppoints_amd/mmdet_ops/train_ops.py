@@ -116,6 +116,99 @@ def pointset_target(gt_inds, valid, gt_boxes, gt_labels, gt_offset, pos_weight=-
     return out
 
 
+class _SegmentGIoULoss(Function):
+    """loss[s] = loss_weight * sum_{i in s} w_i (1 - GIoU_i) / max(denom[s], 1) for the rows' segments s (GIoULoss with
+    reduction 'mean' applied per segment, iou_loss.py:69-129).  As in the reference the gradient comes out of the forward
+    kernel and the incoming gradient is ignored: d/d pred_i = -grad_i w_i / denom[seg_i] * loss_weight, rows with any
+    component > 1 replaced by 1e-6 first (iou_loss.py:87-89).  convex_giou + two launches (rows, fixed-order segment sum)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: fp32 inputs, autocast off inside
+    def forward(ctx, pred, target, weight, seg, nseg, denom, loss_weight):
+        from .iou_wrapper import convex_giou
+        P = pred.size(0)
+        dev = pred.device
+        loss = torch.zeros((nseg,), dtype=torch.float32, device=dev)
+        if P == 0:                                                       # no row at all: zero loss, empty gradient
+            ctx.save_for_backward(torch.zeros_like(pred))
+            return loss
+        gious, grad = convex_giou(pred, target)
+        gious = gious.float().contiguous()
+        grad = grad.float().reshape(P, 18).contiguous()
+        w = weight.detach().float().contiguous()
+        sg = seg.to(torch.long).contiguous()
+        d = denom.detach().float().reshape(nseg).contiguous()
+        contrib = torch.empty((P,), dtype=torch.float32, device=dev)
+        gsave = torch.empty((P, 18), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            st = _lib.stream_of(gious)
+            _lib.check(L.orp_giou_rows(_lib.ptr(gious), _lib.ptr(grad), _lib.ptr(w), _lib.ptr(sg), _lib.ptr(d), P,
+                                       float(loss_weight), _lib.ptr(contrib), _lib.ptr(gsave), st), "orp_giou_rows")
+            _lib.check(L.orp_segment_finish(_lib.ptr(contrib), None, _lib.ptr(sg), P, int(nseg), _lib.ptr(d),
+                                            float(loss_weight), 0, _lib.ptr(loss), None, st), "orp_segment_finish")
+        ctx.save_for_backward(gsave.reshape(pred.shape))
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out=None):
+        return ctx.saved_tensors[0], None, None, None, None, None, None
+
+
+def segment_giou_loss(pred, target, weight, seg, nseg, denom, loss_weight):
+    return _SegmentGIoULoss.apply(pred, target, weight, seg, nseg, denom, loss_weight)
+
+
+class _SegmentBorderLoss(Function):
+    """SpatialBorderLoss per segment (spatial_border_loss.py:8-92): for the points of rows with weight > 0 that lie
+    outside their gt quad, 0.2 * distance to the quad centre, summed, divided by the number of such points and by
+    denom[s] + 1e-6.  Two launches forward (rows, fixed-order segment sums), the stored direction field backward."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, pts, gt, weight, seg, nseg, denom, loss_weight):
+        P = pts.size(0)
+        dev = pts.device
+        loss = torch.zeros((nseg,), dtype=torch.float32, device=dev)
+        if P == 0:
+            ctx.empty = True
+            ctx.shape = tuple(pts.shape)
+            return loss
+        ctx.empty = False
+        p = pts.detach().float().reshape(P, 18).contiguous()
+        g = gt.detach().float().reshape(P, 8).contiguous()
+        w = weight.detach().float().contiguous()
+        sg = seg.to(torch.long).contiguous()
+        d = denom.detach().float().reshape(nseg).contiguous()
+        row_sum = torch.empty((P,), dtype=torch.float32, device=dev)
+        row_cnt = torch.empty((P,), dtype=torch.float32, device=dev)
+        gdir = torch.empty((P, 18), dtype=torch.float32, device=dev)
+        scale = torch.empty((nseg,), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            st = _lib.stream_of(p)
+            _lib.check(L.orp_border_rows(_lib.ptr(p), _lib.ptr(g), _lib.ptr(w), P, _lib.ptr(row_sum), _lib.ptr(row_cnt),
+                                         _lib.ptr(gdir), st), "orp_border_rows")
+            _lib.check(L.orp_segment_finish(_lib.ptr(row_sum), _lib.ptr(row_cnt), _lib.ptr(sg), P, int(nseg), _lib.ptr(d),
+                                            float(loss_weight), 1, _lib.ptr(loss), _lib.ptr(scale), st), "orp_segment_finish")
+        ctx.save_for_backward(gdir, scale, sg)
+        ctx.shape = tuple(pts.shape)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        if ctx.empty:
+            return grad_out.new_zeros(ctx.shape), None, None, None, None, None, None
+        gdir, scale, sg = ctx.saved_tensors
+        return (gdir * (grad_out.float() * scale)[sg][:, None]).reshape(ctx.shape), None, None, None, None, None, None
+
+
+def segment_border_loss(pts, gt, weight, seg, nseg, denom, loss_weight):
+    return _SegmentBorderLoss.apply(pts, gt, weight, seg, nseg, denom, loss_weight)
+
+
 _ratios = {}
 
 

@@ -148,6 +148,61 @@ def _chamfer(a, b, distance_weight=0.05, eps=1e-12, use_cuda=True):
     return (d1.mean(-1) + d2.mean(-1)) / 2.0 * distance_weight
 
 
+class SegmentGIoULossReference(torch.autograd.Function):
+    """The plain tensor-op composition of the per-segment GIoU loss (iou_loss.py:69-129 with reduction 'mean' per segment):
+    the CPU stand-in, and the reference the GPU test holds `train_ops._SegmentGIoULoss` against.  `giou_fn`: the
+    convex_giou to use (class attribute, set by the caller)."""
+    giou_fn = None
+
+    @staticmethod
+    def forward(ctx, pred, target, weight, seg, nseg, denom, loss_weight):
+        if pred.size(0) == 0:
+            ctx.save_for_backward(torch.zeros_like(pred))
+            return pred.new_zeros((nseg,))
+        gious, grad = SegmentGIoULossReference.giou_fn(pred, target)
+        w = weight.to(gious.dtype)
+        d = denom.to(gious.dtype).clamp(min=1.0)
+        loss = torch.zeros((nseg,), dtype=gious.dtype, device=gious.device).index_add_(0, seg, (1 - gious) * w) / d
+        unvalid = (grad > 1).sum(1) > 0
+        grad = torch.where(unvalid[:, None], torch.full_like(grad, 1e-6), grad)
+        ctx.save_for_backward(-grad * (w / d[seg])[:, None] * loss_weight)
+        return loss * loss_weight
+
+    @staticmethod
+    def backward(ctx, grad_out=None):
+        return ctx.saved_tensors[0], None, None, None, None, None, None
+
+
+def segment_border_loss_reference(pts, gt, weight, seg, nseg, denom, loss_weight, inside_fn):
+    """SpatialBorderLoss per segment as plain differentiable tensor operations (spatial_border_loss.py:8-92)."""
+    P = pts.size(0)
+    out = pts.new_zeros((nseg,))
+    if P == 0:
+        return out
+    inside = inside_fn(pts.detach(), gt)
+    outside = (inside == 0) & (weight > 0)[:, None]
+    p9 = pts.reshape(P, 9, 2)
+    centre = torch.stack([(gt[:, 0] + gt[:, 4]) / 2.0, (gt[:, 1] + gt[:, 5]) / 2.0], 1)[:, None, :]
+    d2 = ((p9 - centre) ** 2).sum(-1)
+    dist = 0.2 * torch.where(outside, d2, torch.ones_like(d2)).sqrt()
+    dist = torch.where(outside, dist, torch.zeros_like(dist))
+    s_sum = out.index_add(0, seg, dist.sum(1))
+    n_out = out.index_add(0, seg, outside.sum(1).to(out.dtype))
+    return loss_weight * (s_sum / n_out.clamp(min=1.0)) / (denom.to(out.dtype) + 1e-6)
+
+
+class _CpuSegmentGIoU:
+    @staticmethod
+    def apply(pred, target, weight, seg, nseg, denom, loss_weight):
+        SegmentGIoULossReference.giou_fn = staticmethod(_convex_giou)
+        return SegmentGIoULossReference.apply(pred, target, weight, seg, nseg, denom, loss_weight)
+
+
+def _cpu_border(pts, gt, weight, seg, nseg, denom, loss_weight):
+    return segment_border_loss_reference(pts, gt, weight, seg, nseg, denom, loss_weight,
+                                         lambda p, q: torch.from_numpy(O.points_in_quad_aligned(_np(p), _np(q))))
+
+
 @contextlib.contextmanager
 def installed():
     """Patch the operator entry points the detector's training step reaches; restores them on exit."""
@@ -167,8 +222,8 @@ def installed():
         (losses, '_sigmoid_focal_loss', _focal), (losses, 'convex_giou', _convex_giou),
         (losses, 'points_in_quad_aligned', lambda p, q: torch.from_numpy(O.points_in_quad_aligned(_np(p), _np(q)))),
         (ht, 'convex_giou', _convex_giou), (ht, 'ChamferDistance2D', _chamfer),
+        (ht, '_SegmentGIoULoss', _CpuSegmentGIoU), (ht, '_segment_border_loss', _cpu_border),
         (ht, 'minaerarect', lambda p: torch.from_numpy(O.minarearect(_np(p)).astype(np.float32)) if p.numel() else torch.zeros((0, 8))),
-        (ht, 'points_in_quad_aligned', lambda p, q: torch.from_numpy(O.points_in_quad_aligned(_np(p), _np(q)))),
         (asg, 'convex_iou', _convex_iou),
     ]
     saved = [(mod, name, getattr(mod, name)) for mod, name, _ in patches]

@@ -183,3 +183,65 @@ def test_group_norm_act_train_forward_backward_vs_torch(dev, relu, C, sizes):
         assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
     for a, b in zip(mine[2], ref[2]):
         assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
+
+
+def _loss_rows(dev, P, seed):
+    """P (point set, gt quad) rows: point sets scattered around quads of mixed size, some far outside, some inside."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from orientedreppoints_amd import synthetic as S
+    rng = np.random.RandomState(seed)
+    gt = S.gen_polys(P, seed, wh=(8, 60))[:, :8].astype(np.float32) / 8.0
+    c = gt.reshape(P, 4, 2).mean(1)
+    spread = rng.uniform(0.5, 12.0, size=(P, 1, 1)).astype(np.float32)
+    pts = (c[:, None, :] + rng.normal(size=(P, 9, 2)).astype(np.float32) * spread).reshape(P, 18)
+    return torch.from_numpy(pts).to(dev), torch.from_numpy(gt).to(dev)
+
+
+@pytest.mark.parametrize("P,nseg", [(700, 5), (33, 1), (1, 3), (0, 5), (4100, 5)])
+def test_segment_losses_equal_the_tensor_op_composition(dev, P, nseg):
+    """train_ops._SegmentGIoULoss / segment_border_loss (rows kernel + one fixed-order segment reduction each) against the
+    plain PyTorch composition the reference's GIoULoss / SpatialBorderLoss amount to per segment (tests/cpu_standins.py:
+    the same convex_giou / pointsJf operators underneath, tensor operations around them): losses to 1e-6 of their scale,
+    gradients to 1e-6, empty segments and zero weights included; twice the same bits."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_standins as CS
+    from orientedreppoints_amd.mmdet_ops import train_ops
+    from orientedreppoints_amd.mmdet_ops.iou_wrapper import convex_giou
+    from orientedreppoints_amd.mmdet_ops.point_justify import points_in_quad_aligned
+    pts, gt = _loss_rows(dev, max(P, 1), 3 + P)
+    pts, gt = pts[:P], gt[:P]
+    g = torch.Generator(device="cpu").manual_seed(P)
+    seg = torch.randint(0, nseg, (P,), generator=g).to(dev)
+    if nseg > 2:
+        seg[seg == 1] = 0                                                     # an empty segment
+    weight = (torch.rand(P, generator=g) > 0.25).float().to(dev)
+    denom_int = torch.bincount(seg, minlength=nseg)                            # the init stage passes integer counts
+    denom_f = torch.rand(nseg, generator=g).to(dev) * 40                       # the refine stage a float (may be < 1)
+    for denom in (denom_int, denom_f):
+        for lw in (0.375, 1.0):
+            a = pts.clone().requires_grad_(True)
+            b = pts.clone().requires_grad_(True)
+            got = train_ops._SegmentGIoULoss.apply(a, gt, weight, seg, nseg, denom, lw)
+            CS.SegmentGIoULossReference.giou_fn = staticmethod(convex_giou)
+            want = CS.SegmentGIoULossReference.apply(b, gt, weight, seg, nseg, denom, lw)
+            assert got.shape == want.shape == (nseg,)
+            assert float((got - want).detach().abs().max()) <= 1e-6 * max(1.0, float(want.detach().abs().max()))
+            if P:
+                got.sum().backward(); want.sum().backward()
+                assert float((a.grad - b.grad).abs().max()) <= 1e-6 * max(1.0, float(b.grad.abs().max()))
+            again = train_ops._SegmentGIoULoss.apply(pts, gt, weight, seg, nseg, denom, lw)
+            assert torch.equal(again, got.detach())
+            # border loss
+            a = pts.clone().requires_grad_(True)
+            b = pts.clone().requires_grad_(True)
+            got = train_ops.segment_border_loss(a, gt, weight, seg, nseg, denom, lw)
+            want = CS.segment_border_loss_reference(b, gt, weight, seg, nseg, denom, lw, points_in_quad_aligned)
+            assert float((got - want).detach().abs().max()) <= 2e-6 * max(1.0, float(want.detach().abs().max()))
+            coef = torch.arange(1, nseg + 1, device=dev, dtype=torch.float32)
+            if P:
+                (got * coef).sum().backward(); (want * coef).sum().backward()
+                assert b.grad.abs().max() > 0 or weight.sum() == 0
+                assert float((a.grad - b.grad).abs().max()) <= 2e-6 * max(1.0, float(b.grad.abs().max()))
+            assert torch.equal(train_ops.segment_border_loss(pts, gt, weight, seg, nseg, denom, lw), got.detach())
