@@ -30,3 +30,15 @@ def pytest_collection_modifyitems(config, items):
     may depend on allocator / cache state left by an earlier one; logs under profiles/r03_gputest_*.log)."""
     if os.environ.get("ORP_TEST_ORDER", "") == "reverse":
         items.reverse()
+
+
+# Lines a test wants in the run's log whatever its outcome (e.g. how many APAA quality values fell under the min-area-rect
+# tie rule): tests append to REPORT, the summary hook prints them at the end of the session (also under -q).
+REPORT = []
+
+
+def pytest_terminal_summary(terminalreporter):
+    if REPORT:
+        terminalreporter.write_sep("-", "reported by tests")
+        for line in REPORT:
+            terminalreporter.write_line(line)

@@ -235,7 +235,7 @@ def test_head_loss_vs_reference_python(dev, G, oracle, name):
     assert np.array_equal(np.stack([t.cpu().numpy() for t in rt[0]]), G[p + 'refine_labels'])
     assert np.array_equal(np.stack([t.cpu().numpy() for t in rt[1]]).astype(np.uint8), G[p + 'refine_label_weights'])
     assert np.array_equal(np.stack([t.cpu().numpy() for t in rt[4]]).astype(np.uint8), G[p + 'refine_rbox_weights'])
-    n_tie = 0
+    n_tie, max_tie = 0, 0.0
     for i in range(B):
         pos = rt[5][i].cpu().numpy()
         assert np.array_equal(pos, G[p + 'refine_pos_inds_%d' % i])
@@ -248,6 +248,7 @@ def test_head_loss_vs_reference_python(dev, G, oracle, name):
         assert np.max(d[~tie], initial=0.0) <= 1e-4, "Q differs from the reference beyond 1e-4 off a min-area-rect tie"
         assert np.all(d[tie] <= 2e-2)
         n_tie += int(tie.sum())
+        max_tie = max(max_tie, float(np.max(d[tie], initial=0.0)))
         # ---- selection ------------------------------------------------------------------------------------------------
         lab, lw, rw, npos, pnt = rec['sel'][i]
         assert np.array_equal(lab.cpu().numpy(), G[p + 'sel_label_%d' % i])
@@ -281,7 +282,11 @@ def test_head_loss_vs_reference_python(dev, G, oracle, name):
         want = np.zeros_like(ga.transpose(0, 2, 1))
         want[rows[:, 0], rows[:, 1]] = G[p + 'grad_%s_vals' % nm]
         assert np.max(np.abs(ga.transpose(0, 2, 1) - want)) <= 1e-4, nm
-    assert n_tie < 0.1 * sum(len(G[p + 'qa_%d' % i]) for i in range(B))       # ties are the exception, not a loophole
+    n_q = sum(len(G[p + 'qa_%d' % i]) for i in range(B))
+    import conftest
+    conftest.REPORT.append("a15 tie rule, head_loss case %r: %d of %d quality values are proven min-area-rect ties (%.2f %%), "
+                           "largest difference on a tie %.2e" % (name, n_tie, n_q, 100.0 * n_tie / max(n_q, 1), max_tie))
+    assert n_tie < 0.1 * n_q       # ties are the exception, not a loophole
 
 
 def test_candidate_selection_radix_select_equals_topk(dev):
