@@ -408,13 +408,23 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   const int taps = P.kh * P.kw;
   // XCD-aware remap: hardware places block b on XCD b % 8; give XCD x a contiguous slab of the work
   //   plain:  workgroup = tile, XCD x takes the tiles [x*per, (x+1)*per)
-  //   KSPLIT: a layer is the linear sequence of its (tile, tap) steps, cut into equal ranges: a workgroup walks
-  //           [seq, seq_end), i.e. the tail of one tile, whole tiles, and the head of another.  228 tiles x 9 taps over
-  //           128 workgroups: 16.03 tap steps each instead of 18 on 228 CUs and none on 28.  In a pair launch XCDs 0-3 take
-  //           the first layer and XCDs 4-7 the second: an XCD's 4 MB L2 then only ever holds ONE layer's 2.36 MB of packed
-  //           weights (workgroups at different points of a (tile, layer, tap) sequence over both layers need all 4.7 MB at
-  //           once and thrash it: measured, no gain over whole tiles) and each layer's weights are fetched by 4 L2s, not 8.
+  //   KSPLIT: a layer is the linear sequence of its (tile, tap) steps, cut into equal ranges [seq, seq_end): the TAIL of
+  //           one tile (taps t0A .. 8), whole tiles, and the HEAD of another (taps 0 .. t1B - 1).  228 tiles x 9 taps over
+  //           128 workgroups: 16.03 tap steps each instead of 18 on 228 CUs and none on 28.  Measured (round 3, 1024^2,
+  //           one image): 479 us against 488 us with whole tiles in the bench loop (0.684 vs 0.670 of peak), 2 x 1024^2:
+  //           906 - 925 against 964 us.  The step count drops by 11 %, the time by 2 - 6 %: a third segment and a second
+  //           coefficient table per workgroup cost ~15 us, and the L2 serves less of the traffic (rocprofv3 FETCH_SIZE:
+  //           105 MB per launch with whole tiles -- every workgroup of an XCD reads the same tap's 262 KB of weights at the
+  //           same time and the live band of input rows is 28 tiles of ONE layer; 1.0 GB in range order, tail first; 0.6 GB
+  //           as built), which two choices limit:
+  //           * in a pair launch XCDs 0-3 take the first layer and XCDs 4-7 the second: an XCD's 4 MB L2 only ever holds
+  //             ONE layer's 2.36 MB of packed weights, and each layer's weights are fetched by 4 L2s, not 8;
+  //           * a workgroup walks its whole tiles FIRST, then its head, then its tail, so that the workgroups of an XCD
+  //             are within two taps of each other most of the time (in range order each starts at a different tap).
+  //           Cutting between weight chunks inside a tap (16.03 steps for everyone instead of 16 or 17) was measured slower:
+  //           a partial tap still gathers and stages its whole A tile.
   int tile = 0, wg = 0, seq = 0, seq_end = NCONV * taps, ks_conv = 0;
+  int ks_stage = 0, ks_cur = 0, ks_last = -1, ks_fa = 0, ks_t0 = 0, ks_fb = 0, ks_t1 = 0;
   if (KSPLIT) {
     const int b = blockIdx.x, xcd = b & 7, per = P.ks_nwg >> 3;
     int idx, wpl;
@@ -423,6 +433,9 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
     wg = ks_conv * wpl + idx;
     seq = (int)(((long)idx * P.ks_total) / wpl);
     seq_end = (int)(((long)(idx + 1) * P.ks_total) / wpl);
+    ks_fa = seq / taps; ks_t0 = seq - ks_fa * taps;              // tail: taps [t0, 9) of tile fa (none when t0 == 0)
+    ks_fb = seq_end / taps; ks_t1 = seq_end - ks_fb * taps;      // head: taps [0, t1) of tile fb (none when t1 == 0)
+    ks_cur = ks_t0 ? ks_fa + 1 : ks_fa; ks_last = ks_fb - 1;     // whole tiles in between
   } else {
     const int b = blockIdx.x, per = (total_tiles + 7) >> 3;
     tile = (b & 7) * per + (b >> 3);
@@ -437,14 +450,29 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   // a pair launch runs its two layers one after the other on the SAME coefficient table (same offsets / masks)
   // (NCONV == 1 with gridDim.z == 2: "pair as grid" -- the second layer is a second workgroup of the same tile)
 #pragma unroll 1
-  while (seq < seq_end) {
+  for (;;) {
   int conv, t0, t1;
+  bool seg_head = false, seg_tail = false;
   if (KSPLIT) {
-    tile = seq / taps;
-    conv = ks_conv; t0 = seq - tile * taps;
-    t1 = min(taps, t0 + (seq_end - seq));
+    conv = ks_conv;
+    if (ks_stage == 0) {
+      if (ks_cur <= ks_last) { tile = ks_cur++; t0 = 0; t1 = taps; }
+      else { ks_stage = 1; continue; }
+    } else if (ks_stage == 1) {
+      ks_stage = 2;
+      if (ks_t1 == 0) continue;
+      tile = ks_fb; t0 = 0; t1 = ks_t1; seg_head = true;
+    } else if (ks_stage == 2) {
+      ks_stage = 3;
+      if (ks_t0 == 0) continue;
+      tile = ks_fa; t0 = ks_t0; t1 = taps; seg_tail = true;
+    } else {
+      break;
+    }
   } else {
+    if (seq >= seq_end) break;
     conv = NCONV == 1 ? (int)blockIdx.z : seq / taps; t0 = 0; t1 = taps;
+    seq += taps;
   }
   if (!first_seg) __syncthreads();                          // every wave is past its last read of the previous segment's A tile / table
   first_seg = false;
@@ -697,20 +725,20 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   // ---- epilogue ------------------------------------------------------------------------------------------------
   auto finish = [&](float v, int ch) { if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
   bool store_out = true;
-  if (KSPLIT && !(t0 == 0 && t1 == taps)) {
-    // a cut tile: the TAIL part (taps [k, 9)) is the first segment of workgroup wg and is finished early in its
-    // life; the HEAD part (taps [0, k)) is the last segment of workgroup wg - 1 (same layer).  The tail's accumulators go to scratch
-    // slot wg - 1 in register layout; the head's owner waits for them at its very end (they are nearly always there),
-    // adds them -- head + tail, the same order whoever arrives first: reproducible -- and finishes the tile.  Workgroups
-    // are dispatched in order and a tail never waits, so the wait cannot deadlock.
-    const bool tail = t0 > 0;
+  if (KSPLIT && (seg_head || seg_tail)) {
+    // a cut tile: its HEAD part (taps [0, k)) belongs to workgroup wg, which computes it in the middle of its life and
+    // leaves the accumulators in scratch slot wg (register layout); its TAIL part (taps [k, 9)) is the LAST segment of
+    // workgroup wg + 1, which then adds the head's image -- tail + head, a fixed order: reproducible -- and finishes the
+    // tile.  A workgroup never waits before it has published its own head, and lower-numbered workgroups are dispatched
+    // first, so the wait cannot deadlock.
+    const bool tail = seg_tail;
     const int slot = tail ? wg - 1 : wg;
     float* sc = P.ks_scratch + (size_t)slot * (MT * 8 * 16 * 64) + (size_t)wave * 16 * 64 + lane;
     int* flag = P.ks_flags + slot;
 #if ORP_DCN_KS_DBG & 1
-    if (tail) store_out = false;
+    if (!tail) store_out = false;
 #elif ORP_DCN_KS_DBG & 2
-    if (tail) {
+    if (!tail) {
 #pragma unroll
       for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -734,7 +762,7 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
     // Every access to the scratch image and its flag is an agent-scope atomic (write-through / cache-bypassing per
     // INSTRUCTION): an agent-scope fence instead would write back and invalidate the whole L2 of the XCD -- the packed
     // weights every other workgroup streams from it (measured: 575 us with fences vs 520 us without the split).
-    if (tail) {
+    if (!tail) {
 #pragma unroll
       for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -835,7 +863,6 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
     }
   }
   }
-  seq += t1 - t0;
   }
 }
 
