@@ -804,7 +804,9 @@ def main():
         if d and args.batch == d.get('batch') and IMG == d.get('img', 1024):
             traffic = d.get('hbm_bytes_per_launch')
         traffic_src = pmc_note
-        roof = dict(kernel='dcn_fwd_mfma2_kernel<3, nchw, 2 layers, tap-granular split>' if os.environ.get('ORP_DCN_KSPLIT') != '0'
+        tiles = sum((args.batch * (IMG // s_) ** 2 + 95) // 96 for s_ in (8, 16, 32, 64, 128))
+        split = os.environ.get('ORP_DCN_KSPLIT') != '0' and tiles > 256 and tiles * 9 * 105 <= ((tiles + 255) // 256) * 18 * 128 * 100   # the library's rule (csrc/orp_dcn.hip)
+        roof = dict(kernel='dcn_fwd_mfma2_kernel<3, nchw, 2 layers, tap-granular split>' if split
                     else 'dcn_fwd_mfma2_kernel<3, nchw, 2 layers>', bound='mfma', achieved=achieved,
                     peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=traffic,
                     traffic_source=traffic_src, avg_launch_us=avg_s * 1e6, launches=dcn_n, layers_per_launch=layers,
@@ -812,8 +814,8 @@ def main():
                     algorithmic_bytes_per_launch=alg_bytes,
                     note='exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense = the fp32 vector peak; a register-'
                          'operand microbenchmark of the instruction sustains 146-156 TFLOP/s on this part: '
-                         'tests/checks/mfma_rate.hip); one launch per image = cls + refine DeformConv over all levels, the layer\'s '
-                         '(tile, tap) steps split evenly over 128 workgroups per layer (XCDs 0-3 / 4-7)')
+                         'tests/checks/mfma_rate.hip); one launch per image = cls + refine DeformConv over all levels (launches of '
+                         'more tiles than CUs split each layer\'s (tile, tap) steps evenly over 128 workgroups, XCDs 0-3 / 4-7)')
     # ---- the rotated-IoU + NMS stage (HBM is the formal bound, the work is fp32 VALU) --------------------------------
     mask_ms, mask_n = prof['nms_mask']
     nms = None

@@ -143,6 +143,8 @@ int orp_dcn_fast_path_ok(int c_in, int c_out, int kh, int kw, int groups, int de
 /* `packed` holds orp_dcn_packed_weight_floats() floats: [kh*kw][Cin][Cout] followed by [kh*kw][Cin/4][Cout][4]. */
 size_t orp_dcn_packed_weight_floats(int c_out, int c_in, int kh, int kw);
 int orp_dcn_pack_weight(const float* weight, int c_out, int c_in, int kh, int kw, float* packed, void* stream);
+/* (includes 25 MB of scratch for launches of more tiles than CUs: those split every layer's (tile, tap) steps evenly over
+ * the workgroups, and the accumulators of a tile cut between two workgroups pass through it -- fixed order, reproducible) */
 size_t orp_dcn_forward_workspace_bytes(const orp_dcn_level* levels_host, int nlevels, int batch, int c_in, int in_layout);
 int orp_dcn_forward_multi(const orp_dcn_level* levels_host, int nlevels, int batch, int c_in, int c_out,
                           const float* weight_packed, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,

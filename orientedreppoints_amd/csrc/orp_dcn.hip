@@ -1120,8 +1120,11 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
     for (int i = ntl; i < 2 * MAX_LEVELS; i++) { TL.in[i] = TL.in[0]; TL.out[i] = TL.out[0]; TL.hw[i] = 0; }
     hipLaunchKernelGGL(nchw_to_nhwc_multi_kernel, dim3(tbx, (c_in + 31) / 32, batch), dim3(256), 0, st, TL, c_in);
   }
-  // tap-granular split: when whole tiles leave the CUs unevenly loaded (228 tiles on 256 CUs: 18 tap steps on the busy
-  // ones, 16.03 on average).  ORP_DCN_KSPLIT=0 / 1: dev aid (off / whenever possible)
+  // tap-granular split: for launches of MORE tiles than CUs, where whole tiles leave a partly filled last round (456 tiles
+  // on 256 CUs: 36 tap steps on the busiest CU, 32.06 on average: 906 - 925 us against 964 us, 0.72 against 0.68 of peak at
+  // 2 x 1024^2).  A one-round launch (228 tiles, one 1024^2 image) gains 2 % in time (479 against 488 us) and pays for it
+  // with 4.5 x the fabric traffic (672 MB against 150 MB per launch: each XCD then has twice the span of input rows live,
+  // see the kernel) -- not taken.  ORP_DCN_KSPLIT=0 / 1: dev aid (off / whenever possible)
   static const int ks_env = getenv("ORP_DCN_KSPLIT") ? atoi(getenv("ORP_DCN_KSPLIT")) : -1;
   bool use_ks = false;
   if (gen == 2 && MT == 3 && !heads && c_in == 256 && c_out == 256 && ks_env != 0 && workspace &&
@@ -1131,7 +1134,7 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
     const long per_old = (long)((tiles + nwg - 1) / nwg) * nconv * taps;          // ... of the busiest CU with whole tiles
     wsp = reinterpret_cast<char*>(align256_(reinterpret_cast<size_t>(wsp)));
     if (wsp + ks_bytes() <= ws_end && total / wpl >= taps && total < (1L << 30) &&
-        (ks_env == 1 || total * 105 <= per_old * wpl * 100)) {
+        (ks_env == 1 || (tiles > nwg && total * 105 <= per_old * wpl * 100))) {
       P.ks_scratch = reinterpret_cast<float*>(wsp);
       P.ks_flags = reinterpret_cast<int*>(wsp + align256_((size_t)nwg * kKsSlotBytes));
       P.ks_nwg = nwg; P.ks_total = (int)total;

@@ -449,12 +449,13 @@ def test_dcn_pair_at_1536_patch_shapes_vs_torch_reference(dev, oracle):
             assert float((got - want).abs().max()) <= 1e-4 * scale, lvl
 
 
-@pytest.mark.parametrize("B,channels_last,relu", [(1, False, True), (1, True, False), (2, False, False)])
+@pytest.mark.parametrize("B,channels_last,relu", [(1, False, True), (1, True, False), (2, False, False), (2, True, True),
+                                                   (3, False, True)])
 def test_dcn_pair_tap_split_launch_at_1024_shapes(dev, B, channels_last, relu):
     """The configs[1] / configs[2] launches themselves: all five levels of 1024^2 image(s), both head DeformConvs in one
-    launch.  228 (456) tiles do not divide over 256 CUs, so the launch is the tap-granular split: workgroups walk equal
-    ranges of the (tile, layer, tap) sequence and a cut tile is finished by the owner of its head part (head + tail
-    partial sums).  Checker: the plain PyTorch fp32 DeformConv (pinned to the oracle in the 1536 test); the result must
+    launch.  B = 1: 228 whole tiles, one round.  B = 2, 3: 456 / 683 tiles do not divide over 256 CUs, so the launch is
+    the tap-granular split: XCDs 0-3 / 4-7 take one layer each, workgroups walk equal ranges of the layer's (tile, tap)
+    sequence and a cut tile is finished by the owner of its tail part (tail + head partial sums).  Checker: the plain PyTorch fp32 DeformConv (pinned to the oracle in the 1536 test); the result must
     also be bitwise reproducible launch to launch (the partial sums are always added in the same order)."""
     from orientedreppoints_amd.mmdet_ops import deform_conv_forward_pair
     torch.manual_seed(6 + B)
