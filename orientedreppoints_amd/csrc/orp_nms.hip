@@ -176,16 +176,24 @@ nms_rankprep_kernel(const float* __restrict__ dets, int32_t* __restrict__ seg_of
 //      terms the tree does not cover); B3 one lane per pair -- ordered sum, threshold, atomicOr into the row's word.
 //      Heavy work is thus packed densely into wavefronts instead of idling next to resolved pairs.
 // one (rpb rows x 64 columns) tile: phase A, queue, phase B, mask words out
-// Compile-time switches of the round-3 changes (all on; tools/build_variant.py builds A/B variants with -D...=0):
-//   ORP_NMS_ROWLDS    phase A reads its wave-uniform row (vertices, max |coordinate|, |area|, flags) from the tile's LDS
+// Compile-time switches of the round-3 changes (tools/build_variant.py builds A/B variants with -D...=0 / 1; measured on the
+// 2 000-box, 15-class scene of the bench, profiles/r03_nms_variants_*.log, r03_nms_decomp_a.log):
+//   ORP_NMS_ROWLDS    (off) phase A reads its wave-uniform row (vertices, max |coordinate|, |area|, flags) from the tile's LDS
 //                     copy with the NEXT row's reads issued before the current row's arithmetic, instead of ~11 scalar
 //                     global loads per row in front of it; the unresolved columns of a row are parked as one mask word
-//                     and filed after the row loop with ONE LDS reservation per wave (was one returning LDS atomic per row)
-//   ORP_NMS_DIAGLAST  tiles on the diagonal (half of their pairs are below it: half the work) are enumerated last, so the
-//                     final partial round of workgroups is made of the cheap tiles
-//   ORP_NMS_XCD       XCD-aware tile map for single segments with >= 16 column blocks: workgroup b (XCD b % 8 on gfx950)
-//                     only visits the column blocks of its XCD's set, so a column record is fetched into ONE L2
-//   ORP_NMS_AGGAPPEND the non-zero words of a tile are appended to the segment's side list with one reservation per tile
+//                     and filed after the row loop with ONE LDS reservation per wave.  Measured slower: the row operands
+//                     move from SGPRs to VGPRs and the VALU count, which is what bounds the kernel, goes up
+//   ORP_NMS_DIAGLAST  (on) tiles on the diagonal (half of their pairs are below it: half the work) are enumerated last, so
+//                     the final partial round of workgroups is made of the cheap tiles
+//   ORP_NMS_XCD       (on, where it applies) XCD-aware tile map for single segments whose column-block count is a multiple
+//                     of 16 (2 048-box capacity launches): workgroup b (XCD b % 8 on gfx950) only visits the column blocks of
+//                     its XCD's set, so a column record is fetched into ONE L2 (FETCH 2.7 -> 2.2 MB per launch)
+//   ORP_NMS_AGGAPPEND (on) the non-zero words of a tile are appended to the segment's side list with one reservation per tile
+//                     (WRITE 2.4 -> 1.4 MB per launch)
+// Together with the padded edge tables (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.46 -> 0.33): 83 -> 75 us.  What bounds the
+// kernel is fp32 VALU issue: per-workgroup timeline (ORP_NMS_PHASE_PROF) shows 4 resident workgroups per CU for the first
+// 45 us of the launch, phase A 22 k + drain 28 k of the 57 k cycles of a tile, and the timing-only variants (ORP_NMS_DBG) put
+// the classifier alone at 34 us, the term evaluation at another 47 us.
 #ifndef ORP_NMS_ROWLDS
 #define ORP_NMS_ROWLDS 0
 #endif
