@@ -241,8 +241,11 @@ __device__ inline float half_wave_sum(float v) {
 }
 
 // ---- kernel A: grad_input + grad_offset ---------------------------------------------------------------------------
-// One tile = one 32-position chunk (MT = 1: three workgroups per CU hide the epilogue's load / atomic latency; two
-// sub-tiles per workgroup measured 5 % slower).
+// One tile = one 32-position chunk (MT = 1: two to three workgroups per CU hide the epilogue's load / atomic latency; two
+// sub-tiles per workgroup measured 5 % slower in round 2, and again in round 3 for the G-row variant: 64 positions per
+// workgroup halve the L2 -> CU weight stream (3.2 GB per launch) but leave one workgroup per CU (140 KB of LDS); even with
+// the x values of a tap's coordinate derivatives loaded one group of rows ahead of their use: 1 356 vs 1 231 us for
+// grad_input + grad_offset at 2 x 21 824 positions).
 template <int MT, bool STORE_G>
 __global__ void __launch_bounds__(kThreads)
 dcn_bwd_input_kernel(const BwdParams P) {
