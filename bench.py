@@ -770,6 +770,7 @@ def main():
     dets = cap.get('dets')
     M = int(dets.shape[0]) if dets is not None else 0
     nms_us = None
+    nms_graph_us = None
     if M > 0:
         from orientedreppoints_amd.mmdet_ops.nms_wrapper import rnms_device
         for _ in range(3):
@@ -781,6 +782,29 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         nms_us = e0.elapsed_time(e1) / 20 * 1e3
+        # the same call as the deployment runs it: inside a captured graph (no launch gaps between its three kernels)
+        nms_graph_us = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                rnms_device(dets, cap['thr'])
+            torch.cuda.current_stream().wait_stream(side)
+            g_nms = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_nms):
+                for _ in range(10):
+                    rnms_device(dets, cap['thr'])
+            g_nms.replay()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(4):
+                g_nms.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            nms_graph_us = e0.elapsed_time(e1) / 40 * 1e3
+            del g_nms
+        except Exception as ex:   # noqa: BLE001
+            nms_graph_us = 'failed: %s' % (str(ex)[:120],)
 
     # ---- roofline of the dominant hot-path kernel: the DeformConv implicit GEMM (exact-fp32 MFMA) -------------------
     # ONE launch per image runs both DeformConvs of the head (cls + refine share their offsets: orp_dcn_forward_pair) over
@@ -824,7 +848,7 @@ def main():
         cb = (M + 63) // 64
         alg_bytes = 36.0 * M + 8.0 * M * cb       # SURVEY 8d, mask formulation
         pairs = M * (M - 1) / 2.0
-        nms = dict(stage_us_per_img=nms_us, boxes=M, mask_kernel_us=avg_s * 1e6,
+        nms = dict(stage_us_per_img=nms_us, stage_us_per_img_in_graph=nms_graph_us, boxes=M, mask_kernel_us=avg_s * 1e6,
                    sweep_kernel_us=(prof['nms_sweep'][0] / prof['nms_sweep'][1] * 1e3) if prof['nms_sweep'][1] else None,
                    algorithmic_bytes_per_launch=alg_bytes, hbm_gbs=alg_bytes / avg_s / 1e9,
                    hbm_frac=alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, pairs_per_launch=pairs,
