@@ -51,6 +51,9 @@
 #ifndef ORP_BWD_SPLITACC
 #define ORP_BWD_SPLITACC 0   // kernel A: even / odd k-steps into two independent accumulator tiles (measured: 792 vs 791 us, +16 VGPRs: off)
 #endif
+#ifndef ORP_BWD_WDIST
+#define ORP_BWD_WDIST 3      // kernel A: weight fragments fetched this many chunks ahead (ring of WDIST + 1 slots; 1, 3 or 7)
+#endif
 #ifndef ORP_BWD_DBG
 #define ORP_BWD_DBG 0      // dev aid, compile-time (timing only, wrong results): 1 = no grad_input atomics, 2 = no x loads / derivative reduction, 4 = no G store, 8 = no epilogue at all, 16 = scatter kernel without G row reads, 32 = scatter kernel without accumulator updates
 #endif
@@ -245,7 +248,10 @@ __device__ inline float half_wave_sum(float v) {
 // sub-tiles per workgroup measured 5 % slower in round 2, and again in round 3 for the G-row variant: 64 positions per
 // workgroup halve the L2 -> CU weight stream (3.2 GB per launch) but leave one workgroup per CU (140 KB of LDS); even with
 // the x values of a tap's coordinate derivatives loaded one group of rows ahead of their use: 1 356 vs 1 231 us for
-// grad_input + grad_offset at 2 x 21 824 positions).
+// grad_input + grad_offset at 2 x 21 824 positions).  Also measured on the one-chunk kernel, dense path: the epilogue's x
+// loads issued one group of four rows ahead of their use (1 203 - 1 215 vs 1 217 - 1 219 us: nothing; +40 VGPRs).  PMC:
+// ~1 400 non-MFMA VALU instructions per wave and tap next to 128 MFMAs -- the per-row address / select / DPP work of the
+// epilogue, replicated over the 64 lanes, is what the matrix pipe waits for.
 template <int MT, bool STORE_G>
 __global__ void __launch_bounds__(kThreads)
 dcn_bwd_input_kernel(const BwdParams P) {
@@ -301,8 +307,12 @@ dcn_bwd_input_kernel(const BwdParams P) {
     r[0] = *reinterpret_cast<const float4*>(base);
     r[1] = *reinterpret_cast<const float4*>(base + (size_t)2 * CH * 4);
   };
-  float4 bq[2];
-  load_bq(0, 0, bq);
+  // the weight fragments of chunk (tap, j) are fetched WD chunks ahead of their use: one chunk is 8 MFMAs = 512 cycles
+  // of matrix work per wave, an L2 hit takes longer than that (measured: 1 221 vs 1 245 us at WD = 3 vs 1; 7 costs occupancy)
+  constexpr int WD = ORP_BWD_WDIST;
+  float4 bqr[WD + 1][2];
+#pragma unroll
+  for (int d = 0; d < WD; d++) load_bq(d / (CH / 16), d % (CH / 16), bqr[d]);
 
 #pragma unroll 1
   for (int tap = 0; tap < taps; tap++) {
@@ -316,10 +326,16 @@ dcn_bwd_input_kernel(const BwdParams P) {
 #endif
 #pragma unroll
     for (int j = 0; j < CH / 16; j++) {
-      float4 bn[2];
-      const bool last = (j + 1 == CH / 16);
-      if (!(last && tap + 1 == taps)) load_bq(last ? tap + 1 : tap, last ? 0 : j + 1, bn);
-      else bn[0] = bn[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // (16 chunks per tap and WD + 1 ring slots: the slot of chunk (tap, j) is j % (WD + 1), a compile-time index because
+      // the ring length divides 16)
+      static_assert((CH / 16) % (WD + 1) == 0, "ring length must divide the chunks per tap");
+      float4 (&bq)[2] = bqr[j % (WD + 1)];
+      {
+        const int jn = j + WD;                                       // the chunk WD ahead: this tap's or the next one's
+        float4 (&bn)[2] = bqr[(j + WD) % (WD + 1)];
+        if (jn < CH / 16) load_bq(tap, jn, bn);
+        else if (tap + 1 < taps) load_bq(tap + 1, jn - CH / 16, bn);
+      }
       const float* arow = sG + (size_t)mrow * ASTR + j * 16 + 4 * kh;
 #pragma unroll
       for (int t = 0; t < 2; t++) {
@@ -340,7 +356,6 @@ dcn_bwd_input_kernel(const BwdParams P) {
           }
         }
       }
-      bq[0] = bn[0]; bq[1] = bn[1];
     }
 #if ORP_BWD_SPLITACC
 #pragma unroll
