@@ -7,6 +7,10 @@ cd $R
 O=gpurun_out
 mkdir -p $O
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${TAG}_smoke.log 2>&1
+# counter passes first: bench.py quotes `traffic` from profiles/<tag>_pmc.json only when it was collected on the running build
+bash tools/pmc_all.sh > $O/${TAG}_pmc_all.log 2>&1
+python tools/make_pmc_json.py profiles/${TAG} $O/pmc_fetch $O/pmc_write $O/pmc_sqa $O/pmc_sqb > /dev/null 2>&1
+cp profiles/${TAG}_pmc.json profiles/${TAG}_pmc.txt $O/ 2>/dev/null
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python bench.py --model r101 --batch 2 --steps 60 --no-cpu-baseline > $O/${TAG}_bench_r101_b2.json 2>/dev/null
 python bench.py --size 1536 --steps 60 --no-cpu-baseline > $O/${TAG}_bench_1536.json 2>/dev/null
@@ -18,9 +22,8 @@ python tests/checks/time_dcn_pair.py > $O/${TAG}_dcn_pair.log 2>&1
 ORP_DCN_KSPLIT=0 python tests/checks/time_dcn_pair.py >> $O/${TAG}_dcn_pair.log 2>&1
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/${TAG}_prof_bench -- python $R/bench.py --steps 30 --no-cpu-baseline --pipeline 1 > $R/$O/${TAG}_prof_bench.log 2>&1)
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/${TAG}_prof_train -- python $R/bench.py --mode train --steps 12 > $R/$O/${TAG}_prof_train.log 2>&1)
-bash tools/pmc_all.sh > $O/${TAG}_pmc_all.log 2>&1
 tail -2 $O/${TAG}_smoke.log; tail -c 600 $O/${TAG}_bench.json; echo; tail -c 300 $O/${TAG}_bench_train.json
-# locally afterwards:
+# locally afterwards (profiles/ on the GPU box is a scratch copy):
 #   python tools/make_pmc_json.py profiles/<tag> gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sqa gpurun_out/pmc_sqb
 #   python tools/summarize_prof.py gpurun_out/<tag>_prof_bench profiles/<tag>_bench
 #   python tools/summarize_train_prof.py gpurun_out/<tag>_prof_train profiles/<tag>_train_step.txt
