@@ -49,7 +49,7 @@
 #define ORP_DCN_WDIST 1    // weight prefetch distance (chunks) of the single-layer second-generation kernel: 1 or 2 (2: measured, no gain)
 #endif
 #ifndef ORP_DCN_KS_DBG
-#define ORP_DCN_KS_DBG 0   // dev aid for the tap-granular split (timing only unless 2): 1 = no hand-over of the cut tiles at all, 2 = hand-over with agent-scope fences instead of scoped accesses, 4 = coefficient table built once only
+#define ORP_DCN_KS_DBG 0   // dev aid for the tap-granular split (timing only): 1 = no hand-over of the cut tiles at all, 4 = coefficient table built once only
 #endif
 #ifndef ORP_DCN_DBG
 #define ORP_DCN_DBG 0      // dev aid, compile-time (timing only, wrong results): 1 = no A gather, 2 = no weight loads, 4 = no per-tap barriers / LDS refill, 8 = no MFMA
@@ -408,34 +408,38 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   const int taps = P.kh * P.kw;
   // XCD-aware remap: hardware places block b on XCD b % 8; give XCD x a contiguous slab of the work
   //   plain:  workgroup = tile, XCD x takes the tiles [x*per, (x+1)*per)
-  //   KSPLIT: a layer is the linear sequence of its (tile, tap) steps, cut into equal ranges [seq, seq_end): the TAIL of
-  //           one tile (taps t0A .. 8), whole tiles, and the HEAD of another (taps 0 .. t1B - 1).  228 tiles x 9 taps over
-  //           128 workgroups: 16.03 tap steps each instead of 18 on 228 CUs and none on 28.  Measured (round 3, 1024^2,
-  //           one image): 479 us against 488 us with whole tiles in the bench loop (0.684 vs 0.670 of peak), 2 x 1024^2:
-  //           906 - 925 against 964 us.  The step count drops by 11 %, the time by 2 - 6 %: a third segment and a second
-  //           coefficient table per workgroup cost ~15 us, and the L2 serves less of the traffic (rocprofv3 FETCH_SIZE:
-  //           105 MB per launch with whole tiles -- every workgroup of an XCD reads the same tap's 262 KB of weights at the
-  //           same time and the live band of input rows is 28 tiles of ONE layer; 1.0 GB in range order, tail first; 0.6 GB
-  //           as built), which two choices limit:
-  //           * in a pair launch XCDs 0-3 take the first layer and XCDs 4-7 the second: an XCD's 4 MB L2 only ever holds
-  //             ONE layer's 2.36 MB of packed weights, and each layer's weights are fetched by 4 L2s, not 8;
-  //           * a workgroup walks its whole tiles FIRST, then its head, then its tail, so that the workgroups of an XCD
-  //             are within two taps of each other most of the time (in range order each starts at a different tap).
-  //           Cutting between weight chunks inside a tap (16.03 steps for everyone instead of 16 or 17) was measured slower:
-  //           a partial tap still gathers and stages its whole A tile.
+  //   KSPLIT: whole tiles leave the last round of workgroups partly filled (228 tiles on 256 CUs: 18 tap steps on 228 CUs,
+  //           none on 28).  Here an XCD owns a contiguous slab of ONE layer's tiles (pair launch: XCDs 0-3 the first layer,
+  //           4-7 the second -- an XCD's L2 then only ever holds one layer's 2.36 MB of packed weights); its W workgroups
+  //           take the slab's tiles round by round, workgroup i tile r * W + i, exactly as whole-tile scheduling would --
+  //           neighbouring tiles run at the same time and share their halo rows in the L2, every workgroup is at the same
+  //           tap -- and only the LAST, partial round is split: its `rem` tiles form a sequence of rem * 9 tap steps cut
+  //           into W equal ranges.  A range is shorter than a tile, so a workgroup gets the tail (or a middle part) of one
+  //           tile and possibly the head of the next; the parts of a tile hand their accumulators down the chain head ->
+  //           middle -> tail through scratch images (see the epilogue).  57 tiles on 32 workgroups: 9 + 7.03 tap steps.
+  //           Measured (round 3): 2 x 1024^2 (456 tiles) 933 us against 962 us with whole tiles, FETCH_SIZE 316 MB against
+  //           220 MB per launch; ONE image (228 tiles) 529 against 516 us -- a third segment per workgroup (coefficient
+  //           table, exposed first gather, hand-over) costs what 1.5 tap steps save, so one-round launches keep whole
+  //           tiles.  First version: one contiguous range of the layer's (tile, tap) sequence per workgroup -- same step
+  //           count, but concurrently running workgroups were 1.8 tiles apart and at different taps: 906 - 925 us at
+  //           2 x 1024^2 with 1.92 GB fetched per launch (the whole weight stream and every halo row from the Infinity Cache).
+  //           Cutting inside a tap: slower, a partial tap still gathers and stages its whole A tile.
   int tile = 0, wg = 0, seq = 0, seq_end = NCONV * taps, ks_conv = 0;
-  int ks_stage = 0, ks_cur = 0, ks_last = -1, ks_fa = 0, ks_t0 = 0, ks_fb = 0, ks_t1 = 0;
+  int ks_stage = 0, ks_round = 0, ks_nfull = 0, ks_tb = 0, ks_i = 0, ks_per = 1, ks_rs = 0, ks_re = 0, ks_rbase = 0;
   if (KSPLIT) {
-    const int b = blockIdx.x, xcd = b & 7, per = P.ks_nwg >> 3;
-    int idx, wpl;
-    if (NCONV == 2) { ks_conv = xcd >> 2; idx = (xcd & 3) * per + (b >> 3); wpl = P.ks_nwg >> 1; }
-    else { idx = xcd * per + (b >> 3); wpl = P.ks_nwg; }
-    wg = ks_conv * wpl + idx;
-    seq = (int)(((long)idx * P.ks_total) / wpl);
-    seq_end = (int)(((long)(idx + 1) * P.ks_total) / wpl);
-    ks_fa = seq / taps; ks_t0 = seq - ks_fa * taps;              // tail: taps [t0, 9) of tile fa (none when t0 == 0)
-    ks_fb = seq_end / taps; ks_t1 = seq_end - ks_fb * taps;      // head: taps [0, t1) of tile fb (none when t1 == 0)
-    ks_cur = ks_t0 ? ks_fa + 1 : ks_fa; ks_last = ks_fb - 1;     // whole tiles in between
+    const int b = blockIdx.x, xcd = b & 7;
+    ks_per = P.ks_nwg >> 3;                                         // workgroups per XCD
+    ks_i = b >> 3;
+    int xq, nx;
+    if (NCONV == 2) { ks_conv = xcd >> 2; xq = xcd & 3; nx = 4; } else { xq = xcd; nx = 8; }
+    wg = (ks_conv * nx + xq) * ks_per + ks_i;                        // scratch slot; predecessor in the same XCD = wg - 1
+    ks_tb = (int)(((long)xq * total_tiles) / nx);
+    const int te = (int)(((long)(xq + 1) * total_tiles) / nx), slab = te - ks_tb;
+    ks_nfull = slab / ks_per;
+    const int rem = slab - ks_nfull * ks_per;
+    ks_rbase = ks_tb + ks_nfull * ks_per;                            // first tile of the partial round
+    ks_rs = (int)(((long)ks_i * rem * taps) / ks_per);
+    ks_re = (int)(((long)(ks_i + 1) * rem * taps) / ks_per);
   } else {
     const int b = blockIdx.x, per = (total_tiles + 7) >> 3;
     tile = (b & 7) * per + (b >> 3);
@@ -452,20 +456,21 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
 #pragma unroll 1
   for (;;) {
   int conv, t0, t1;
-  bool seg_head = false, seg_tail = false;
   if (KSPLIT) {
     conv = ks_conv;
-    if (ks_stage == 0) {
-      if (ks_cur <= ks_last) { tile = ks_cur++; t0 = 0; t1 = taps; }
+    if (ks_stage == 0) {                                    // whole tiles, round by round
+      if (ks_round < ks_nfull) { tile = ks_tb + ks_round * ks_per + ks_i; ks_round++; t0 = 0; t1 = taps; }
       else { ks_stage = 1; continue; }
-    } else if (ks_stage == 1) {
+    } else if (ks_stage == 1) {                             // the HEAD of the second tile of this range, if it reaches one
       ks_stage = 2;
-      if (ks_t1 == 0) continue;
-      tile = ks_fb; t0 = 0; t1 = ks_t1; seg_head = true;
-    } else if (ks_stage == 2) {
+      const int a = ks_rs / taps;
+      if (ks_re <= (a + 1) * taps) continue;
+      tile = ks_rbase + a + 1; t0 = 0; t1 = ks_re - (a + 1) * taps;
+    } else if (ks_stage == 2) {                             // the part of the first tile: [rs, min(re, end of that tile))
       ks_stage = 3;
-      if (ks_t0 == 0) continue;
-      tile = ks_fa; t0 = ks_t0; t1 = taps; seg_tail = true;
+      if (ks_re <= ks_rs) continue;
+      const int a = ks_rs / taps;
+      tile = ks_rbase + a; t0 = ks_rs - a * taps; t1 = min(ks_re - a * taps, taps);
     } else {
       break;
     }
@@ -725,54 +730,23 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
   // ---- epilogue ------------------------------------------------------------------------------------------------
   auto finish = [&](float v, int ch) { if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
   bool store_out = true;
-  if (KSPLIT && (seg_head || seg_tail)) {
-    // a cut tile: its HEAD part (taps [0, k)) belongs to workgroup wg, which computes it in the middle of its life and
-    // leaves the accumulators in scratch slot wg (register layout); its TAIL part (taps [k, 9)) is the LAST segment of
-    // workgroup wg + 1, which then adds the head's image -- tail + head, a fixed order: reproducible -- and finishes the
-    // tile.  A workgroup never waits before it has published its own head, and lower-numbered workgroups are dispatched
-    // first, so the wait cannot deadlock.
-    const bool tail = seg_tail;
-    const int slot = tail ? wg - 1 : wg;
-    float* sc = P.ks_scratch + (size_t)slot * (MT * 8 * 16 * 64) + (size_t)wave * 16 * 64 + lane;
-    int* flag = P.ks_flags + slot;
-#if ORP_DCN_KS_DBG & 1
-    if (!tail) store_out = false;
-#elif ORP_DCN_KS_DBG & 2
-    if (!tail) {
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) sc[(size_t)(mt * 8 * 16 + r) * 64] = acc[mt][r];
-      __threadfence();
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      store_out = false;
-    } else {
-      if (tid == 0) {
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(4);
-      }
-      __syncthreads();
-      __threadfence();
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[mt][r] += sc[(size_t)(mt * 8 * 16 + r) * 64];
-    }
-#else
-    // Every access to the scratch image and its flag is an agent-scope atomic (write-through / cache-bypassing per
-    // INSTRUCTION): an agent-scope fence instead would write back and invalidate the whole L2 of the XCD -- the packed
+  if (KSPLIT && !(t0 == 0 && t1 == taps)) {
+    // a tile of the partial round is cut into two or three parts owned by consecutive workgroups of the XCD.  The part
+    // that starts at tap 0 (HEAD) leaves its accumulators in its owner's scratch image (register layout) and raises the
+    // owner's flag; a part that starts later waits for its predecessor's image, adds it -- own + (predecessor's), a fixed
+    // order: reproducible -- and either publishes the sum in turn (MIDDLE) or finishes the tile (the part that ends at
+    // tap 9).  A workgroup computes its head BEFORE the part that waits, waits only on a lower-numbered workgroup (those
+    // are dispatched first) and publishes at most once, so the waits cannot deadlock.
+    const bool waits = t0 > 0, publishes = t1 < taps;
+    constexpr size_t kImage = (size_t)MT * 8 * 16 * 64;
+    const size_t lane_off = (size_t)wave * 16 * 64 + lane;
+#if !(ORP_DCN_KS_DBG & 1)
+    // Every access to the scratch images and flags is an agent-scope atomic (write-through / cache-bypassing per
+    // INSTRUCTION): an agent-scope FENCE instead would write back and invalidate the whole L2 of the XCD -- the packed
     // weights every other workgroup streams from it (measured: 575 us with fences vs 520 us without the split).
-    if (!tail) {
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-          __hip_atomic_store(sc + (size_t)(mt * 8 * 16 + r) * 64, acc[mt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // this wave's stores have left (s_waitcnt vmcnt(0)) ...
-      __syncthreads();                                          // ... and so have every other wave's
-      if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      store_out = false;
-    } else {
+    if (waits) {
+      const float* src = P.ks_scratch + (size_t)(wg - 1) * kImage + lane_off;
+      const int* flag = P.ks_flags + (wg - 1);
       if (tid == 0) {
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(4);
       }
@@ -782,9 +756,21 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
       for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int r = 0; r < 16; r++)
-          acc[mt][r] += __hip_atomic_load(sc + (size_t)(mt * 8 * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc[mt][r] += __hip_atomic_load(src + (size_t)(mt * 8 * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (publishes) {
+      float* dst = P.ks_scratch + (size_t)wg * kImage + lane_off;
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          __hip_atomic_store(dst + (size_t)(mt * 8 * 16 + r) * 64, acc[mt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // this wave's stores have left (s_waitcnt vmcnt(0)) ...
+      __syncthreads();                                          // ... and so have every other wave's
+      if (tid == 0) __hip_atomic_store(P.ks_flags + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif
+    if (publishes) store_out = false;
   }
   if (HEADS) {
     // out1[p, k] = sum_c relu(dcn[p, c]) * W1[k, c] + b1[k] (+ residual): every wave holds 32 of the 256 channels of its
@@ -1120,24 +1106,32 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
     for (int i = ntl; i < 2 * MAX_LEVELS; i++) { TL.in[i] = TL.in[0]; TL.out[i] = TL.out[0]; TL.hw[i] = 0; }
     hipLaunchKernelGGL(nchw_to_nhwc_multi_kernel, dim3(tbx, (c_in + 31) / 32, batch), dim3(256), 0, st, TL, c_in);
   }
-  // tap-granular split: for launches of MORE tiles than CUs, where whole tiles leave a partly filled last round (456 tiles
-  // on 256 CUs: 36 tap steps on the busiest CU, 32.06 on average: 906 - 925 us against 964 us, 0.72 against 0.68 of peak at
-  // 2 x 1024^2).  A one-round launch (228 tiles, one 1024^2 image) gains 2 % in time (479 against 488 us) and pays for it
-  // with 4.5 x the fabric traffic (672 MB against 150 MB per launch: each XCD then has twice the span of input rows live,
-  // see the kernel) -- not taken.  ORP_DCN_KSPLIT=0 / 1: dev aid (off / whenever possible)
+  // tap-granular split of the last round of tiles: for launches of MORE tiles than CUs (456 tiles on 256 CUs: 36 tap steps
+  // on the busiest CU with whole tiles, 32.06 on average; 933 against 962 us at 2 x 1024^2).  One-round launches (228 tiles,
+  // one 1024^2 image) keep whole tiles: measured 529 against 516 us (see the kernel).  ORP_DCN_KSPLIT=0 / 1: dev aid (off /
+  // whenever the ranges are at least three taps long)
   static const int ks_env = getenv("ORP_DCN_KSPLIT") ? atoi(getenv("ORP_DCN_KSPLIT")) : -1;
   bool use_ks = false;
   if (gen == 2 && MT == 3 && !heads && c_in == 256 && c_out == 256 && ks_env != 0 && workspace &&
       !(getenv("ORP_DCN_PAIR_GRID") && atoi(getenv("ORP_DCN_PAIR_GRID")) == 1)) {
-    const int nwg = ks_workgroups(), taps = kh * kw, wpl = nwg / nconv;        // workgroups per layer
-    const long total = (long)tiles * taps;                                        // tap steps of one layer
-    const long per_old = (long)((tiles + nwg - 1) / nwg) * nconv * taps;          // ... of the busiest CU with whole tiles
+    const int nwg = ks_workgroups(), taps = kh * kw, per = nwg >> 3, nx = 8 / nconv;      // workgroups per XCD, XCDs per layer
+    // steps of the busiest workgroup: whole tiles (both layers in one workgroup) vs whole-tile rounds + the split last round
+    const long per_old = (long)((tiles + nwg - 1) / nwg) * nconv * taps;
+    long per_new = 0, min_range = taps;
+    for (int x = 0; x < nx; x++) {
+      const int slab = (int)(((long)(x + 1) * tiles) / nx) - (int)(((long)x * tiles) / nx);
+      const int nfull = slab / per, rem = slab - nfull * per;
+      const long steps = (long)nfull * taps + ((long)rem * taps + per - 1) / per;
+      if (steps > per_new) per_new = steps;
+      if (rem > 0 && (long)rem * taps / per < min_range) min_range = (long)rem * taps / per;
+    }
     wsp = reinterpret_cast<char*>(align256_(reinterpret_cast<size_t>(wsp)));
-    if (wsp + ks_bytes() <= ws_end && total / wpl >= taps && total < (1L << 30) &&
-        (ks_env == 1 || (tiles > nwg && total * 105 <= per_old * wpl * 100))) {
+    // (ranges of fewer than 3 taps would cut a tile into long hand-over chains: whole tiles then)
+    if (wsp + ks_bytes() <= ws_end && (long)tiles * taps < (1L << 30) && per >= 1 && min_range >= 3 &&
+        (ks_env == 1 || (tiles > nwg && per_new * 100 <= per_old * 95))) {
       P.ks_scratch = reinterpret_cast<float*>(wsp);
       P.ks_flags = reinterpret_cast<int*>(wsp + align256_((size_t)nwg * kKsSlotBytes));
-      P.ks_nwg = nwg; P.ks_total = (int)total;
+      P.ks_nwg = nwg; P.ks_total = tiles * taps;
       const hipError_t me = hipMemsetAsync(P.ks_flags, 0, sizeof(int) * nwg, st);
       if (me != hipSuccess) return (int)me;
       use_ks = true;

@@ -454,8 +454,9 @@ def test_dcn_pair_at_1536_patch_shapes_vs_torch_reference(dev, oracle):
 def test_dcn_pair_tap_split_launch_at_1024_shapes(dev, B, channels_last, relu):
     """The configs[1] / configs[2] launches themselves: all five levels of 1024^2 image(s), both head DeformConvs in one
     launch.  B = 1: 228 whole tiles, one round.  B = 2, 3: 456 / 683 tiles do not divide over 256 CUs, so the launch is
-    the tap-granular split: XCDs 0-3 / 4-7 take one layer each, workgroups walk equal ranges of the layer's (tile, tap)
-    sequence and a cut tile is finished by the owner of its tail part (tail + head partial sums).  Checker: the plain PyTorch fp32 DeformConv (pinned to the oracle in the 1536 test); the result must
+    the tap-granular split: XCDs 0-3 / 4-7 take one layer each, their workgroups take the tiles round by round and the
+    last, partial round is cut into equal ranges of its (tile, tap) sequence; a cut tile's parts hand their accumulators
+    down the chain head -> middle -> tail (3 images: ranges of 2.8 taps would make the chains long: whole tiles).  Checker: the plain PyTorch fp32 DeformConv (pinned to the oracle in the 1536 test); the result must
     also be bitwise reproducible launch to launch (the partial sums are always added in the same order)."""
     from orientedreppoints_amd.mmdet_ops import deform_conv_forward_pair
     torch.manual_seed(6 + B)
