@@ -45,6 +45,9 @@ SLICES = [
     ("dcn_im2col",       "mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu",        84, 243),
     ("dcn_col2im",       "mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu",       279, 335),
     ("dcn_col2im_coord", "mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu",       373, 436),
+    # DCNv2: dmcn_im2col_bilinear / dmcn_get_gradient_weight / dmcn_get_coordinate_weight (:467-568) and the three
+    # modulated kernels im2col (:570-633), col2im (:635-693), col2im_coord (:695-767)
+    ("dcn_modulated",    "mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu",       467, 767),
 ]
 
 

@@ -478,6 +478,70 @@ def dcn_backward(x, offset, weight, grad_out, stride=1, pad=1, dil=1, dg=1, use_
     return gi, goff, gw
 
 
+def dcn_v2_im2col(x, offset, mask, kh, kw, pad, stride, dil, dg=1, use_ref=False):
+    """Modulated columns [C*kh*kw, B, Ho, Wo] (deform_conv_cuda_kernel.cu:570-633).  use_ref: the reference's own kernel,
+    driven per image with batch_size = 1 as deform_conv_cuda.cpp:540-545 does."""
+    x, offset, mask = _f32(x), _f32(offset), _f32(mask)
+    B, C, H, W = x.shape
+    Ho, Wo = _odim(H, pad, dil, kh, stride), _odim(W, pad, dil, kw, stride)
+    col = np.zeros((C * kh * kw, B, Ho, Wo), np.float32)
+    if use_ref:
+        for b in range(B):
+            cb = np.zeros((C * kh * kw, Ho, Wo), np.float32)
+            xb, ob, mb = (np.ascontiguousarray(a[b]) for a in (x, offset, mask))
+            ref().ref_dcn_v2_im2col(_p(xb), _p(ob), _p(mb), C, H, W, kh, kw, pad, pad, stride, stride, dil, dil, dg, _p(cb))
+            col[:, b] = cb
+    else:
+        lib().orc_dcn_v2_im2col(_p(x), _p(offset), _p(mask), B, C, H, W, kh, kw, pad, pad, stride, stride, dil, dil, dg,
+                                _p(col))
+    return col
+
+
+def dcn_v2_forward(x, offset, mask, weight, bias=None, stride=1, pad=1, dil=1, dg=1, use_ref=False):
+    """ModulatedDeformConv forward (groups = 1) through the column formulation of deform_conv_cuda.cpp:490-567:
+    out = W . col (fp64 GEMM) + bias, col from the oracle or (use_ref) the reference's modulated im2col kernel."""
+    weight = _f32(weight)
+    Cout, C, kh, kw = weight.shape
+    col = dcn_v2_im2col(x, offset, mask, kh, kw, pad, stride, dil, dg, use_ref)
+    _, B, Ho, Wo = col.shape
+    out = weight.reshape(Cout, -1).astype(np.float64) @ col.reshape(C * kh * kw, -1).astype(np.float64)
+    if bias is not None:
+        out = out + _f32(bias).astype(np.float64)[:, None]
+    return np.ascontiguousarray(out.reshape(Cout, B, Ho, Wo).transpose(1, 0, 2, 3)).astype(np.float32)
+
+
+def dcn_v2_backward(x, offset, mask, weight, grad_out, stride=1, pad=1, dil=1, dg=1, use_ref=False):
+    """(grad_input, grad_offset, grad_mask, grad_weight, grad_bias) of the groups = 1 ModulatedDeformConv through the
+    column formulation of deform_conv_cuda.cpp:569-685: grad_col = W^T grad_out (fp64 GEMM), col2im_coord -> offset and
+    mask gradients, col2im -> input gradient, grad_W = grad_out . col^T over the MODULATED columns, grad_bias = row sums.
+    use_ref: the three column kernels are the reference's own (deform_conv_cuda_kernel.cu:570-767), per image."""
+    x, offset, mask, weight, grad_out = _f32(x), _f32(offset), _f32(mask), _f32(weight), _f32(grad_out)
+    B, C, H, W = x.shape
+    Cout, _, kh, kw = weight.shape
+    Ho, Wo = grad_out.shape[2], grad_out.shape[3]
+    go = grad_out.transpose(1, 0, 2, 3).reshape(Cout, -1).astype(np.float64)           # [Cout, B*Ho*Wo]
+    gcol = (weight.reshape(Cout, -1).astype(np.float64).T @ go).astype(np.float32)     # [C*taps, B*Ho*Wo]
+    gcol = np.ascontiguousarray(gcol).reshape(C * kh * kw, B, Ho, Wo)
+    gi = np.zeros_like(x); goff = np.zeros_like(offset); gm = np.zeros_like(mask)
+    if use_ref:
+        for b in range(B):
+            cb = np.ascontiguousarray(gcol[:, b])
+            xb, ob, mb = (np.ascontiguousarray(a[b]) for a in (x, offset, mask))
+            gib = np.zeros_like(xb); gob = np.zeros_like(ob); gmb = np.zeros_like(mb)
+            ref().ref_dcn_v2_col2im_coord(_p(cb), _p(xb), _p(ob), _p(mb), C, H, W, kh, kw, pad, pad, stride, stride, dil,
+                                          dil, dg, _p(gob), _p(gmb))
+            ref().ref_dcn_v2_col2im(_p(cb), _p(ob), _p(mb), C, H, W, kh, kw, pad, pad, stride, stride, dil, dil, dg,
+                                    _p(gib))
+            gi[b], goff[b], gm[b] = gib, gob, gmb
+    else:
+        lib().orc_dcn_v2_backward_input(_p(gcol), _p(x), _p(offset), _p(mask), B, C, H, W, kh, kw, pad, pad, stride,
+                                        stride, dil, dil, dg, _p(gi), _p(goff), _p(gm))
+    col = dcn_v2_im2col(x, offset, mask, kh, kw, pad, stride, dil, dg, use_ref).reshape(C * kh * kw, -1).astype(np.float64)
+    gw = (go @ col.T).reshape(weight.shape).astype(np.float32)
+    gb = go.sum(axis=1).astype(np.float32)
+    return gi, goff, gm, gw, gb
+
+
 def box_iou_rotated(b1, b2, use_ref=False):
     a, b = _f32(b1), _f32(b2)
     out = np.empty((a.shape[0], b.shape[0]), np.float32)

@@ -266,6 +266,94 @@ void orc_dcn_backward_input(const float* col, const float* im, const float* offs
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
+/* a2, DCNv2 (modulated) column kernels, restated per image exactly as the host side drives them                 */
+/*   (deform_conv_cuda.cpp:490-685 loops over the batch and calls every kernel with batch_size = 1):            */
+/*   modulated_deformable_im2col_gpu_kernel (deform_conv_cuda_kernel.cu:570-633): col = bilinear * mask;         */
+/*   modulated_deformable_col2im_gpu_kernel (:635-693): grad_im += gradient_weight * col * mask;                 */
+/*   modulated_deformable_col2im_coord_gpu_kernel (:695-767): grad_offset = sum_c coordinate_weight * col * mask, */
+/*   grad_mask = sum_c col * bilinear (only where the sample lies inside (-1, H) x (-1, W)).                     */
+/*   All sums over channels are carried in double here (the reference: float, thread-serial over channels).      */
+/* ------------------------------------------------------------------------------------------------------- */
+/* col [C*taps][B][Ho][Wo], mask [B, dg*taps, Ho, Wo] */
+void orc_dcn_v2_im2col(const float* im, const float* offset, const float* mask, int B, int C, int H, int W, int kh,
+                       int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg,
+                       float* col) {
+  int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  int taps = kh * kw, cpdg = C / dg;
+  for (int c = 0; c < C; c++)
+    for (int b = 0; b < B; b++) {
+      const float* imp = im + ((size_t)b * C + c) * H * W;
+      const float* op = offset + ((size_t)b * dg + c / cpdg) * 2 * taps * Ho * Wo;
+      const float* mp = mask + ((size_t)b * dg + c / cpdg) * taps * Ho * Wo;
+      for (int t = 0; t < taps; t++)
+        for (int ho = 0; ho < Ho; ho++)
+          for (int wo = 0; wo < Wo; wo++) {
+            size_t sp = (size_t)ho * Wo + wo;
+            float h_im = (ho * stride_h - pad_h) + (t / kw) * dil_h + op[(size_t)(2 * t) * Ho * Wo + sp];
+            float w_im = (wo * stride_w - pad_w) + (t % kw) * dil_w + op[(size_t)(2 * t + 1) * Ho * Wo + sp];
+            float val = 0;
+            if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) val = dcn_bilinear(imp, W, H, W, h_im, w_im);
+            col[(((size_t)c * taps + t) * B + b) * Ho * Wo + sp] = val * mp[(size_t)t * Ho * Wo + sp];
+          }
+    }
+}
+
+/* col [C*taps][B][Ho][Wo] -> grad_im [B,C,H,W], grad_offset [B,dg*2*taps,Ho,Wo], grad_mask [B,dg*taps,Ho,Wo] */
+void orc_dcn_v2_backward_input(const float* col, const float* im, const float* offset, const float* mask, int B, int C,
+                               int H, int W, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                               int dil_h, int dil_w, int dg, float* grad_im, float* grad_offset, float* grad_mask) {
+  int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  int taps = kh * kw, cpdg = C / dg;
+  size_t nI = (size_t)B * C * H * W, nO = (size_t)B * dg * 2 * taps * Ho * Wo, nM = nO / 2;
+  double* gi = (double*)calloc(nI, sizeof(double));
+  double* go = (double*)calloc(nO, sizeof(double));
+  double* gm = (double*)calloc(nM, sizeof(double));
+  for (int c = 0; c < C; c++)
+    for (int t = 0; t < taps; t++)
+      for (int b = 0; b < B; b++)
+        for (int ho = 0; ho < Ho; ho++)
+          for (int wo = 0; wo < Wo; wo++) {
+            int g = c / cpdg;
+            size_t sp = (size_t)ho * Wo + wo;
+            const float* op = offset + ((size_t)b * dg + g) * 2 * taps * Ho * Wo;
+            float m = mask[(((size_t)b * dg + g) * taps + t) * Ho * Wo + sp];
+            float h_im = (ho * stride_h - pad_h) + (t / kw) * dil_h + op[(size_t)(2 * t) * Ho * Wo + sp];
+            float w_im = (wo * stride_w - pad_w) + (t % kw) * dil_w + op[(size_t)(2 * t + 1) * Ho * Wo + sp];
+            float top = col[(((size_t)c * taps + t) * B + b) * Ho * Wo + sp];
+            const float* imp = im + ((size_t)b * C + c) * H * W;
+            int inside = (h_im > -1 && w_im > -1 && h_im < H && w_im < W);
+            if (inside) {
+              /* (:657) cur_top_grad = col * mask, then the bilinear gradient weights of the four neighbours */
+              float topm = top * m;
+              int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+              float lh = h_im - hl, lw = w_im - wl;
+              for (int dy = 0; dy < 2; dy++)
+                for (int dx = 0; dx < 2; dx++) {
+                  int y = hl + dy, x = wl + dx;
+                  if (y < 0 || y >= H || x < 0 || x >= W) continue;
+                  float wgt = (dy ? lh : 1 - lh) * (dx ? lw : 1 - lw);
+                  gi[(((size_t)b * C + c) * H + y) * W + x] += (double)wgt * topm;
+                }
+              /* (:748-751) mval += col * bilinear */
+              gm[(((size_t)b * dg + g) * taps + t) * Ho * Wo + sp] += (double)top * dcn_bilinear(imp, W, H, W, h_im, w_im);
+            }
+            float ih = h_im, iw = w_im;
+            if (!inside) { ih = iw = -2; }
+            /* (:753-756) val += weight * col * mask */
+            go[(((size_t)b * dg + g) * 2 * taps + 2 * t) * Ho * Wo + sp] +=
+                (double)(dcn_coordinate_weight(ih, iw, H, W, imp, W, 0) * top * m);
+            go[(((size_t)b * dg + g) * 2 * taps + 2 * t + 1) * Ho * Wo + sp] +=
+                (double)(dcn_coordinate_weight(ih, iw, H, W, imp, W, 1) * top * m);
+          }
+  for (size_t i = 0; i < nI; i++) grad_im[i] = (float)gi[i];
+  for (size_t i = 0; i < nO; i++) grad_offset[i] = (float)go[i];
+  for (size_t i = 0; i < nM; i++) grad_mask[i] = (float)gm[i];
+  free(gi); free(go); free(gm);
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
 /* a9: box_iou_rotated (cx,cy,w,h,theta[rad])                                                                */
 /*   mmdet/ops/box_iou_rotated/src/box_iou_rotated_utils.h:50-341: vertices (:57-76), edge intersections +      */
 /*   contained vertices (:78-156), Graham scan with the CUDA branch's exchange sort (:159-271), fan area          */

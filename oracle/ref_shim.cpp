@@ -71,6 +71,7 @@ namespace nsref_dcn { using std::min; using std::max;
 #include "dcn_im2col.inc"
 #include "dcn_col2im.inc"
 #include "dcn_col2im_coord.inc"
+#include "dcn_modulated.inc"
 }
 // polyiou.cpp is plain C++: include it whole (its std headers are already guarded above).
 namespace nsref_polyiou {
@@ -292,6 +293,56 @@ void ref_dcn_col2im_coord(const float* col, const float* im, const float* offset
     nsref_dcn::deformable_col2im_coord_gpu_kernel<float>(n, col, im, offset, C, H, W, kh, kw, pad_h, pad_w, stride_h,
                                                          stride_w, dil_h, dil_w, C * kh * kw / dg, B,
                                                          2 * kh * kw * dg, dg, Ho, Wo, grad_offset);
+  }
+  blockIdx.x = 0; gridDim.x = 1;
+}
+
+// DCNv2: modulated_deformable_{im2col,col2im,col2im_coord}_gpu_kernel (deform_conv_cuda_kernel.cu:570-767) under the
+// 1-thread-per-block emulation, driven PER IMAGE with batch_size = 1 exactly as the reference's host side does
+// (deform_conv_cuda.cpp:540-545, 636-655).  Single-image layouts: im [C,H,W], offset [dg*2*taps,Ho,Wo],
+// mask [dg*taps,Ho,Wo], col [C*taps][Ho*Wo].
+void ref_dcn_v2_im2col(const float* im, const float* offset, const float* mask, int C, int H, int W, int kh, int kw,
+                       int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg, float* col) {
+  int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  int n = C * 1 * Ho * Wo;
+  blockDim.x = 1; threadIdx.x = 0; gridDim.x = n;
+  for (int b = 0; b < n; b++) {
+    blockIdx.x = b;
+    nsref_dcn::modulated_deformable_im2col_gpu_kernel<float>(n, im, offset, mask, H, W, kh, kw, pad_h, pad_w, stride_h,
+                                                             stride_w, dil_h, dil_w, C / dg, 1, C, dg, Ho, Wo, col);
+  }
+  blockIdx.x = 0; gridDim.x = 1;
+}
+// grad_im [C,H,W] accumulated (caller zeroes)
+void ref_dcn_v2_col2im(const float* col, const float* offset, const float* mask, int C, int H, int W, int kh, int kw,
+                       int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg, float* grad_im) {
+  int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  int n = C * kh * kw * 1 * Ho * Wo;
+  blockDim.x = 1; threadIdx.x = 0; gridDim.x = n;
+  for (int b = 0; b < n; b++) {
+    blockIdx.x = b;
+    nsref_dcn::modulated_deformable_col2im_gpu_kernel<float>(n, col, offset, mask, C, H, W, kh, kw, pad_h, pad_w,
+                                                             stride_h, stride_w, dil_h, dil_w, C / dg, 1, dg, Ho, Wo,
+                                                             grad_im);
+  }
+  blockIdx.x = 0; gridDim.x = 1;
+}
+// grad_offset [dg*2*taps,Ho,Wo], grad_mask [dg*taps,Ho,Wo]
+void ref_dcn_v2_col2im_coord(const float* col, const float* im, const float* offset, const float* mask, int C, int H,
+                             int W, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                             int dil_w, int dg, float* grad_offset, float* grad_mask) {
+  int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  int n = 1 * Ho * Wo * 2 * kh * kw * dg;
+  blockDim.x = 1; threadIdx.x = 0; gridDim.x = n;
+  for (int b = 0; b < n; b++) {
+    blockIdx.x = b;
+    nsref_dcn::modulated_deformable_col2im_coord_gpu_kernel<float>(n, col, im, offset, mask, C, H, W, kh, kw, pad_h,
+                                                                   pad_w, stride_h, stride_w, dil_h, dil_w,
+                                                                   C * kh * kw / dg, 1, 2 * kh * kw * dg, dg, Ho, Wo,
+                                                                   grad_offset, grad_mask);
   }
   blockIdx.x = 0; gridDim.x = 1;
 }

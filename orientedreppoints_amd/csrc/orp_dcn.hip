@@ -765,8 +765,14 @@ dcn_fwd_mfma2_kernel(const FwdParams P, int total_tiles) {
 #pragma unroll
         for (int r = 0; r < 16; r++)
           __hip_atomic_store(dst + (size_t)(mt * 8 * 16 + r) * 64, acc[mt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // this wave's stores have left (s_waitcnt vmcnt(0)) ...
-      __syncthreads();                                          // ... and so have every other wave's
+      // Drain THIS wave's scratch stores before the barrier: a workgroup-scope release fence emits no s_waitcnt vmcnt(0)
+      // on gfx950 (the ISA showed the last `global_store_dword ... sc1` directly followed by s_barrier), so without the
+      // explicit wait a store could still be in flight to another L2 channel when the flag becomes visible and the
+      // consumer would add whatever the previous launch left in the (reused) scratch image.  The stores are sc1
+      // write-through, so once vmcnt reaches 0 they are visible at agent scope; no L2 write-back is needed.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();                                          // ... and every other wave has drained its own
       if (tid == 0) __hip_atomic_store(P.ks_flags + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif

@@ -41,7 +41,7 @@ struct GnParams {
   int nlev, B, C, G;
   float eps; int relu;
   float2* partial;        // [total_chunks] (mean, M2)
-  float2* stats;          // training: [sum_levels B * G] (mean, rstd) per (image, group), level i at chunk0 / cpg; or NULL
+  float2* stats;          // training: [nlev][B * G] (mean, rstd) per (image, group): level i, image b, group g at (i * B + b) * G + g; or NULL
   // backward (orp_groupnorm_act_multi_backward)
   const float* dy[kGnMaxLevels];
   float* dx[kGnMaxLevels];

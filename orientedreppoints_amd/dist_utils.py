@@ -107,7 +107,13 @@ class OverlappedGradientReducer(object):
     def _close(self, plist):
         n = sum(p.numel() for p in plist)
         flat = torch.zeros(n + len(plist), dtype=plist[0].dtype, device=plist[0].device)     # gradients | one flag per parameter
-        self.buckets.append(dict(flat=flat, nel=n, params=list(plist), pending=0, ready=False, handle=None))
+        # host staging for the flag region: PINNED for a GPU bucket, so the copy issued from inside the autograd hook is a
+        # real asynchronous H2D (a pageable source makes non_blocking a no-op and blocks the autograd thread until the
+        # bucket's preceding backward kernels have run -- one host sync per bucket, serialising the overlap)
+        stage = torch.zeros(len(plist), dtype=plist[0].dtype)
+        if flat.is_cuda:
+            stage = stage.pin_memory()
+        self.buckets.append(dict(flat=flat, nel=n, params=list(plist), pending=0, ready=False, handle=None, stage=stage))
 
     def zero_grad(self):
         """Zero the flat buffers and (re)attach the gradient views; call instead of optimizer.zero_grad()."""
@@ -125,8 +131,12 @@ class OverlappedGradientReducer(object):
         while self._next < len(self.buckets) and self.buckets[self._next]['ready']:
             b = self.buckets[self._next]
             # flags of the parameters that produced a gradient on this rank (world: > 0 after the averaged sum = some rank)
-            b['flat'][b['nel']:] = torch.tensor([float(self.world) if id(p) in self._used else 0.0 for p in b['params']],
-                                                dtype=b['flat'].dtype).to(b['flat'].device, non_blocking=True)
+            # (the staging buffer is rewritten at most once per step and finish() ends every step with a host read, so the
+            # previous step's copy has long completed)
+            st = b['stage']
+            for k, p in enumerate(b['params']):
+                st[k] = float(self.world) if id(p) in self._used else 0.0
+            b['flat'][b['nel']:].copy_(st, non_blocking=True)
             if self.world > 1:
                 b['flat'].div_(self.world)
                 b['handle'] = dist.all_reduce(b['flat'], async_op=True)

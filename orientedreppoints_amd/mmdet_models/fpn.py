@@ -57,7 +57,8 @@ class FPN(nn.Module):
             return False
         used = len(self.lateral_convs)
         mods = list(self.lateral_convs) + list(self.fpn_convs[:used])
-        return all(m.with_norm and isinstance(m.norm, nn.GroupNorm) and not m.with_activation and m.conv.bias is None
+        return all(m.with_norm and isinstance(m.norm, nn.GroupNorm) and m.norm.affine and not m.with_activation
+                   and isinstance(m.conv, nn.Conv2d) and m.conv.bias is None
                    and m.norm.num_groups == mods[0].norm.num_groups and m.norm.eps == mods[0].norm.eps for m in mods)
 
     def forward(self, inputs):

@@ -28,6 +28,28 @@ def build_norm_layer(cfg, num_features, postfix=''):
     return name, layer
 
 
+def _conv_types():
+    """The reference's conv registry (mmdet/ops/conv.py:6-12): 'Conv', 'DCN' (DeformConvPack), 'DCNv2'
+    (ModulatedDeformConvPack).  'ConvWS' is not used by any DOTA config and is not provided."""
+    from ..mmdet_ops.deform_conv import DeformConvPack, ModulatedDeformConvPack
+    return {'Conv': nn.Conv2d, 'DCN': DeformConvPack, 'DCNv2': ModulatedDeformConvPack}
+
+
+def build_conv_layer(cfg, *args, **kwargs):
+    """mmdet/ops/conv.py:15-42: cfg None -> nn.Conv2d; dict(type='DCN' | 'DCNv2', deformable_groups=..) -> the
+    offset-predicting DeformConv packs, whose sampling + contraction run on the HIP DeformConv kernels."""
+    if cfg is None:
+        cfg_ = dict(type='Conv')
+    else:
+        assert isinstance(cfg, dict) and 'type' in cfg
+        cfg_ = dict(cfg)
+    layer_type = cfg_.pop('type')
+    table = _conv_types()
+    if layer_type not in table:
+        raise KeyError('Unrecognized conv type {}'.format(layer_type))
+    return table[layer_type](*args, **kwargs, **cfg_)
+
+
 def constant_init(module, val, bias=0):
     if hasattr(module, 'weight') and module.weight is not None:
         nn.init.constant_(module.weight, val)
@@ -70,15 +92,14 @@ class ConvModule(nn.Module):
                  bias='auto', conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'), inplace=True,
                  order=('conv', 'norm', 'act')):
         super(ConvModule, self).__init__()
-        assert conv_cfg is None or conv_cfg.get('type', 'Conv') == 'Conv', 'only plain Conv in ConvModule here'
         assert tuple(order) == ('conv', 'norm', 'act')
         self.with_norm = norm_cfg is not None
         self.with_activation = act_cfg is not None
         if bias == 'auto':
             bias = False if self.with_norm else True
         self.with_bias = bias
-        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
-                              dilation=dilation, groups=groups, bias=bias)
+        self.conv = build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                     dilation=dilation, groups=groups, bias=bias)
         self.in_channels, self.out_channels = in_channels, out_channels
         if self.with_norm:
             self.norm_name, norm = build_norm_layer(norm_cfg, out_channels)

@@ -64,8 +64,11 @@ class FocalLoss(nn.Module):
 
 
 class GIoULossFuction(Function):
-    """Loss AND gradient come out of one kernel call; backward returns the stashed gradient and ignores the incoming
-    one, exactly as the reference does (iou_loss.py:96-100)."""
+    """Loss AND gradient come out of one kernel call (iou_loss.py:69-100).  The reference's backward returns the stashed
+    gradient and ignores the incoming one; here the stashed gradient is multiplied by the incoming one -- identical
+    whenever that is 1 (every use in the reference: the losses are summed and `.backward()` is called on the sum), and
+    correct under fp16 loss scaling (`GradScaler.scale(loss).backward()`), where ignoring it would leave these two
+    localisation losses unscaled and then divide them by the scale."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: fp32 inputs, autocast off inside
@@ -88,8 +91,12 @@ class GIoULossFuction(Function):
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, input=None):
-        return ctx.convex_points_grad, None, None, None, None, None
+    def backward(ctx, grad_out=None):
+        g = ctx.convex_points_grad
+        if grad_out is not None:
+            go = grad_out.to(g.dtype)
+            g = g * (go.reshape(()) if go.numel() == 1 else go.reshape(-1, 1))   # scalar (mean / sum) or per row (none)
+        return g, None, None, None, None, None
 
 
 convex_giou_loss = GIoULossFuction.apply

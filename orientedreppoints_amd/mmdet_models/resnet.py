@@ -5,7 +5,7 @@ is the part BASELINE.json says stays stock."""
 import torch
 import torch.nn as nn
 
-from .layers import build_norm_layer, constant_init, kaiming_init
+from .layers import build_conv_layer, build_norm_layer, constant_init, kaiming_init
 from .registry import BACKBONES
 
 
@@ -13,17 +13,31 @@ class Bottleneck(nn.Module):
     expansion = 4
 
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch',
-                 norm_cfg=dict(type='BN')):
+                 norm_cfg=dict(type='BN'), dcn=None):
         super(Bottleneck, self).__init__()
         assert style in ['pytorch', 'caffe']
+        assert dcn is None or isinstance(dcn, dict)
         if style == 'pytorch':
             conv1_stride, conv2_stride = 1, stride
         else:
             conv1_stride, conv2_stride = stride, 1
         self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=conv1_stride, bias=False)
         self.add_module('bn1', build_norm_layer(norm_cfg, planes)[1])
-        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=conv2_stride, padding=dilation,
-                               dilation=dilation, bias=False)
+        # dcn = dict(type='DCN' | 'DCNv2', deformable_groups=1, fallback_on_stride=False) turns conv2 into the
+        # offset-predicting deformable convolution (mmdet/models/backbones/resnet.py:140-170); its parameters are
+        # conv2.weight and conv2.conv_offset.{weight,bias}, as in the released DCN checkpoints
+        self.with_dcn = dcn is not None
+        fallback_on_stride = False
+        if self.with_dcn:
+            dcn = dict(dcn)
+            fallback_on_stride = dcn.pop('fallback_on_stride', False)
+            if 'modulated' in dcn:                                   # the older spelling of the same choice
+                dcn.setdefault('type', 'DCNv2' if dcn.pop('modulated') else 'DCN')
+            dcn.setdefault('type', 'DCN')
+        use_dcn = self.with_dcn and not (fallback_on_stride and conv2_stride > 1)
+        self.conv2 = build_conv_layer(dcn if use_dcn else None, planes, planes, kernel_size=3, stride=conv2_stride,
+                                      padding=dilation, dilation=dilation, bias=False)
+        self.conv2_is_dcn = use_dcn
         self.add_module('bn2', build_norm_layer(norm_cfg, planes)[1])
         self.conv3 = nn.Conv2d(planes, planes * self.expansion, kernel_size=1, bias=False)
         self.add_module('bn3', build_norm_layer(norm_cfg, planes * self.expansion)[1])
@@ -65,13 +79,18 @@ class ResNet(nn.Module):
 
     def __init__(self, depth, in_channels=3, num_stages=4, strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1),
                  out_indices=(0, 1, 2, 3), style='pytorch', frozen_stages=-1, conv_cfg=None,
-                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None, stage_with_dcn=None,
-                 gcb=None, stage_with_gcb=None, gen_attention=None, stage_with_gen_attention=None,
-                 with_cp=False, zero_init_residual=True):
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None,
+                 stage_with_dcn=(False, False, False, False), gcb=None, stage_with_gcb=None, gen_attention=None,
+                 stage_with_gen_attention=None, with_cp=False, zero_init_residual=True):
         super(ResNet, self).__init__()
         if depth not in self.arch_settings:
             raise KeyError('invalid depth {} for resnet'.format(depth))
-        assert dcn is None and gcb is None and gen_attention is None, 'plain ResNet only (as the DOTA configs use)'
+        assert gcb is None and gen_attention is None, 'context / attention blocks are not part of the DOTA configs'
+        assert conv_cfg is None, 'the backbone convolutions are stock nn.Conv2d (dcn= selects the deformable conv2)'
+        self.dcn = dcn
+        self.stage_with_dcn = tuple(stage_with_dcn) if stage_with_dcn is not None else (False,) * num_stages
+        if dcn is not None:
+            assert len(self.stage_with_dcn) == num_stages
         self.depth, self.num_stages, self.out_indices = depth, num_stages, out_indices
         self.frozen_stages, self.norm_eval = frozen_stages, norm_eval
         self.zero_init_residual = zero_init_residual
@@ -90,10 +109,11 @@ class ResNet(nn.Module):
                 downsample = nn.Sequential(
                     nn.Conv2d(inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
                     build_norm_layer(norm_cfg, planes * block.expansion)[1])
-            layers = [block(inplanes, planes, stride, dilation, downsample, style, norm_cfg)]
+            stage_dcn = self.dcn if (self.dcn is not None and self.stage_with_dcn[i]) else None
+            layers = [block(inplanes, planes, stride, dilation, downsample, style, norm_cfg, stage_dcn)]
             inplanes = planes * block.expansion
             for _ in range(1, num_blocks):
-                layers.append(block(inplanes, planes, 1, dilation, None, style, norm_cfg))
+                layers.append(block(inplanes, planes, 1, dilation, None, style, norm_cfg, stage_dcn))
             name = 'layer{}'.format(i + 1)
             self.add_module(name, nn.Sequential(*layers))
             self.res_layers.append(name)
@@ -142,6 +162,10 @@ class ResNet(nn.Module):
                 kaiming_init(m)
             elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
                 constant_init(m, 1)
+        if self.dcn is not None:                                      # resnet.py:478-482: offsets (and masks) start at zero
+            for m in self.modules():
+                if isinstance(m, Bottleneck) and hasattr(m.conv2, 'conv_offset'):
+                    constant_init(m.conv2.conv_offset, 0)
         if self.zero_init_residual:
             for m in self.modules():
                 if isinstance(m, Bottleneck):

@@ -119,8 +119,10 @@ def pointset_target(gt_inds, valid, gt_boxes, gt_labels, gt_offset, pos_weight=-
 class _SegmentGIoULoss(Function):
     """loss[s] = loss_weight * sum_{i in s} w_i (1 - GIoU_i) / max(denom[s], 1) for the rows' segments s (GIoULoss with
     reduction 'mean' applied per segment, iou_loss.py:69-129).  As in the reference the gradient comes out of the forward
-    kernel and the incoming gradient is ignored: d/d pred_i = -grad_i w_i / denom[seg_i] * loss_weight, rows with any
-    component > 1 replaced by 1e-6 first (iou_loss.py:87-89).  convex_giou + two launches (rows, fixed-order segment sum)."""
+    kernel: d/d pred_i = -grad_i w_i / denom[seg_i] * loss_weight, rows with any component > 1 replaced by 1e-6 first
+    (iou_loss.py:87-89), times the incoming gradient of the row's segment (the reference ignores it; it is 1 in the
+    reference's training loop, and under fp16 loss scaling it must not be dropped).  convex_giou + two launches (rows,
+    fixed-order segment sum)."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: fp32 inputs, autocast off inside
@@ -130,7 +132,7 @@ class _SegmentGIoULoss(Function):
         dev = pred.device
         loss = torch.zeros((nseg,), dtype=torch.float32, device=dev)
         if P == 0:                                                       # no row at all: zero loss, empty gradient
-            ctx.save_for_backward(torch.zeros_like(pred))
+            ctx.save_for_backward(torch.zeros_like(pred), torch.zeros((0,), dtype=torch.long, device=dev))
             return loss
         gious, grad = convex_giou(pred, target)
         gious = gious.float().contiguous()
@@ -147,13 +149,16 @@ class _SegmentGIoULoss(Function):
                                        float(loss_weight), _lib.ptr(contrib), _lib.ptr(gsave), st), "orp_giou_rows")
             _lib.check(L.orp_segment_finish(_lib.ptr(contrib), None, _lib.ptr(sg), P, int(nseg), _lib.ptr(d),
                                             float(loss_weight), 0, _lib.ptr(loss), None, st), "orp_segment_finish")
-        ctx.save_for_backward(gsave.reshape(pred.shape))
+        ctx.save_for_backward(gsave.reshape(pred.shape), sg)
         return loss
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out=None):
-        return ctx.saved_tensors[0], None, None, None, None, None, None
+        g, sg = ctx.saved_tensors
+        if grad_out is not None and g.numel():
+            g = g * grad_out.to(g.dtype).reshape(-1)[sg].reshape((-1,) + (1,) * (g.dim() - 1))
+        return g, None, None, None, None, None, None
 
 
 def segment_giou_loss(pred, target, weight, seg, nseg, denom, loss_weight):

@@ -5,6 +5,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from orientedreppoints_amd.mmdet_ops import deform_conv_forward_pair
+from orientedreppoints_amd import _lib
+POISON = os.environ.get("SOAK_POISON", "1") == "1"
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -25,6 +27,8 @@ for B in (2, 3):
         if i % 4 == 0:
             with torch.cuda.stream(side):
                 a = (a @ a).clamp_(-1, 1)                       # keeps CUs / LDS busy next to the split launch
+        if POISON:
+            _lib.workspace(dev, 1).fill_(0xFF)                 # NaN patterns in the reused scratch images
         out = deform_conv_forward_pair(fa, fb, of, w1, w2, 1, 1, 1, relu=True)
         if i % 50 == 0 or i == N - 1:
             bad += sum(0 if torch.equal(x, y) else 1 for x, y in zip(out[0] + out[1], ref))

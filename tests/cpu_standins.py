@@ -36,6 +36,31 @@ class _CpuDeformConv(Function):
         return (torch.from_numpy(gi), torch.from_numpy(goff), torch.from_numpy(gw), None, None, None, None, None, None)
 
 
+class _CpuModulatedDeformConv(Function):
+    """ModulatedDeformConvFunction on the CPU through oracle.dcn_v2_forward / dcn_v2_backward (groups = 1)."""
+
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+        s = stride[0] if isinstance(stride, (tuple, list)) else stride
+        p = padding[0] if isinstance(padding, (tuple, list)) else padding
+        d = dilation[0] if isinstance(dilation, (tuple, list)) else dilation
+        assert groups == 1
+        ctx.geo = (s, p, d, deformable_groups)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(input, offset, mask, weight)
+        return torch.from_numpy(O.dcn_v2_forward(_np(input), _np(offset), _np(mask), _np(weight),
+                                                 _np(bias) if bias is not None else None, s, p, d, deformable_groups))
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, offset, mask, weight = ctx.saved_tensors
+        s, p, d, dg = ctx.geo
+        gi, goff, gm, gw, gb = O.dcn_v2_backward(_np(input), _np(offset), _np(mask), _np(weight),
+                                                 _np(grad_output.contiguous()), s, p, d, dg)
+        return (torch.from_numpy(gi), torch.from_numpy(goff), torch.from_numpy(gm), torch.from_numpy(gw),
+                torch.from_numpy(gb) if ctx.has_bias else None, None, None, None, None, None)
+
+
 def _focal(logits, targets, gamma, alpha):
     """sigmoid focal loss per element (sigmoid_focal_loss_cuda.cu:23-97), labels 1..C, 0 = background -- differentiable."""
     C = logits.size(1)
@@ -214,7 +239,7 @@ def installed():
     ht = m('orientedreppoints_amd.mmdet_models.orientedreppoints_head_train')
     asg = m('orientedreppoints_amd.mmdet_models.assigners')
     patches = [
-        (dc, 'deform_conv', _CpuDeformConv.apply),
+        (dc, 'deform_conv', _CpuDeformConv.apply), (dc, 'modulated_deform_conv', _CpuModulatedDeformConv.apply),
         (apaa, 'point_assign', _point_assign), (apaa, 'max_iou_assign', _max_iou_assign),
         (apaa, 'apaa_feature_dissimilarity', _feature_dissimilarity), (apaa, 'apaa_select', _apaa_select),
         (tro, 'pointset_target', _pointset_target), (tro, 'points_from_offsets', _points_from_offsets),

@@ -34,3 +34,37 @@ def test_reference_configs_load_unchanged_and_build():
     assert {k: v for k, v in theirs['backbone'].items()} == ours['backbone']
     assert dict(cfg.test_cfg) == dota_configs.test_cfg
     assert dict(cfg.train_cfg) == dota_configs.train_cfg
+
+
+def test_dcn_conv_types_and_resnet_stage_with_dcn():
+    """mmdet/ops/conv.py:6-12 ('DCN' / 'DCNv2' conv types) and mmdet/models/backbones/resnet.py:118-161,365-410
+    (`dcn=`, `stage_with_dcn`): the model route to DeformConvPack / ModulatedDeformConvPack, with the parameter names of the
+    released DCN checkpoints (conv2.weight, conv2.conv_offset.{weight,bias}) and zero-initialised offset predictors."""
+    import torch
+    from orientedreppoints_amd.mmdet_models import build_backbone
+    from orientedreppoints_amd.mmdet_models.layers import ConvModule, build_conv_layer
+    from orientedreppoints_amd.mmdet_ops.deform_conv import DeformConvPack, ModulatedDeformConvPack
+    assert isinstance(build_conv_layer(dict(type='DCN'), 8, 8, 3, padding=1), DeformConvPack)
+    m = build_conv_layer(dict(type='DCNv2', deformable_groups=2), 8, 8, 3, padding=1, bias=False)
+    assert isinstance(m, ModulatedDeformConvPack) and m.conv_offset.out_channels == 2 * 27 and m.bias is None
+    assert isinstance(build_conv_layer(None, 8, 8, 3), torch.nn.Conv2d)
+    with pytest.raises(KeyError):
+        build_conv_layer(dict(type='ConvWS'), 8, 8, 3)
+    cm = ConvModule(8, 8, 3, padding=1, conv_cfg=dict(type='DCN'), norm_cfg=dict(type='GN', num_groups=2))
+    assert isinstance(cm.conv, DeformConvPack)
+    for dcn, cls, mult in ((dict(type='DCNv2', deformable_groups=1, fallback_on_stride=False), ModulatedDeformConvPack, 27),
+                           (dict(modulated=False, deformable_groups=1, fallback_on_stride=False), DeformConvPack, 18)):
+        net = build_backbone(dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                                  style='pytorch', dcn=dcn, stage_with_dcn=(False, True, True, True)))
+        net.init_weights(None)
+        assert isinstance(net.layer1[0].conv2, torch.nn.Conv2d)
+        for name in ('layer2', 'layer3', 'layer4'):
+            for blk in getattr(net, name):
+                assert isinstance(blk.conv2, cls) and blk.conv2.conv_offset.out_channels == mult
+                assert float(blk.conv2.conv_offset.weight.detach().abs().max()) == 0.0
+        assert net.layer2[0].conv2.stride == (2, 2) or net.layer2[0].conv2.stride == 2
+        keys = set(net.state_dict().keys())
+        assert {'layer2.0.conv2.weight', 'layer2.0.conv2.conv_offset.weight', 'layer2.0.conv2.conv_offset.bias'} <= keys
+    net = build_backbone(dict(type='ResNet', depth=50, dcn=dict(type='DCN', fallback_on_stride=True),
+                              stage_with_dcn=(False, True, True, True)))
+    assert isinstance(net.layer2[0].conv2, torch.nn.Conv2d) and isinstance(net.layer2[1].conv2, DeformConvPack)

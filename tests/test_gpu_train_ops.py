@@ -231,6 +231,12 @@ def test_segment_losses_equal_the_tensor_op_composition(dev, P, nseg):
             if P:
                 got.sum().backward(); want.sum().backward()
                 assert float((a.grad - b.grad).abs().max()) <= 1e-6 * max(1.0, float(b.grad.abs().max()))
+                # loss scaling (GradScaler.scale(loss).backward()): the incoming gradient must reach the stashed one --
+                # a per-segment factor here; power-of-two scales reproduce the unscaled gradient's bits exactly
+                c = pts.clone().requires_grad_(True)
+                sc = torch.tensor([2.0 ** (k % 5) for k in range(nseg)], device=dev)
+                (train_ops._SegmentGIoULoss.apply(c, gt, weight, seg, nseg, denom, lw) * sc).sum().backward()
+                assert torch.equal(c.grad, a.grad * sc[seg].reshape((-1,) + (1,) * (a.grad.dim() - 1)))
             again = train_ops._SegmentGIoULoss.apply(pts, gt, weight, seg, nseg, denom, lw)
             assert torch.equal(again, got.detach())
             # border loss

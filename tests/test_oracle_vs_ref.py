@@ -124,6 +124,41 @@ def test_deform_conv_im2col_and_backward(ref):
         assert np.max(np.abs(u - v)) <= 1e-5 * max(1.0, float(np.max(np.abs(v))))
 
 
+@pytest.mark.parametrize("dg", [1, 2])
+def test_modulated_deform_conv_forward_and_backward(ref, dg):
+    # DCNv2: deform_conv_cuda_kernel.cu:570-633 (modulated im2col), :635-693 (col2im), :695-767 (col2im_coord: offset AND
+    # mask gradients) through the reference's own device functions, driven per image with batch_size = 1 like
+    # deform_conv_cuda.cpp:490-685; stride 2 / dilation 2 legs cover the index arithmetic of the column layout
+    rng = np.random.RandomState(131 + dg)
+    for (stride, pad, dil) in ((1, 1, 1), (2, 1, 1), (1, 2, 2)):
+        x = rng.normal(size=(2, 8, 9, 11)).astype(np.float32)
+        Ho, Wo = ref._odim(9, pad, dil, 3, stride), ref._odim(11, pad, dil, 3, stride)
+        off = rng.normal(0, 2.5, size=(2, dg * 18, Ho, Wo)).astype(np.float32)   # incl. samples outside the image
+        mask = rng.uniform(0, 1, size=(2, dg * 9, Ho, Wo)).astype(np.float32)
+        w = rng.normal(0, 0.2, size=(6, 8, 3, 3)).astype(np.float32)
+        bias = rng.normal(size=6).astype(np.float32)
+        a = ref.dcn_v2_im2col(x, off, mask, 3, 3, pad, stride, dil, dg)
+        b = ref.dcn_v2_im2col(x, off, mask, 3, 3, pad, stride, dil, dg, use_ref=True)
+        assert np.array_equal(a, b)                                         # same float expressions: bit for bit
+        # the direct fp64-accumulated forward == the column formulation over the reference's columns
+        fa = ref.dcn_forward(x, off, w, stride, pad, dil, 1, dg, mask=mask, bias=bias)
+        fb = ref.dcn_v2_forward(x, off, mask, w, bias, stride, pad, dil, dg, use_ref=True)
+        assert np.max(np.abs(fa - fb)) <= 1e-6 * max(1.0, float(np.max(np.abs(fb))))
+        go = rng.normal(size=fb.shape).astype(np.float32)
+        got = ref.dcn_v2_backward(x, off, mask, w, go, stride, pad, dil, dg)
+        want = ref.dcn_v2_backward(x, off, mask, w, go, stride, pad, dil, dg, use_ref=True)
+        # the reference sums over channels in float (thread-serial) and scatters with atomics; the oracle in double
+        for name, u, v in zip(("input", "offset", "mask", "weight", "bias"), got, want):
+            assert np.max(np.abs(u - v)) <= 1e-5 * max(1.0, float(np.max(np.abs(v)))), name
+        assert float(np.max(np.abs(want[2]))) > 0.1                         # the mask gradient is really exercised
+    # mask == 1 reduces to DCNv1 (the two kernel families agree)
+    one = np.ones_like(mask)
+    gi1, go1, gw1 = ref.dcn_backward(x, off, w, go, stride, pad, dil, dg, use_ref=True)
+    gi2, go2, _, gw2, _ = ref.dcn_v2_backward(x, off, one, w, go, stride, pad, dil, dg, use_ref=True)
+    for u, v in ((gi1, gi2), (go1, go2), (gw1, gw2)):
+        assert np.max(np.abs(u - v)) <= 1e-5 * max(1.0, float(np.max(np.abs(v))))
+
+
 def test_box_iou_rotated(ref):
     # box_iou_rotated_utils.h:314-341 single_box_iou_rotated
     a = S.gen_rboxes(60, 111).astype(np.float32)
