@@ -41,14 +41,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from orientedreppoints_amd import _lib  # noqa: E402
-from orientedreppoints_amd.dota_configs import r50_model, r101_model, test_cfg as TEST_CFG  # noqa: E402
+from orientedreppoints_amd.dota_configs import (r50_model, r101_model, swin_t_model, r50_dcnv2_model,  # noqa: E402
+                                                swin_t_optimizer, test_cfg as TEST_CFG)
 from orientedreppoints_amd.mmdet_models import ConfigDict, build_detector  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD at 2.4 GHz
 IMG = 1024                       # --size
-MODELS = {'r50': r50_model, 'r101': r101_model}
+MODELS = {'r50': r50_model, 'r101': r101_model, 'swin_t': swin_t_model, 'r50_dcnv2': r50_dcnv2_model}
+TRAIN_SIZES = None               # --mode train with --size a,b,...: the multi-scale patch sizes (configs[4]: 1024,1536)
 TARGET_DETS = 2000               # (point, class) pairs above score_thr per image: the "dense scene" of BASELINE configs
 
 
@@ -512,22 +514,35 @@ def main_train(args):
     torch.manual_seed(0)                                  # identical initial weights on every rank
     model = build_detector(ConfigDict(MODELS[args.model]), train_cfg=ConfigDict(TRAIN_CFG),
                            test_cfg=ConfigDict(TEST_CFG)).to(dev).train()
-    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-4, momentum=0.9,
-                          weight_decay=1e-4)
+    if args.model == 'swin_t':
+        # the Swin config's optimizer: AdamW, weight decay 0.05 except norms / position-bias tables (paramwise_cfg)
+        oc = swin_t_optimizer
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        plain = [p for n, p in named if not any(k in n for k in oc['no_decay_keys'])]
+        nodecay = [p for n, p in named if any(k in n for k in oc['no_decay_keys'])]
+        opt = torch.optim.AdamW([dict(params=plain), dict(params=nodecay, weight_decay=0.0)], lr=oc['lr'],
+                                betas=oc['betas'], weight_decay=oc['weight_decay'])
+    else:
+        opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-4, momentum=0.9,
+                              weight_decay=1e-4)
     # N > 1: bucketed all-reduce overlapped with backward (32 MB buckets over RCCL / xGMI)
     amp_dtype = dict(f32=None, fp16=torch.float16, bf16=torch.bfloat16)[args.dtype]
     scaler = torch.amp.GradScaler('cuda') if args.dtype == 'fp16' else None
     hook = D.DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2), overlap=True, scaler=scaler)
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
-    data = dict(
-        img=torch.randn(batch, 3, IMG, IMG, generator=g).to(dev),
-        img_meta=[dict(img_shape=(IMG, IMG, 3), pad_shape=(IMG, IMG, 3), scale_factor=1.0, flip=False)] * batch,
+    sizes = TRAIN_SIZES or [IMG]                            # multi-scale: the steps cycle through the patch sizes
+    datas = [dict(
+        img=torch.randn(batch, 3, sz, sz, generator=g).to(dev),
+        img_meta=[dict(img_shape=(sz, sz, 3), pad_shape=(sz, sz, 3), scale_factor=1.0, flip=False)] * batch,
         gt_bboxes=[torch.from_numpy(S.gen_polys(args.gts, 40 + i + 7 * rank, wh=(16, 120))[:, :8]
-                                    .astype(np.float32)).to(dev) for i in range(batch)],
-        gt_labels=[torch.randint(1, 16, (args.gts,), generator=g).to(dev) for _ in range(batch)])
+                                    .astype(np.float32) * (sz / 1024.0)).to(dev) for i in range(batch)],
+        gt_labels=[torch.randint(1, 16, (args.gts,), generator=g).to(dev) for _ in range(batch)]) for sz in sizes]
+    count = [0]
 
     def step():
         # parse_losses all-reduces + .item()s the logged scalars every iteration as the reference's batch_processor does
+        data = datas[count[0] % len(datas)]
+        count[0] += 1
         return D.train_step(model, opt, data, hook, autocast_dtype=amp_dtype)
 
     for _ in range(args.warmup):
@@ -557,7 +572,8 @@ def main_train(args):
             dist.destroy_process_group()
         return
     out = {
-        'metric': 'training images/sec (OrientedRepPoints %s FPN, %dx%d DOTA patch, APAA on, SGD step)' % (args.model, IMG, IMG),
+        'metric': 'training images/sec (OrientedRepPoints %s FPN, %s DOTA patches, APAA on, %s step)'
+                  % (args.model, '/'.join('%dx%d' % (z, z) for z in sizes), 'AdamW' if args.model == 'swin_t' else 'SGD'),
         'value': round(batch * args.steps * world / elapsed, 3),
         'unit': 'images/s',
         'n_gpus': world,
@@ -570,8 +586,10 @@ def main_train(args):
         'dtype': {'f32': 'f32', 'fp16': 'fp16 autocast (hot-path operators f32, GradScaler)',
                   'bf16': 'bf16 autocast (hot-path operators f32)'}[args.dtype],
         'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[2]: train step, %d img/GPU x %d gts, %dx%d, 15 classes'
-                               % (batch, args.gts, IMG, IMG),
+        'config': {'workload': 'BASELINE configs[%s]: train step, %d img/GPU x %d gts, %s, 15 classes'
+                               % ('4' if args.model == 'swin_t' else '2', batch, args.gts,
+                                  ' / '.join('%dx%d' % (z, z) for z in sizes)),
+                   'model': args.model, 'patch_sizes': sizes,
                    'imgs_per_gpu': batch, 'gts_per_image': args.gts,
                    'parallelism': 'dp%d (image-parallel, bucketed gradient all-reduce overlapped with backward)' % world},
         'loss': round(float(log_vars['loss']), 4),
@@ -589,7 +607,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--model', choices=sorted(MODELS), default='r50',
                     help='r50 (default, BASELINE configs[1]); r101 with --batch 2 is the per-GPU load of configs[3]')
-    ap.add_argument('--size', type=int, default=1024, help='square patch size: 1024 (configs[1]) or 1536 (configs[4] shapes)')
+    ap.add_argument('--size', type=str, default='1024',
+                    help='square patch size: 1024 (configs[1]) or 1536 (configs[4] shapes); --mode train accepts a list '
+                         '"1024,1536" = multi-scale training, the steps cycle through the sizes')
     ap.add_argument('--device', choices=('cuda', 'cpu'), default='cuda', help='cpu only together with --dry (gloo)')
     ap.add_argument('--dry', action='store_true',
                     help='launcher / rank / timing plumbing only, stand-in step (the CPU test of the N > 1 path)')
@@ -611,8 +631,13 @@ def main():
                     help='--mode train only: f32 (default, the reference\'s arithmetic) or torch.autocast in fp16 (with a '
                          'GradScaler) / bf16: library convolutions in half, hot-path operators on fp32-cast inputs')
     args = ap.parse_args()
-    global IMG
-    IMG = args.size
+    global IMG, TRAIN_SIZES
+    size_list = [int(z) for z in str(args.size).split(',')]
+    IMG = args.size = size_list[0]
+    if len(size_list) > 1:
+        if args.mode != 'train':
+            raise SystemExit('bench.py: a list of sizes is only valid with --mode train')
+        TRAIN_SIZES = size_list
     if args.device == 'cpu' and not args.dry:
         raise SystemExit('bench.py: the hot path has no CPU fallback; --device cpu is only valid with --dry')
     maybe_spawn(args)                                     # --gpus N by hand -> N ranks (no-op under a launcher)
@@ -647,8 +672,21 @@ def main():
     # the step is meant to be bitwise reproducible (fixed-order sums in every HIP kernel; the library convolutions the
     # detector keeps are deterministic for its shapes): checked, reported, and the replay checks below then compare
     # detection COUNTS with a 0.5 % allowance so that a library kernel that is not cannot cost the throughput figure
-    res2 = step()
-    step_reproducible = all(a.shape == b.shape and np.array_equal(a, b) for r, q in zip(res, res2) for a, b in zip(r, q))
+    def same(ra, rb):
+        return all(a.shape == b.shape and np.array_equal(a, b) for r, q in zip(ra, rb) for a, b in zip(r, q))
+
+    step_reproducible = all(same(res, step()) for _ in range(3))
+    library_deterministic_mode = False
+    if not step_reproducible:
+        # some library convolution of this shape accumulates with atomics (1536^2: the stride-2 / 48^2 3x3 convolutions of
+        # layer2 / layer4 get a split-K solver, tests/checks/determinism_modules.py): ask MIOpen for reproducible solvers
+        # only (torch.backends.cudnn.deterministic -> MIOPEN_CONVOLUTION_ATTRIB_DETERMINISTIC) and measure THAT
+        torch.backends.cudnn.deterministic = True
+        library_deterministic_mode = True
+        for _ in range(max(3, args.warmup)):
+            res = step()
+        ndet = int(sum(sum(len(c) for c in r) for r in res))
+        step_reproducible = all(same(res, step()) for _ in range(3))
     count_slack = 0 if step_reproducible else max(2, ndet // 200)
     torch.cuda.synchronize()
     if distributed:
@@ -898,7 +936,7 @@ def main():
                                   {'r50': 'R-50', 'r101': 'R-101'}[args.model], IMG, IMG, args.batch, TARGET_DETS),
                    'global_batch': args.batch * world, 'parallelism': 'replicas x%d (image-parallel, no collective)' % world,
                    'images_in_flight_per_gpu': args.pipeline if isinstance(pipe_ms, float) else 1},
-        'detections_per_step': ndet, 'step_bitwise_reproducible': bool(step_reproducible), 'nms_classes_present': int(len(set(cap['labels'].tolist()))) if cap.get('labels') is not None else None,
+        'detections_per_step': ndet, 'step_bitwise_reproducible': bool(step_reproducible), 'library_deterministic_mode': library_deterministic_mode, 'nms_classes_present': int(len(set(cap['labels'].tolist()))) if cap.get('labels') is not None else None,
         'library_build': _lib.lib().orp_version().decode(),
         'rotated_iou_nms_us_per_img': nms_us, 'nms_boxes': M,
         'kernel_us': {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()},

@@ -29,6 +29,34 @@ def _model(depth):
 r50_model = _model(50)
 r101_model = _model(101)
 
+
+def _with_backbone(base, backbone, neck=None):
+    m = dict(base)
+    m['backbone'] = backbone
+    if neck is not None:
+        m['neck'] = neck
+    return m
+
+
+# configs/dota/orientedrepoints_swin_tiny_demo.py:4-53 (Swin-T; three backbone outputs, FPN levels 4 / 5 max-pooled)
+swin_t_model = _with_backbone(
+    r50_model,
+    dict(type='SwinTransformer', embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4.,
+         qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, ape=False, patch_norm=True,
+         out_indices=(1, 2, 3), use_checkpoint=False),
+    dict(type='FPN', in_channels=[192, 384, 768], out_channels=256, num_outs=5, norm_cfg=_norm_cfg))
+# the optimizer of that config (:128-131): AdamW, no weight decay on norms / position-bias tables
+swin_t_optimizer = dict(type='AdamW', lr=0.0001, betas=(0.9, 0.999), weight_decay=0.05,
+                        no_decay_keys=('absolute_pos_embed', 'relative_position_bias_table', 'norm'))
+
+# not a reference config file: the R-50 model with the backbone's DCN option of mmdet/models/backbones/resnet.py:365-410
+# switched on (conv2 of stages 2-4 = ModulatedDeformConvPack) -- the model route to the DCNv2 kernels BASELINE configs[4] names
+r50_dcnv2_model = _with_backbone(
+    r50_model,
+    dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+         norm_cfg=dict(type='BN', requires_grad=True), style='pytorch',
+         dcn=dict(type='DCNv2', deformable_groups=1, fallback_on_stride=False), stage_with_dcn=(False, True, True, True)))
+
 train_cfg = dict(
     init=dict(assigner=dict(type='PointAssigner', scale=4, pos_num=1), allowed_border=-1, pos_weight=-1, debug=False),
     refine=dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.1, neg_iou_thr=0.1, min_pos_iou=0,

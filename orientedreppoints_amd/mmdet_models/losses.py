@@ -65,14 +65,16 @@ class FocalLoss(nn.Module):
 
 class GIoULossFuction(Function):
     """Loss AND gradient come out of one kernel call (iou_loss.py:69-100).  The reference's backward returns the stashed
-    gradient and ignores the incoming one; here the stashed gradient is multiplied by the incoming one -- identical
-    whenever that is 1 (every use in the reference: the losses are summed and `.backward()` is called on the sum), and
-    correct under fp16 loss scaling (`GradScaler.scale(loss).backward()`), where ignoring it would leave these two
-    localisation losses unscaled and then divide them by the scale."""
+    gradient (loss_weight folded in) and ignores the incoming one: that is what `convex_giou_loss(...)` does here too
+    (`chain=False`).  The GIoULoss module calls it with `chain=True`: the stash then carries no loss_weight and is multiplied
+    by the incoming gradient, which is loss_weight (the module's outer product) times whatever is upstream -- the same bits
+    as the reference whenever upstream is 1 (every use in the reference: the losses are summed and `.backward()` is called
+    on the sum), and correct under fp16 loss scaling (`GradScaler.scale(loss).backward()`), where ignoring it would leave
+    the two localisation losses unscaled and then divide them by the scale."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: fp32 inputs, autocast off inside
-    def forward(ctx, pred, target, weight=None, reduction=None, avg_factor=None, loss_weight=1.0):
+    def forward(ctx, pred, target, weight=None, reduction=None, avg_factor=None, loss_weight=1.0, chain=False):
         ctx.save_for_backward(pred)
         convex_gious, grad = convex_giou(pred, target)
         loss = 1 - convex_gious
@@ -86,17 +88,18 @@ class GIoULossFuction(Function):
         # rows with any gradient component > 1 are replaced by 1e-6 (iou_loss.py:87-89)
         unvalid = (grad > 1).sum(1) > 0
         grad = torch.where(unvalid[:, None], torch.full_like(grad, 1e-6), grad)
-        ctx.convex_points_grad = -grad / grad.size(0) * loss_weight
+        ctx.chain = bool(chain)
+        ctx.convex_points_grad = -grad / grad.size(0) * (1.0 if chain else loss_weight)
         return loss
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out=None):
         g = ctx.convex_points_grad
-        if grad_out is not None:
+        if ctx.chain and grad_out is not None:
             go = grad_out.to(g.dtype)
             g = g * (go.reshape(()) if go.numel() == 1 else go.reshape(-1, 1))   # scalar (mean / sum) or per row (none)
-        return g, None, None, None, None, None
+        return g, None, None, None, None, None, None
 
 
 convex_giou_loss = GIoULossFuction.apply
@@ -115,7 +118,7 @@ class GIoULoss(nn.Module):
             return (pred * weight.unsqueeze(-1)).sum()  # 0
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
-        return self.loss_weight * convex_giou_loss(pred, target, weight, reduction, avg_factor, self.loss_weight)
+        return self.loss_weight * convex_giou_loss(pred, target, weight, reduction, avg_factor, self.loss_weight, True)
 
 
 def spatial_border_loss(pts, gt_bboxes, reduction='mean', y_first=False):

@@ -18,14 +18,19 @@ def test_reference_configs_load_unchanged_and_build():
         cfg = Config.fromfile(os.path.join(REF_CFG, f))
         assert cfg.model.type == 'OrientedRepPointsDetector'
         assert cfg.test_cfg.nms.type == 'rnms' and cfg.dist_params.backend == 'nccl'
-        if cfg.model.backbone.type == 'ResNet':
-            m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
-            keys = set(m.state_dict().keys())
-            for k in ('bbox_head.cls_convs.0.conv.weight', 'bbox_head.cls_convs.0.gn.weight',
-                      'bbox_head.reppoints_cls_conv.weight', 'bbox_head.reppoints_cls_out.bias',
-                      'bbox_head.reppoints_pts_init_conv.weight', 'bbox_head.reppoints_pts_refine_out.weight',
-                      'backbone.layer1.0.conv1.weight', 'neck.lateral_convs.0.conv.weight', 'neck.fpn_convs.4.gn.weight'):
-                assert k in keys, k
+        # every config builds -- ResNet-50 / 101 and Swin-T (its `pretrained` path is a file of the authors' machine: the
+        # builder warns and keeps the random initialisation)
+        m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+        keys = set(m.state_dict().keys())
+        first = 'backbone.layer1.0.conv1.weight' if cfg.model.backbone.type == 'ResNet' else \
+            'backbone.layers.0.blocks.0.attn.relative_position_bias_table'
+        for k in ('bbox_head.cls_convs.0.conv.weight', 'bbox_head.cls_convs.0.gn.weight',
+                  'bbox_head.reppoints_cls_conv.weight', 'bbox_head.reppoints_cls_out.bias',
+                  'bbox_head.reppoints_pts_init_conv.weight', 'bbox_head.reppoints_pts_refine_out.weight',
+                  first, 'neck.lateral_convs.0.conv.weight',
+                  # (the Swin config has no extra FPN convolutions: levels 4 and 5 are max-pooled)
+                  'neck.fpn_convs.%d.gn.weight' % (4 if cfg.model.backbone.type == 'ResNet' else 2)):
+            assert k in keys, k
     cfg = Config.fromfile(os.path.join(REF_CFG, 'orientedrepoints_r50_demo.py'))
     ours = dict(dota_configs.r50_model)
     theirs = dict(cfg.model)
@@ -34,6 +39,13 @@ def test_reference_configs_load_unchanged_and_build():
     assert {k: v for k, v in theirs['backbone'].items()} == ours['backbone']
     assert dict(cfg.test_cfg) == dota_configs.test_cfg
     assert dict(cfg.train_cfg) == dota_configs.train_cfg
+    cfg = Config.fromfile(os.path.join(REF_CFG, 'orientedrepoints_swin_tiny_demo.py'))
+    theirs = dict(cfg.model)
+    for part in ('backbone', 'neck', 'bbox_head'):
+        assert dict(theirs[part]) == dota_configs.swin_t_model[part], part
+    assert cfg.optimizer.type == dota_configs.swin_t_optimizer['type'] and cfg.optimizer.lr == dota_configs.swin_t_optimizer['lr']
+    assert cfg.optimizer.weight_decay == dota_configs.swin_t_optimizer['weight_decay']
+    assert tuple(cfg.optimizer.paramwise_cfg.custom_keys.keys()) == dota_configs.swin_t_optimizer['no_decay_keys']
 
 
 def test_dcn_conv_types_and_resnet_stage_with_dcn():
