@@ -140,9 +140,17 @@ int orp_sigmoid_focal_loss_backward(const float* logits, const int64_t* targets,
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct { const float* input; const float* offset; float* output; int height; int width; } orp_dcn_level;
 int orp_dcn_fast_path_ok(int c_in, int c_out, int kh, int kw, int groups, int deformable_groups);
-/* `packed` holds orp_dcn_packed_weight_floats() floats: [kh*kw][Cin][Cout] followed by [kh*kw][Cin/4][Cout][4]. */
+/* `packed` holds orp_dcn_packed_weight_floats() floats: [kh*kw][Cin][Cout] followed by [kh*kw][Cin/4][Cout][4], followed
+ * (Cin % 64 == 0) by the weights split exactly into three bf16 planes [3][kh*kw][Cin/16][2][Cout][8]. */
 size_t orp_dcn_packed_weight_floats(int c_out, int c_in, int kh, int kw);
 int orp_dcn_pack_weight(const float* weight, int c_out, int c_in, int kh, int kw, float* packed, void* stream);
+/* The contraction of the fp32 forward entry points below (same tensors, same fp32 accumulation) can be issued on the bf16
+ * matrix pipe with every fp32 operand split EXACTLY into three bf16 pieces (csrc/orp_dcn_split.hip): mode 0 = off (exact
+ * fp32 MFMA, the default), 9 = all nine partial products of the pieces (no representation error), 6 = without the three
+ * below 2^-24 of the product; -1 = back to the environment's choice (ORP_DCN_SPLIT = 0 | 1 (= 6) | 6 | 9).  Process-wide;
+ * takes effect for Cin % 64 == 0, Cout % 64 == 0 (the reference has one arithmetic: deform_conv_cuda.cpp:222-237). */
+int orp_dcn_set_split_mode(int mode);
+int orp_dcn_get_split_mode(void);
 /* (includes 25 MB of scratch for launches of more tiles than CUs: those split every layer's (tile, tap) steps evenly over
  * the workgroups, and the accumulators of a tile cut between two workgroups pass through it -- fixed order, reproducible) */
 size_t orp_dcn_forward_workspace_bytes(const orp_dcn_level* levels_host, int nlevels, int batch, int c_in, int in_layout);

@@ -58,6 +58,8 @@ _SIGNATURES = {
     "orp_dcn_fast_path_ok": (_i, [_i, _i, _i, _i, _i, _i]),
     "orp_dcn_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "orp_dcn_packed_weight_floats": (_sz, [_i, _i, _i, _i]),
+    "orp_dcn_set_split_mode": (_i, [_i]),
+    "orp_dcn_get_split_mode": (_i, []),
     "orp_dcn_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "orp_dcn_forward_multi": (_i, [_vp, _i, _i, _i, _i, _vp] + [_i] * 10 + [_vp, _sz, _vp]),
     "orp_dcn_forward_multi_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp]),

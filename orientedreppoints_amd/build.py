@@ -35,12 +35,13 @@ SOURCES = [
     ("orp_conv_small.hip", []),
     ("orp_conv1x1.hip", []),
     ("orp_dcn.hip", []),
+    ("orp_dcn_split.hip", ["-ffp-contract=off"]),    # the bilinear combine is the reference's unfused float expression
     ("orp_dcn_half.hip", []),
     ("orp_dcn_bwd.hip", []),
     ("orp_dcn_bwd_mfma.hip", []),
     ("orp_prof.hip", []),
 ]
-HEADERS = ["orp_geom.hpp", "orp_quadfast.hpp", "orp_tile.hpp", "orp_hull.hpp", "orp_prof.hpp", "orp_launch.hpp", os.path.join("..", "..", "include", "orp_hip.h")]
+HEADERS = ["orp_geom.hpp", "orp_quadfast.hpp", "orp_tile.hpp", "orp_hull.hpp", "orp_prof.hpp", "orp_launch.hpp", "orp_dcn_split.hpp", os.path.join("..", "..", "include", "orp_hip.h")]
 
 
 def _stale(target, deps):

@@ -29,6 +29,7 @@
 #include "../../include/orp_hip.h"
 #include "orp_launch.hpp"
 #include "orp_prof.hpp"
+#include "orp_dcn_split.hpp"
 
 #ifndef ORP_DCN_APF_PIN
 #define ORP_DCN_APF_PIN 0    // 1: sched_barrier behind the prefetch reads (measured: 6 spills, 487 vs 483 us)
@@ -981,12 +982,35 @@ int orp_dcn_pack_weight(const float* weight, int c_out, int c_in, int kh, int kw
   hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, c_out, c_in, kh * kw,
                      packed);
   hipError_t e = hipGetLastError();
+  if (e == hipSuccess && orp_split::shape_ok(c_in, c_out, kh, kw))        // the three bf16 planes of the split path
+    e = orp_split::pack_planes(weight, c_out, c_in, kh * kw, reinterpret_cast<uint16_t*>(packed + 2 * total), (hipStream_t)stream);
   return e == hipSuccess ? ORP_OK : (int)e;
 }
 
 size_t orp_dcn_packed_weight_floats(int c_out, int c_in, int kh, int kw) {
-  return (size_t)2 * c_out * c_in * kh * kw;          // [tap][c][o] followed by [tap][c/4][o][4]
+  // [tap][c][o] followed by [tap][c/4][o][4], followed (shapes the split path takes) by the weights split exactly into
+  // three bf16 planes [3][tap][c/16][2][o][8] = 6 bytes per weight
+  const size_t n = (size_t)c_out * c_in * kh * kw;
+  return 2 * n + (orp_split::shape_ok(c_in, c_out, kh, kw) ? (orp_split::plane_elems(c_out, c_in, kh * kw) + 1) / 2 : 0);
 }
+
+// fp32-by-bf16-splitting path (orp_dcn_split.hip): 0 = off (exact fp32 MFMA), 6 / 9 = partial products per operand pair.
+// Default from the environment (ORP_DCN_SPLIT = 0 | 1 (= 6) | 6 | 9), overridden by orp_dcn_set_split_mode().
+static int g_split_mode = -1;
+static int split_mode() {
+  if (g_split_mode < 0) {
+    const char* e = getenv("ORP_DCN_SPLIT");
+    const int v = e ? atoi(e) : 0;
+    g_split_mode = v == 9 ? 9 : (v == 1 || v == 6) ? 6 : 0;
+  }
+  return g_split_mode;
+}
+int orp_dcn_set_split_mode(int mode) {
+  if (mode != 0 && mode != 6 && mode != 9 && mode != -1) return ORP_EINVAL;
+  g_split_mode = mode;                                   // -1: back to the environment's choice
+  return ORP_OK;
+}
+int orp_dcn_get_split_mode(void) { return split_mode(); }
 
 int orp_dcn_fast_path_ok(int c_in, int c_out, int kh, int kw, int groups, int deformable_groups) {
   return (groups == 1 && deformable_groups == 1 && kh * kw <= MAX_TAPS && c_in % 32 == 0 && c_in >= 32 &&
@@ -1111,6 +1135,26 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
     for (int i = ntl; i <= 2 * MAX_LEVELS; i++) TL.bx0[i] = tbx;
     for (int i = ntl; i < 2 * MAX_LEVELS; i++) { TL.in[i] = TL.in[0]; TL.out[i] = TL.out[0]; TL.hw[i] = 0; }
     hipLaunchKernelGGL(nchw_to_nhwc_multi_kernel, dim3(tbx, (c_in + 31) / 32, batch), dim3(256), 0, st, TL, c_in);
+  }
+  // opt-in: the contraction on the bf16 matrix pipe with every fp32 operand split exactly into three bf16 pieces
+  if (split_mode() != 0 && !heads && orp_split::shape_ok(c_in, c_out, kh, kw)) {
+    orp_split::Args A;
+    A.nlev = nlevels; A.B = batch; A.Cin = c_in; A.Cout = c_out;
+    A.kh = kh; A.kw = kw; A.sh = stride_h; A.sw = stride_w; A.ph = pad_h; A.pw = pad_w; A.dh = dil_h; A.dw = dil_w;
+    const size_t plane_off = (size_t)2 * kh * kw * c_in * c_out;
+    A.planes[0] = reinterpret_cast<const uint16_t*>(weight_packed + plane_off);
+    A.planes[1] = weight2_packed ? reinterpret_cast<const uint16_t*>(weight2_packed + plane_off) : A.planes[0];
+    A.bias[0] = bias; A.bias[1] = bias2;
+    A.relu = relu ? 1 : 0; A.nconv = nconv; A.out_nchw = out_layout == 0 ? 1 : 0; A.nprod = split_mode();
+    for (int i = 0; i < nlevels; i++) {
+      const LevelDesc& D = P.lv[i];
+      orp_split::Level& S = A.lv[i];
+      S.x[0] = D.x; S.x[1] = D.x2; S.off = D.off; S.mask = D.mask; S.out[0] = D.out; S.out[1] = D.out2;
+      S.H = D.H; S.W = D.W; S.Ho = D.Ho; S.Wo = D.Wo;
+    }
+    OrpProfScope prof(ORP_PROF_DCN_FWD, st);
+    const hipError_t se = orp_split::launch(A, st);
+    return se == hipSuccess ? ORP_OK : (int)se;
   }
   // tap-granular split of the last round of tiles: for launches of MORE tiles than CUs (456 tiles on 256 CUs: 36 tap steps
   // on the busiest CU with whole tiles, 32.06 on average; 933 against 962 us at 2 x 1024^2).  One-round launches (228 tiles,

@@ -1,0 +1,484 @@
+// orp_dcn_split.hip -- fp32 deformable convolution forward on the bf16 matrix pipe, for gfx950 (MI355X).
+//
+// Same operator as orp_dcn.hip (deform_conv_forward_cuda / modulated_deform_conv_cuda_forward,
+// mmdet/ops/dcn/src/deform_conv_cuda.cpp:152-260, 490-567; kernels deform_conv_cuda_kernel.cu:190-243, 570-633): fp32 tensors
+// in, fp32 tensors out, fp32 accumulation.  What changes is the instruction the contraction is issued on.  gfx950 has no
+// fast fp32 matrix path: v_mfma_f32_32x32x2_f32 runs at the VECTOR rate (64 FLOP/clk/SIMD, 157 TF/s), 1/16 of
+// v_mfma_f32_32x32x16_bf16.  Two rounds of scheduling work left the exact-fp32 kernel at 0.68 of that peak.  Here every fp32
+// operand is split EXACTLY into three bf16 pieces by truncation,
+//
+//      v = hi + mid + lo,   hi = v & 0xffff0000,   mid = (v - hi) & 0xffff0000,   lo = (v - hi) - mid
+//
+// (8 + 8 + 8 significant bits: the subtractions are exact in fp32 and lo has no bits left below its bf16 mantissa), once per
+// weight at pack time and once per bilinear sample when the A tile is produced, and the product  v * w  becomes partial
+// products of bf16 pieces -- each EXACT in the fp32 accumulator the MFMA adds them into:
+//      nprod = 9: all of them: the sum of products is formed with no representation error at all, only the accumulator's
+//                 roundings remain (9 per 16 channels, where the fp32 MFMA chain has 8);
+//      nprod = 6: without lo*lo, lo*mid, mid*lo (each <= 2^-24 |v w|, below one fp32 rounding of the product itself).
+// Small terms are issued first.  Matrix time per 16 channels of a 32 x 32 tile: 8 fp32 MFMAs x 64 clk = 512 clk before,
+// 9 (6) bf16 MFMAs x 32 clk = 288 (192) clk now.
+//
+// Kernel organisation (one workgroup = 8 waves = MT*32 positions x 256 output channels, all FPN levels in one launch, one
+// or two layers over the same offsets as grid halves: XCDs 0-3 layer 0, XCDs 4-7 layer 1):
+//   * K runs in phases of 64 input channels of one tap.  The A tile (bilinear samples, never in HBM) lives in LDS as three
+//     bf16 planes [MT*32][64 + 8], DOUBLE buffered: while the waves contract phase p out of buffer p & 1, every wave
+//     gathers its 4*MT rows of phase p + 1 (fp32 NHWC rows: 16 lanes x float4 = one 256 B row piece, four rows per
+//     instruction), combines them with the four bilinear weights in fp32, splits, and writes the other buffer.  One
+//     barrier per phase.
+//   * weights: three bf16 planes per layer packed [plane][tap][Cin/16][2][Cout][8] (one 16 B load = the 8 k-values of an
+//     MFMA lane), streamed from L2 into a register ring of one phase (4 chunks x 3 planes), refilled in place for the next
+//     phase right after use.
+//   * output NCHW (operands swapped: lanes along positions) or NHWC; bias / ReLU in the epilogue.
+// Bit-level behaviour: deterministic (fixed order), not bit-identical to the exact-fp32 kernel (different summation
+// grouping); tests/test_gpu_dcn_split.py holds both against the fp64-accumulated oracle and prints both errors.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "orp_dcn_split.hpp"
+#include "orp_launch.hpp"
+
+#ifndef ORP_DCNS_DBG
+#define ORP_DCNS_DBG 0     // dev aid, compile-time (timing only, wrong results): 1 = no gathers, 2 = no weight refills, 4 = no MFMA, 8 = no combine / split / LDS write, 16 = no A-fragment LDS reads, 32 = no per-phase barrier
+#endif
+
+#ifndef ORP_DCNS_COMBINE_IN_LAST
+#define ORP_DCNS_COMBINE_IN_LAST 1   // 0: combine + split as a VALU-only tail after the phase's last MFMA (measured: the matrix pipe idles through it)
+#endif
+#ifndef ORP_DCNS_REFILL_LAG
+#define ORP_DCNS_REFILL_LAG 0
+#endif
+#ifndef ORP_DCNS_DRAIN
+#define ORP_DCNS_DRAIN 0             // dev aid: 1 = wait for the accumulators (all issued MFMAs done) before the A-fragment prefetch, 2 = before the weight refill
+#endif
+#ifndef ORP_DCNS_INTERLEAVE
+#define ORP_DCNS_INTERLEAVE 4        // VALU instructions of the combine pinned behind every MFMA of the chunk that carries it (0: scheduler's choice)
+#endif
+
+namespace orp_split {
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+constexpr int kTapsMax = 9;
+constexpr int CBS = 64;            // input channels per phase
+constexpr int ASTRS = CBS + 8;     // A row stride in bf16 elements (36 dwords: conflict-free ds_read_b128 over 16 rows)
+constexpr int NCH = CBS / 16;      // MFMA chunks (16 channels) per phase
+constexpr int kThreadsS = 512;
+
+struct LevelK {
+  const float* x[2];
+  const float* off;
+  const float* mask;
+  float* out[2];
+  int H, W, Ho, Wo;
+  int tile0;
+};
+struct FwdS {
+  LevelK lv[kMaxLevels];
+  int nlev, B, Cin, Cout;
+  int kh, kw, sh, sw, ph, pw, dh, dw;
+  const uint16_t* planes[2];
+  const float* bias[2];
+  int relu, nconv;
+  size_t plane_stride;            // elements between two planes of a layer
+};
+
+// w [o][c][tap] fp32 -> three bf16 planes [pl][tap][c/16][kg][o][8]  (kg = (c % 16) / 8, e = c % 8), exact truncation split
+__global__ void pack_planes_kernel(const float* __restrict__ w, int cout, int cin, int taps, uint16_t* __restrict__ planes) {
+  const long total = (long)cout * cin * taps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7);
+    long r = i >> 3;
+    const int o = (int)(r % cout); r /= cout;
+    const int kg = (int)(r & 1); r >>= 1;
+    const int cblk = (int)(r % (cin / 16)), tap = (int)(r / (cin / 16));
+    const int c = cblk * 16 + kg * 8 + e;
+    const float v = w[((long)o * cin + c) * taps + tap];
+    const float hi = __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+    const float r1 = v - hi;
+    const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    const float lo = r1 - mid;
+    planes[i] = (uint16_t)(__float_as_uint(hi) >> 16);
+    planes[total + i] = (uint16_t)(__float_as_uint(mid) >> 16);
+    planes[2 * total + i] = (uint16_t)(__float_as_uint(lo) >> 16);
+  }
+}
+
+// two fp32 values whose low 16 bits are zero (or may be dropped) -> one dword of two bf16: (a >> 16) | (b & 0xffff0000)
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+
+// partial products (A plane, W plane), smallest first: 0 = hi, 1 = mid, 2 = lo.  Base-3 digit strings, so that the unrolled
+// loop indexes registers with compile-time constants (a constexpr array would be materialised in scratch memory)
+__device__ __forceinline__ constexpr int prod_a(int t) { const int tab[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}; return tab[t]; }
+__device__ __forceinline__ constexpr int prod_b(int t) { const int tab[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}; return tab[t]; }
+
+template <int T, int TEND, int MT, bool OUT_NCHW>
+struct Products {
+  static __device__ __forceinline__ void run(floatx16 (&acc)[MT], const bf8 (&a)[MT][3], const bf8 (&b)[3]) {
+    constexpr int pa = prod_a(T), pb = prod_b(T);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+      if (ORP_DCNS_DBG & 4) { acc[mt][0] += (float)a[mt][pa][0] * (float)b[pb][0]; continue; }
+      if (OUT_NCHW) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[pb], a[mt][pa], acc[mt], 0, 0, 0);   // D[channel][position]
+      else          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][pa], b[pb], acc[mt], 0, 0, 0);   // D[position][channel]
+    }
+    Products<T + 1, TEND, MT, OUT_NCHW>::run(acc, a, b);
+  }
+};
+template <int TEND, int MT, bool OUT_NCHW>
+struct Products<TEND, TEND, MT, OUT_NCHW> {
+  static __device__ __forceinline__ void run(floatx16 (&)[MT], const bf8 (&)[MT][3], const bf8 (&)[3]) {}
+};
+
+template <int MT, int NPROD, bool OUT_NCHW>
+__global__ void __launch_bounds__(kThreadsS)
+dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
+  constexpr int BMS = 32 * MT;
+  constexpr int PLANE = BMS * ASTRS;                                          // elements of one plane of one buffer
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* sA = reinterpret_cast<uint16_t*>(smem);                           // [2 buffers][3 planes][BMS][ASTRS]
+  float4* sCw = reinterpret_cast<float4*>(sA + 2 * 3 * PLANE);                // [BMS * taps] bilinear weights
+  int4* sCi = reinterpret_cast<int4*>(sCw + BMS * kTapsMax);                  // [BMS * taps] pixel indices
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int taps = P.kh * P.kw;
+  int tile, conv;
+  {   // XCD-aware map: an XCD takes a contiguous slab of ONE layer's tiles (the layer's weights stay in that XCD's L2)
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int nx = P.nconv == 2 ? 4 : 8;
+    conv = P.nconv == 2 ? (xcd >> 2) : 0;
+    const int xl = P.nconv == 2 ? (xcd & 3) : xcd;
+    const int per = (total_tiles + nx - 1) / nx;
+    tile = xl * per + slot;
+    if (slot >= per || tile >= total_tiles) return;
+  }
+  int lvl = 0;
+#pragma unroll 1
+  for (int i = 1; i < P.nlev; i++) if (tile >= P.lv[i].tile0) lvl = i;
+  const LevelK L = P.lv[lvl];
+  const int HoWo = L.Ho * L.Wo;
+  const long npos = (long)P.B * HoWo;
+  const long p0 = (long)(tile - L.tile0) * BMS;
+  const float* xin = conv ? L.x[1] : L.x[0];
+
+  // ---- bilinear coefficient table, one entry per (position, tap): deformable_im2col_bilinear (:84-115) hoisted out of the
+  //      channel loop; a sample outside (-1, H) x (-1, W) has weight 0 (:229); DCNv2 folds the modulation scalar in (:620) ----
+  for (int e = tid; e < BMS * taps; e += kThreadsS) {
+    const int m = e / taps, tap = e - m * taps;
+    const long p = p0 + m;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 ix = make_int4(0, 0, 0, 0);
+    if (p < npos) {
+      const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+      const int ho = hw / L.Wo, wo = hw - ho * L.Wo;
+      const int ki = tap / P.kw, kj = tap - ki * P.kw;
+      const float* ob = L.off + ((size_t)b * 2 * taps + 2 * tap) * HoWo + hw;
+      const float h_im = (float)(ho * P.sh - P.ph + ki * P.dh) + ob[0];
+      const float w_im = (float)(wo * P.sw - P.pw + kj * P.dw) + ob[HoWo];
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)L.H && w_im < (float)L.W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+        const float hh = 1.f - lh, hw_ = 1.f - lw;
+        const bool t_ok = h_low >= 0, b_ok = h_high <= L.H - 1, l_ok = w_low >= 0, r_ok = w_high <= L.W - 1;
+        const int hl = t_ok ? h_low : 0, hhg = b_ok ? h_high : L.H - 1, wl = l_ok ? w_low : 0, whg = r_ok ? w_high : L.W - 1;
+        w.x = (t_ok && l_ok) ? hh * hw_ : 0.f;
+        w.y = (t_ok && r_ok) ? hh * lw : 0.f;
+        w.z = (b_ok && l_ok) ? lh * hw_ : 0.f;
+        w.w = (b_ok && r_ok) ? lh * lw : 0.f;
+        const int base = b * L.H;
+        ix.x = (base + hl) * L.W + wl;
+        ix.y = (base + hl) * L.W + whg;
+        ix.z = (base + hhg) * L.W + wl;
+        ix.w = (base + hhg) * L.W + whg;
+        if (L.mask) {
+          const float mm = L.mask[((size_t)b * taps + tap) * HoWo + hw];
+          w.x *= mm; w.y *= mm; w.z *= mm; w.w *= mm;
+        }
+      }
+    }
+    sCw[e] = w; sCi[e] = ix;
+  }
+  __syncthreads();
+
+  const int ncb = P.Cin / CBS;
+  const int nphase = taps * ncb;
+  // A rows: one row piece = 64 channels fp32 = 16 lanes x float4; a wave fetches one neighbour of FOUR rows per instruction
+  const int q4 = lane >> 4, c4 = (lane & 15) * 4;
+  auto row_of = [&](int g) { return g * 32 + wave * 4 + q4; };
+  auto gather_issue = [&](int tap, int cb, int g, float4 (&v)[4]) {
+    const int4 ix = sCi[row_of(g) * taps + tap];
+    const float* base = xin + cb * CBS + c4;
+    if (ORP_DCNS_DBG & 1) { v[0] = v[1] = v[2] = v[3] = make_float4((float)ix.x, (float)ix.y, (float)ix.z, (float)ix.w); return; }
+    v[0] = *reinterpret_cast<const float4*>(base + (size_t)ix.x * P.Cin);
+    v[1] = *reinterpret_cast<const float4*>(base + (size_t)ix.y * P.Cin);
+    v[2] = *reinterpret_cast<const float4*>(base + (size_t)ix.z * P.Cin);
+    v[3] = *reinterpret_cast<const float4*>(base + (size_t)ix.w * P.Cin);
+  };
+  auto combine_store = [&](int tap, int g, const float4 (&v)[4], int buf) {
+    const int m = row_of(g);
+    if (ORP_DCNS_DBG & 8) return;
+    const float4 cw = sCw[m * taps + tap];
+    // the reference's own float expression, w1*v1 + w2*v2 + w3*v3 + w4*v4 evaluated left to right WITHOUT contraction
+    // (deform_conv_cuda_kernel.cu:111-113): the samples are the reference's bits (DCNv1), and the value does not depend on
+    // which fused / packed forms the compiler would pick in one instantiation or another
+    auto bil = [&](float a, float b, float c, float d) {
+      return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(cw.x, a), __fmul_rn(cw.y, b)), __fmul_rn(cw.z, c)), __fmul_rn(cw.w, d));
+    };
+    float s[4];
+    s[0] = bil(v[0].x, v[1].x, v[2].x, v[3].x);
+    s[1] = bil(v[0].y, v[1].y, v[2].y, v[3].y);
+    s[2] = bil(v[0].z, v[1].z, v[2].z, v[3].z);
+    s[3] = bil(v[0].w, v[1].w, v[2].w, v[3].w);
+    float hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      hi[i] = __uint_as_float(__float_as_uint(s[i]) & 0xffff0000u);
+      const float r1 = s[i] - hi[i];                                           // exact
+      mid[i] = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+      lo[i] = r1 - mid[i];                                                     // exact, <= 8 significant bits
+    }
+    uint16_t* dst = sA + (size_t)buf * 3 * PLANE + (size_t)m * ASTRS + c4;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]));
+    *reinterpret_cast<uint2*>(dst + PLANE) = make_uint2(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]));
+    *reinterpret_cast<uint2*>(dst + 2 * PLANE) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
+  };
+  // weight fragments of (tap, cb, chunk j): lane (n = lane & 31, kg = lane >> 5) -> 8 k-values of each plane, 16 B loads
+  const int n_wave = blockIdx.y * 256 + wave * 32;
+  const int mrow = lane & 31, kg = lane >> 5;
+  const bool live = n_wave < P.Cout;                      // c_out % 64 == 0 -> ... % 32 == 0: a wave is live or idle as a whole
+  const uint16_t* wp = (conv ? P.planes[1] : P.planes[0]) + ((size_t)kg * P.Cout + (live ? n_wave : 0) + mrow) * 8;
+  const size_t wblk = (size_t)2 * P.Cout * 8;             // elements per 16-channel block
+  auto load_b = [&](int tap, int cb, int j, bf8 (&b)[3]) {
+    const uint16_t* a = wp + ((size_t)tap * (P.Cin / 16) + cb * NCH + j) * wblk;
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) b[pl] = *reinterpret_cast<const bf8*>(a + (size_t)pl * P.plane_stride);
+  };
+
+  // ---- prologue: weight ring and A tile of phase 0 -------------------------------------------------------------------------
+  bf8 bq[NCH][3];
+#pragma unroll
+  for (int j = 0; j < NCH; j++) load_b(0, 0, j, bq[j]);
+  {
+    float4 g[MT][4];
+#pragma unroll
+    for (int r = 0; r < MT; r++) gather_issue(0, 0, r, g[r]);
+#pragma unroll
+    for (int r = 0; r < MT; r++) combine_store(0, r, g[r], 0);
+  }
+  __syncthreads();
+
+  floatx16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) acc[mt] = floatx16{0};
+
+  // (tap, cb) of the NEXT phase, advanced incrementally; past the end it stays on the last phase: the loads of the loop
+  // body are UNCONDITIONAL (the final iteration re-fetches the last phase's rows and weights and drops them), so that the
+  // compiler's s_waitcnt vmcnt counts are exact -- with the loads under `if (next_phase)` it has to assume the shortest
+  // path and made the first MFMA of every phase wait for this phase's own gathers
+  int tap_n = 0, cb_n = 0;
+  auto advance = [&](int phase) {
+    if (phase + 1 < nphase) { if (++cb_n == ncb) { cb_n = 0; tap_n++; } }
+  };
+  advance(0);
+  auto load_a = [&](const uint16_t* abase, int j, bf8 (&a)[MT][3]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++)
+        if (!(ORP_DCNS_DBG & 16)) a[mt][pl] = *reinterpret_cast<const bf8*>(abase + (size_t)pl * PLANE + (size_t)mt * 32 * ASTRS + j * 16);
+  };
+
+#pragma unroll 1
+  for (int phase = 0; phase < nphase; phase++) {
+    const int cur = phase & 1;
+    // (1) the gathers of the next phase's rows go out first: a whole phase of matrix work to land
+    float4 g[MT][4];
+#pragma unroll
+    for (int r = 0; r < MT; r++) gather_issue(tap_n, cb_n, r, g[r]);
+    // (the scheduler would otherwise SINK these loads down to their use to save registers -- measured in the ISA: the
+    //  gathers ended up between the last MFMAs with s_waitcnt vmcnt(0) right behind them; the barriers pin the pipeline)
+    __builtin_amdgcn_sched_barrier(0);
+    const uint16_t* abase = sA + (size_t)cur * 3 * PLANE + (size_t)mrow * ASTRS + 8 * kg;
+    // (2) the phase: the A fragments of chunk j + 1 are read from LDS BEFORE the MFMAs of chunk j are issued (a second
+    //     register set), the weight registers of chunk j are refilled for the next phase right after use
+    bf8 a[2][MT][3];
+    if (ORP_DCNS_DBG & 16) {
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+          for (int pl = 0; pl < 3; pl++) a[i][mt][pl] = bq[(i + mt + pl) & 3][pl];
+    }
+    load_a(abase, 0, a[0]);
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+#if ORP_DCNS_DRAIN & 1
+      { float t_; 
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) asm volatile("v_mov_b32 %0, %1" : "=v"(t_) : "v"(acc[mt][15])); }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if (j + 1 < NCH) load_a(abase, j + 1, a[(j + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      // (3) the last chunk's scheduling region also holds the combine + split of the gathered rows into the OTHER buffer
+      //     (nobody reads it before the barrier below; everybody finished reading it before the barrier that ended the
+      //     previous phase): ~70 VALU per row group that the scheduler can place in the shadow of the region's MFMAs
+      //     (a 32-cycle MFMA leaves ~5 issue slots) instead of a VALU-only tail during which the matrix pipe idles
+      const bool with_combine = ORP_DCNS_COMBINE_IN_LAST && j >= NCH - MT;       // row group j - (NCH - MT) rides in chunk j
+      if (with_combine) combine_store(tap_n, j - (NCH - MT), g[j - (NCH - MT)], cur ^ 1);
+      Products<9 - NPROD, 9, MT, OUT_NCHW>::run(acc, a[j & 1], bq[j]);
+#if ORP_DCNS_DRAIN & 2
+      __builtin_amdgcn_sched_barrier(0);
+      { float t_; 
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) asm volatile("v_mov_b32 %0, %1" : "=v"(t_) : "v"(acc[mt][15])); }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#if ORP_DCNS_REFILL_LAG
+      // the registers of chunk j - 1 are refilled one chunk LATER, behind the MFMAs of chunk j (chunk NCH - 1: after the loop)
+      if (!(ORP_DCNS_DBG & 2) && j > 0) load_b(tap_n, cb_n, j - 1, bq[j - 1]);
+#else
+      if (!(ORP_DCNS_DBG & 2)) load_b(tap_n, cb_n, j, bq[j]);
+#endif
+      if (with_combine && ORP_DCNS_INTERLEAVE > 0) {
+        // pin the interleave: one MFMA, then ORP_DCNS_INTERLEAVE VALU of the combine in its 32-cycle shadow, ...
+#pragma unroll
+        for (int i = 0; i < NPROD * MT; i++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, ORP_DCNS_INTERLEAVE, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!ORP_DCNS_COMBINE_IN_LAST) {
+#pragma unroll
+      for (int r = 0; r < MT; r++) combine_store(tap_n, r, g[r], cur ^ 1);
+    }
+#if ORP_DCNS_REFILL_LAG
+    if (!(ORP_DCNS_DBG & 2)) load_b(tap_n, cb_n, NCH - 1, bq[NCH - 1]);
+#endif
+    advance(phase + 1);
+    if (!(ORP_DCNS_DBG & 32)) __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+  if (!live) return;
+  const float* bias = conv ? P.bias[1] : P.bias[0];
+  float* outp = conv ? L.out[1] : L.out[0];
+  auto finish = [&](float v, int ch) { if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) {
+    if (OUT_NCHW) {
+      const long p = p0 + mt * 32 + (lane & 31);
+      if (p < npos) {
+        const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+        float* ob = outp + (size_t)b * P.Cout * HoWo + hw;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int ch = n_wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          ob[(size_t)ch * HoWo] = finish(acc[mt][r], ch);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const long p = p0 + mt * 32 + m;
+        if (p < npos) outp[(size_t)p * P.Cout + n_wave + (lane & 31)] = finish(acc[mt][r], n_wave + (lane & 31));
+      }
+    }
+  }
+}
+
+template <int MT>
+constexpr size_t split_smem() { return (size_t)2 * 3 * 32 * MT * ASTRS * 2 + (sizeof(float4) + sizeof(int4)) * 32 * MT * kTapsMax; }
+
+template <int MT, int NPROD, bool OUT_NCHW>
+hipError_t launch_one(const FwdS& P, int tiles, int nblk_n, hipStream_t st) {
+  // ONE workgroup per CU, always: the launch asks for at least 84 KB of LDS (2 x 84 > 160).  The MT = 1 instantiation (37 KB,
+  // 119 VGPRs) would otherwise run two workgroups = four waves per SIMD side by side, and in that configuration single A
+  // rows came out wrong in multi-round launches (tests/checks/split_diag2.py: a few positions per level, all channels,
+  // different ones every run; correct with ORP_DCNS_PAD_LDS >= 84, correct with every issued MFMA drained before the weight
+  // registers are refilled (-DORP_DCNS_DRAIN=2), fewer errors with the refill one chunk later) -- i.e. with the matrix pipe
+  // backlogged four deep an asynchronous register write (LDS / VMEM return) can overtake a queued MFMA's operand read.
+  // Two waves per SIMD is the configuration every test and the soak (tests/checks/soak_dcn_split.py) run bit-stable.
+  static const int pad_env = getenv("ORP_DCNS_PAD_LDS") ? atoi(getenv("ORP_DCNS_PAD_LDS")) : 84;   // KB; dev aid: 0 = no floor
+  const size_t smem = split_smem<MT>() < (size_t)pad_env * 1024 ? (size_t)pad_env * 1024 : split_smem<MT>();
+  struct Tag {};
+  hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_split_kernel<MT, NPROD, OUT_NCHW>), smem);
+  if (e != hipSuccess) return e;
+  const int nx = P.nconv == 2 ? 4 : 8;
+  const int per = (tiles + nx - 1) / nx;
+  hipLaunchKernelGGL((dcn_fwd_split_kernel<MT, NPROD, OUT_NCHW>), dim3(per * 8, nblk_n), dim3(kThreadsS), smem, st, P, tiles);
+  return hipGetLastError();
+}
+
+template <int MT, int NPROD>
+hipError_t launch_l(const FwdS& P, int tiles, int nblk_n, bool nchw, hipStream_t st) {
+  return nchw ? launch_one<MT, NPROD, true>(P, tiles, nblk_n, st) : launch_one<MT, NPROD, false>(P, tiles, nblk_n, st);
+}
+template <int NPROD>
+hipError_t launch_m(int MT, const FwdS& P, int tiles, int nblk_n, bool nchw, hipStream_t st) {
+  return MT == 1 ? launch_l<1, NPROD>(P, tiles, nblk_n, nchw, st)
+       : MT == 2 ? launch_l<2, NPROD>(P, tiles, nblk_n, nchw, st) : launch_l<3, NPROD>(P, tiles, nblk_n, nchw, st);
+}
+
+inline int out_dim(int in, int pad, int dil, int k, int stride) { return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1; }
+
+}  // namespace
+
+bool shape_ok(int c_in, int c_out, int kh, int kw) {
+  return kh * kw <= kTapsMax && c_in % CBS == 0 && c_in >= CBS && c_out % 64 == 0 && c_out >= 64;
+}
+
+size_t plane_elems(int c_out, int c_in, int taps) { return (size_t)3 * c_out * c_in * taps; }
+
+hipError_t pack_planes(const float* weight, int c_out, int c_in, int taps, uint16_t* planes, hipStream_t st) {
+  const long total = (long)c_out * c_in * taps;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_planes_kernel, dim3(blocks), dim3(256), 0, st, weight, c_out, c_in, taps, planes);
+  return hipGetLastError();
+}
+
+hipError_t launch(const Args& a, hipStream_t st) {
+  FwdS P;
+  P.nlev = a.nlev; P.B = a.B; P.Cin = a.Cin; P.Cout = a.Cout;
+  P.kh = a.kh; P.kw = a.kw; P.sh = a.sh; P.sw = a.sw; P.ph = a.ph; P.pw = a.pw; P.dh = a.dh; P.dw = a.dw;
+  P.planes[0] = a.planes[0]; P.planes[1] = a.planes[1]; P.bias[0] = a.bias[0]; P.bias[1] = a.bias[1];
+  P.relu = a.relu; P.nconv = a.nconv;
+  P.plane_stride = (size_t)a.Cout * a.Cin * a.kh * a.kw;
+  long npos_all = 0;
+  for (int i = 0; i < a.nlev; i++) npos_all += (long)a.B * a.lv[i].Ho * a.lv[i].Wo;
+  // tile height: rounds x height on 256 CUs (one layer) / 128 CUs per layer (pair: the grid halves run side by side)
+  const int cus = a.nconv == 2 ? 128 : 256;
+  int MT = 1;
+  long best = -1;
+  for (int mt = 1; mt <= 3; mt++) {
+    const long t = (npos_all + 32 * mt - 1) / (32 * mt) + a.nlev;
+    const long cost = ((t + cus - 1) / cus) * mt * 100 + (mt == 1 ? 40 : mt == 2 ? 10 : 0);
+    if (best < 0 || cost < best) { best = cost; MT = mt; }
+  }
+  static const int force_mt = getenv("ORP_DCNS_MT") ? atoi(getenv("ORP_DCNS_MT")) : 0;
+  if (force_mt >= 1 && force_mt <= 3) MT = force_mt;
+  int tiles = 0;
+  for (int i = 0; i < a.nlev; i++) {
+    LevelK& D = P.lv[i];
+    D.x[0] = a.lv[i].x[0]; D.x[1] = a.lv[i].x[1]; D.off = a.lv[i].off; D.mask = a.lv[i].mask;
+    D.out[0] = a.lv[i].out[0]; D.out[1] = a.lv[i].out[1];
+    D.H = a.lv[i].H; D.W = a.lv[i].W; D.Ho = a.lv[i].Ho; D.Wo = a.lv[i].Wo;
+    D.tile0 = tiles;
+    tiles += (int)(((long)a.B * D.Ho * D.Wo + 32 * MT - 1) / (32 * MT));
+  }
+  for (int i = a.nlev; i < kMaxLevels; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; }
+  const int nblk_n = (a.Cout + 255) / 256;
+  return a.nprod == 9 ? launch_m<9>(MT, P, tiles, nblk_n, a.out_nchw != 0, st)
+                      : launch_m<6>(MT, P, tiles, nblk_n, a.out_nchw != 0, st);
+}
+
+}  // namespace orp_split

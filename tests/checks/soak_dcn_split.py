@@ -19,8 +19,16 @@ for B in (2, 3):
     fa = [torch.randn(B, 256, n, n, device=dev) for n in sizes]
     fb = [torch.randn(B, 256, n, n, device=dev) for n in sizes]
     of = [torch.randn(B, 18, n, n, device=dev) * 2 for n in sizes]
+    mode = _lib.lib().orp_dcn_get_split_mode()               # ORP_DCN_SPLIT: 0 = exact fp32 MFMA (tap-granular split), 6 / 9 = bf16-split products
+    _lib.lib().orp_dcn_set_split_mode(0)
+    exact = deform_conv_forward_pair(fa, fb, of, w1, w2, 1, 1, 1, relu=True)
+    exact = [t.clone() for t in exact[0] + exact[1]]
+    _lib.lib().orp_dcn_set_split_mode(mode)
     ref = deform_conv_forward_pair(fa, fb, of, w1, w2, 1, 1, 1, relu=True)
     ref = [t.clone() for t in ref[0] + ref[1]]
+    dev_rel = max(float((x - y).abs().max()) / float(y.abs().max()) for x, y in zip(ref, exact))
+    print("B=%d: arithmetic mode %d, first result vs the exact-fp32 launch: max |diff| / max |out| = %.2e" % (B, mode, dev_rel))
+    assert dev_rel <= 1e-5
     bad = 0
     t0 = time.time()
     for i in range(N):

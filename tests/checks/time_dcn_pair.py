@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from orientedreppoints_amd.mmdet_ops import deform_conv_forward_pair
 
+from orientedreppoints_amd import _lib
 dev = torch.device("cuda:0")
+MODE = _lib.lib().orp_dcn_get_split_mode()        # ORP_DCN_SPLIT = 0 (exact fp32 MFMA) | 6 | 9 (bf16-split products)
 torch.manual_seed(0)
 w1, w2 = torch.randn(256, 256, 3, 3, device=dev) * 0.02, torch.randn(256, 256, 3, 3, device=dev) * 0.02
 for size, B in ((1024, 1), (1024, 2), (1536, 1)):
@@ -28,5 +30,5 @@ for size, B in ((1024, 1), (1024, 2), (1536, 1)):
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / n * 1e3
         flop = 2 * 2 * B * sum(s * s for s in sizes) * 256 * 256 * 9
-        print("pair %4d^2 B=%d %s: %.1f us per call (incl. transposition for nchw), %.1f TFLOP/s = %.3f of 157.3  [KSPLIT env %s]"
-              % (size, B, name, us, flop / us / 1e6, flop / us / 1e6 / 157.3, os.environ.get('ORP_DCN_KSPLIT', 'default')))
+        print("pair %4d^2 B=%d %s: %.1f us per call (incl. transposition for nchw), %.1f TFLOP/s = %.3f of 157.3  [KSPLIT env %s, split mode %d]"
+              % (size, B, name, us, flop / us / 1e6, flop / us / 1e6 / 157.3, os.environ.get('ORP_DCN_KSPLIT', 'default'), MODE))
