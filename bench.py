@@ -48,8 +48,10 @@ from orientedreppoints_amd.mmdet_models import ConfigDict, build_detector  # noq
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD at 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), 16x the fp32 matrix rate
 IMG = 1024                       # --size
 MODELS = {'r50': r50_model, 'r101': r101_model, 'swin_t': swin_t_model, 'r50_dcnv2': r50_dcnv2_model}
+MODEL_LABEL = {'r50': 'R-50', 'r101': 'R-101', 'swin_t': 'Swin-T', 'r50_dcnv2': 'R-50-DCNv2'}
 TRAIN_SIZES = None               # --mode train with --size a,b,...: the multi-scale patch sizes (configs[4]: 1024,1536)
 TARGET_DETS = 2000               # (point, class) pairs above score_thr per image: the "dense scene" of BASELINE configs
 
@@ -256,8 +258,9 @@ def batched_nms_line(dev, images=16, boxes=2000, thr=0.4):
 
 def per_op_table(dev, budget_s=2.0):
     """Per-op microseconds at the configs[1] shapes next to the CPU reference port (oracle/, 1 host core) of the same op
-    on a bounded sample -- BASELINE.json: "per-op us reported next to the CPU reference".  GPU: HIP-event pairs around
-    >= 10 launches after warm-up; CPU: the oracle timed once on the stated sample, scaled linearly to the full size."""
+    -- BASELINE.json: "per-op us reported next to the CPU reference".  GPU: HIP-event pairs around >= 10 launches after
+    warm-up; CPU: the oracle timed once AT THE SAME SIZE (nothing is extrapolated; an op whose CPU port needs more than
+    ~10 s has no CPU figure)."""
     from oracle import orp_oracle as O
     from orientedreppoints_amd import synthetic as S
     from orientedreppoints_amd.mmdet_ops import convex_iou, deform_conv_forward_multi, minaerarect
@@ -284,10 +287,8 @@ def per_op_table(dev, budget_s=2.0):
     # min-area-rect decode of the <= 5344 candidates of one image
     pts = S.gen_pointsets(5344, 2).astype(np.float32)
     tp = torch.from_numpy(pts).to(dev)
-    n_s = 1024
-    out['minaerarect_5344_sets'] = dict(gpu_us=gpu_us(lambda: minaerarect(tp)),
-                                        cpu_us=cpu_us(lambda: O.minarearect(pts[:n_s])) * 5344 / n_s,
-                                        cpu_sample='%d sets, scaled x%.2f' % (n_s, 5344 / n_s))
+    out['minaerarect_5344_sets'] = dict(gpu_us=gpu_us(lambda: minaerarect(tp)), cpu_us=cpu_us(lambda: O.minarearect(pts)),
+                                        cpu_sample='full size')
     # refine-stage assigner IoU: all 21824 point sets of an image x 32 gts (grid-ordered, as the head produces them)
     ar = []
     for st in (8, 16, 32, 64, 128):
@@ -298,32 +299,28 @@ def per_op_table(dev, budget_s=2.0):
     pall = np.ascontiguousarray(S.gen_pointsets(len(around), 6, around=around), np.float32)
     gts = S.gen_gts(32, 3).astype(np.float32)
     tpa, tg = torch.from_numpy(pall).to(dev), torch.from_numpy(gts).to(dev)
-    n_s = 1024
-    sel = np.linspace(0, len(pall) - 1, n_s).astype(np.int64)
     out['convex_iou_21824x32'] = dict(gpu_us=gpu_us(lambda: convex_iou(tpa, tg), iters=5),
-                                      cpu_us=cpu_us(lambda: O.convex_iou(pall[sel], gts)) * len(pall) / n_s,
-                                      cpu_sample='%d point sets x 32 gts, scaled x%.2f' % (n_s, len(pall) / n_s))
+                                      cpu_us=cpu_us(lambda: O.convex_iou(pall, gts)), cpu_sample='full size')
     # rotated NMS of a 2000-box class-offset dense scene (fp32 reference arithmetic on both sides)
     d = S.gen_dense_scene(2000, 1)[0].astype(np.float32)
     td = torch.from_numpy(d).to(dev)
-    n_s = 1000
-    out['rnms_2000_boxes'] = dict(gpu_us=gpu_us(lambda: rnms_device(td, 0.4)),
-                                  cpu_us=cpu_us(lambda: O.rnms(d[:n_s], 0.4)) * (2000.0 / n_s) ** 2,
-                                  cpu_sample='%d boxes (fp32 devrIoU port), scaled x%.1f (pairs)' % (n_s, (2000.0 / n_s) ** 2))
+    out['rnms_2000_boxes'] = dict(gpu_us=gpu_us(lambda: rnms_device(td, 0.4)), cpu_us=cpu_us(lambda: O.rnms(d, 0.4)),
+                                  cpu_sample='full size (fp32 devrIoU port)')
     # DeformConv forward: GPU = all five levels of one image in one launch; CPU = the 16x16 level, scaled by positions
     torch.manual_seed(0)
     w = torch.randn(256, 256, 3, 3, device=dev) * 0.01
     xs = [torch.randn(1, 256, IMG // st, IMG // st, device=dev).contiguous(memory_format=torch.channels_last)
           for st in (8, 16, 32, 64, 128)]
     offs = [torch.randn(1, 18, IMG // st, IMG // st, device=dev) * 2 for st in (8, 16, 32, 64, 128)]
-    xc = xs[3].contiguous().cpu().numpy()[:, :64]
-    oc = offs[3].cpu().numpy()
-    wc = w.cpu().numpy()[:64, :64]
-    scale = (21824.0 / 256.0) * (256.0 * 256.0) / (64.0 * 64.0)
+    # (the CPU port needs ~40 s for the whole launch: no CPU figure here, none extrapolated; the 32 x 32 level alone follows)
     out['deform_conv_21824_positions'] = dict(
-        gpu_us=gpu_us(lambda: deform_conv_forward_multi(xs, offs, w, 1, 1, 1)),
-        cpu_us=cpu_us(lambda: O.dcn_forward(xc, oc, wc, 1, 1, 1)) * scale,
-        cpu_sample='16x16 level, 64 -> 64 channels, scaled x%.0f (positions x channel pairs)' % scale)
+        gpu_us=gpu_us(lambda: deform_conv_forward_multi(xs, offs, w, 1, 1, 1)), cpu_us=None,
+        cpu_sample='not timed (tens of seconds); see deform_conv_32x32_level')
+    xc, oc, wc = xs[2].contiguous().cpu().numpy(), offs[2].cpu().numpy(), w.cpu().numpy()
+    out['deform_conv_32x32_level'] = dict(
+        gpu_us=gpu_us(lambda: deform_conv_forward_multi(xs[2:3], offs[2:3], w, 1, 1, 1)),
+        cpu_us=cpu_us(lambda: O.dcn_forward(xc, oc, wc, 1, 1, 1)),
+        cpu_sample='full size: the 1 024 positions of the 32 x 32 level, 256 -> 256 channels (4.7 % of the launch above)')
     # the same layer in fp16 / bf16 (the reference's half dispatch; BASELINE configs[4]): v_mfma_f32_32x32x16, fp32 accumulate
     for dt, nm in ((torch.float16, 'fp16'), (torch.bfloat16, 'bf16')):
         hx, ho, hw = [x.to(dt) for x in xs], [o.to(dt) for o in offs], w.to(dt)
@@ -334,20 +331,18 @@ def per_op_table(dev, budget_s=2.0):
                                                  sigmoid_focal_loss)
     from orientedreppoints_amd.mmdet_ops.apaa import max_iou_assign, point_assign
     t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)   # noqa: E731
-    P, n_s = 5000, 500
+    P = 5000
     pp, gg = S.gen_pointsets(P, 2).astype(np.float32), S.gen_gts(P, 3).astype(np.float32)
     tpp, tgg = t32(pp), t32(gg)
     out['convex_giou_5000_pairs'] = dict(gpu_us=gpu_us(lambda: convex_giou(tpp, tgg)),
-                                         cpu_us=cpu_us(lambda: O.convex_giou(pp[:n_s], gg[:n_s])) * P / n_s,
-                                         cpu_sample='%d pairs, scaled x%.0f' % (n_s, P / n_s))
+                                         cpu_us=cpu_us(lambda: O.convex_giou(pp, gg)), cpu_sample='full size')
     out['points_in_quad_5000x9'] = dict(gpu_us=gpu_us(lambda: points_in_quad_aligned(tpp, tgg)),
                                         cpu_us=cpu_us(lambda: O.points_in_quad_aligned(pp, gg)), cpu_sample='full size')
     rng = np.random.RandomState(0)
     ca, cb_ = (rng.rand(P, 40, 2) * 100).astype(np.float32), (rng.rand(P, 40, 2) * 100).astype(np.float32)
     tca, tcb = t32(ca), t32(cb_)
     out['chamfer_5000x40x40'] = dict(gpu_us=gpu_us(lambda: ChamferDistance2D(tca, tcb)),
-                                     cpu_us=cpu_us(lambda: O.chamfer_forward(ca[:n_s], cb_[:n_s])) * P / n_s,
-                                     cpu_sample='%d samples, scaled x%.0f' % (n_s, P / n_s))
+                                     cpu_us=cpu_us(lambda: O.chamfer_forward(ca, cb_)), cpu_sample='full size')
     N = 2 * 21824
     lg = rng.randn(N, 15).astype(np.float32); lb = rng.randint(0, 16, N).astype(np.int64)
     tlg, tlb = t32(lg), torch.from_numpy(lb).to(dev)
@@ -366,9 +361,88 @@ def per_op_table(dev, budget_s=2.0):
     rb = S.gen_rboxes(1000, 1).astype(np.float32)
     trb = t32(rb)
     out['box_iou_rotated_1000x1000'] = dict(gpu_us=gpu_us(lambda: box_iou_rotated(trb, trb)),
-                                            cpu_us=cpu_us(lambda: O.box_iou_rotated(rb[:200], rb)) * 5.0,
-                                            cpu_sample='200 x 1000, scaled x5')
+                                            cpu_us=cpu_us(lambda: O.box_iou_rotated(rb, rb)), cpu_sample='full size')
     return out
+
+
+def dcn_pair_modes_us(dev, batch, img, modes):
+    """The head's DeformConv pair launch (both layers, five levels of `batch` img x img images, NCHW in / out as the towers
+    hand the features over) in each arithmetic mode of the library: average kernel time from the library's own HIP events."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv_forward_pair
+    L = _lib.lib()
+    g = torch.Generator(device='cpu').manual_seed(11)
+    sizes = [img // s_ for s_ in (8, 16, 32, 64, 128)]
+    fa = [torch.randn(batch, 256, n, n, generator=g).to(dev) for n in sizes]
+    fb = [torch.randn(batch, 256, n, n, generator=g).to(dev) for n in sizes]
+    of = [(torch.randn(batch, 18, n, n, generator=g) * 2).to(dev) for n in sizes]
+    w1, w2 = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(dev), (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(dev)
+    out = {}
+    try:
+        for m in modes:
+            L.orp_dcn_set_split_mode(int(m))
+            for _ in range(3):
+                deform_conv_forward_pair(fa, fb, of, w1, w2, 1, 1, 1, relu=True)
+            torch.cuda.synchronize()
+            L.orp_profile_enable(1)
+            read_prof(3)
+            for _ in range(20):
+                deform_conv_forward_pair(fa, fb, of, w1, w2, 1, 1, 1, relu=True)
+            torch.cuda.synchronize()
+            ms, n = read_prof(3)
+            out[int(m)] = (ms / n * 1e3) if n else None
+    finally:
+        L.orp_dcn_set_split_mode(-1)
+        L.orp_profile_enable(0)
+    return out
+
+
+def train_probe(dev, model_name='r50', steps=10, warmup=4, gts=64):
+    """BASELINE configs[2] at its per-GPU load inside the default run (rank 0, N = 1): `steps` SGD iterations of the R-50
+    detector on 2 synthetic 1024^2 images x `gts` polygons (forward, APAA losses, backward, clip, step), wall time per
+    iteration and the library's own HIP events around the hot-path kernels of the training step."""
+    from orientedreppoints_amd import dist_utils as D
+    from orientedreppoints_amd import synthetic as S
+    from orientedreppoints_amd.dota_configs import train_cfg as TRAIN_CFG
+    L = _lib.lib()
+    torch.manual_seed(0)
+    model = build_detector(ConfigDict(MODELS[model_name]), train_cfg=ConfigDict(TRAIN_CFG),
+                           test_cfg=ConfigDict(TEST_CFG)).to(dev).train()
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-4, momentum=0.9, weight_decay=1e-4)
+    hook = D.DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2), overlap=False)
+    g = torch.Generator(device='cpu').manual_seed(4321)
+    batch = 2
+    data = dict(
+        img=torch.randn(batch, 3, 1024, 1024, generator=g).to(dev),
+        img_meta=[dict(img_shape=(1024, 1024, 3), pad_shape=(1024, 1024, 3), scale_factor=1.0, flip=False)] * batch,
+        gt_bboxes=[torch.from_numpy(S.gen_polys(gts, 40 + i, wh=(16, 120))[:, :8].astype(np.float32)).to(dev) for i in range(batch)],
+        gt_labels=[torch.randint(1, 16, (gts,), generator=g).to(dev) for _ in range(batch)])
+    for _ in range(warmup):
+        log_vars = D.train_step(model, opt, data, hook)
+    torch.cuda.synchronize()
+    slots = dict(dcn_fwd=3, dcn_bwd_all=8, dcn_bwd_input_gemm=9, dcn_bwd_scatter=10, dcn_bwd_weight=11, convex_iou=5,
+                 convex_giou=6, minarearect=4)
+    L.orp_profile_enable(1)
+    for sl in slots.values():
+        read_prof(sl)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        log_vars = D.train_step(model, opt, data, hook)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    L.orp_profile_enable(0)
+    ev = {}
+    for name, sl in slots.items():
+        ms, n = read_prof(sl)
+        ev[name] = dict(us_per_step=round(ms / steps * 1e3, 1), launches_per_step=round(n / steps, 2)) if n else None
+    del model, opt
+    torch.cuda.empty_cache()
+    return {'workload': 'BASELINE configs[2] per-GPU load: train step, 2 img/GPU x %d gts, 1024x1024, R-50 FPN, SGD, f32' % gts,
+            'steps': steps, 'warmup': warmup, 'ms_per_step': round(elapsed / steps * 1e3, 3),
+            'images_per_s': round(batch * steps / elapsed, 2), 'loss': round(float(log_vars['loss']), 4),
+            'dcn_forward_mode': int(L.orp_dcn_get_split_mode()), 'hip_events': ev,
+            'note': 'hot-path kernels are ~10 % of this step; ~30 ms is the library\'s convolution_backward (backbone / towers), '
+                    'outside the hot path'}
 
 
 def _free_port():
@@ -615,6 +689,9 @@ def main():
                     help='launcher / rank / timing plumbing only, stand-in step (the CPU test of the N > 1 path)')
     ap.add_argument('--batch', type=int, default=1, help='images per GPU per step (config 1: 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--train-probe', type=int, default=1,
+                    help='1 (default): the line also carries `train` = 10 SGD iterations of BASELINE configs[2] at its per-GPU load '
+                         '(rank 0, N = 1, after the timed inference loops)')
     ap.add_argument('--pipeline', type=int, default=4,
                     help='captured graphs in flight in the throughput measurement (PipelinedInference); 1 = off')
     ap.add_argument('--graph', type=int, default=1,
@@ -859,25 +936,45 @@ def main():
         avg_s = dcn_ms / dcn_n * 1e-3
         flops = layers * 2.0 * npos * cout * cin * 9
         alg_bytes = 4.0 * (layers * (npos * cin + 9 * cin * cout + npos * cout) + npos * 18)
-        achieved = flops / avg_s / 1e12
-        traffic, traffic_src = None, None
+        mode = int(_lib.lib().orp_dcn_get_split_mode())          # 0 = exact-fp32 MFMA, 6 / 9 = bf16-split products per multiply
         pmc, pmc_note = load_pmc()
-        d = pmc.get('dcn_fwd_pair', {}) if pmc else {}
-        if d and args.batch == d.get('batch') and IMG == d.get('img', 1024):
-            traffic = d.get('hbm_bytes_per_launch')
-        traffic_src = pmc_note
+        d = pmc.get('dcn_fwd_split' if mode else 'dcn_fwd_pair', {}) if pmc else {}
+        traffic = d.get('hbm_bytes_per_launch') if d and args.batch == d.get('batch') and IMG == d.get('img', 1024) else None
         tiles = sum((args.batch * (IMG // s_) ** 2 + 95) // 96 for s_ in (8, 16, 32, 64, 128))
-        split = os.environ.get('ORP_DCN_KSPLIT') != '0' and tiles > 256 and tiles * 9 * 105 <= ((tiles + 255) // 256) * 18 * 128 * 100   # the library's rule (csrc/orp_dcn.hip)
-        roof = dict(kernel='dcn_fwd_mfma2_kernel<3, nchw, 2 layers, tap-granular split>' if split
-                    else 'dcn_fwd_mfma2_kernel<3, nchw, 2 layers>', bound='mfma', achieved=achieved,
-                    peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=traffic,
-                    traffic_source=traffic_src, avg_launch_us=avg_s * 1e6, launches=dcn_n, layers_per_launch=layers,
-                    positions_per_launch=npos, algorithmic_flops_per_launch=flops,
-                    algorithmic_bytes_per_launch=alg_bytes,
-                    note='exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense = the fp32 vector peak; a register-'
-                         'operand microbenchmark of the instruction sustains 146-156 TFLOP/s on this part: '
-                         'tests/checks/mfma_rate.hip); one launch per image = cls + refine DeformConv over all levels (launches of '
-                         'more tiles than CUs split each layer\'s (tile, tap) steps evenly over 128 workgroups, XCDs 0-3 / 4-7)')
+        ksplit = os.environ.get('ORP_DCN_KSPLIT') != '0' and tiles > 256 and tiles * 9 * 105 <= ((tiles + 255) // 256) * 18 * 128 * 100   # the library's rule (csrc/orp_dcn.hip)
+        # the SAME pair launch in the other arithmetic mode, on the same shapes (random feature maps), HIP events inside the
+        # library around the kernel: so that both the figure of the instruction actually issued and the exact-fp32 figure
+        # are in the line whichever mode the timed loops ran in
+        modes_us = dcn_pair_modes_us(dev, args.batch, IMG, (0, 6, 9))
+        exact_us = modes_us.get(0)
+        exact = dict(kernel='dcn_fwd_mfma2_kernel<3, nchw, 2 layers, tap-granular split>' if ksplit
+                     else 'dcn_fwd_mfma2_kernel<3, nchw, 2 layers>', instruction='v_mfma_f32_32x32x2_f32',
+                     avg_launch_us=exact_us, achieved=(flops / (exact_us * 1e-6) / 1e12) if exact_us else None,
+                     peak=FP32_MFMA_PEAK_TFLOPS, frac=(flops / (exact_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if exact_us else None)
+        common = dict(unit='TFLOP/s', traffic=traffic, traffic_source=pmc_note, avg_launch_us=avg_s * 1e6, launches=dcn_n,
+                      layers_per_launch=layers, positions_per_launch=npos, algorithmic_flops_per_launch=flops,
+                      algorithmic_bytes_per_launch=alg_bytes, algorithmic_tflops=flops / avg_s / 1e12,
+                      pair_launch_us_by_mode={str(k): v for k, v in modes_us.items()}, arithmetic_mode=mode)
+        if mode == 0:
+            roof = dict(kernel=exact['kernel'], bound='mfma', achieved=flops / avg_s / 1e12, peak=FP32_MFMA_PEAK_TFLOPS,
+                        frac=flops / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                        note='exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense = the fp32 vector peak; a register-'
+                             'operand microbenchmark of the instruction sustains 146-156 TFLOP/s on this part: '
+                             'tests/checks/mfma_rate.hip); one launch per image = cls + refine DeformConv over all levels', **common)
+        else:
+            issued = mode * flops / avg_s / 1e12
+            roof = dict(kernel='dcn_fwd_split_kernel<MT 3, %d products, nchw, 2 layers as grid halves>' % mode, bound='mfma',
+                        achieved=issued, peak=BF16_MFMA_PEAK_TFLOPS, frac=issued / BF16_MFMA_PEAK_TFLOPS,
+                        instruction='v_mfma_f32_32x32x16_bf16', products_per_fp32_multiply=mode,
+                        frac_of_fp32_mfma_peak_equivalent=flops / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, exact_fp32=exact,
+                        note='fp32 tensors, fp32 accumulation; every fp32 operand split EXACTLY into three bf16 pieces and the '
+                             'product formed from %d partial products on the bf16 matrix pipe (csrc/orp_dcn_split.hip). '
+                             '`achieved` counts the bf16 MFMA flops actually issued (%d x the algorithmic fp32 flops) against '
+                             'the 2.5 PFLOP/s dense bf16 peak; `algorithmic_tflops` is the fp32-equivalent rate (the exact-'
+                             'fp32 MFMA kernel, kept as `exact_fp32`, cannot exceed 157.3). The kernel runs at the 1.4 kW '
+                             'socket power cap (2.14 GHz instead of 2.4; a register-operand microbenchmark of the instruction '
+                             'sustains 1.7-2.0 PFLOP/s there: tests/checks/mfma_rate_bf16.hip, clock_under_split.sh)'
+                             % (mode, mode), **common)
     # ---- the rotated-IoU + NMS stage (HBM is the formal bound, the work is fp32 VALU) --------------------------------
     mask_ms, mask_n = prof['nms_mask']
     nms = None
@@ -923,8 +1020,14 @@ def main():
         except Exception as e:   # noqa: BLE001
             batched = 'failed: %s' % (str(e)[:200],)
 
+    train = None
+    if not args.no_cpu_baseline and world == 1 and args.train_probe:
+        try:
+            train = train_probe(dev)
+        except Exception as e:   # noqa: BLE001
+            train = 'failed: %s' % (str(e)[:200],)
     out = {
-        'metric': 'images/sec (%dx%d DOTA, %s FPN)' % (IMG, IMG, {'r50': 'R-50', 'r101': 'R-101'}[args.model]), 'value': value,
+        'metric': 'images/sec (%dx%d DOTA, %s FPN)' % (IMG, IMG, MODEL_LABEL[args.model]), 'value': value,
         'value_serial': value_serial, 'unit': 'images/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -933,7 +1036,7 @@ def main():
                                'random-init weights, head biases calibrated to ~%d dets/img'
                                % ('configs[1]' if (args.model, IMG, args.batch) == ('r50', 1024, 1) else
                                   ('configs[3] per-GPU load' if (args.model, args.batch) == ('r101', 2) else 'variant'),
-                                  {'r50': 'R-50', 'r101': 'R-101'}[args.model], IMG, IMG, args.batch, TARGET_DETS),
+                                  MODEL_LABEL[args.model], IMG, IMG, args.batch, TARGET_DETS),
                    'global_batch': args.batch * world, 'parallelism': 'replicas x%d (image-parallel, no collective)' % world,
                    'images_in_flight_per_gpu': args.pipeline if isinstance(pipe_ms, float) else 1},
         'detections_per_step': ndet, 'step_bitwise_reproducible': bool(step_reproducible), 'library_deterministic_mode': library_deterministic_mode, 'nms_classes_present': int(len(set(cap['labels'].tolist()))) if cap.get('labels') is not None else None,
@@ -945,7 +1048,8 @@ def main():
         'eager_ms_per_step': round(eager_elapsed / args.steps * 1e3, 4),
         'graph_replay_ms': graph_ms,
         'pipelined_ms_per_step': pipe_ms,
-        'roofline': roof, 'nms': nms, 'nms_batched_16_images': batched, 'per_op_us': per_op, 'cpu_baseline': cpu,
+        'roofline': roof, 'nms': nms, 'nms_batched_16_images': batched, 'per_op_us': per_op, 'train': train,
+        'cpu_baseline': cpu,
     }
     print(json.dumps(out))
     if distributed:

@@ -146,8 +146,8 @@ size_t orp_dcn_packed_weight_floats(int c_out, int c_in, int kh, int kw);
 int orp_dcn_pack_weight(const float* weight, int c_out, int c_in, int kh, int kw, float* packed, void* stream);
 /* The contraction of the fp32 forward entry points below (same tensors, same fp32 accumulation) can be issued on the bf16
  * matrix pipe with every fp32 operand split EXACTLY into three bf16 pieces (csrc/orp_dcn_split.hip): mode 0 = off (exact
- * fp32 MFMA, the default), 9 = all nine partial products of the pieces (no representation error), 6 = without the three
- * below 2^-24 of the product; -1 = back to the environment's choice (ORP_DCN_SPLIT = 0 | 1 (= 6) | 6 | 9).  Process-wide;
+ * fp32 MFMA), 9 = all nine partial products of the pieces (no representation error), 6 = without the three below 2^-24 of
+ * the product (the default); -1 = back to the environment's choice (ORP_DCN_SPLIT = 0 | 1 (= 6) | 6 | 9; unset = 6).  Process-wide;
  * takes effect for Cin % 64 == 0, Cout % 64 == 0 (the reference has one arithmetic: deform_conv_cuda.cpp:222-237). */
 int orp_dcn_set_split_mode(int mode);
 int orp_dcn_get_split_mode(void);

@@ -996,11 +996,13 @@ int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float*
       struct T1 { int unused; };
       e = orp::set_max_dynamic_lds_once<T1>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT, false>), input_smem<MT>());
       if (e != hipSuccess) return (int)e;
+      OrpProfScope prof_in(ORP_PROF_DCN_BWD_INPUT, st);
       hipLaunchKernelGGL((dcn_bwd_input_kernel<MT, false>), dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
     } else {
       P.G = reinterpret_cast<float*>(ws + pl.G_off);
       // (region, sample) slots -> stable sort by region: every region's list in ascending sample order
       const long E = pl.nslots / 4;
+      orp_prof_begin(ORP_PROF_DCN_BWD_SCATTER, st);          // pre-passes + scatter kernel (ends behind the scatter launch)
       hipLaunchKernelGGL(bin_samples_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, P);
       size_t cub_bytes = pl.cub_bytes;
       e = hipcub::DeviceRadixSort::SortPairs(ws + pl.cub_off, cub_bytes, P.keys, reinterpret_cast<unsigned*>(ws + pl.keys_out_off),
@@ -1012,7 +1014,12 @@ int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float*
       struct T2 { int unused; };
       e = orp::set_max_dynamic_lds_once<T2>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT, true>), input_smem<MT>());
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL((dcn_bwd_input_kernel<MT, true>), dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
+      orp_prof_end(ORP_PROF_DCN_BWD_SCATTER, st);            // (paused around the GEMM kernel, which has its own slot)
+      {
+        OrpProfScope prof_in(ORP_PROF_DCN_BWD_INPUT, st);
+        hipLaunchKernelGGL((dcn_bwd_input_kernel<MT, true>), dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
+      }
+      orp_prof_begin(ORP_PROF_DCN_BWD_SCATTER, st);
       struct T3 { int unused; };
       e = orp::set_max_dynamic_lds_once<T3>(reinterpret_cast<const void*>(&dcn_bwd_scatter_kernel), scatter_smem());
       if (e != hipSuccess) return (int)e;
@@ -1021,6 +1028,7 @@ int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float*
       hipLaunchKernelGGL(build_desc_kernel, dim3((unsigned)((pl.nslots + 255) / 256)), dim3(256), 0, st, P,
                          reinterpret_cast<const unsigned*>(ws + pl.keys_out_off), desc);
       hipLaunchKernelGGL(dcn_bwd_scatter_kernel, dim3(rper * 8), dim3(kScatterThreads), scatter_smem(), st, P, desc);
+      orp_prof_end(ORP_PROF_DCN_BWD_SCATTER, st);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -1032,6 +1040,7 @@ int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float*
     struct TW { int unused; };
     e = orp::set_max_dynamic_lds_once<TW>(reinterpret_cast<const void*>(&dcn_bwd_weight_kernel), weight_smem());
     if (e != hipSuccess) return (int)e;
+    OrpProfScope prof_w(ORP_PROF_DCN_BWD_WEIGHT, st);
     hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(pl.nsplit, taps), dim3(kThreads), weight_smem(), st, P);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -49,7 +49,15 @@
 #define ORP_DCNS_REFILL_LAG 0
 #endif
 #ifndef ORP_DCNS_DRAIN
-#define ORP_DCNS_DRAIN 0             // dev aid: 1 = wait for the accumulators (all issued MFMAs done) before the A-fragment prefetch, 2 = before the weight refill
+// 2 (default): before the weight registers of a chunk are refilled in place, the wave reads one element of every accumulator
+// -- a VALU read that cannot issue before the chain's last MFMA has written back, i.e. before every MFMA the wave has issued
+// so far has executed and read its operands.  Without it asynchronous register writes (the refill's VMEM return, the next
+// chunk's LDS return) overtook queued MFMAs whenever other waves kept the SIMD's matrix pipe backlogged: wrong rows with two
+// workgroups per CU (tests/checks/split_diag2.py) and with other streams' kernels beside it (PipelinedInference test); the
+// in-order-issue model ("an MFMA has read its operands once the next instruction issues") does not hold under that load.
+// Costs nothing measurable: the partner wave's MFMAs fill the pipe meanwhile (332 vs 352 us per pair launch).
+// 1 = drain before the A-fragment prefetch instead, 3 = both, 0 = none (dev aid).
+#define ORP_DCNS_DRAIN 2
 #endif
 #ifndef ORP_DCNS_INTERLEAVE
 #define ORP_DCNS_INTERLEAVE 4        // VALU instructions of the combine pinned behind every MFMA of the chunk that carries it (0: scheduler's choice)
@@ -401,14 +409,11 @@ constexpr size_t split_smem() { return (size_t)2 * 3 * 32 * MT * ASTRS * 2 + (si
 
 template <int MT, int NPROD, bool OUT_NCHW>
 hipError_t launch_one(const FwdS& P, int tiles, int nblk_n, hipStream_t st) {
-  // ONE workgroup per CU, always: the launch asks for at least 84 KB of LDS (2 x 84 > 160).  The MT = 1 instantiation (37 KB,
-  // 119 VGPRs) would otherwise run two workgroups = four waves per SIMD side by side, and in that configuration single A
-  // rows came out wrong in multi-round launches (tests/checks/split_diag2.py: a few positions per level, all channels,
-  // different ones every run; correct with ORP_DCNS_PAD_LDS >= 84, correct with every issued MFMA drained before the weight
-  // registers are refilled (-DORP_DCNS_DRAIN=2), fewer errors with the refill one chunk later) -- i.e. with the matrix pipe
-  // backlogged four deep an asynchronous register write (LDS / VMEM return) can overtake a queued MFMA's operand read.
-  // Two waves per SIMD is the configuration every test and the soak (tests/checks/soak_dcn_split.py) run bit-stable.
-  static const int pad_env = getenv("ORP_DCNS_PAD_LDS") ? atoi(getenv("ORP_DCNS_PAD_LDS")) : 84;   // KB; dev aid: 0 = no floor
+  // (dev aid) ORP_DCNS_PAD_LDS=<KB>: a floor under the LDS request, e.g. 84 = exactly one workgroup per CU.  The MT = 1
+  // instantiation (37 KB, 119 VGPRs) runs two workgroups = four waves per SIMD side by side; before the accumulator drain of
+  // ORP_DCNS_DRAIN that configuration produced wrong rows (see there), with it both residencies are bit-stable under soak
+  // (tests/checks/soak_dcn_split.py) and the shared one is 1-2 % faster on multi-round launches.
+  static const int pad_env = getenv("ORP_DCNS_PAD_LDS") ? atoi(getenv("ORP_DCNS_PAD_LDS")) : 0;
   const size_t smem = split_smem<MT>() < (size_t)pad_env * 1024 ? (size_t)pad_env * 1024 : split_smem<MT>();
   struct Tag {};
   hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_split_kernel<MT, NPROD, OUT_NCHW>), smem);

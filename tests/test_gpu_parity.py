@@ -22,6 +22,17 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=[0, 6], ids=["exact_fp32_mfma", "bf16_split_6"])
+def dcn_mode(request, dev):
+    """The two arithmetic modes of the fp32 DeformConv forward entry points: 0 = exact-fp32 MFMA (csrc/orp_dcn.hip, incl. its
+    tap-granular split of multi-round launches), 6 = the library default, the bf16-split products of csrc/orp_dcn_split.hip."""
+    from orientedreppoints_amd import _lib
+    L = _lib.lib()
+    assert L.orp_dcn_set_split_mode(request.param) == 0
+    yield request.param
+    L.orp_dcn_set_split_mode(-1)
+
+
 def _g(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
@@ -344,7 +355,7 @@ def _rel_err(got, want):
 
 @pytest.mark.parametrize("B,C,H,W,Cout", [(1, 64, 9, 11, 64), (2, 256, 16, 16, 256), (1, 32, 5, 40, 128),
                                           (1, 96, 7, 7, 192)])
-def test_dcn_forward_mfma_vs_oracle(dev, oracle, B, C, H, W, Cout):
+def test_dcn_forward_mfma_vs_oracle(dev, oracle, B, C, H, W, Cout, dcn_mode):
     """MFMA implicit GEMM (fp32-exact MFMA) against the oracle's double-accumulated contraction: <= 1e-4 relative."""
     from orientedreppoints_amd.mmdet_ops import deform_conv
     x, off, w = _dcn_case(0, B, C, H, W, Cout)
@@ -359,7 +370,7 @@ def test_dcn_forward_mfma_vs_oracle(dev, oracle, B, C, H, W, Cout):
     assert _rel_err(got2.cpu().numpy(), want) <= 1e-4
 
 
-def test_dcn_forward_multi_level_and_offsets_out_of_range(dev, oracle):
+def test_dcn_forward_multi_level_and_offsets_out_of_range(dev, oracle, dcn_mode):
     from orientedreppoints_amd.mmdet_ops import deform_conv_forward_multi
     cases = [_dcn_case(10 + i, 1, 64, h, h, 64, std_off=4.0) for i, h in enumerate((16, 8, 4, 2, 1))]
     w = cases[0][2]
@@ -368,7 +379,7 @@ def test_dcn_forward_multi_level_and_offsets_out_of_range(dev, oracle):
         assert _rel_err(o.cpu().numpy(), oracle.dcn_forward(x, off, w)) <= 1e-4
 
 
-def test_dcn_pair_launch_equals_two_launches_and_oracle(dev, oracle):
+def test_dcn_pair_launch_equals_two_launches_and_oracle(dev, oracle, dcn_mode):
     """orp_dcn_forward_pair: the head's two DeformConvs (same offsets) in ONE launch -- against the oracle on a small
     multi-level case, and bit-identical to two single launches of the same kernel generation at the head's channel
     count (the per-layer accumulation order is the same)."""
@@ -425,7 +436,7 @@ def _dcn_torch_reference(x, off, w):
     return out
 
 
-def test_dcn_pair_at_1536_patch_shapes_vs_torch_reference(dev, oracle):
+def test_dcn_pair_at_1536_patch_shapes_vs_torch_reference(dev, oracle, dcn_mode):
     """BASELINE configs[4] shapes: a 1536x1536 patch = levels 192^2 .. 12^2 = 49 104 positions, both head DeformConvs in
     one launch (tile table, MT selection and the XCD map at 512 tiles / two rounds).  Checker: a plain PyTorch fp32
     DeformConv, itself pinned to the oracle on a small case first."""
@@ -451,7 +462,7 @@ def test_dcn_pair_at_1536_patch_shapes_vs_torch_reference(dev, oracle):
 
 @pytest.mark.parametrize("B,channels_last,relu", [(1, False, True), (1, True, False), (2, False, False), (2, True, True),
                                                    (3, False, True)])
-def test_dcn_pair_tap_split_launch_at_1024_shapes(dev, B, channels_last, relu):
+def test_dcn_pair_tap_split_launch_at_1024_shapes(dev, B, channels_last, relu, dcn_mode):
     """The configs[1] / configs[2] launches themselves: all five levels of 1024^2 image(s), both head DeformConvs in one
     launch.  B = 1: 228 whole tiles, one round.  B = 2, 3: 456 / 683 tiles do not divide over 256 CUs, so the launch is
     the tap-granular split: XCDs 0-3 / 4-7 take one layer each, their workgroups take the tiles round by round and the
@@ -590,7 +601,7 @@ def test_dcn_forward_half_precision_vs_fp32_oracle(dev, oracle, dtype, tol):
         assert float((a.float() - b).abs().max()) <= tol * float(b.abs().max())
 
 
-def test_dcn_full_size_properties(dev):
+def test_dcn_full_size_properties(dev, dcn_mode):
     """BASELINE shapes (all five levels of a 1024^2 image, 256 -> 256, one launch, MT = 3 tiles): with zero offsets the
     DeformConv IS the plain 3x3 convolution (independent implementation: the library's), and with random offsets it is
     linear in its input."""
@@ -615,7 +626,7 @@ def test_dcn_full_size_properties(dev):
             assert float((c_ - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
 
 
-def test_dcn_v2_and_fused_epilogue_on_mfma_path(dev, oracle):
+def test_dcn_v2_and_fused_epilogue_on_mfma_path(dev, oracle, dcn_mode):
     """DCNv2 (mask + bias) and the fused ReLU epilogue on both MFMA kernel generations, against the oracle."""
     from orientedreppoints_amd.mmdet_ops import deform_conv_forward_multi, modulated_deform_conv
     rng = np.random.RandomState(11)
