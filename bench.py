@@ -85,7 +85,7 @@ def calibrate_head(model, img, target=TARGET_DETS):
             head.reppoints_cls_out.bias[c] += thr_logit - kth + 1e-4
 
 
-PMC_FILE = 'profiles/r03_pmc.json'
+PMC_FILE = 'profiles/r04_pmc.json'
 
 
 def load_pmc():
@@ -362,6 +362,38 @@ def per_op_table(dev, budget_s=2.0):
     trb = t32(rb)
     out['box_iou_rotated_1000x1000'] = dict(gpu_us=gpu_us(lambda: box_iou_rotated(trb, trb)),
                                             cpu_us=cpu_us(lambda: O.box_iou_rotated(rb, rb)), cpu_sample='full size')
+    # ---- roofline entry per op: algorithmic bytes -> HBM GB/s and its fraction of 8 TB/s (the formal bound of
+    #      these scan-type ops; at these sizes they are ALU / latency limited), pair rate where the op is pairwise, and -- when
+    #      profiles/<round>_pmc.json was collected on THIS build (tools/pmc_all.sh on the same shapes) -- the counters that say
+    #      what the kernel is really bound by: VALU busy, VALU issue fraction, resident waves per SIMD, HBM traffic
+    P_ = 5000
+    alg = {
+        'minaerarect_5344_sets': (104.0 * 5344, None, 'minarearect'),
+        'convex_iou_21824x32': (72.0 * 21824 + 32.0 * 32 + 4.0 * 21824 * 32, 21824.0 * 32, 'convex_iou'),
+        'rnms_2000_boxes': (36.0 * 2000 + 8.0 * 2000 * 32, 2000.0 * 1999 / 2, 'nms_mask'),
+        'convex_giou_5000_pairs': (180.0 * P_, float(P_), 'convex_giou'),
+        'points_in_quad_5000x9': (140.0 * P_, None, 'points_in_quad_aligned'),
+        'chamfer_5000x40x40': (1280.0 * P_, P_ * 1600.0, 'chamfer_nn'),
+        'sigmoid_focal_43648x15': (4.0 * N * 15 * 2 + 8.0 * N, None, 'focal_fwd'),
+        'point_assign_21824x64': (12.0 * 21824 + 32.0 * 64 + 8.0 * 21824, 21824.0 * 64, 'point_assign_gt'),
+        'max_iou_assign_21824x64': (4.0 * 21824 * 64 + 12.0 * 21824, None, 'max_iou_assign'),
+        'box_iou_rotated_1000x1000': (20.0 * 2000 + 4.0e6, 1.0e6, 'box_iou_rotated'),
+    }
+    pmc, _note = load_pmc()
+    for name, (nbytes, pairs, key) in alg.items():
+        e = out.get(name)
+        if not e or not e.get('gpu_us'):
+            continue
+        t = e['gpu_us'] * 1e-6
+        r = dict(algorithmic_bytes=nbytes, hbm_gbs=round(nbytes / t / 1e9, 2), hbm_frac=nbytes / t / 1e9 / HBM_PEAK_GBS)
+        if pairs:
+            r['gpairs_per_s'] = round(pairs / t / 1e9, 3)
+        c = (pmc or {}).get(key)
+        if c:
+            for k_ in ('valu_busy_frac', 'valu_issue_frac', 'waves_per_simd', 'hbm_bytes_per_launch', 'kernel_us_at_2p4ghz'):
+                if k_ in c:
+                    r[k_] = c[k_]
+        e['roofline'] = r
     return out
 
 
@@ -999,7 +1031,11 @@ def main():
             nms.update(traffic=pm.get('hbm_bytes_per_launch'), valu_busy_frac=4.0 * c['SQ_ACTIVE_INST_VALU'] / simd_cycles,
                        waves_per_simd=4.0 * c['SQ_WAVE_CYCLES'] / simd_cycles,
                        lds_bank_conflict_frac=(c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'])
-                       if c.get('SQ_LDS_IDX_ACTIVE') else None, traffic_source=pmc_note)
+                       if c.get('SQ_LDS_IDX_ACTIVE') else None, traffic_source=pmc_note,
+                       # this kernel's real roofline: a VALU instruction of a 64-wide wave occupies its SIMD for 4 cycles, so
+                       # 4 * SQ_INSTS_VALU / SIMD-cycles of the launch is the fraction of the chip's VALU issue slots it used
+                       valu_issue_frac=(4.0 * c['SQ_INSTS_VALU'] / simd_cycles) if c.get('SQ_INSTS_VALU') else None,
+                       valu_insts_per_launch=c.get('SQ_INSTS_VALU'))
         except Exception:   # noqa: BLE001
             pass
     per_op = None

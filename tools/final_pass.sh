@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's measurement set at HEAD (run on the GPU box through gpurun; everything lands in gpurun_out/, the summaries are
 # then folded into profiles/<tag>_* locally -- see the tail of this file).  usage: tools/final_pass.sh <tag>
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out

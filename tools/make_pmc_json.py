@@ -9,6 +9,10 @@ usage: tools/make_pmc_json.py profiles/r01 gpurun_out/pmc_a gpurun_out/pmc_b ...
 import collections, csv, glob, json, os, sys
 
 dst, dirs = sys.argv[1], sys.argv[2:]
+# the other hot-path kernels (tools/run_hot_kernels.py ops), keyed by kernel name without the suffix
+OPS = ('convex_iou_kernel', 'convex_giou_kernel', 'minarearect_kernel', 'chamfer_nn_kernel', 'points_in_quad_aligned_kernel',
+       'focal_fwd_kernel', 'point_assign_gt_kernel', 'point_assign_finish_kernel', 'max_iou_assign_kernel', 'gt_max_kernel',
+       'gt_argmax_assign_kernel', 'box_iou_rotated_kernel', 'apaa_select_kernel')
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in dirs:
     for f in glob.glob(d + '/*/*counter_collection.csv'):
@@ -16,8 +20,14 @@ for d in dirs:
             k = r['Kernel_Name']
             key = ('dcn_bwd_scatter' if 'dcn_bwd_scatter' in k else
                    'dcn_bwd_input' if 'dcn_bwd_input' in k else 'dcn_bwd_weight' if 'dcn_bwd_weight' in k else
-                   'dcn_fwd_half' if 'dcn_fwd_half' in k else 'dcn_fwd_pair' if 'dcn_fwd_mfma2' in k else 'nms_mask' if 'nms_mask' in k
+                   'dcn_fwd_half' if 'dcn_fwd_half' in k else 'dcn_fwd_split' if 'dcn_fwd_split' in k else
+                   'dcn_fwd_pair' if 'dcn_fwd_mfma2' in k else 'nms_mask' if 'nms_mask' in k
                    else 'nms_sweep' if 'nms_sweep' in k else 'nms_rankprep' if 'nms_rankprep' in k else None)
+            if key is None:
+                for name in OPS:
+                    if name in k:
+                        key = name.replace('_kernel', '')
+                        break
             if key:
                 agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {}
@@ -31,6 +41,16 @@ for k, c in agg.items():
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in m and 'GRBM_GUI_ACTIVE' in m and m['GRBM_GUI_ACTIVE'] > 0:
         # MFMA busy is summed over 1024 SIMDs, GRBM_GUI_ACTIVE over 8 XCDs
         e['mfma_busy_frac'] = (m['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0) / (m['GRBM_GUI_ACTIVE'] / 8.0)
+    if m.get('GRBM_GUI_ACTIVE', 0) > 0:
+        simd_cycles = m['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0          # SIMD-cycles of the launch (SQ_* count quad-cycles)
+        e['kernel_us_at_2p4ghz'] = m['GRBM_GUI_ACTIVE'] / 8.0 / 2400.0
+        if 'SQ_ACTIVE_INST_VALU' in m:
+            e['valu_busy_frac'] = 4.0 * m['SQ_ACTIVE_INST_VALU'] / simd_cycles
+        if 'SQ_WAVE_CYCLES' in m:
+            e['waves_per_simd'] = 4.0 * m['SQ_WAVE_CYCLES'] / simd_cycles
+        if 'SQ_INSTS_VALU' in m:
+            # one VALU instruction of a 64-wide wave occupies its SIMD's 16 lanes for 4 cycles
+            e['valu_issue_frac'] = 4.0 * m['SQ_INSTS_VALU'] / simd_cycles
     if k.startswith('dcn_bwd'):
         e['batch'] = 2
         e['img'] = 1024
@@ -49,7 +69,8 @@ with open(dst + '_pmc.txt', 'w') as f:
         f.write('%s  launches %d\n' % (k, e['launches']))
         for n, v in sorted(e['counters'].items()):
             f.write('    %-28s %.4g\n' % (n, v))
-        for n in ('fetch_bytes_per_launch', 'write_bytes_per_launch', 'hbm_bytes_per_launch', 'mfma_busy_frac'):
+        for n in ('fetch_bytes_per_launch', 'write_bytes_per_launch', 'hbm_bytes_per_launch', 'mfma_busy_frac', 'valu_busy_frac',
+                  'valu_issue_frac', 'waves_per_simd', 'kernel_us_at_2p4ghz'):
             if n in e:
                 f.write('    %-28s %.4g\n' % (n, e[n]))
 print(open(dst + '_pmc.txt').read())
