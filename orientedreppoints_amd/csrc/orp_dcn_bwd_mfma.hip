@@ -54,6 +54,9 @@
 #ifndef ORP_BWD_WDIST
 #define ORP_BWD_WDIST 3      // kernel A: weight fragments fetched this many chunks ahead (ring of WDIST + 1 slots; 1, 3 or 7)
 #endif
+#ifndef ORP_BWD_LANEPOS
+#define ORP_BWD_LANEPOS 1    // kernel A, dense path: accumulator as D[channel][position] (lane = position) and the in-lane derivative sums; 0 = the round-3 lane = channel epilogue
+#endif
 #ifndef ORP_BWD_DBG
 #define ORP_BWD_DBG 0      // dev aid, compile-time (timing only, wrong results): 1 = no grad_input atomics, 2 = no x loads / derivative reduction, 4 = no G store, 8 = no epilogue at all, 16 = scatter kernel without G row reads, 32 = scatter kernel without accumulator updates
 #endif
@@ -352,7 +355,10 @@ dcn_bwd_input_kernel(const BwdParams P) {
             if (i & 1) acc_odd[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc_odd[mt], 0, 0, 0);
             else
 #endif
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[mt], 0, 0, 0);       // D[position][channel]
+            if (STORE_G && ORP_BWD_LANEPOS)
+              acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, av, acc[mt], 0, 0, 0);     // D[channel][position]: lane = position
+            else
+              acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[mt], 0, 0, 0);     // D[position][channel]: lane = channel
           }
         }
       }
@@ -362,6 +368,70 @@ dcn_bwd_input_kernel(const BwdParams P) {
     for (int mt = 0; mt < MT; mt++) acc[mt] += acc_odd[mt];
 #endif
     // ---- consume G_t: scatter into grad_input, coordinate derivatives into the tile's grad_offset ---------------
+    if (STORE_G && ORP_BWD_LANEPOS) {
+      // Dense gradients, round 4: the accumulator holds D[channel][position] -- lane = position m (lane & 31), register r =
+      // channel n_wave + (r & 3) + 8 (r >> 2) + 4 kh.  The sums over channels the coordinate derivatives need
+      //     S_k = sum_c G[m, c] * x[corner_k, c],  k = 1 .. 4
+      // are then IN-LANE multiply-adds over the 16 registers (x arrives as four 16-byte loads per corner: the lane's four
+      // channel quadruples of its wave's 128-byte row piece), one cross-half exchange adds the other 16 channels, and the
+      // bilinear factors are applied ONCE to the four sums:
+      //     dh = mm (uw (S3 - S1) + lw (S4 - S2)),  dw = mm (uh (S2 - S1) + lh (S4 - S3)),  dm = uh uw S1 + uh lw S2 + lh uw S3 + lh lw S4
+      // (get_coordinate_weight, deform_conv_cuda_kernel.cu:145-188, regrouped).  Before: lane = channel, every one of the 16
+      // rows did its own address arithmetic, validity selects, expanded formulas and two to three 5-step DPP reductions,
+      // replicated over 64 lanes: ~1 400 VALU instructions per wave and tap beside 128 MFMAs (profiles/r03_pmc.json).
+      const int m = mrow;                                              // this lane's position of the tile
+      const int e = m * taps + tap;
+      const bool row_ok = p0 + m < npos;
+      // (a) the row G_t[m, :] for kernel A2: 16 channels per lane as four 16-byte stores (the two half-waves interleave
+      //     into whole 32-byte sectors; the row's 1 KB is completed by the 8 waves)
+      if (!(ORP_BWD_DBG & 4) && row_ok) {
+        float* grow = P.G + ((size_t)((long)tile * BM2 + m) * taps + tap) * CH + wave * 32 + 4 * kh;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          *reinterpret_cast<float4*>(grow + 8 * q) = make_float4(acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]);
+      }
+      // (b) the derivative sums
+      const bool live = !(ORP_BWD_DBG & 8) && sNZ[m] != 0;             // a zero grad_out row gives G = 0: nothing to add
+      float S[4] = {0.f, 0.f, 0.f, 0.f};
+      if (__ballot(live) != 0) {
+        const int4 ix = sCi[e];
+        const int ixs[4] = {ix.x, ix.y, ix.z, ix.w};
+        const float* xb = L.x + wave * 32 + 4 * kh;
+#if !(ORP_BWD_DBG & 2)
+        float4 v[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float* xr = xb + (size_t)(live && ixs[k] >= 0 ? ixs[k] : 0) * CH;   // an invalid corner reads pixel 0 and is dropped below
+#pragma unroll
+          for (int q = 0; q < 4; q++) v[k][q] = *reinterpret_cast<const float4*>(xr + 8 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          float sk = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            sk = __builtin_fmaf(acc[0][4 * q], v[k][q].x, sk);
+            sk = __builtin_fmaf(acc[0][4 * q + 1], v[k][q].y, sk);
+            sk = __builtin_fmaf(acc[0][4 * q + 2], v[k][q].z, sk);
+            sk = __builtin_fmaf(acc[0][4 * q + 3], v[k][q].w, sk);
+          }
+          S[k] = (live && ixs[k] >= 0) ? sk : 0.f;
+        }
+#endif
+        // the other half-wave holds the other 16 channels of the same position: lanes m and m + 32
+#pragma unroll
+        for (int k = 0; k < 4; k++) S[k] += __shfl_xor(S[k], 32, 64);
+        if (kh == 0) {
+          const float4 fr = sCl[e];
+          const float lh = fr.x, lw = fr.y, uh = 1.f - lh, uw = 1.f - lw, mm = fr.z;
+          float* slot = sGO + (size_t)(wave * BM2 * MAXT + e) * 3;
+          slot[0] = mm * (uw * (S[2] - S[0]) + lw * (S[3] - S[1]));
+          slot[1] = mm * (uh * (S[1] - S[0]) + lh * (S[3] - S[2]));
+          slot[2] = L.gmask ? (uh * uw * S[0] + uh * lw * S[1] + lh * uw * S[2] + lh * lw * S[3]) : 0.f;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
 #pragma unroll 4

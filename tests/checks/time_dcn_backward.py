@@ -47,6 +47,26 @@ def main():
     w = torch.randn(256, 256, 3, 3, device=dev) * 0.05
     args = ((1, 1), (1, 1), (1, 1))
     t_all = timed(lambda: bw.backward_mfma(xs, offs, w, gos, *args))
+    # the library's own HIP events around the parts of one call: GEMM kernel (grad_input rows + grad_offset), sort + region
+    # scatter, weight-gradient kernel + reduction
+    import ctypes
+    from orientedreppoints_amd import _lib
+    L = _lib.lib()
+
+    def prof(slot):
+        tot = ctypes.c_double(0); cnt = ctypes.c_int(0)
+        L.orp_profile_read(slot, ctypes.cast(ctypes.byref(tot), ctypes.c_void_p), ctypes.cast(ctypes.byref(cnt), ctypes.c_void_p), 1)
+        return tot.value * 1e3
+    L.orp_profile_enable(1)
+    for sl in (8, 9, 10, 11):
+        prof(sl)
+    for _ in range(10):
+        bw.backward_mfma(xs, offs, w, gos, *args)
+    torch.cuda.synchronize()
+    parts = [prof(sl) / 10 for sl in (8, 9, 10, 11)]
+    L.orp_profile_enable(0)
+    print("  per call (HIP events inside the library): whole %.1f us | input GEMM kernel %.1f us (%.1f TF/s) | bin + sort + bounds + descriptors + scatter %.1f us | "
+          "weight kernel + reduction %.1f us" % (parts[0], parts[1], 2.0 * sum(B * s * s for s in (128, 64, 32, 16, 8)) * 2304 * 256 / parts[1] * 1e-6, parts[2], parts[3]))
     t_in = timed(lambda: bw.backward_mfma(xs, offs, w, gos, *args, need_input=True, need_weight=False))
     t_w = timed(lambda: bw.backward_mfma(xs, offs, w, gos, *args, need_input=False, need_weight=True))
     bw.USE_MFMA = False
