@@ -392,6 +392,14 @@ int orp_groupnorm_act_multi(const orp_norm_level* levels_host, int nlevels, int 
 int orp_groupnorm_act_multi_ex(const orp_norm_level* levels, const float* const* gammas_host,
                                const float* const* betas_host, int nlevels, int batch, int channels, int groups,
                                float eps, int relu, void* workspace, size_t workspace_bytes, void* stream);
+/* the same normalisation written TRANSPOSED: nhwc_out_host[i] = [B, H*W, C] (channels-last), through an LDS tile; where
+ * levels[i].output != NULL the NCHW result is written as well (may alias the input), NULL = channels-last only.  The head's
+ * DeformConv (orp_dcn_forward_pair, in_layout 1) reads the towers' last layer channels-last: this replaces a separate
+ * transposition launch.  channels % 32 == 0, 32 % (channels / groups) == 0.  Same values as orp_groupnorm_act_multi_ex. */
+int orp_groupnorm_act_multi_nhwc(const orp_norm_level* levels, const float* const* gammas_host,
+                                 const float* const* betas_host, float* const* nhwc_out_host, int nlevels, int batch,
+                                 int channels, int groups, float eps, int relu, void* workspace, size_t workspace_bytes,
+                                 void* stream);
 /* training: the same launch pair, additionally storing (mean, rstd) of every (image, group) in
  * stats [sum over tensors of batch * groups][2] (tensor i's rows follow tensor i-1's), and the backward:
  *   grad_inputs[i] = d loss / d x_i given grad_outputs[i] = d loss / d y_i (dy masked where y <= 0 when relu),

@@ -95,6 +95,7 @@ _SIGNATURES = {
     "orp_groupnorm_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "orp_groupnorm_act_multi": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _sz, _vp]),
     "orp_groupnorm_act_multi_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
+    "orp_groupnorm_act_multi_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "orp_groupnorm_act_multi_train": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "orp_groupnorm_backward_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "orp_groupnorm_act_multi_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

@@ -176,6 +176,74 @@ gn_apply_kernel(const GnParams P) {
   }
 }
 
+// Pass 2 of orp_groupnorm_act_multi_nhwc: the same normalise + scale + activate as gn_apply_kernel, written TRANSPOSED --
+// y_nhwc[b, p, c] -- through a 32 x 33 LDS tile (32 channels = 4 groups x 32 positions per workgroup: 128-byte rows on both
+// sides), and optionally also in place / NCHW (the regression tower's last layer feeds a plain convolution AND the
+// DeformConv).  The head's DeformConv reads its input channels-last; this replaces the separate nchw_to_nhwc launch (one
+// more read + write of every tower output per image).  Same arithmetic as gn_apply_kernel: identical values.
+struct GnNhwc {
+  float* out[kGnMaxLevels];       // [B, hw, C] per level
+  float* nchw[kGnMaxLevels];      // nullptr, or the NCHW output (may alias x)
+  int bx0[kGnMaxLevels + 1];      // first blockIdx.x of each level (32-position tiles)
+};
+__global__ void __launch_bounds__(kThreads)
+gn_apply_nhwc_kernel(const GnParams P, const GnNhwc T) {
+  __shared__ float tile[32][33];
+  __shared__ float2 sStat[8];                     // (mean, rstd) of the tile's groups (32 channels / (C / G) <= 8 groups)
+  int lvl = 0;
+#pragma unroll 1
+  for (int i = 1; i < P.nlev; i++) if ((int)blockIdx.x >= T.bx0[i]) lvl = i;
+  const GnLevel& L = P.lv[lvl];
+  const int hw = L.hw, cg = P.C / P.G;
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, p0 = ((int)blockIdx.x - T.bx0[lvl]) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int ngrp = (32 + cg - 1) / cg;            // groups touched by this channel tile (c0 is a multiple of cg: cg | 32)
+  const int span = cg * hw;
+  __shared__ float red[4];
+  for (int gi = 0; gi < ngrp; gi++) {
+    const int grp = c0 / cg + gi;
+    if (grp >= P.G) break;                          // (block-uniform)
+    // merge this group's partials (Chan et al.) with gn_apply_kernel's own statements and reduction order: the same bits
+    const float2* part = P.partial + L.chunk0 + (size_t)(b * P.G + grp) * L.cpg;
+    float sm = 0.f;
+    for (int k = threadIdx.x; k < L.cpg; k += kThreads) {
+      const int nk = min(kChunk, span - k * kChunk);
+      sm += (float)nk * part[k].x;
+    }
+    const float mean = block_sum(sm, red) / (float)span;
+    float m2 = 0.f;
+    for (int k = threadIdx.x; k < L.cpg; k += kThreads) {
+      const int nk = min(kChunk, span - k * kChunk);
+      const float2 pk = part[k];
+      const float d = pk.x - mean;
+      m2 += pk.y + (float)nk * d * d;
+    }
+    const float var = block_sum(m2, red) / (float)span;
+    if (threadIdx.x == 0) sStat[gi] = make_float2(mean, rsqrtf(var + P.eps));
+  }
+  __syncthreads();
+  const float* src = L.x + (size_t)b * P.C * hw;
+  float* nchw = T.nchw[lvl] ? T.nchw[lvl] + (size_t)b * P.C * hw : nullptr;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    float t = 0.f;
+    if (c < P.C && p < hw) {
+      const float2 st = sStat[r / cg];
+      const float a = st.y * L.gamma[c], bb = L.beta[c] - st.x * a;
+      t = src[(size_t)c * hw + p] * a + bb;
+      if (P.relu) t = fmaxf(t, 0.f);
+      if (nchw) nchw[(size_t)c * hw + p] = t;
+    }
+    tile[r][tx] = t;
+  }
+  __syncthreads();
+  float* dst = T.out[lvl] + (size_t)b * hw * P.C;
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    if (p < hw && c < P.C) dst[(size_t)p * P.C + c] = tile[tx][r];
+  }
+}
+
 // y = act(x * scale[c] + shift[c] (+ residual)), NCHW.  grid.y = (image, channel) plane, so the per-channel constants are
 // block-uniform scalars and no integer division sits in the element loop; float4 traffic when HW % 4 == 0.
 __global__ void __launch_bounds__(kThreads)
@@ -401,6 +469,41 @@ int orp_groupnorm_act_multi_ex(const orp_norm_level* levels, const float* const*
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_groupnorm_act_multi_nhwc(const orp_norm_level* levels, const float* const* gammas_host,
+                                 const float* const* betas_host, float* const* nhwc_out_host, int nlevels, int batch,
+                                 int channels, int groups, float eps, int relu, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  GnParams P;
+  if (!levels || nlevels <= 0 || nlevels > kGnMaxLevels) return ORP_EINVAL;
+  orp_norm_level tmp[kGnMaxLevels];
+  for (int i = 0; i < nlevels; i++) { tmp[i] = levels[i]; if (!tmp[i].output) tmp[i].output = const_cast<float*>(tmp[i].input); }
+  const int chunks = fill(tmp, nlevels, batch, channels, groups, P);
+  if (chunks == -2) return ORP_ETOOBIG;
+  if (chunks <= 0 || !gammas_host || !betas_host || !nhwc_out_host) return ORP_EINVAL;
+  if (channels % 32 != 0 || 32 % (channels / groups) != 0 || batch > 65535) return ORP_EINVAL;
+  if (!workspace || workspace_bytes < sizeof(float2) * (size_t)chunks) return ORP_EWORKSPACE;
+  GnNhwc T;
+  int bx = 0;
+  for (int i = 0; i < nlevels; i++) {
+    if (!gammas_host[i] || !betas_host[i] || !nhwc_out_host[i]) return ORP_EINVAL;
+    P.lv[i].gamma = gammas_host[i]; P.lv[i].beta = betas_host[i];
+    T.out[i] = nhwc_out_host[i];
+    T.nchw[i] = levels[i].output;                       // NULL: the channels-last tensor is the only output
+    T.bx0[i] = bx;
+    bx += (P.lv[i].hw + 31) / 32;
+  }
+  for (int i = nlevels; i <= kGnMaxLevels; i++) T.bx0[i] = 0x7fffffff;
+  for (int i = nlevels; i < kGnMaxLevels; i++) { T.out[i] = T.out[0]; T.nchw[i] = nullptr; }
+  P.eps = eps; P.relu = relu;
+  P.partial = reinterpret_cast<float2*>(workspace);
+  P.stats = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
+  hipLaunchKernelGGL(gn_apply_nhwc_kernel, dim3(bx, channels / 32, batch), dim3(kThreads), 0, st, P, T);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }

@@ -146,18 +146,21 @@ class OrientedRepPointsHead(nn.Module):
         return F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
 
     @staticmethod
-    def _tower_multi(convs, feats):
+    def _tower_multi(convs, feats, last_nhwc=None):
         """One tower over all levels, layer by layer: big-level convolutions on the library, the small levels in one HIP
         launch, then ONE GroupNorm+ReLU launch pair right behind them while the activations are cache-resident.
         (Running both towers in lockstep -- one small-level launch / one normalisation pair for ten tensors -- was
         measured 0.5-1 % slower: the pair then reads 178 MB written two convolutions earlier.)"""
         from ..mmdet_ops.fused_norm import conv3x3_multi, group_norm_act_multi
         cur = list(feats)
-        for m in convs:
-            cur = group_norm_act_multi(conv3x3_multi(cur, m.conv), m.norm, relu=True, inplace=True)
+        for k, m in enumerate(convs):
+            # last_nhwc ('only' | 'both'): the LAST layer's normalisation writes its result channels-last (as well), the
+            # layout the DeformConv gathers from -- instead of a separate transposition launch over both towers' outputs
+            last = last_nhwc if k == len(convs) - 1 else None
+            cur = group_norm_act_multi(conv3x3_multi(cur, m.conv), m.norm, relu=True, inplace=True, nhwc=last)
         return cur
 
-    def _dcn_pair(self, cls_feats, pts_feats, offsets):
+    def _dcn_pair(self, cls_feats, pts_feats, offsets, out_channels_last=None):
         a, b = self.reppoints_cls_conv, self.reppoints_pts_refine_conv
         from ..mmdet_ops.deform_conv import deform_conv_forward_pair, fast_path_ok
         same = (a.stride == b.stride and a.padding == b.padding and a.dilation == b.dilation and
@@ -165,7 +168,8 @@ class OrientedRepPointsHead(nn.Module):
         if same and cls_feats[0].is_cuda and fast_path_ok(a.weight, a.groups, a.deformable_groups) and \
                 fast_path_ok(b.weight, b.groups, b.deformable_groups):
             return deform_conv_forward_pair(cls_feats, pts_feats, offsets, a.weight, b.weight, a.stride, a.padding,
-                                            a.dilation, relu=True)
+                                            a.dilation, relu=True, out_channels_last=out_channels_last)
+        assert out_channels_last is None
         return a.forward_multi(cls_feats, offsets, relu=True), b.forward_multi(pts_feats, offsets, relu=True)
 
     def forward_single(self, x):
@@ -246,11 +250,27 @@ class OrientedRepPointsHead(nn.Module):
                     self._side_stream = torch.cuda.Stream(device=feats[0].device)
                 side = self._side_stream
                 side.wait_stream(cur)
+            # channels-last hand-over to the DeformConv pair launch (round 4): the last GroupNorm of each tower writes its
+            # result transposed -- the classification tower ONLY so (nothing else reads it), the regression tower both ways
+            # (the init branch's 3x3 convolution reads NCHW) -- which removes the pair launch's transposition kernel
+            # (one more read + write of both towers' outputs per image).  ORP_HEAD_NHWC=0: off (A/B timing).
+            a_, b_ = self.reppoints_cls_conv, self.reppoints_pts_refine_conv
+            hand = getattr(self, 'nhwc_handover', None)
+            if hand is None:
+                hand = os.environ.get('ORP_HEAD_NHWC', '1') == '1'
+            hand = bool(hand) and not getattr(self, 'fuse_output_convs', False) and a_.weight.size(1) % 256 == 0 and \
+                tuple(a_.weight.shape) == tuple(b_.weight.shape) and a_.stride == b_.stride and a_.padding == b_.padding and \
+                a_.dilation == b_.dilation and a_.groups == 1 and b_.groups == 1 and a_.deformable_groups == 1 and \
+                b_.deformable_groups == 1 and min(min(f.size(2), f.size(3)) for f in feats) > 1
+            if side is not None:
                 with torch.cuda.stream(side):
-                    cls_feats = self._tower_multi(self.cls_convs, feats)
+                    cls_feats = self._tower_multi(self.cls_convs, feats, 'only' if hand else None)
             else:
-                cls_feats = self._tower_multi(self.cls_convs, feats)
-            pts_feats = self._tower_multi(self.reg_convs, feats)
+                cls_feats = self._tower_multi(self.cls_convs, feats, 'only' if hand else None)
+            pts_feats = self._tower_multi(self.reg_convs, feats, 'both' if hand else None)
+            pts_dcn_in = pts_feats
+            if hand:
+                pts_feats, pts_dcn_in = pts_feats
             # bias-carrying convolutions: the convolution runs without its bias, ONE launch per layer then adds it for
             # all levels together with what follows (ReLU / `- dcn_base_offset` / `+ pts_out_init`), same op order
             from ..mmdet_ops.fused_norm import bias_act_multi, conv3x3_multi
@@ -288,7 +308,10 @@ class OrientedRepPointsHead(nn.Module):
                     self.reppoints_cls_out, self.reppoints_pts_refine_out, residuals_b=inits)
                 return cls_outs, inits, refines, list(feats)
         # both DeformConvs take the same offsets: ONE launch for the two layers and all levels, ReLU fused in the epilogue
-        dcn_cls, dcn_pts = self._dcn_pair(cls_feats, pts_feats, offsets)
+        if fused and hand:
+            dcn_cls, dcn_pts = self._dcn_pair(cls_feats, pts_dcn_in, offsets, out_channels_last=False)
+        else:
+            dcn_cls, dcn_pts = self._dcn_pair(cls_feats, pts_feats, offsets)
         if fused and one_by_one:
             cls_outs = conv1x1_multi(dcn_cls, self.reppoints_cls_out)
             refines = conv1x1_multi(dcn_pts, self.reppoints_pts_refine_out, residuals=inits)

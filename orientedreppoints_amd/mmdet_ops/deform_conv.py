@@ -209,11 +209,13 @@ def deform_conv_forward_multi_half(inputs, offsets, weight, stride, padding, dil
 
 
 def deform_conv_forward_pair(inputs_a, inputs_b, offsets, weight_a, weight_b, stride, padding, dilation, masks=None,
-                             bias_a=None, bias_b=None, relu=False, cache_pack=True):
+                             bias_a=None, bias_b=None, relu=False, cache_pack=True, out_channels_last=None):
     """Two DeformConv layers with the SAME offsets (the head's cls / refine pair) over a list of feature maps in ONE
     launch (`orp_dcn_forward_pair`): the bilinear coefficient table of every tile is built once for both layers.
     fp32, no autograd.  Returns (outs_a, outs_b).  Falls back to two `deform_conv_forward_multi` launches when the
-    channel count is not a multiple of 256."""
+    channel count is not a multiple of 256.  Outputs follow the inputs' memory format unless `out_channels_last` says
+    otherwise (the head hands the towers' last layer over channels-last -- no transposition launch -- and wants NCHW
+    outputs for its 1x1 convolutions)."""
     L = _lib.lib()
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     x0 = inputs_a[0]
@@ -238,7 +240,8 @@ def deform_conv_forward_pair(inputs_a, inputs_b, offsets, weight_a, weight_b, st
         ho, wo = _out_hw(xa.size(2), xa.size(3), weight_a, stride, padding, dilation)
         if off.size(1) != 2 * kh * kw or off.size(2) != ho or off.size(3) != wo:
             raise ValueError("offset must be [B, 2*kh*kw, Ho, Wo]")
-        fmt = torch.channels_last if nhwc else torch.contiguous_format
+        out_cl = nhwc if out_channels_last is None else bool(out_channels_last)
+        fmt = torch.channels_last if out_cl else torch.contiguous_format
         oa = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=xa.device, memory_format=fmt)
         ob = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=xa.device, memory_format=fmt)
         keep += [xa, xb, off]; outs_a.append(oa); outs_b.append(ob)
@@ -261,7 +264,8 @@ def deform_conv_forward_pair(inputs_a, inputs_b, offsets, weight_a, weight_b, st
     with torch.cuda.device(x0.device):
         rc = L.orp_dcn_forward_pair(lev_a, lev_b, mask_ptrs, n, B, cin, cout, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(ba),
                                     _lib.ptr(bb), 1 if relu else 0, kh, kw, stride[0], stride[1], padding[0], padding[1],
-                                    dilation[0], dilation[1], layout, layout, _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
+                                    dilation[0], dilation[1], layout, 1 if out_cl else 0, _lib.ptr(ws), ws.numel(),
+                                    _lib.stream_of(x0))
     _lib.check(rc, "orp_dcn_forward_pair")
     return outs_a, outs_b
 

@@ -16,10 +16,13 @@ class _NormLevel(ctypes.Structure):
                 ("width", ctypes.c_int)]
 
 
-def group_norm_act_multi(xs, gn, relu=True, inplace=True):
+def group_norm_act_multi(xs, gn, relu=True, inplace=True, nhwc=None):
     """[GroupNorm(+ReLU)(x) for x in xs] -- xs: list of [B,C,H,W] fp32 CUDA tensors (FPN levels, possibly of several
     towers: up to 16); gn: one nn.GroupNorm for all of them, or a list with one module per tensor (same num_groups and
-    eps).  ONE launch pair."""
+    eps).  ONE launch pair.
+    nhwc='only': the results come back as channels-last tensors ONLY (same logical shape, memory [B,H,W,C]) -- written
+    transposed by the normalisation's second pass; nhwc='both': (NCHW list, channels-last list).  What the head's DeformConv
+    consumes without a transposition launch."""
     L = _lib.lib()
     x0 = xs[0]
     B, C = x0.size(0), x0.size(1)
@@ -47,6 +50,19 @@ def group_norm_act_multi(xs, gn, relu=True, inplace=True):
         gam[i], bet[i] = ptrs
     nbytes = L.orp_groupnorm_workspace_bytes(levels, len(xs), B, C, gns[0].num_groups)
     ws = _lib.workspace(x0.device, nbytes)
+    if nhwc is not None:
+        if nhwc not in ('only', 'both') or C % 32 != 0 or 32 % (C // gns[0].num_groups) != 0:
+            raise ValueError("group_norm_act_multi(nhwc=...): 'only' | 'both', channels % 32 == 0, 32 % (channels / groups) == 0")
+        cl = [torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last) for x in ins]
+        cl_ptrs = (ctypes.c_void_p * len(xs))(*[t.data_ptr() for t in cl])
+        if nhwc == 'only':
+            for i in range(len(xs)):
+                levels[i].output = None
+        with torch.cuda.device(x0.device):
+            rc = L.orp_groupnorm_act_multi_nhwc(levels, gam, bet, cl_ptrs, len(xs), B, C, gns[0].num_groups, float(gns[0].eps),
+                                                1 if relu else 0, _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
+        _lib.check(rc, "orp_groupnorm_act_multi_nhwc")
+        return cl if nhwc == 'only' else (outs, cl)
     with torch.cuda.device(x0.device):
         rc = L.orp_groupnorm_act_multi_ex(levels, gam, bet, len(xs), B, C, gns[0].num_groups, float(gns[0].eps),
                                           1 if relu else 0, _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))

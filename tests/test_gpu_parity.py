@@ -1452,6 +1452,43 @@ def test_inference_step_at_1536_is_bitwise_reproducible_in_library_deterministic
         torch.backends.cudnn.deterministic = saved
 
 
+def test_groupnorm_channels_last_output_and_head_handover(dev):
+    """orp_groupnorm_act_multi_nhwc: the normalisation's second pass written transposed (channels-last), alone or next to the
+    NCHW result -- the same bits as the plain launch pair, levels whose sizes are not multiples of the 32 x 32 tile, B = 2;
+    and the head's inference forward with the towers' last layer handed to the DeformConv pair launch channels-last (no
+    transposition kernel) == the NCHW hand-over, bit for bit."""
+    from orientedreppoints_amd.mmdet_ops.fused_norm import group_norm_act_multi
+    torch.manual_seed(4)
+    gn = torch.nn.GroupNorm(32, 256).to(dev)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5); gn.bias.normal_(0, 0.2)
+    xs = [torch.randn(2, 256, h, w, device=dev) * 3 + 1 for h, w in ((37, 41), (16, 16), (5, 3), (2, 2))]
+    want = group_norm_act_multi([x.clone() for x in xs], gn, relu=True, inplace=True)
+    only = group_norm_act_multi([x.clone() for x in xs], gn, relu=True, inplace=True, nhwc='only')
+    both_nchw, both_cl = group_norm_act_multi([x.clone() for x in xs], gn, relu=True, inplace=True, nhwc='both')
+    for w_, o, bn, bc in zip(want, only, both_nchw, both_cl):
+        assert o.is_contiguous(memory_format=torch.channels_last) and bc.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(o, w_) and torch.equal(bc, w_) and torch.equal(bn, w_) and bn.is_contiguous()
+    ref = torch.nn.functional.relu(gn(xs[0]))
+    assert float((want[0] - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # the head
+    from orientedreppoints_amd.dota_configs import r50_model
+    from orientedreppoints_amd.mmdet_models import ConfigDict
+    from orientedreppoints_amd.mmdet_models.registry import build_head
+    head = build_head(ConfigDict(r50_model['bbox_head'])).to(dev).eval()
+    with torch.no_grad():
+        head.reppoints_pts_init_out.weight.normal_(0, 0.05)
+        feats = [torch.randn(1, 256, n, n, device=dev) for n in (40, 20, 10, 5, 3)]
+        outs = {}
+        for flag in (True, False):
+            head.nhwc_handover = flag
+            o = head(feats)
+            outs[flag] = [[t.clone() for t in lv] for lv in o[:3]]
+    for la, lb in zip(outs[True], outs[False]):
+        for a, b in zip(la, lb):
+            assert a.is_contiguous() and torch.equal(a, b)
+
+
 def test_multi_launch_ops_with_per_tensor_parameters(dev):
     """group_norm_act_multi / conv3x3_multi with one module PER TENSOR (the *_ex entry points): each tensor must get
     its own affine parameters / weights."""
