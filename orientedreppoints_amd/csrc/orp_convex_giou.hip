@@ -21,6 +21,8 @@ struct D2 { double x, y; };
 constexpr int CAP = 8;            // clipped-triangle vertices (<= 6 in exact arithmetic)
 constexpr int HCAP = 20;          // hull of 9 + 4 points
 constexpr int kThreads = 64;
+constexpr int kPW = 1;            // pairs per wave (measured round 4: 4 pairs per wave = 112 us for 5 000 pairs against 85 -- the serial parts are branchy, lanes on different pairs diverge and their paths serialise)
+constexpr int kPL = kThreads / kPW;   // lanes per pair
 
 __device__ __forceinline__ int sg(double d) { return (int)(d > 1E-8) - (int)(d < -1E-8); }
 __device__ __forceinline__ bool same(D2 a, D2 b) { return sg(a.x - b.x) == 0 && sg(a.y - b.y) == 0; }
@@ -40,54 +42,63 @@ __device__ void area_grad(const D2* ps, int n, double* g) {
   }
 }
 
-struct CutRec { int kind, src; double j[8]; };   // j = dxp_dxc, dyp_dxc, dxp_dyc, dyp_dyc, dxp_dxd, dyp_dxd, dxp_dyd, dyp_dyd
-
-__device__ int cut(D2* p, int n, D2 a, D2 b, CutRec* rec) {
-  D2 pp[CAP]; CutRec rr[CAP];
+// One half-plane cut of polygon in[0..n) by the line a->b (keep the left side), written to out[]; rec[r] = (kind << 8) | src
+// of output vertex r: kind 0 = input vertex src kept, 1 = crossing of edge (src, src + 1) with the line, 2 = degenerate
+// crossing (no gradient).  The 2 x 2 Jacobians of a crossing w.r.t. its edge's end points are NOT stored: the backward pass
+// recomputes them from the stage's input polygon with the very same expressions (the per-lane state drops from 2.9 KB of
+// scratch -- which throttled the kernel to ~3 waves per CU -- to 0.7 KB).
+__device__ int cut(const D2* in, int n, D2 a, D2 b, D2* out, int* rec) {
   int m = 0;
   for (int i = 0; i < n; i++) {
-    const D2 c = p[i], d = p[(i + 1 < n) ? i + 1 : 0];
+    const D2 c = in[i], d = in[(i + 1 < n) ? i + 1 : 0];
     const double s1 = crs(a, b, c), s2 = crs(a, b, d);
     const int si = sg(s1), sj = sg(s2);
-    if (si > 0 && m < CAP) { pp[m] = c; rr[m].kind = 0; rr[m].src = i; m++; }
+    if (si > 0 && m < CAP) { out[m] = c; rec[m] = i; m++; }
     if (si != sj && m < CAP) {
-      rr[m].kind = 2; rr[m].src = i; pp[m].x = 0; pp[m].y = 0;
+      D2 x; x.x = 0; x.y = 0;
+      int kind = 2;
       if (!(si == 0 && sj == 0) && sg(s2 - s1) != 0) {
-        const double k1x = -(b.y - a.y), k1y = b.x - a.x;        // ds1/dxc = ds2/dxd, ds1/dyc = ds2/dyd
-        const double den = s2 - s1, den2 = den * den;
+        const double den = s2 - s1;
         const double nx = c.x * s2 - d.x * s1, ny = c.y * s2 - d.y * s1;
-        rr[m].kind = 1;
-        rr[m].j[0] = ((s2 - d.x * k1x) * den - nx * (-k1x)) / den2;   // dxp_dxc
-        rr[m].j[2] = ((0 - d.x * k1y) * den - nx * (-k1y)) / den2;    // dxp_dyc
-        rr[m].j[4] = ((c.x * k1x - s1) * den - nx * (k1x)) / den2;    // dxp_dxd
-        rr[m].j[6] = ((c.x * k1y - 0) * den - nx * (k1y)) / den2;     // dxp_dyd
-        rr[m].j[1] = ((0 - d.y * k1x) * den - ny * (-k1x)) / den2;    // dyp_dxc
-        rr[m].j[3] = ((s2 - d.y * k1y) * den - ny * (-k1y)) / den2;   // dyp_dyc
-        rr[m].j[5] = ((c.y * k1x - 0) * den - ny * (k1x)) / den2;     // dyp_dxd
-        rr[m].j[7] = ((c.y * k1y - s1) * den - ny * (k1y)) / den2;    // dyp_dyd
-        pp[m].x = nx / den; pp[m].y = ny / den;
+        kind = 1;
+        x.x = nx / den; x.y = ny / den;
       }
-      m++;
+      out[m] = x; rec[m] = (kind << 8) | i; m++;
     }
   }
   int nn = 0;
   for (int i = 0; i < m; i++)
-    if (!i || !same(pp[i], pp[i - 1])) { p[nn] = pp[i]; rec[nn] = rr[i]; nn++; }
-  while (nn > 1 && same(p[nn - 1], p[0])) nn--;
+    if (!i || !same(out[i], out[i - 1])) { out[nn] = out[i]; rec[nn] = rec[i]; nn++; }
+  while (nn > 1 && same(out[nn - 1], out[0])) nn--;
   return nn;
 }
 
-__device__ void cut_backward(const CutRec* rec, int n_out, int k, const double* g_out, double* g_in) {
+// pull the gradient w.r.t. the cut's output vertices back to its k input vertices
+__device__ void cut_backward(const D2* in, int k, D2 a, D2 b, const int* rec, int n_out, const double* g_out, double* g_in) {
   for (int i = 0; i < 2 * k; i++) g_in[i] = 0;
   for (int r = 0; r < n_out; r++) {
     const double gx = g_out[2 * r], gy = g_out[2 * r + 1];
-    if (rec[r].kind == 0) { g_in[2 * rec[r].src] += gx; g_in[2 * rec[r].src + 1] += gy; }
-    else if (rec[r].kind == 1) {
-      const int c = rec[r].src, d = (rec[r].src + 1 == k) ? 0 : rec[r].src + 1;
-      g_in[2 * c] += gx * rec[r].j[0] + gy * rec[r].j[1];
-      g_in[2 * c + 1] += gx * rec[r].j[2] + gy * rec[r].j[3];
-      g_in[2 * d] += gx * rec[r].j[4] + gy * rec[r].j[5];
-      g_in[2 * d + 1] += gx * rec[r].j[6] + gy * rec[r].j[7];
+    const int kind = rec[r] >> 8, src = rec[r] & 255;
+    if (kind == 0) { g_in[2 * src] += gx; g_in[2 * src + 1] += gy; }
+    else if (kind == 1) {
+      const int ci = src, di = (src + 1 == k) ? 0 : src + 1;
+      const D2 c = in[ci], d = in[di];
+      const double s1 = crs(a, b, c), s2 = crs(a, b, d);
+      const double k1x = -(b.y - a.y), k1y = b.x - a.x;        // ds1/dxc = ds2/dxd, ds1/dyc = ds2/dyd
+      const double den = s2 - s1, den2 = den * den;
+      const double nx = c.x * s2 - d.x * s1, ny = c.y * s2 - d.y * s1;
+      const double j0 = ((s2 - d.x * k1x) * den - nx * (-k1x)) / den2;   // dxp_dxc
+      const double j2 = ((0 - d.x * k1y) * den - nx * (-k1y)) / den2;    // dxp_dyc
+      const double j4 = ((c.x * k1x - s1) * den - nx * (k1x)) / den2;    // dxp_dxd
+      const double j6 = ((c.x * k1y - 0) * den - nx * (k1y)) / den2;     // dxp_dyd
+      const double j1 = ((0 - d.y * k1x) * den - ny * (-k1x)) / den2;    // dyp_dxc
+      const double j3 = ((s2 - d.y * k1y) * den - ny * (-k1y)) / den2;   // dyp_dyc
+      const double j5 = ((c.y * k1x - 0) * den - ny * (k1x)) / den2;     // dyp_dxd
+      const double j7 = ((c.y * k1y - s1) * den - ny * (k1y)) / den2;    // dyp_dyd
+      g_in[2 * ci] += gx * j0 + gy * j1;
+      g_in[2 * ci + 1] += gx * j2 + gy * j3;
+      g_in[2 * di] += gx * j4 + gy * j5;
+      g_in[2 * di + 1] += gx * j6 + gy * j7;
     }
   }
 }
@@ -109,34 +120,34 @@ __device__ double tri_term_grad4(D2 a, D2 b, D2 c, D2 d, double* g4) {
     const double ca = c.x * a.y - a.x * c.y, cb = c.x * b.y - b.x * c.y;     // crs(o, c, a), crs(o, c, b)
     if (!(ca > 1E-8) && !(cb > 1E-8)) return 0.0;
   }
-  D2 p[CAP];
-  CutRec r1[CAP], r2[CAP], r3[CAP];
-  p[0] = o; p[1] = a; p[2] = b;
-  const int n1 = cut(p, 3, o, c, r1);
-  const int n2 = cut(p, n1, c, d, r2);
-  const int n3 = cut(p, n2, d, o, r3);
-  double res = area_of(p, n3);
-  double g3[2 * CAP], g2[2 * CAP], g1[2 * CAP], g0[6];
-  area_grad(p, n3, g3);
-  cut_backward(r3, n3, n2, g3, g2);
-  cut_backward(r2, n2, n1, g2, g1);
-  cut_backward(r1, n1, 3, g1, g0);
+  D2 q0[3], q1[CAP], q2[CAP], q3[CAP];
+  int r1[CAP], r2[CAP], r3[CAP];
+  q0[0] = o; q0[1] = a; q0[2] = b;
+  const int n1 = cut(q0, 3, o, c, q1, r1);
+  const int n2 = cut(q1, n1, c, d, q2, r2);
+  const int n3 = cut(q2, n2, d, o, q3, r3);
+  double res = area_of(q3, n3);
+  double ga[2 * CAP], gb[2 * CAP];
+  area_grad(q3, n3, ga);
+  cut_backward(q2, n2, d, o, r3, n3, ga, gb);
+  cut_backward(q1, n1, c, d, r2, n2, gb, ga);
+  cut_backward(q0, 3, o, c, r1, n1, ga, gb);
   double sgn = 1.0;
   if (s1 * s2 == -1) { sgn = -1.0; res = -res; }
-  double gax = sgn * g0[2], gay = sgn * g0[3], gbx = sgn * g0[4], gby = sgn * g0[5];
+  double gax = sgn * gb[2], gay = sgn * gb[3], gbx = sgn * gb[4], gby = sgn * gb[5];
   if (swapped) { double t = gax; gax = gbx; gbx = t; t = gay; gay = gby; gby = t; }
   g4[0] = gax; g4[1] = gay; g4[2] = gbx; g4[3] = gby;
   return res;
 }
 
 // Jarvis march, reference order and tie rules (convex_giou_kernel.cu:454-542, 618-728); chains capped
-__device__ int jarvis(D2* in_poly, int n_poly, int* to_input, int cap) {
+// (input_poly / right_point / left_point: HCAP-vertex work arrays in LDS -- one lane runs this, private arrays would be
+//  scratch memory with a DRAM-like latency on every dynamically indexed access)
+__device__ int jarvis(D2* in_poly, int n_poly, int* to_input, int cap, D2* input_poly, D2* right_point, D2* left_point) {
   const int n_input = n_poly;
-  D2 input_poly[HCAP];
   for (int i = 0; i < n_input; i++) input_poly[i] = in_poly[i];
   D2 p_max = in_poly[0], p_k;
   int max_index = 0, k_index;
-  D2 right_point[HCAP], left_point[HCAP];
   for (int i = 0; i < n_poly; i++) {
     if (in_poly[i].y < in_poly[0].y || (in_poly[i].y == in_poly[0].y && in_poly[i].x < in_poly[0].x)) {
       D2 t = in_poly[0]; in_poly[0] = in_poly[i]; in_poly[i] = t;
@@ -174,55 +185,63 @@ __device__ int jarvis(D2* in_poly, int n_poly, int* to_input, int cap) {
   return n_poly;
 }
 
-// One WAVE per (point set, gt) pair.  Lane 0 builds the hull and orients both polygons (LDS), then the <= 36 fan terms
-// (hull edge i, gt edge j) run one per lane -- each with its clip records and reverse-mode pull-back -- and park their
-// value + 4 gradient components in LDS; lane 0 accumulates them in the reference's (i outer, j inner) order, so values
-// and gradients are what the serial loop produced, and finishes union / enclosing hull / GIoU.  The previous shape
-// (one THREAD per pair, 36 serial terms on private arrays) left a call with a few thousand positives running on a few
-// dozen waves for 0.6 ms.
+// kPW (point set, gt) pairs per wave.  A pair's first lane builds the hull and orients both polygons (LDS), then the <= 36
+// fan terms (hull edge i, gt edge j) run on the pair's lanes -- each with its clip records and reverse-mode pull-back --
+// and park their value + 4 gradient components in LDS; the first lane accumulates them in the reference's (i outer, j
+// inner) order, so values and gradients are what the serial loop produced, and finishes union / enclosing hull / GIoU.
+// History: one THREAD per pair (36 serial terms on private arrays) ran a few thousand positives on a few dozen waves for
+// 0.6 ms; one WAVE per pair with 2.9 KB of scratch per lane (clip records with their 2 x 2 Jacobians, the first lane's
+// hull work arrays): 237 us for 5 000 pairs at ~3 resident waves per CU; round 4: Jacobians recomputed in the pull-back,
+// the first lane's arrays in LDS, 0.75 KB of scratch: 85 us.  A single wave takes ~50 us (two serial hull marches around
+// the parallel term phase); several pairs per wave (kPW > 1) were measured and are SLOWER (see kPW).
 __global__ void __launch_bounds__(kThreads)
 convex_giou_kernel(const float* __restrict__ pts, const float* __restrict__ gts, int n, float* __restrict__ out19) {
-  const int idx = blockIdx.x;
-  const int lane = threadIdx.x;
-  __shared__ D2 s_ps1[HCAP];
-  __shared__ D2 s_ps2[5];
-  __shared__ int s_to_input[HCAP];
-  __shared__ int s_n1;
-  __shared__ double s_val[36];
-  __shared__ double s_g4[36][4];
-  const float* p = pts + (size_t)idx * 18;
-  const float* q = gts + (size_t)idx * 8;
+  // kPW pairs per wave, kPL = 64 / kPW lanes each: the serial parts (hull marches, finish) of kPW pairs run side by side on
+  // the groups' first lanes, the <= 36 fan terms of a pair take ceil(36 / kPL) rounds on its kPL lanes.
+  const int grp = threadIdx.x / kPL, lane = threadIdx.x % kPL;
+  const int idx = blockIdx.x * kPW + grp;
+  const bool valid = idx < n;
+  __shared__ D2 sh_ps1[kPW][HCAP];
+  __shared__ D2 sh_ps2[kPW][5];
+  __shared__ int sh_to_input[kPW][HCAP];
+  __shared__ int sh_n1[kPW];
+  __shared__ double sh_val[kPW][36];
+  __shared__ double sh_g4[kPW][36][4];
+  __shared__ D2 sh_w0[kPW][HCAP], sh_w1[kPW][HCAP], sh_w2[kPW][HCAP], sh_poly[kPW][HCAP];   // the first lane's work arrays
+  __shared__ double sh_gA[kPW][18], sh_gAB[kPW][20], sh_gC[kPW][18], sh_gh[kPW][2 * HCAP];
+  D2* s_ps1 = sh_ps1[grp]; D2* s_ps2 = sh_ps2[grp]; int* s_to_input = sh_to_input[grp];
+  double* s_val = sh_val[grp]; double (*s_g4)[4] = sh_g4[grp];
+  D2* s_w0 = sh_w0[grp]; D2* s_w1 = sh_w1[grp]; D2* s_w2 = sh_w2[grp]; D2* s_poly = sh_poly[grp];
+  double* s_gA = sh_gA[grp]; double* s_gAB = sh_gAB[grp]; double* s_gC = sh_gC[grp]; double* s_gh = sh_gh[grp];
+  const float* p = pts + (size_t)(valid ? idx : 0) * 18;
+  const float* q = gts + (size_t)(valid ? idx : 0) * 8;
   const int n2 = 4;
   if (lane == 0) {
-    D2 ps1[HCAP], ps2[5];
-    int to_input[HCAP];
-    for (int i = 0; i < HCAP; i++) to_input[i] = -1;
+    D2* ps1 = s_ps1; D2* ps2 = s_ps2;
+    for (int i = 0; i < HCAP; i++) s_to_input[i] = -1;
     for (int i = 0; i < 9; i++) { ps1[i].x = (double)p[2 * i]; ps1[i].y = (double)p[2 * i + 1]; }
-    int n1 = jarvis(ps1, 9, to_input, 9);
+    int n1 = jarvis(ps1, 9, s_to_input, 9, s_w0, s_w1, s_w2);
     if (n1 > 9) n1 = 9;
     for (int i = 0; i < 4; i++) { ps2[i].x = (double)q[2 * i]; ps2[i].y = (double)q[2 * i + 1]; }
     if (area_of(ps1, n1) < 0) for (int a = 0, b = n1 - 1; a < b; a++, b--) { D2 t = ps1[a]; ps1[a] = ps1[b]; ps1[b] = t; }
     if (area_of(ps2, n2) < 0) for (int a = 0, b = n2 - 1; a < b; a++, b--) { D2 t = ps2[a]; ps2[a] = ps2[b]; ps2[b] = t; }
-    for (int i = 0; i < HCAP; i++) { s_ps1[i] = ps1[i < n1 ? i : 0]; s_to_input[i] = to_input[i]; }
-    for (int i = 0; i < 4; i++) s_ps2[i] = ps2[i];
-    s_n1 = n1;
+    for (int i = n1; i < HCAP; i++) s_ps1[i] = ps1[0];
+    sh_n1[grp] = n1;
   }
   __syncthreads();
-  const int n1 = s_n1;
-  if (lane < 4 * n1 && lane < 36) {
-    const int i = lane >> 2, j = lane & 3;
+  const int n1 = sh_n1[grp];
+  for (int t = lane; t < 4 * n1 && t < 36; t += kPL) {
+    const int i = t >> 2, j = t & 3;
     double g4[4];
     const double v = tri_term_grad4(s_ps1[i], s_ps1[(i + 1 < n1) ? i + 1 : 0], s_ps2[j], s_ps2[(j + 1 < n2) ? j + 1 : 0], g4);
-    s_val[lane] = v;
-    s_g4[lane][0] = g4[0]; s_g4[lane][1] = g4[1]; s_g4[lane][2] = g4[2]; s_g4[lane][3] = g4[3];
+    s_val[t] = v;
+    s_g4[t][0] = g4[0]; s_g4[t][1] = g4[1]; s_g4[t][2] = g4[2]; s_g4[t][3] = g4[3];
   }
   __syncthreads();
-  if (lane != 0) return;
+  if (lane != 0 || !valid) return;
 
-  D2 ps1[HCAP], ps2[5];
-  for (int i = 0; i < n1; i++) ps1[i] = s_ps1[i];
-  for (int i = 0; i < 4; i++) ps2[i] = s_ps2[i];
-  double grad_A[18], grad_AB[20], grad_C[18];
+  D2* ps1 = s_ps1; D2* ps2 = s_ps2;
+  double* grad_A = s_gA; double* grad_AB = s_gAB; double* grad_C = s_gC;
   for (int i = 0; i < 18; i++) { grad_A[i] = 0; grad_AB[i] = 0; grad_C[i] = 0; }
   grad_AB[18] = grad_AB[19] = 0;
   double inter = 0;
@@ -249,13 +268,13 @@ convex_giou_kernel(const float* __restrict__ pts, const float* __restrict__ gts,
     for (int j = 0; j < 4; j++)
       if (same(ps1[i], ps2[j])) { for (int k = j; k < 3; k++) ps2[k] = ps2[k + 1]; m2--; break; }
   if (m2 < 0) m2 = 0;
-  D2 poly[HCAP];
+  D2* poly = s_poly;
   int n_poly = n1 + m2;
   for (int i = 0; i < n_poly; i++) poly[i] = (i < n1) ? ps1[i] : ps2[i - n1];
-  n_poly = jarvis(poly, n_poly, nullptr, 18);
+  n_poly = jarvis(poly, n_poly, nullptr, 18, s_w0, s_w1, s_w2);
   double c_area = area_of(poly, n_poly);
   {
-    double gh[2 * HCAP];
+    double* gh = s_gh;
     area_grad(poly, n_poly, gh);
     bool any = false;
     for (int v = 0; v < n_poly; v++)            // ascending: a later hull vertex naming the same ps1 point overwrites
@@ -285,7 +304,7 @@ extern "C" int orp_convex_giou(const float* pts, const float* gts, int n, float*
   if (n < 0 || (n > 0 && (!pts || !gts || !out19))) return ORP_EINVAL;
   if (n == 0) return ORP_OK;
   OrpProfScope prof(ORP_PROF_CONVEX_GIOU, (hipStream_t)stream);
-  hipLaunchKernelGGL(convex_giou_kernel, dim3(n), dim3(kThreads), 0, (hipStream_t)stream, pts, gts, n, out19);
+  hipLaunchKernelGGL(convex_giou_kernel, dim3((n + kPW - 1) / kPW), dim3(kThreads), 0, (hipStream_t)stream, pts, gts, n, out19);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }

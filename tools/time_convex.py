@@ -24,3 +24,10 @@ for k in (8, 64, 256):
     gts = torch.from_numpy(S.gen_gts(k, 3).astype(np.float32)).to(dev)
     us = timeit(lambda: convex_iou(pts, gts))
     print("convex_iou grid-ordered %d x %d: %.1f us (%.2f ns/pair)" % (pts.size(0), k, us, us * 1e3 / (pts.size(0) * k)))
+# convex_giou (aligned pairs, value + 18 gradients): the loss-side shapes
+from orientedreppoints_amd.mmdet_ops import convex_giou
+for P in (500, 5000, 20000):
+    pp = torch.from_numpy(S.gen_pointsets(P, 2).astype(np.float32)).to(dev)
+    gg = torch.from_numpy(S.gen_gts(P, 3).astype(np.float32)).to(dev)
+    us = timeit(lambda: convex_giou(pp, gg))
+    print("convex_giou %d pairs: %.1f us (%.1f ns/pair)" % (P, us, us * 1e3 / P))
