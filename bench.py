@@ -1077,6 +1077,8 @@ def main():
                    'images_in_flight_per_gpu': args.pipeline if isinstance(pipe_ms, float) else 1},
         'detections_per_step': ndet, 'step_bitwise_reproducible': bool(step_reproducible), 'library_deterministic_mode': library_deterministic_mode, 'nms_classes_present': int(len(set(cap['labels'].tolist()))) if cap.get('labels') is not None else None,
         'library_build': _lib.lib().orp_version().decode(),
+        # (a library swapped in through the environment -- dev aid -- must show in the line)
+        'library_path': _lib.LIB_PATH if os.environ.get('ORP_HIP_LIB') else 'in-tree (orientedreppoints_amd/csrc/liborp_hip.so)',
         'rotated_iou_nms_us_per_img': nms_us, 'nms_boxes': M,
         'kernel_us': {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()},
         'mode': ('hipgraph replay, %d images in flight' % args.pipeline) if isinstance(pipe_ms, float) else

@@ -293,6 +293,7 @@ def gen_postprocess(R, h, g):
             print('  scene %s seed %d is not ulp-robust, next seed' % (name, seed + 100 * attempt))
         assert ok, name
         g['pp_%s_seed' % name] = np.array(seed + 100 * attempt)
+        g['pp_%s_rejected' % name] = np.array(attempt)       # scenes tried before this one that were NOT ulp-robust
         g['pp_%s_dets' % name] = dets.astype(np.float32)
         g['pp_%s_labels' % name] = labels.astype(np.int64)
         g['pp_%s_class_counts' % name] = np.array([r.shape[0] for r in res], dtype=np.int64)
@@ -409,6 +410,7 @@ def gen_loss(R, h, g):
         assert ok, name
         p = 'loss_%s_' % name
         g[p + 'seed'] = np.array(seed + 100 * attempt)
+        g[p + 'rejected'] = np.array(attempt)
         for k, v in flat.items():
             g[p + k] = v
         # ---- targets (pointset_target.py), per image over all levels ------------------------------------------------
@@ -488,6 +490,8 @@ def main():
     out = os.path.join(HERE, 'compose_py.npz')
     np.savez_compressed(out, **g)
     print('written', out, '%.1f KB' % (os.path.getsize(out) / 1024))
+    print('scenes rejected by the ulp-robustness filter before the accepted one:',
+          {k[:-9]: int(v) for k, v in g.items() if k.endswith('_rejected')})
 
 
 if __name__ == '__main__':

@@ -30,9 +30,19 @@ def dev():
     return torch.device("cuda:0")
 
 
+# base seeds of tests/golden/make_golden_compose.py (PP_SCENES / LOSS_CASES): a scene is re-drawn with seed + 100 until all
+# its discrete outcomes survive ulp-level input noise, so (accepted seed - base seed) / 100 = scenes REJECTED by that filter
+BASE_SEEDS = {'pp_small': 11, 'pp_empty': 12, 'pp_full': 13, 'pp_over_max': 14, 'loss_a': 21, 'loss_b': 22, 'loss_c': 23}
+
+
 @pytest.fixture(scope="module")
 def G(golden_dir):
-    return np.load(os.path.join(golden_dir, "compose_py.npz"))
+    import conftest
+    g = np.load(os.path.join(golden_dir, "compose_py.npz"))
+    rej = {k: (int(g[k + '_seed']) - b) // 100 for k, b in BASE_SEEDS.items()}
+    conftest.REPORT.append("compose goldens are pre-filtered for ulp-robustness (borderline scenes are NOT in the end-to-end tests; "
+                           "the kernel-level bit-exact IoU / NMS tests cover them): scenes rejected before the accepted one: %s" % rej)
+    return g
 
 
 def _head(dev):
