@@ -15,8 +15,12 @@ if which in ('dcn', 'all'):
     xs = [torch.randn(1, 256, h, h, device=dev) for h in (128, 64, 32, 16, 8)]      # NCHW, as the towers hand them over
     xs2 = [torch.randn_like(x) for x in xs]
     offs = [torch.randn(1, 18, h, h, device=dev) * 2 for h in (128, 64, 32, 16, 8)]
-    for _ in range(iters):
-        deform_conv_forward_pair(xs, xs2, offs, w, w2, 1, 1, 1, relu=True)      # the head's launch: both layers, all levels
+    from orientedreppoints_amd import _lib
+    for mode in (-1, 0):          # the library's default arithmetic (bf16-split products), then the exact-fp32 MFMA kernel
+        _lib.lib().orp_dcn_set_split_mode(mode)
+        for _ in range(iters):
+            deform_conv_forward_pair(xs, xs2, offs, w, w2, 1, 1, 1, relu=True)  # the head's launch: both layers, all levels
+    _lib.lib().orp_dcn_set_split_mode(-1)
     hx, ho, hw = [x.half() for x in xs], [o.half() for o in offs], w.half()
     for _ in range(iters):
         deform_conv_forward_multi(hx, ho, hw, 1, 1, 1)                          # fp16 path
