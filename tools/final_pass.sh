@@ -17,9 +17,16 @@ python bench.py --size 1536 --steps 60 --no-cpu-baseline > $O/${TAG}_bench_1536.
 python bench.py --mode train --steps 30 > $O/${TAG}_bench_train.json 2>/dev/null
 python bench.py --mode train --dtype fp16 --steps 30 > $O/${TAG}_bench_train_fp16.json 2>/dev/null
 python bench.py --mode train --dtype bf16 --steps 30 > $O/${TAG}_bench_train_bf16.json 2>/dev/null
+python bench.py --model swin_t --mode train --dtype fp16 --size 1024,1536 --steps 20 --warmup 4 > $O/${TAG}_bench_swin_train.json 2>/dev/null
+python bench.py --model r50_dcnv2 --mode train --steps 12 --warmup 3 > $O/${TAG}_bench_r50dcnv2_train.json 2>/dev/null
+python bench.py --gpus 2 --device cpu --dry --mode train > $O/${TAG}_bench_dry_2ranks_train.json 2>/dev/null
+SOAK_N=1500 python tests/checks/soak_dcn_split.py > $O/${TAG}_soak.log 2>&1
+python tools/time_convex.py > $O/${TAG}_convex.log 2>&1
+bash tests/checks/clock_under_split.sh > $O/${TAG}_clock_under_split.log 2>&1
 python tests/checks/time_dcn_backward.py > $O/${TAG}_dcn_backward.log 2>&1
 python tests/checks/time_dcn_pair.py > $O/${TAG}_dcn_pair.log 2>&1
-ORP_DCN_KSPLIT=0 python tests/checks/time_dcn_pair.py >> $O/${TAG}_dcn_pair.log 2>&1
+ORP_DCN_SPLIT=0 python tests/checks/time_dcn_pair.py >> $O/${TAG}_dcn_pair.log 2>&1
+ORP_DCN_SPLIT=9 python tests/checks/time_dcn_pair.py >> $O/${TAG}_dcn_pair.log 2>&1
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/${TAG}_prof_bench -- python $R/bench.py --steps 30 --no-cpu-baseline --pipeline 1 > $R/$O/${TAG}_prof_bench.log 2>&1)
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/${TAG}_prof_train -- python $R/bench.py --mode train --steps 12 > $R/$O/${TAG}_prof_train.log 2>&1)
 tail -2 $O/${TAG}_smoke.log; tail -c 600 $O/${TAG}_bench.json; echo; tail -c 300 $O/${TAG}_bench_train.json
