@@ -19,7 +19,7 @@ python bench.py --mode train --dtype fp16 --steps 30 > $O/${TAG}_bench_train_fp1
 python bench.py --mode train --dtype bf16 --steps 30 > $O/${TAG}_bench_train_bf16.json 2>/dev/null
 python bench.py --model swin_t --mode train --dtype fp16 --size 1024,1536 --steps 20 --warmup 4 > $O/${TAG}_bench_swin_train.json 2>/dev/null
 python bench.py --model r50_dcnv2 --mode train --steps 12 --warmup 3 > $O/${TAG}_bench_r50dcnv2_train.json 2>/dev/null
-python bench.py --gpus 2 --device cpu --dry --mode train > $O/${TAG}_bench_dry_2ranks_train.json 2>/dev/null
+python bench.py --gpus 2 --device cpu --dry --mode train 2>/dev/null | grep "^{" > $O/${TAG}_bench_dry_2ranks_train.json
 SOAK_N=1500 python tests/checks/soak_dcn_split.py > $O/${TAG}_soak.log 2>&1
 python tools/time_convex.py > $O/${TAG}_convex.log 2>&1
 bash tests/checks/clock_under_split.sh > $O/${TAG}_clock_under_split.log 2>&1
