@@ -400,6 +400,14 @@ int orp_groupnorm_act_multi_nhwc(const orp_norm_level* levels, const float* cons
                                  const float* const* betas_host, float* const* nhwc_out_host, int nlevels, int batch,
                                  int channels, int groups, float eps, int relu, void* workspace, size_t workspace_bytes,
                                  void* stream);
+/* GroupNorm(+ReLU) of channels-last tensors, [B, H, W, C] in and out (in place allowed): what sits between two
+ * orp_conv_split_multi launches.  Three launches for all tensors (up to 16): per-chunk (mean, M2) partials of every group,
+ * their fixed-order merge into (mean, rstd) per (tensor, image, group), one elementwise pass.  1024 % channels == 0,
+ * (channels / groups) % 4 == 0.  workspace: orp_groupnorm_cl_workspace_bytes. */
+size_t orp_groupnorm_cl_workspace_bytes(const orp_norm_level* levels_host, int nlevels, int batch, int channels, int groups);
+int orp_groupnorm_act_multi_cl(const orp_norm_level* levels, const float* const* gammas_host, const float* const* betas_host,
+                               int nlevels, int batch, int channels, int groups, float eps, int relu, void* workspace,
+                               size_t workspace_bytes, void* stream);
 /* training: the same launch pair, additionally storing (mean, rstd) of every (image, group) in
  * stats [sum over tensors of batch * groups][2] (tensor i's rows follow tensor i-1's), and the backward:
  *   grad_inputs[i] = d loss / d x_i given grad_outputs[i] = d loss / d y_i (dy masked where y <= 0 when relu),
@@ -461,6 +469,24 @@ int orp_conv3x3_small_multi_strided(const orp_norm_level* levels_host, const flo
                                     const int* strides_host, int nlevels, int batch, int c_in, int c_out, void* workspace,
                                     size_t workspace_bytes, void* stream);
 
+/* orp_conv_split_multi: the head's tower convolutions (mmdet/models/anchor_heads/orientedreppoints_head.py:91-113 cls_convs /
+ *   reg_convs, :107 reppoints_pts_init_conv; mmdet/ops/conv_module.py:130-140 `self.conv(x)`) -- kh x kw convolution of ALL FPN
+ *   levels, ONE layer (weight_b_packed NULL) or TWO layers of equal shape (the two towers' layer k: grid halves of one
+ *   launch), fp32 in / fp32 out / fp32 accumulation on the bf16 matrix pipe with every operand split exactly into three bf16
+ *   pieces (nprod = 6 or 9 partial products; the DeformConv forward's kernel without offsets, orp_dcn_set_split_mode).
+ *   input_* : channels-last [B, H, W, Cin]; output_* : [B, Cout, Ho, Wo] (out_layout 0) or [B, Ho, Wo, Cout] (1);
+ *   weight_*_packed: orp_dcn_pack_weight of the [Cout, Cin, kh, kw] weight; bias_* [Cout] or NULL; relu fused.
+ *   orp_conv_split_ok: Cin % 64 == 0, Cout % 64 == 0, kh * kw <= 9.
+ * orp_nchw_to_nhwc_multi: [B, C, H, W] -> [B, H, W, C] of up to 16 tensors in one launch (the FPN outputs entering the
+ *   towers); levels_host[i] = {input, output, height, width}. */
+typedef struct { const float* input_a; const float* input_b; float* output_a; float* output_b; int height; int width; } orp_conv_level;
+int orp_conv_split_ok(int c_in, int c_out, int kh, int kw);
+int orp_conv_split_multi(const orp_conv_level* levels_host, int nlevels, int batch, int c_in, int c_out,
+                         const float* weight_a_packed, const float* weight_b_packed, const float* bias_a, const float* bias_b,
+                         int relu, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                         int out_layout, int nprod, void* stream);
+int orp_nchw_to_nhwc_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Fused test-time post-processing around the rotated NMS: replaces the tensor-op chains of
  * get_bboxes_single (orientedreppoints_head.py:707-779), multiclass_rnms (bbox_nms.py:93-182) and rbbox2result
@@ -501,7 +527,8 @@ int orp_pp_pack(const int64_t* keep, const int32_t* num_keep, const float* dets,
 /* ---------------------------------------------------------------------------------------------------------
  * Built-in kernel timing (measurement aid for bench.py): when enabled every instrumented launch is bracketed by
  * a HIP event pair recorded on the launch stream.  Slots: 0 nms mask, 1 nms sweep, 2 nms sort, 3 dcn forward,
- * 4 minaerarect, 5 convex_iou, 6 convex_giou, 7 iou matrix, 8 dcn backward.
+ * 4 minaerarect, 5 convex_iou, 6 convex_giou, 7 iou matrix, 8 dcn backward (9 / 10 / 11: its input-gradient GEMM, scatter,
+ * weight-gradient parts), 12 orp_conv_split_multi.
  * orp_profile_read synchronises on the recorded events and returns their summed duration and count.
  * ------------------------------------------------------------------------------------------------------- */
 int orp_profile_enable(int on);

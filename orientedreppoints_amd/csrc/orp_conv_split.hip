@@ -1,0 +1,115 @@
+// orp_conv_split.hip -- the dense head's 3x3 tower convolutions, ALL FPN levels and one or two layers per launch (gfx950).
+//
+// The head runs seven 256 -> 256 3x3 convolutions over every FPN level (mmdet/models/anchor_heads/orientedreppoints_head.py:
+// 91-113 cls_convs / reg_convs ConvModules, :107 reppoints_pts_init_conv; applied per level by forward_single :148-158).
+// The framework issues them level by level on the library: Winograd on the 128^2 / 64^2 maps (168 + 45 us per layer at
+// 1024^2, 107-115 TF/s effective) plus this library's small-level launch (33 us) -- 246 us per layer, 1.7 ms per image, the
+// largest block of the inference step after the backbone.  fp32 has no fast matrix path on gfx950; the DeformConv forward
+// already contracts on the bf16 pipe with every operand split exactly into three bf16 pieces (orp_dcn_split.hip: error
+// against the fp64-accumulated oracle below the exact-fp32 MFMA chain's own).  A convolution is that operator without
+// offsets: the same kernel, PLAIN instantiation (one row fetch per sample, no bilinear combine), channels-last in, NHWC or
+// NCHW out, bias / ReLU in the epilogue; the two towers' layer k are the two grid halves of ONE launch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orp_hip.h"
+#include "orp_dcn_split.hpp"
+#include "orp_prof.hpp"
+
+namespace {
+
+constexpr int kMaxT = 16;
+struct TrLevels {
+  const float* in[kMaxT];
+  float* out[kMaxT];
+  int hw[kMaxT];
+  int bx0[kMaxT + 1];
+  int nlev;
+};
+
+// [B][C][HW] -> [B][HW][C] through a 32 x 33 LDS tile, every tensor of the launch back to back along blockIdx.x
+__global__ void __launch_bounds__(256)
+to_channels_last_kernel(const TrLevels T, int C) {
+  __shared__ float tile[32][33];
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxT; i++) l = (i < T.nlev && (int)blockIdx.x >= T.bx0[i]) ? i : l;
+  const int HW = T.hw[l];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, p0 = ((int)blockIdx.x - T.bx0[l]) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* src = T.in[l] + (size_t)b * C * HW;
+  float* dst = T.out[l] + (size_t)b * C * HW;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    tile[r][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    if (p < HW && c < C) dst[(size_t)p * C + c] = tile[tx][r];
+  }
+}
+
+inline int out_dim(int in, int pad, int dil, int k, int stride) { return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1; }
+
+}  // namespace
+
+extern "C" {
+
+int orp_conv_split_ok(int c_in, int c_out, int kh, int kw) { return orp_split::shape_ok(c_in, c_out, kh, kw) ? 1 : 0; }
+
+int orp_conv_split_multi(const orp_conv_level* levels_host, int nlevels, int batch, int c_in, int c_out,
+                         const float* weight_a_packed, const float* weight_b_packed, const float* bias_a, const float* bias_b,
+                         int relu, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                         int out_layout, int nprod, void* stream) {
+  if (!levels_host || nlevels <= 0 || nlevels > orp_split::kMaxLevels || batch <= 0 || !weight_a_packed) return ORP_EINVAL;
+  if (!orp_split::shape_ok(c_in, c_out, kh, kw) || (nprod != 6 && nprod != 9) || (out_layout != 0 && out_layout != 1))
+    return ORP_EINVAL;
+  if (stride_h <= 0 || stride_w <= 0 || dil_h <= 0 || dil_w <= 0 || pad_h < 0 || pad_w < 0) return ORP_EINVAL;
+  const int nconv = weight_b_packed ? 2 : 1;
+  orp_split::Args A;
+  A.nlev = nlevels; A.B = batch; A.Cin = c_in; A.Cout = c_out;
+  A.kh = kh; A.kw = kw; A.sh = stride_h; A.sw = stride_w; A.ph = pad_h; A.pw = pad_w; A.dh = dil_h; A.dw = dil_w;
+  const size_t plane_off = (size_t)2 * kh * kw * c_in * c_out;          // orp_dcn_pack_weight: the planes follow the fp32 packings
+  A.planes[0] = reinterpret_cast<const uint16_t*>(weight_a_packed + plane_off);
+  A.planes[1] = nconv == 2 ? reinterpret_cast<const uint16_t*>(weight_b_packed + plane_off) : A.planes[0];
+  A.bias[0] = bias_a; A.bias[1] = nconv == 2 ? bias_b : bias_a;
+  A.relu = relu ? 1 : 0; A.nconv = nconv; A.out_nchw = out_layout == 0 ? 1 : 0; A.nprod = nprod;
+  for (int i = 0; i < nlevels; i++) {
+    const orp_conv_level& lv = levels_host[i];
+    if (!lv.input_a || !lv.output_a || lv.height <= 0 || lv.width <= 0) return ORP_EINVAL;
+    if (nconv == 2 && (!lv.input_b || !lv.output_b)) return ORP_EINVAL;
+    if ((long)batch * lv.height * lv.width >= (1L << 31)) return ORP_ETOOBIG;
+    orp_split::Level& S = A.lv[i];
+    S.x[0] = lv.input_a; S.x[1] = nconv == 2 ? lv.input_b : lv.input_a;
+    S.off = nullptr; S.mask = nullptr;
+    S.out[0] = lv.output_a; S.out[1] = nconv == 2 ? lv.output_b : lv.output_a;
+    S.H = lv.height; S.W = lv.width;
+    S.Ho = out_dim(lv.height, pad_h, dil_h, kh, stride_h);
+    S.Wo = out_dim(lv.width, pad_w, dil_w, kw, stride_w);
+    if (S.Ho <= 0 || S.Wo <= 0) return ORP_EINVAL;
+  }
+  OrpProfScope prof(ORP_PROF_CONV_SPLIT, (hipStream_t)stream);
+  const hipError_t e = orp_split::launch(A, (hipStream_t)stream);
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_nchw_to_nhwc_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, void* stream) {
+  if (!levels_host || nlevels <= 0 || nlevels > kMaxT || batch <= 0 || batch > 65535 || channels <= 0) return ORP_EINVAL;
+  TrLevels T;
+  int bx = 0;
+  for (int i = 0; i < nlevels; i++) {
+    const orp_norm_level& lv = levels_host[i];
+    if (!lv.input || !lv.output || lv.input == lv.output || lv.height <= 0 || lv.width <= 0) return ORP_EINVAL;
+    T.in[i] = lv.input; T.out[i] = lv.output; T.hw[i] = lv.height * lv.width; T.bx0[i] = bx;
+    bx += (T.hw[i] + 31) / 32;
+  }
+  T.nlev = nlevels;
+  for (int i = nlevels; i <= kMaxT; i++) T.bx0[i] = bx;
+  for (int i = nlevels; i < kMaxT; i++) { T.in[i] = T.in[0]; T.out[i] = T.out[0]; T.hw[i] = 0; }
+  hipLaunchKernelGGL(to_channels_last_kernel, dim3(bx, (channels + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, T, channels);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+}  // extern "C"

@@ -59,6 +59,9 @@
 // 1 = drain before the A-fragment prefetch instead, 3 = both, 0 = none (dev aid).
 #define ORP_DCNS_DRAIN 2
 #endif
+#ifndef ORP_DCNS_SIDE_ACC
+#define ORP_DCNS_SIDE_ACC 1          // PLAIN instantiation: second accumulator set for the small partial products (see Products)
+#endif
 #ifndef ORP_DCNS_INTERLEAVE
 #define ORP_DCNS_INTERLEAVE 4        // VALU instructions of the combine pinned behind every MFMA of the chunk that carries it (0: scheduler's choice)
 #endif
@@ -124,25 +127,33 @@ __device__ __forceinline__ unsigned pack_hi16(float a, float b) {
 __device__ __forceinline__ constexpr int prod_a(int t) { const int tab[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}; return tab[t]; }
 __device__ __forceinline__ constexpr int prod_b(int t) { const int tab[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}; return tab[t]; }
 
-template <int T, int TEND, int MT, bool OUT_NCHW>
+// SIDE: the small partial products (everything but hi * hi) go to a second accumulator set that is added once in the
+// epilogue -- the main chain then rounds once per 16 channels at the output's magnitude instead of 6 (9) times, and the
+// roundings of the side chain happen 2^-8 further down (PLAIN instantiation: the registers are there)
+template <int T, int TEND, int MT, bool OUT_NCHW, bool SIDE>
 struct Products {
-  static __device__ __forceinline__ void run(floatx16 (&acc)[MT], const bf8 (&a)[MT][3], const bf8 (&b)[3]) {
+  static __device__ __forceinline__ void run(floatx16 (&acc)[MT], floatx16 (&side)[SIDE ? MT : 1], const bf8 (&a)[MT][3],
+                                             const bf8 (&b)[3]) {
     constexpr int pa = prod_a(T), pb = prod_b(T);
+    constexpr bool to_side = SIDE && T != 8;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
       if (ORP_DCNS_DBG & 4) { acc[mt][0] += (float)a[mt][pa][0] * (float)b[pb][0]; continue; }
-      if (OUT_NCHW) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[pb], a[mt][pa], acc[mt], 0, 0, 0);   // D[channel][position]
-      else          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][pa], b[pb], acc[mt], 0, 0, 0);   // D[position][channel]
+      floatx16& d = to_side ? side[mt] : acc[mt];
+      if (OUT_NCHW) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[pb], a[mt][pa], d, 0, 0, 0);   // D[channel][position]
+      else          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][pa], b[pb], d, 0, 0, 0);   // D[position][channel]
     }
-    Products<T + 1, TEND, MT, OUT_NCHW>::run(acc, a, b);
+    Products<T + 1, TEND, MT, OUT_NCHW, SIDE>::run(acc, side, a, b);
   }
 };
-template <int TEND, int MT, bool OUT_NCHW>
-struct Products<TEND, TEND, MT, OUT_NCHW> {
-  static __device__ __forceinline__ void run(floatx16 (&)[MT], const bf8 (&)[MT][3], const bf8 (&)[3]) {}
+template <int TEND, int MT, bool OUT_NCHW, bool SIDE>
+struct Products<TEND, TEND, MT, OUT_NCHW, SIDE> {
+  static __device__ __forceinline__ void run(floatx16 (&)[MT], floatx16 (&)[SIDE ? MT : 1], const bf8 (&)[MT][3], const bf8 (&)[3]) {}
 };
 
-template <int MT, int NPROD, bool OUT_NCHW>
+// PLAIN: no offsets -- the ordinary convolution (sample = the tap-shifted pixel itself, zero outside the map): one row fetch
+// per sample instead of four, no bilinear combine; everything else (split, planes, MFMA schedule, epilogue) is shared
+template <int MT, int NPROD, bool OUT_NCHW, bool PLAIN>
 __global__ void __launch_bounds__(kThreadsS)
 dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   constexpr int BMS = 32 * MT;
@@ -184,6 +195,12 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
       const int ho = hw / L.Wo, wo = hw - ho * L.Wo;
       const int ki = tap / P.kw, kj = tap - ki * P.kw;
+      if (PLAIN) {
+        const int hi = ho * P.sh - P.ph + ki * P.dh, wi = wo * P.sw - P.pw + kj * P.dw;
+        if (hi >= 0 && hi < L.H && wi >= 0 && wi < L.W) { w.x = 1.f; ix.x = (b * L.H + hi) * L.W + wi; }
+        sCw[e] = w; sCi[e] = ix;
+        continue;
+      }
       const float* ob = L.off + ((size_t)b * 2 * taps + 2 * tap) * HoWo + hw;
       const float h_im = (float)(ho * P.sh - P.ph + ki * P.dh) + ob[0];
       const float w_im = (float)(wo * P.sw - P.pw + kj * P.dw) + ob[HoWo];
@@ -223,6 +240,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     const float* base = xin + cb * CBS + c4;
     if (ORP_DCNS_DBG & 1) { v[0] = v[1] = v[2] = v[3] = make_float4((float)ix.x, (float)ix.y, (float)ix.z, (float)ix.w); return; }
     v[0] = *reinterpret_cast<const float4*>(base + (size_t)ix.x * P.Cin);
+    if (PLAIN) return;
     v[1] = *reinterpret_cast<const float4*>(base + (size_t)ix.y * P.Cin);
     v[2] = *reinterpret_cast<const float4*>(base + (size_t)ix.z * P.Cin);
     v[3] = *reinterpret_cast<const float4*>(base + (size_t)ix.w * P.Cin);
@@ -238,10 +256,15 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(cw.x, a), __fmul_rn(cw.y, b)), __fmul_rn(cw.z, c)), __fmul_rn(cw.w, d));
     };
     float s[4];
-    s[0] = bil(v[0].x, v[1].x, v[2].x, v[3].x);
-    s[1] = bil(v[0].y, v[1].y, v[2].y, v[3].y);
-    s[2] = bil(v[0].z, v[1].z, v[2].z, v[3].z);
-    s[3] = bil(v[0].w, v[1].w, v[2].w, v[3].w);
+    if (PLAIN) {
+      const bool in = cw.x != 0.f;
+      s[0] = in ? v[0].x : 0.f; s[1] = in ? v[0].y : 0.f; s[2] = in ? v[0].z : 0.f; s[3] = in ? v[0].w : 0.f;
+    } else {
+      s[0] = bil(v[0].x, v[1].x, v[2].x, v[3].x);
+      s[1] = bil(v[0].y, v[1].y, v[2].y, v[3].y);
+      s[2] = bil(v[0].z, v[1].z, v[2].z, v[3].z);
+      s[3] = bil(v[0].w, v[1].w, v[2].w, v[3].w);
+    }
     float hi[4], mid[4], lo[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -280,9 +303,12 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   }
   __syncthreads();
 
-  floatx16 acc[MT];
+  constexpr bool SIDE = PLAIN && ORP_DCNS_SIDE_ACC;
+  floatx16 acc[MT], side[SIDE ? MT : 1];
 #pragma unroll
   for (int mt = 0; mt < MT; mt++) acc[mt] = floatx16{0};
+#pragma unroll
+  for (int mt = 0; mt < (SIDE ? MT : 1); mt++) side[mt] = floatx16{0};
 
   // (tap, cb) of the NEXT phase, advanced incrementally; past the end it stays on the last phase: the loads of the loop
   // body are UNCONDITIONAL (the final iteration re-fetches the last phase's rows and weights and drops them), so that the
@@ -340,7 +366,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       //     (a 32-cycle MFMA leaves ~5 issue slots) instead of a VALU-only tail during which the matrix pipe idles
       const bool with_combine = ORP_DCNS_COMBINE_IN_LAST && j >= NCH - MT;       // row group j - (NCH - MT) rides in chunk j
       if (with_combine) combine_store(tap_n, j - (NCH - MT), g[j - (NCH - MT)], cur ^ 1);
-      Products<9 - NPROD, 9, MT, OUT_NCHW>::run(acc, a[j & 1], bq[j]);
+      Products<9 - NPROD, 9, MT, OUT_NCHW, SIDE>::run(acc, side, a[j & 1], bq[j]);
 #if ORP_DCNS_DRAIN & 2
       __builtin_amdgcn_sched_barrier(0);
       { float t_; 
@@ -377,6 +403,10 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------------------
   if (!live) return;
+  if (SIDE) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] += side[mt];
+  }
   const float* bias = conv ? P.bias[1] : P.bias[0];
   float* outp = conv ? L.out[1] : L.out[0];
   auto finish = [&](float v, int ch) { if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
@@ -407,7 +437,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
 template <int MT>
 constexpr size_t split_smem() { return (size_t)2 * 3 * 32 * MT * ASTRS * 2 + (sizeof(float4) + sizeof(int4)) * 32 * MT * kTapsMax; }
 
-template <int MT, int NPROD, bool OUT_NCHW>
+template <int MT, int NPROD, bool OUT_NCHW, bool PLAIN>
 hipError_t launch_one(const FwdS& P, int tiles, int nblk_n, hipStream_t st) {
   // (dev aid) ORP_DCNS_PAD_LDS=<KB>: a floor under the LDS request, e.g. 84 = exactly one workgroup per CU.  The MT = 1
   // instantiation (37 KB, 119 VGPRs) runs two workgroups = four waves per SIMD side by side; before the accumulator drain of
@@ -416,22 +446,22 @@ hipError_t launch_one(const FwdS& P, int tiles, int nblk_n, hipStream_t st) {
   static const int pad_env = getenv("ORP_DCNS_PAD_LDS") ? atoi(getenv("ORP_DCNS_PAD_LDS")) : 0;
   const size_t smem = split_smem<MT>() < (size_t)pad_env * 1024 ? (size_t)pad_env * 1024 : split_smem<MT>();
   struct Tag {};
-  hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_split_kernel<MT, NPROD, OUT_NCHW>), smem);
+  hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_split_kernel<MT, NPROD, OUT_NCHW, PLAIN>), smem);
   if (e != hipSuccess) return e;
   const int nx = P.nconv == 2 ? 4 : 8;
   const int per = (tiles + nx - 1) / nx;
-  hipLaunchKernelGGL((dcn_fwd_split_kernel<MT, NPROD, OUT_NCHW>), dim3(per * 8, nblk_n), dim3(kThreadsS), smem, st, P, tiles);
+  hipLaunchKernelGGL((dcn_fwd_split_kernel<MT, NPROD, OUT_NCHW, PLAIN>), dim3(per * 8, nblk_n), dim3(kThreadsS), smem, st, P, tiles);
   return hipGetLastError();
 }
 
-template <int MT, int NPROD>
+template <int MT, int NPROD, bool PLAIN>
 hipError_t launch_l(const FwdS& P, int tiles, int nblk_n, bool nchw, hipStream_t st) {
-  return nchw ? launch_one<MT, NPROD, true>(P, tiles, nblk_n, st) : launch_one<MT, NPROD, false>(P, tiles, nblk_n, st);
+  return nchw ? launch_one<MT, NPROD, true, PLAIN>(P, tiles, nblk_n, st) : launch_one<MT, NPROD, false, PLAIN>(P, tiles, nblk_n, st);
 }
-template <int NPROD>
+template <int NPROD, bool PLAIN>
 hipError_t launch_m(int MT, const FwdS& P, int tiles, int nblk_n, bool nchw, hipStream_t st) {
-  return MT == 1 ? launch_l<1, NPROD>(P, tiles, nblk_n, nchw, st)
-       : MT == 2 ? launch_l<2, NPROD>(P, tiles, nblk_n, nchw, st) : launch_l<3, NPROD>(P, tiles, nblk_n, nchw, st);
+  return MT == 1 ? launch_l<1, NPROD, PLAIN>(P, tiles, nblk_n, nchw, st)
+       : MT == 2 ? launch_l<2, NPROD, PLAIN>(P, tiles, nblk_n, nchw, st) : launch_l<3, NPROD, PLAIN>(P, tiles, nblk_n, nchw, st);
 }
 
 inline int out_dim(int in, int pad, int dil, int k, int stride) { return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1; }
@@ -460,13 +490,16 @@ hipError_t launch(const Args& a, hipStream_t st) {
   P.plane_stride = (size_t)a.Cout * a.Cin * a.kh * a.kw;
   long npos_all = 0;
   for (int i = 0; i < a.nlev; i++) npos_all += (long)a.B * a.lv[i].Ho * a.lv[i].Wo;
-  // tile height: rounds x height on 256 CUs (one layer) / 128 CUs per layer (pair: the grid halves run side by side)
+  // tile height: rounds x height on 256 CUs (one layer) / 128 CUs per layer (pair: the grid halves run side by side), times
+  // what a 32-position unit costs at that height -- a shorter tile streams the layer's weight planes more often per position
+  // (measured per unit and round, pair launches at 1024^2 x 2 and 1536^2: MT = 1 1.30, MT = 2 1.09 of MT = 3;
+  // tests/checks/time_towers.py, time_dcn_pair.py with ORP_DCNS_MT)
   const int cus = a.nconv == 2 ? 128 : 256;
   int MT = 1;
   long best = -1;
   for (int mt = 1; mt <= 3; mt++) {
     const long t = (npos_all + 32 * mt - 1) / (32 * mt) + a.nlev;
-    const long cost = ((t + cus - 1) / cus) * mt * 100 + (mt == 1 ? 40 : mt == 2 ? 10 : 0);
+    const long cost = ((t + cus - 1) / cus) * mt * (mt == 1 ? 130 : mt == 2 ? 110 : 100);
     if (best < 0 || cost < best) { best = cost; MT = mt; }
   }
   static const int force_mt = getenv("ORP_DCNS_MT") ? atoi(getenv("ORP_DCNS_MT")) : 0;
@@ -482,8 +515,14 @@ hipError_t launch(const Args& a, hipStream_t st) {
   }
   for (int i = a.nlev; i < kMaxLevels; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; }
   const int nblk_n = (a.Cout + 255) / 256;
-  return a.nprod == 9 ? launch_m<9>(MT, P, tiles, nblk_n, a.out_nchw != 0, st)
-                      : launch_m<6>(MT, P, tiles, nblk_n, a.out_nchw != 0, st);
+  bool plain = a.lv[0].off == nullptr;                   // no offsets anywhere: the ordinary convolution
+  for (int i = 0; i < a.nlev; i++)
+    if ((a.lv[i].off == nullptr) != plain || (plain && a.lv[i].mask)) return hipErrorInvalidValue;
+  if (plain)
+    return a.nprod == 9 ? launch_m<9, true>(MT, P, tiles, nblk_n, a.out_nchw != 0, st)
+                        : launch_m<6, true>(MT, P, tiles, nblk_n, a.out_nchw != 0, st);
+  return a.nprod == 9 ? launch_m<9, false>(MT, P, tiles, nblk_n, a.out_nchw != 0, st)
+                      : launch_m<6, false>(MT, P, tiles, nblk_n, a.out_nchw != 0, st);
 }
 
 }  // namespace orp_split

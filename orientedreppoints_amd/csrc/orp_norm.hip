@@ -419,6 +419,165 @@ __global__ void gn_bwd_param_kernel(const GnParams P, const float* gamma, float*
   dbeta[c] = s1; dgamma[c] = s2;
 }
 
+// ---- GroupNorm (+ ReLU) of channels-last tensors [B][HW][C] (orp_groupnorm_act_multi_cl) ---------------------------------------
+// What sits between two orp_conv_split_multi launches (orp_conv_split.hip): the convolution reads and writes channels-last, so
+// the normalisation does too.  A chunk = 4096 / C whole positions (rows of C floats): with 1024 % C == 0 every thread's
+// float4s all fall on the SAME four channels, i.e. one group -- the per-channel constants are per-thread constants, and the
+// chunk's per-group statistics are a sum over a fixed set of threads.
+//   pass 1 (gn_cl_stats): (mean, M2 around that mean) of every group over the chunk's positions, the chunk held in registers;
+//   pass 2 (gn_cl_merge): one wave per (tensor, image, group): Chan's merge of the chunk partials -> (mean, rstd);
+//   pass 3 (gn_cl_apply): y = relu?(x * a[c] + b[c]), a = rstd * gamma, b = beta - mean * a -- one float4 pass, in place allowed.
+struct GnClLevel {
+  const float* x; float* y;
+  const float* gamma; const float* beta;
+  int hw;                 // H*W
+  int cpi;                // chunks per image
+  int chunk0;             // first chunk of this tensor
+};
+struct GnClParams {
+  GnClLevel lv[kGnMaxLevels];
+  int nlev, B, C, G;
+  float eps; int relu;
+  float2* partial;        // [total_chunks][G] (mean, M2)
+  float2* stats;          // [nlev][B][G] (mean, rstd)
+};
+
+struct ClGeom { int lvl, b, p0, np; };
+__device__ __forceinline__ ClGeom cl_locate(const GnClParams& P, int chunk) {
+  ClGeom g;
+  g.lvl = 0;
+#pragma unroll 1
+  for (int i = 1; i < P.nlev; i++) if (chunk >= P.lv[i].chunk0) g.lvl = i;
+  const GnClLevel& L = P.lv[g.lvl];
+  const int id = chunk - L.chunk0, ppc = kChunk / P.C;
+  g.b = id / L.cpi;
+  g.p0 = (id - g.b * L.cpi) * ppc;
+  g.np = min(ppc, L.hw - g.p0);
+  return g;
+}
+
+// sum over the threads that hold this thread's group, in a fixed order: thread t holds channels 4 * (t % tpc) .. + 3 of rows
+// t / tpc, t / tpc + 256 / tpc, ...; its group's members are rep * tpc + grp * tg + j  (rep < 256 / tpc, j < tg)
+__device__ __forceinline__ float group_total(float v, float* sh, int tpc, int tg, int grp) {
+  __syncthreads();
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int rep = 0; rep < kThreads / tpc; rep++)
+    for (int j = 0; j < tg; j++) s += sh[rep * tpc + grp * tg + j];
+  return s;
+}
+
+__global__ void __launch_bounds__(kThreads)
+gn_cl_stats_kernel(const GnClParams P) {
+  __shared__ float sh[kThreads];
+  const ClGeom g = cl_locate(P, blockIdx.x);
+  const GnClLevel& L = P.lv[g.lvl];
+  const int n = g.np * P.C;
+  const float* src = L.x + ((size_t)g.b * L.hw + g.p0) * P.C;
+  const int tpc = P.C >> 2, cg = P.C / P.G, tg = cg >> 2;
+  const int grp = (threadIdx.x % tpc) / tg;
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int e = (threadIdx.x + q * kThreads) * 4;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < n) t = *reinterpret_cast<const float4*>(src + e);
+    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; q++) s += v[q];
+  const float mean = group_total(s, sh, tpc, tg, grp) / (float)(g.np * cg);
+  float m2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int e = (threadIdx.x + q * kThreads) * 4;
+    if (e < n) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const float d = v[4 * q + u] - mean; m2 += d * d; }
+    }
+  }
+  m2 = group_total(m2, sh, tpc, tg, grp);
+  // partials of one (tensor, image, group) are contiguous over the image's chunks: [tensor][image][group][chunk]
+  if (threadIdx.x < tpc && threadIdx.x % tg == 0)
+    P.partial[(size_t)L.chunk0 * P.G + ((size_t)g.b * P.G + grp) * L.cpi + g.p0 / (kChunk / P.C)] = make_float2(mean, m2);
+}
+
+// one workgroup per (tensor, image, group)
+__global__ void __launch_bounds__(kThreads)
+gn_cl_merge_kernel(const GnClParams P) {
+  __shared__ float red[4];
+  const int grp = blockIdx.x, b = blockIdx.y, lvl = blockIdx.z;
+  const GnClLevel& L = P.lv[lvl];
+  const int ppc = kChunk / P.C, cg = P.C / P.G;
+  const float2* part = P.partial + (size_t)L.chunk0 * P.G + ((size_t)b * P.G + grp) * L.cpi;
+  const float total = (float)L.hw * (float)cg;
+  float sm = 0.f;
+  for (int k = threadIdx.x; k < L.cpi; k += kThreads) {
+    const int nk = min(ppc, L.hw - k * ppc) * cg;
+    sm += (float)nk * part[k].x;
+  }
+  const float mean = block_sum(sm, red) / total;
+  float m2 = 0.f;
+  for (int k = threadIdx.x; k < L.cpi; k += kThreads) {
+    const int nk = min(ppc, L.hw - k * ppc) * cg;
+    const float2 pk = part[k];
+    const float d = pk.x - mean;
+    m2 += pk.y + (float)nk * d * d;
+  }
+  const float var = block_sum(m2, red) / total;
+  if (threadIdx.x == 0) P.stats[((size_t)lvl * P.B + b) * P.G + grp] = make_float2(mean, rsqrtf(var + P.eps));
+}
+
+__global__ void __launch_bounds__(kThreads)
+gn_cl_apply_kernel(const GnClParams P) {
+  const ClGeom g = cl_locate(P, blockIdx.x);
+  const GnClLevel& L = P.lv[g.lvl];
+  const int n = g.np * P.C;
+  const size_t base = ((size_t)g.b * L.hw + g.p0) * P.C;
+  const int tpc = P.C >> 2, cg = P.C / P.G;
+  const int c0 = (threadIdx.x % tpc) * 4;
+  const float2 st = P.stats[((size_t)g.lvl * P.B + g.b) * P.G + c0 / cg];
+  const float4 ga = *reinterpret_cast<const float4*>(L.gamma + c0), be = *reinterpret_cast<const float4*>(L.beta + c0);
+  const float a0 = st.y * ga.x, a1 = st.y * ga.y, a2 = st.y * ga.z, a3 = st.y * ga.w;
+  const float b0 = be.x - st.x * a0, b1 = be.y - st.x * a1, b2 = be.z - st.x * a2, b3 = be.w - st.x * a3;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int e = (threadIdx.x + q * kThreads) * 4;
+    if (e < n) {
+      float4 t = *reinterpret_cast<const float4*>(L.x + base + e);
+      t.x = t.x * a0 + b0; t.y = t.y * a1 + b1; t.z = t.z * a2 + b2; t.w = t.w * a3 + b3;
+      if (P.relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+      *reinterpret_cast<float4*>(L.y + base + e) = t;
+    }
+  }
+}
+
+// fills P's levels; returns the number of chunks, -1 on bad arguments, -2 when a tensor is too large
+int fill_cl(const orp_norm_level* levels, int nlevels, int batch, int channels, int groups, GnClParams& P) {
+  if (!levels || nlevels <= 0 || nlevels > kGnMaxLevels || batch <= 0 || batch > 65535 || channels <= 0 || groups <= 0 ||
+      channels % groups != 0 || 1024 % channels != 0 || (channels / groups) % 4 != 0)
+    return -1;
+  P.nlev = nlevels; P.B = batch; P.C = channels; P.G = groups;
+  const int ppc = kChunk / channels;
+  long chunks = 0;
+  for (int i = 0; i < nlevels; i++) {
+    const orp_norm_level& lv = levels[i];
+    if (!lv.input || !lv.output || lv.height <= 0 || lv.width <= 0) return -1;
+    const long hw = (long)lv.height * lv.width;
+    if (hw >= (1L << 31) / channels) return -2;
+    GnClLevel& L = P.lv[i];
+    L.x = lv.input; L.y = lv.output; L.gamma = nullptr; L.beta = nullptr;
+    L.hw = (int)hw; L.cpi = (int)((hw + ppc - 1) / ppc); L.chunk0 = (int)chunks;
+    chunks += (long)batch * L.cpi;
+    if (chunks >= (1L << 30)) return -2;
+  }
+  for (int i = nlevels; i < kGnMaxLevels; i++) { P.lv[i] = P.lv[0]; P.lv[i].chunk0 = 0x7fffffff; }
+  return (int)chunks;
+}
+
+
 int fill(const orp_norm_level* levels, int nlevels, int batch, int channels, int groups, GnParams& P) {
   if (!levels || nlevels <= 0 || nlevels > kGnMaxLevels || batch <= 0 || channels <= 0 || groups <= 0 ||
       channels % groups)
@@ -504,6 +663,39 @@ int orp_groupnorm_act_multi_nhwc(const orp_norm_level* levels, const float* cons
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
   hipLaunchKernelGGL(gn_apply_nhwc_kernel, dim3(bx, channels / 32, batch), dim3(kThreads), 0, st, P, T);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+static size_t gn_cl_stat_offset(size_t chunks, int groups) { return (sizeof(float2) * chunks * groups + 255) & ~(size_t)255; }
+
+size_t orp_groupnorm_cl_workspace_bytes(const orp_norm_level* levels, int nlevels, int batch, int channels, int groups) {
+  GnClParams P;
+  const int chunks = fill_cl(levels, nlevels, batch, channels, groups, P);
+  if (chunks <= 0) return 0;
+  return gn_cl_stat_offset(chunks, groups) + sizeof(float2) * (size_t)nlevels * batch * groups;
+}
+
+int orp_groupnorm_act_multi_cl(const orp_norm_level* levels, const float* const* gammas_host, const float* const* betas_host,
+                               int nlevels, int batch, int channels, int groups, float eps, int relu, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  GnClParams P;
+  const int chunks = fill_cl(levels, nlevels, batch, channels, groups, P);
+  if (chunks == -2) return ORP_ETOOBIG;
+  if (chunks <= 0 || !gammas_host || !betas_host) return ORP_EINVAL;
+  const size_t need = gn_cl_stat_offset(chunks, groups) + sizeof(float2) * (size_t)nlevels * batch * groups;
+  if (!workspace || workspace_bytes < need) return ORP_EWORKSPACE;
+  for (int i = 0; i < nlevels; i++) {
+    if (!gammas_host[i] || !betas_host[i]) return ORP_EINVAL;
+    P.lv[i].gamma = gammas_host[i]; P.lv[i].beta = betas_host[i];
+  }
+  P.eps = eps; P.relu = relu;
+  P.partial = reinterpret_cast<float2*>(workspace);
+  P.stats = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + gn_cl_stat_offset(chunks, groups));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_cl_stats_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
+  hipLaunchKernelGGL(gn_cl_merge_kernel, dim3(groups, batch, nlevels), dim3(kThreads), 0, st, P);
+  hipLaunchKernelGGL(gn_cl_apply_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }

@@ -160,6 +160,51 @@ class OrientedRepPointsHead(nn.Module):
             cur = group_norm_act_multi(conv3x3_multi(cur, m.conv), m.norm, relu=True, inplace=True, nhwc=last)
         return cur
 
+    def _split_towers_ok(self, feats):
+        """The channels-last tower path applies: library split mode on (ORP_DCN_SPLIT != 0), `split_towers` not switched off
+        (attribute, or ORP_TOWER_SPLIT=0 for A/B timing), equal-depth towers of stride-1 convolutions of a shape
+        `orp_conv_split_multi` takes, GroupNorm shapes the channels-last kernels take."""
+        import os
+        from .. import _lib
+        from ..mmdet_ops.fused_norm import conv_split_ok
+        on = getattr(self, 'split_towers', None)
+        if on is None:
+            on = os.environ.get('ORP_TOWER_SPLIT', '1') == '1'
+        if not on or _lib.lib().orp_dcn_get_split_mode() == 0 or len(self.cls_convs) != len(self.reg_convs) or len(feats) > 8:
+            return False
+        x = feats[0]
+        mods = list(self.cls_convs) + list(self.reg_convs)
+        if not mods:
+            return False
+        c0, n0 = mods[0].conv, mods[0].norm
+        for m in mods:
+            c = m.conv
+            if not (conv_split_ok(c, x) and tuple(c.stride) == (1, 1) and tuple(c.weight.shape) == tuple(c0.weight.shape) and
+                    c.padding == c0.padding and c.dilation == c0.dilation and c.weight.size(0) == c.weight.size(1) and
+                    2 * c.padding[0] == c.dilation[0] * (c.weight.size(2) - 1) and
+                    2 * c.padding[1] == c.dilation[1] * (c.weight.size(3) - 1) and
+                    m.norm.num_groups == n0.num_groups and m.norm.eps == n0.eps):
+                return False
+        C, G = x.size(1), n0.num_groups
+        if 1024 % C != 0 or C % G != 0 or (C // G) % 4 != 0:
+            return False
+        p = self.reppoints_pts_init_conv
+        return conv_split_ok(p, x) and tuple(p.stride) == (1, 1)
+
+    def _towers_split(self, feats):
+        """Both towers and the init branch's 3x3 convolution, channels-last (see forward).  Returns (classification tower
+        output, regression tower output) as channels-last tensors -- what the DeformConv pair launch gathers from -- and
+        relu(reppoints_pts_init_conv(.)) NCHW for the 1x1 output convolution."""
+        from ..mmdet_ops.fused_norm import conv_split_multi, group_norm_act_multi_cl, to_channels_last_multi
+        n = len(feats)
+        cls_cur = reg_cur = to_channels_last_multi(list(feats))
+        for a, b in zip(self.cls_convs, self.reg_convs):
+            oa, ob = conv_split_multi(cls_cur, a.conv, reg_cur, b.conv)
+            both = group_norm_act_multi_cl(oa + ob, [a.norm] * n + [b.norm] * n, relu=True)
+            cls_cur, reg_cur = both[:n], both[n:]
+        hid = conv_split_multi(reg_cur, self.reppoints_pts_init_conv, bias=True, relu=True, out_channels_last=False)
+        return cls_cur, reg_cur, hid
+
     def _dcn_pair(self, cls_feats, pts_feats, offsets, out_channels_last=None):
         a, b = self.reppoints_cls_conv, self.reppoints_pts_refine_conv
         from ..mmdet_ops.deform_conv import deform_conv_forward_pair, fast_path_ok
@@ -240,16 +285,6 @@ class OrientedRepPointsHead(nn.Module):
         fused = self._fused_towers_ok(feats)
         if fused:
             import os
-            side = None
-            two = getattr(self, 'tower_streams', None)                # None: default on (ORP_TOWER_STREAMS=0: off, for A/B timing)
-            if two if two is not None else os.environ.get('ORP_TOWER_STREAMS', '1') == '1':
-                # the two towers are independent chains: the classification tower runs on a second stream (a fork / join in
-                # a captured graph), so that its small-level kernels fill the CUs the other tower's leave idle
-                cur = torch.cuda.current_stream(feats[0].device)
-                if getattr(self, '_side_stream', None) is None:
-                    self._side_stream = torch.cuda.Stream(device=feats[0].device)
-                side = self._side_stream
-                side.wait_stream(cur)
             # channels-last hand-over to the DeformConv pair launch (round 4): the last GroupNorm of each tower writes its
             # result transposed -- the classification tower ONLY so (nothing else reads it), the regression tower both ways
             # (the init branch's 3x3 convolution reads NCHW) -- which removes the pair launch's transposition kernel
@@ -262,20 +297,38 @@ class OrientedRepPointsHead(nn.Module):
                 tuple(a_.weight.shape) == tuple(b_.weight.shape) and a_.stride == b_.stride and a_.padding == b_.padding and \
                 a_.dilation == b_.dilation and a_.groups == 1 and b_.groups == 1 and a_.deformable_groups == 1 and \
                 b_.deformable_groups == 1 and min(min(f.size(2), f.size(3)) for f in feats) > 1
-            if side is not None:
-                with torch.cuda.stream(side):
-                    cls_feats = self._tower_multi(self.cls_convs, feats, 'only' if hand else None)
-            else:
-                cls_feats = self._tower_multi(self.cls_convs, feats, 'only' if hand else None)
-            pts_feats = self._tower_multi(self.reg_convs, feats, 'both' if hand else None)
-            pts_dcn_in = pts_feats
-            if hand:
-                pts_feats, pts_dcn_in = pts_feats
-            # bias-carrying convolutions: the convolution runs without its bias, ONE launch per layer then adds it for
-            # all levels together with what follows (ReLU / `- dcn_base_offset` / `+ pts_out_init`), same op order
             from ..mmdet_ops.fused_norm import bias_act_multi, conv3x3_multi
-            hid = bias_act_multi(conv3x3_multi(pts_feats, self.reppoints_pts_init_conv),
-                                 self.reppoints_pts_init_conv.bias, relu=True)
+            split = hand and self._split_towers_ok(feats)
+            side = None
+            two = getattr(self, 'tower_streams', None)                # None: default on (ORP_TOWER_STREAMS=0: off, for A/B timing)
+            if not split and (two if two is not None else os.environ.get('ORP_TOWER_STREAMS', '1') == '1'):
+                # the two towers are independent chains: the classification tower runs on a second stream (a fork / join in
+                # a captured graph), so that its small-level kernels fill the CUs the other tower's leave idle
+                cur = torch.cuda.current_stream(feats[0].device)
+                if getattr(self, '_side_stream', None) is None:
+                    self._side_stream = torch.cuda.Stream(device=feats[0].device)
+                side = self._side_stream
+                side.wait_stream(cur)
+            if split:
+                # the towers on the bf16 matrix pipe (round 4, csrc/orp_conv_split.hip): channels-last all the way, the two
+                # towers' layer k = ONE launch over all levels, GroupNorm+ReLU of both towers' ten tensors in one launch
+                # triple, the init branch's 3x3 convolution with bias + ReLU in its epilogue -- 10 launches for what were
+                # 2 x 3 x (5 convolutions + 2) + 6; no second stream
+                cls_feats, pts_dcn_in, hid = self._towers_split(feats)
+            else:
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        cls_feats = self._tower_multi(self.cls_convs, feats, 'only' if hand else None)
+                else:
+                    cls_feats = self._tower_multi(self.cls_convs, feats, 'only' if hand else None)
+                pts_feats = self._tower_multi(self.reg_convs, feats, 'both' if hand else None)
+                pts_dcn_in = pts_feats
+                if hand:
+                    pts_feats, pts_dcn_in = pts_feats
+                # bias-carrying convolutions: the convolution runs without its bias, ONE launch per layer then adds it for
+                # all levels together with what follows (ReLU / `- dcn_base_offset` / `+ pts_out_init`), same op order
+                hid = bias_act_multi(conv3x3_multi(pts_feats, self.reppoints_pts_init_conv),
+                                     self.reppoints_pts_init_conv.bias, relu=True)
             from ..mmdet_ops.fused_norm import conv1x1_multi, conv1x1_ok
             one_by_one = all(conv1x1_ok(m, hid[0]) for m in (self.reppoints_pts_init_out, self.reppoints_cls_out,
                                                               self.reppoints_pts_refine_out))

@@ -360,3 +360,145 @@ def group_norm_act_train(xs, gn, relu=True):
     outs = _GroupNormActTrain.apply(len(xs), gns[0].num_groups, gns[0].eps, bool(relu), tuple(owner), *xs,
                                     *[d.weight for d in distinct], *[d.bias for d in distinct])
     return list(outs)
+
+
+# ---- channels-last tower path (round 4): conv_split_multi -> group_norm_act_multi_cl -> ... -----------------------------------
+
+class _ConvLevel(ctypes.Structure):
+    _fields_ = [("input_a", ctypes.c_void_p), ("input_b", ctypes.c_void_p), ("output_a", ctypes.c_void_p),
+                ("output_b", ctypes.c_void_p), ("height", ctypes.c_int), ("width", ctypes.c_int)]
+
+
+def _is_cl(x):
+    """memory is [B, H, W, C] (channels-last strides of the logical [B, C, H, W] tensor)"""
+    return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+
+
+def to_channels_last_multi(xs):
+    """[x in channels-last memory for x in xs] -- NCHW-contiguous fp32 CUDA tensors [B,C,H,W] with equal B and C, ONE launch
+    (`orp_nchw_to_nhwc_multi`); tensors that already are channels-last pass through."""
+    L = _lib.lib()
+    todo = [i for i, x in enumerate(xs) if not _is_cl(x)]
+    outs = list(xs)
+    if not todo:
+        return outs
+    x0 = xs[todo[0]]
+    B, C = x0.size(0), x0.size(1)
+    levels = (_NormLevel * len(todo))()
+    keep = []
+    for k, i in enumerate(todo):
+        x = xs[i].detach()
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.size(0) == B and x.size(1) == C):
+            raise ValueError("to_channels_last_multi expects fp32 CUDA [B,C,H,W] tensors with equal B and C")
+        x = x.contiguous()
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        keep.append(x); outs[i] = y
+        levels[k] = _NormLevel(x.data_ptr(), y.data_ptr(), x.size(2), x.size(3))
+    with torch.cuda.device(x0.device):
+        rc = L.orp_nchw_to_nhwc_multi(levels, len(todo), B, C, _lib.stream_of(x0))
+    _lib.check(rc, "orp_nchw_to_nhwc_multi")
+    return outs
+
+
+def conv_split_ok(conv, x=None):
+    """the module is a bias-free-or-not kh x kw nn.Conv2d (groups 1, fp32) of a shape `orp_conv_split_multi` takes"""
+    w = conv.weight
+    ok = (isinstance(conv, torch.nn.Conv2d) and conv.groups == 1 and w.dtype == torch.float32 and w.is_cuda and
+          isinstance(conv.padding, tuple) and
+          bool(_lib.lib().orp_conv_split_ok(w.size(1), w.size(0), w.size(2), w.size(3))))
+    if ok and x is not None:
+        ok = x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.size(1) == w.size(1)
+    return ok
+
+
+def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=False, out_channels_last=True, nprod=None):
+    """[conv_a(x) for x in xs_a] (and [conv_b(x) for x in xs_b]: two layers of equal shape in ONE launch -- the two towers'
+    layer k) over all FPN levels, `orp_conv_split_multi`: fp32 on the bf16 matrix pipe with every operand split exactly
+    into three bf16 pieces, fp32 accumulation.  xs_*: channels-last fp32 CUDA tensors (logical [B,C,H,W]); bias=True adds the
+    modules' biases in the epilogue, relu fuses the activation; outputs channels-last or NCHW.  Inference only.
+    nprod: 6 | 9 partial products (None: the library's DeformConv split mode, 6 when that is off)."""
+    from .deform_conv import _packed_weight
+    L = _lib.lib()
+    pair = xs_b is not None
+    w = conv_a.weight
+    cout, cin, kh, kw = w.shape
+    if pair and (tuple(conv_b.weight.shape) != tuple(w.shape) or conv_b.stride != conv_a.stride or conv_b.padding != conv_a.padding
+                 or conv_b.dilation != conv_a.dilation or len(xs_b) != len(xs_a)):
+        raise ValueError("conv_split_multi: the two layers must have equal shapes / strides / paddings / dilations")
+    if nprod is None:
+        nprod = L.orp_dcn_get_split_mode() or 6
+    x0 = xs_a[0]
+    B = x0.size(0)
+    n = len(xs_a)
+    levels = (_ConvLevel * n)()
+    keep, outs_a, outs_b = [], [], []
+    st, pd, dl = conv_a.stride, conv_a.padding, conv_a.dilation
+    fmt = torch.channels_last if out_channels_last else torch.contiguous_format
+    for i in range(n):
+        xa = xs_a[i].detach()
+        xb = xs_b[i].detach() if pair else None
+        for x in (xa, xb):
+            if x is None:
+                continue
+            if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.size(0) == B and x.size(1) == cin and _is_cl(x)):
+                raise ValueError("conv_split_multi expects channels-last fp32 CUDA [B,%d,H,W] tensors" % cin)
+            if xb is not None and x.shape != xa.shape:
+                raise ValueError("conv_split_multi: the two layers' inputs must have equal shapes")
+        H, W = xa.size(2), xa.size(3)
+        ho = (H + 2 * pd[0] - (dl[0] * (kh - 1) + 1)) // st[0] + 1
+        wo = (W + 2 * pd[1] - (dl[1] * (kw - 1) + 1)) // st[1] + 1
+        oa = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=xa.device, memory_format=fmt)
+        ob = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=xa.device, memory_format=fmt) if pair else None
+        keep += [xa, xb]; outs_a.append(oa); outs_b.append(ob)
+        levels[i] = _ConvLevel(xa.data_ptr(), xb.data_ptr() if pair else None, oa.data_ptr(), ob.data_ptr() if pair else None, H, W)
+    pa = _packed_weight(conv_a.weight)
+    pb = _packed_weight(conv_b.weight) if pair else None
+    ba = conv_a.bias.detach().float().contiguous() if (bias and conv_a.bias is not None) else None
+    bb = conv_b.bias.detach().float().contiguous() if (pair and bias and conv_b.bias is not None) else None
+    with torch.cuda.device(x0.device):
+        rc = L.orp_conv_split_multi(levels, n, B, cin, cout, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(ba), _lib.ptr(bb),
+                                    1 if relu else 0, kh, kw, st[0], st[1], pd[0], pd[1], dl[0], dl[1],
+                                    1 if out_channels_last else 0, int(nprod), _lib.stream_of(x0))
+    _lib.check(rc, "orp_conv_split_multi")
+    return (outs_a, outs_b) if pair else outs_a
+
+
+def group_norm_act_multi_cl(xs, gn, relu=True, inplace=True):
+    """[GroupNorm(+ReLU)(x) for x in xs] for CHANNELS-LAST fp32 CUDA tensors (logical [B,C,H,W], memory [B,H,W,C]; up to 16:
+    both towers' levels), results channels-last -- `orp_groupnorm_act_multi_cl`, three launches for all tensors.  gn: one
+    nn.GroupNorm or a list with one per tensor (equal num_groups / eps)."""
+    L = _lib.lib()
+    x0 = xs[0]
+    B, C = x0.size(0), x0.size(1)
+    gns = list(gn) if isinstance(gn, (list, tuple)) else [gn] * len(xs)
+    if len(gns) != len(xs) or any(g.num_groups != gns[0].num_groups or g.eps != gns[0].eps
+                                  for g in {id(g): g for g in gns}.values()):
+        raise ValueError("group_norm_act_multi_cl: one GroupNorm per tensor, equal num_groups / eps")
+    G = gns[0].num_groups
+    if 1024 % C != 0 or C % G != 0 or (C // G) % 4 != 0:
+        raise ValueError("group_norm_act_multi_cl: 1024 % channels == 0 and (channels / groups) % 4 == 0")
+    levels = (_NormLevel * len(xs))()
+    gam = (ctypes.c_void_p * len(xs))()
+    bet = (ctypes.c_void_p * len(xs))()
+    outs, keep, seen = [], [], {}
+    for i, x in enumerate(xs):
+        x = x.detach()
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.size(0) == B and x.size(1) == C and _is_cl(x)):
+            raise ValueError("group_norm_act_multi_cl expects channels-last fp32 CUDA [B,C,H,W] tensors with equal B and C")
+        y = x if inplace else torch.empty_like(x, memory_format=torch.channels_last)
+        keep.append(x); outs.append(y)
+        levels[i] = _NormLevel(x.data_ptr(), y.data_ptr(), x.size(2), x.size(3))
+        ptrs = seen.get(id(gns[i]))
+        if ptrs is None:
+            g_ = gns[i].weight.detach().float().contiguous()
+            b_ = gns[i].bias.detach().float().contiguous()
+            keep += [g_, b_]
+            ptrs = seen[id(gns[i])] = (g_.data_ptr(), b_.data_ptr())
+        gam[i], bet[i] = ptrs
+    nbytes = L.orp_groupnorm_cl_workspace_bytes(levels, len(xs), B, C, G)
+    ws = _lib.workspace(x0.device, nbytes)
+    with torch.cuda.device(x0.device):
+        rc = L.orp_groupnorm_act_multi_cl(levels, gam, bet, len(xs), B, C, G, float(gns[0].eps), 1 if relu else 0,
+                                          _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
+    _lib.check(rc, "orp_groupnorm_act_multi_cl")
+    return outs

@@ -1,0 +1,238 @@
+"""GPU: the head's tower convolutions on the bf16 matrix pipe (csrc/orp_conv_split.hip = the PLAIN instantiation of
+csrc/orp_dcn_split.hip: every fp32 operand split exactly into three bf16 pieces, 6 or 9 partial products, fp32 accumulation)
+and the channels-last GroupNorm(+ReLU) that sits between two of them (csrc/orp_norm.hip gn_cl_*).  Reference operator:
+ConvModule.forward (mmdet/ops/conv_module.py:130-140: conv -> GroupNorm -> ReLU) as the head builds it
+(mmdet/models/anchor_heads/orientedreppoints_head.py:91-113).  Checker: the oracle's DeformConv forward with ZERO offsets (the
+reference's float samples are then the pixels themselves, deform_conv_cuda_kernel.cu:84-115, contracted in DOUBLE) and
+torch's float64 convolution / GroupNorm on the CPU.  Tolerance 1e-5 of the output scale (north_star: 1e-4)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from orientedreppoints_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _conv(cin, cout, k, dev, stride=1, pad=None, dil=1, bias=False, seed=0, std=0.05):
+    g = torch.Generator().manual_seed(seed)
+    m = nn.Conv2d(cin, cout, k, stride=stride, padding=(dil * (k - 1) // 2 if pad is None else pad), dilation=dil, bias=bias)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(m.weight.shape, generator=g) * std)
+        if bias:
+            m.bias.copy_(torch.randn(cout, generator=g))
+    return m.to(dev).eval()
+
+
+def _rel(got, want):
+    want = want.double()
+    return float((got.double().cpu() - want.cpu()).abs().max() / max(1e-6, float(want.abs().max())))
+
+
+@pytest.mark.parametrize("B,C,H,W,Cout", [(2, 256, 16, 16, 256), (1, 64, 9, 11, 64), (1, 128, 5, 40, 192), (3, 256, 7, 9, 256)])
+def test_conv_split_vs_oracle_and_float64(dev, oracle, B, C, H, W, Cout):
+    import conftest
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv_split_multi
+    torch.manual_seed(C + H)
+    conv = _conv(C, Cout, 3, dev, seed=C + W)
+    x = torch.randn(B, C, H, W)
+    want64 = F.conv2d(x.double(), conv.weight.detach().cpu().double(), padding=1)
+    want_orc = oracle.dcn_forward(x.numpy(), np.zeros((B, 18, H, W), np.float32), conv.weight.detach().cpu().numpy(),
+                                  stride=1, pad=1, dil=1)
+    assert float(np.abs(want_orc - want64.numpy()).max()) <= 1e-6 * float(want64.abs().max())    # the two checkers agree
+    errs = {}
+    with torch.no_grad():
+        lib = F.conv2d(x.to(dev), conv.weight, padding=1)
+        errs['library'] = _rel(lib, want64)
+        for nprod in (9, 6):
+            got = conv_split_multi([_cl(x.to(dev))], conv, nprod=nprod)[0]
+            assert got.shape == want64.shape and got.is_contiguous(memory_format=torch.channels_last)
+            errs[nprod] = _rel(got, want64)
+            assert errs[nprod] <= 1e-5, nprod
+            nchw = conv_split_multi([_cl(x.to(dev))], conv, nprod=nprod, out_channels_last=False)[0]
+            assert nchw.is_contiguous() and torch.equal(nchw, got.contiguous()), "NCHW / NHWC outputs: same bits"
+            assert torch.equal(conv_split_multi([_cl(x.to(dev))], conv, nprod=nprod)[0], got)
+    conftest.REPORT.append("3x3 convolution %dx%dx%dx%d -> %d, max |err| / max |out| vs float64: library fp32 %.2e, split 9 products "
+                           "%.2e, split 6 products %.2e" % (B, C, H, W, Cout, errs['library'], errs[9], errs[6]))
+    # what remains is the fp32 accumulator's rounding (one per 16-channel MFMA and product, in a chain over K = 9 Cin): the
+    # same figure the DeformConv forward has on both of its paths (test_gpu_dcn_split.py); six products lose nothing to nine
+    assert errs[6] <= errs[9] + 5e-8
+
+
+def test_conv_split_pair_levels_bias_relu_strides(dev):
+    """Two layers in one launch == two single launches bit for bit; several levels per launch; bias + ReLU epilogue; stride 2,
+    dilation 2, 1 x 1 and 1 x 3 kernels, asymmetric padding -- against float64."""
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv_split_multi
+    torch.manual_seed(11)
+    shapes = [(24, 20), (12, 10), (6, 5), (3, 3), (1, 2)]
+    for B in (1, 2):
+        xa = [torch.randn(B, 256, h, w, device=dev) for h, w in shapes]
+        xb = [torch.randn(B, 256, h, w, device=dev) for h, w in shapes]
+        ca, cb = _conv(256, 256, 3, dev, bias=True, seed=1), _conv(256, 256, 3, dev, bias=True, seed=2)
+        with torch.no_grad():
+            pa, pb = conv_split_multi([_cl(t) for t in xa], ca, [_cl(t) for t in xb], cb, bias=True, relu=True)
+            sa = conv_split_multi([_cl(t) for t in xa], ca, bias=True, relu=True)
+            sb = conv_split_multi([_cl(t) for t in xb], cb, bias=True, relu=True)
+            for u, v in zip(pa + pb, sa + sb):
+                assert torch.equal(u, v)
+            for u, x, c in zip(pa + pb, xa + xb, [ca] * len(xa) + [cb] * len(xb)):
+                want = F.relu(F.conv2d(x.double().cpu(), c.weight.double().cpu(), c.bias.double().cpu(), padding=1))
+                assert _rel(u, want) <= 1e-5
+            # same input for both layers (the towers' first layer reads the FPN output twice)
+            qa, qb = conv_split_multi([_cl(t) for t in xa], ca, [_cl(t) for t in xa], cb)
+            for u, x in zip(qb, xa):
+                assert _rel(u, F.conv2d(x.double().cpu(), cb.weight.double().cpu(), padding=1)) <= 1e-5
+    x = torch.randn(2, 128, 13, 17, device=dev)
+    for k, stride, pad, dil in ((3, 2, 1, 1), (3, 1, 2, 2), (1, 1, 0, 1), (3, 2, 0, 1), ((1, 3), 1, (0, 1), 1), (3, (2, 1), (1, 0), 1)):
+        m = nn.Conv2d(128, 64, k, stride=stride, padding=pad, dilation=dil, bias=True).to(dev).eval()
+        with torch.no_grad():
+            for fmt in (True, False):
+                got = conv_split_multi([_cl(x)], m, bias=True, out_channels_last=fmt)[0]
+                want = F.conv2d(x.double().cpu(), m.weight.double().cpu(), m.bias.double().cpu(), stride=stride, padding=pad, dilation=dil)
+                assert got.shape == want.shape
+                assert _rel(got, want) <= 1e-5, (k, stride, pad, dil)
+
+
+def test_conv_split_is_exact_on_integers_and_rejects_bad_arguments(dev):
+    from orientedreppoints_amd import _lib
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv_split_multi, conv_split_ok
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(-8, 9, (1, 64, 12, 12), generator=g).float().to(dev)
+    m = nn.Conv2d(64, 64, 3, padding=1, bias=False).to(dev)
+    with torch.no_grad():
+        m.weight.copy_(torch.randint(-4, 5, (64, 64, 3, 3), generator=g).float())
+        want = F.conv2d(x.double(), m.weight.double(), padding=1)
+        for nprod in (9, 6):
+            assert torch.equal(conv_split_multi([_cl(x)], m, nprod=nprod)[0].double(), want)
+        assert conv_split_ok(m, x)
+        assert not conv_split_ok(nn.Conv2d(48, 64, 3, padding=1).to(dev))
+        assert not conv_split_ok(nn.Conv2d(64, 64, 5, padding=2).to(dev))
+        with pytest.raises(ValueError):
+            conv_split_multi([x], m)                                   # NCHW memory
+        with pytest.raises(_lib.OrpHipError):
+            conv_split_multi([_cl(x)], m, nprod=7)
+
+
+@pytest.mark.parametrize("C,G", [(256, 32), (64, 8), (128, 32), (1024, 32)])
+def test_groupnorm_channels_last_vs_float64(dev, C, G):
+    from orientedreppoints_amd.mmdet_ops.fused_norm import group_norm_act_multi, group_norm_act_multi_cl
+    torch.manual_seed(C)
+    shapes = [(20, 24), (7, 9), (3, 3), (1, 2), (33, 31)]
+    for B in (1, 3):
+        gns = []
+        for i in range(len(shapes)):
+            gn = nn.GroupNorm(G, C).to(dev)
+            with torch.no_grad():
+                gn.weight.copy_(torch.randn(C) * 0.5 + 1.0); gn.bias.copy_(torch.randn(C) * 0.3)
+            gns.append(gn)
+        xs = [torch.randn(B, C, h, w, device=dev) * (1.0 + i) + 3.0 * i for i, (h, w) in enumerate(shapes)]
+        with torch.no_grad():
+            for relu in (True, False):
+                got = group_norm_act_multi_cl([_cl(x) for x in xs], gns, relu=relu, inplace=False)
+                for x, gn, y in zip(xs, gns, got):
+                    assert y.is_contiguous(memory_format=torch.channels_last)
+                    want = F.group_norm(x.double().cpu(), G, gn.weight.double().cpu(), gn.bias.double().cpu(), gn.eps)
+                    want = F.relu(want) if relu else want
+                    assert float((y.double().cpu() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+            # one module for all tensors, in place; close to the NCHW kernel pair (different summation grouping)
+            ins = [_cl(x) for x in xs]
+            outs = group_norm_act_multi_cl(ins, gns[0], relu=True)
+            ref = group_norm_act_multi([x.clone() for x in xs], gns[0], relu=True, inplace=False)
+            for a, b, c in zip(outs, ins, ref):
+                assert a.data_ptr() == b.data_ptr()
+                assert float((a - c).abs().max()) <= 1e-5 * max(1.0, float(c.abs().max()))
+            again = group_norm_act_multi_cl([_cl(x) for x in xs], gns[0], relu=True)
+            for a, b in zip(outs, again):
+                assert torch.equal(a, b)
+
+
+def test_to_channels_last_multi(dev):
+    from orientedreppoints_amd.mmdet_ops.fused_norm import to_channels_last_multi
+    torch.manual_seed(2)
+    xs = [torch.randn(2, 96, h, w, device=dev) for h, w in ((17, 33), (5, 5), (1, 1), (64, 3))]
+    xs[1] = _cl(xs[1])
+    outs = to_channels_last_multi(xs)
+    assert outs[1] is xs[1]
+    for x, y in zip(xs, outs):
+        assert y.shape == x.shape and y.is_contiguous(memory_format=torch.channels_last) and torch.equal(x, y)
+
+
+def test_head_inference_with_channels_last_towers_vs_reference_forward(dev):
+    """OrientedRepPointsHead.forward at inference with both towers on the channels-last path (to_channels_last ->
+    [pair convolution -> GroupNorm+ReLU] x 3 -> init convolution with bias + ReLU -> DeformConv pair gathering the towers'
+    outputs as they are) against the reference's per-level forward_single (head :148-171: stock modules, one level at a time)
+    and against the library-convolution towers; B = 1 and 2; off when the library's split mode is off."""
+    import conftest
+    from orientedreppoints_amd import _lib
+    from orientedreppoints_amd.dota_configs import r50_model
+    from orientedreppoints_amd.mmdet_models import ConfigDict
+    from orientedreppoints_amd.mmdet_models.registry import build_head
+    torch.manual_seed(9)
+    head = build_head(ConfigDict(r50_model['bbox_head'])).to(dev).eval()
+    with torch.no_grad():
+        head.reppoints_pts_init_out.weight.normal_(0, 0.05)
+        for m in list(head.cls_convs) + list(head.reg_convs):
+            m.conv.weight.normal_(0, 0.03); m.norm.weight.uniform_(0.5, 1.5); m.norm.bias.normal_(0, 0.2)
+        for B in (1, 2):
+            feats = [torch.randn(B, 256, h, w, device=dev) for h, w in ((40, 36), (20, 18), (10, 9), (5, 5), (3, 2))]
+            head.split_towers = None
+            assert head._split_towers_ok(feats)
+            head.split_towers = True
+            got = head(feats)
+            head.split_towers = False
+            lib = head(feats)
+            want = [head.forward_single(f) for f in feats]
+            worst = 0.0
+            for k in range(3):                                   # cls_out, pts_out_init, pts_out_refine
+                for lvl in range(len(feats)):
+                    g, l, w = got[k][lvl], lib[k][lvl], want[lvl][k]
+                    assert g.shape == w.shape and g.is_contiguous()
+                    scale = max(1.0, float(w.abs().max()))
+                    worst = max(worst, float((g - w).abs().max()) / scale)
+                    assert float((g - w).abs().max()) <= 1e-4 * scale, (k, lvl)
+                    assert float((g - l).abs().max()) <= 1e-4 * scale, (k, lvl)
+            conftest.REPORT.append("head inference, channels-last towers vs forward_single, B = %d: max |diff| / scale %.2e" % (B, worst))
+        L = _lib.lib()
+        L.orp_dcn_set_split_mode(0)
+        try:
+            head.split_towers = None
+            assert not head._split_towers_ok(feats)              # exact-fp32 mode: the library-convolution towers
+        finally:
+            L.orp_dcn_set_split_mode(-1)
+
+
+def test_conv_split_at_a_head_level_vs_float64_and_the_library(dev):
+    """One 256 -> 256 layer at a 64^2 level (the library's pick there is Winograd F(2x2, 3x3)): both against torch's float64
+    convolution on the CPU; the split path's error is reported next to the library's and must be of the same order."""
+    import conftest
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv_split_multi
+    torch.manual_seed(21)
+    conv = _conv(256, 256, 3, dev, seed=5, std=0.03)
+    x = torch.randn(1, 256, 64, 64) * 2.0
+    want = F.conv2d(x.double(), conv.weight.detach().cpu().double(), padding=1)
+    with torch.no_grad():
+        e_lib = _rel(F.conv2d(x.to(dev), conv.weight, padding=1), want)
+        e6 = _rel(conv_split_multi([_cl(x.to(dev))], conv, nprod=6)[0], want)
+        e9 = _rel(conv_split_multi([_cl(x.to(dev))], conv, nprod=9)[0], want)
+    conftest.REPORT.append("3x3 convolution 1x256x64x64 -> 256, max |err| / max |out| vs float64: library fp32 %.2e, split 9 products "
+                           "%.2e, split 6 products %.2e" % (e_lib, e9, e6))
+    assert e6 <= 1e-5 and e9 <= 1e-5
+    # the same order as the library's own fp32 convolution at this shape (measured 8.8e-7 against 7.7e-7; 2.0e-6 before the
+    # small partial products got their own accumulator set)
+    assert e6 <= 1.5 * e_lib + 5e-8

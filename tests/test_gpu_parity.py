@@ -1478,6 +1478,7 @@ def test_groupnorm_channels_last_output_and_head_handover(dev):
     head = build_head(ConfigDict(r50_model['bbox_head'])).to(dev).eval()
     with torch.no_grad():
         head.reppoints_pts_init_out.weight.normal_(0, 0.05)
+        head.split_towers = False           # the library-convolution towers (the channels-last towers: test_gpu_conv_split.py)
         feats = [torch.randn(1, 256, n, n, device=dev) for n in (40, 20, 10, 5, 3)]
         outs = {}
         for flag in (True, False):
