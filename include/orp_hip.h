@@ -485,6 +485,13 @@ int orp_conv_split_multi(const orp_conv_level* levels_host, int nlevels, int bat
                          const float* weight_a_packed, const float* weight_b_packed, const float* bias_a, const float* bias_b,
                          int relu, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                          int out_layout, int nprod, void* stream);
+/* one layer PER LEVEL (the FPN's output convolutions, mmdet/models/necks/fpn.py:150-153 `self.fpn_convs[i](laterals[i])`):
+ * weights_packed_host[i] / biases_host[i] (biases_host or its entries may be NULL) belong to levels_host[i]; input_b / output_b
+ * are ignored */
+int orp_conv_split_multi_ex(const orp_conv_level* levels_host, const float* const* weights_packed_host,
+                            const float* const* biases_host, int nlevels, int batch, int c_in, int c_out, int relu, int kh, int kw,
+                            int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int out_layout, int nprod,
+                            void* stream);
 int orp_nchw_to_nhwc_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -58,10 +58,10 @@ extern "C" {
 
 int orp_conv_split_ok(int c_in, int c_out, int kh, int kw) { return orp_split::shape_ok(c_in, c_out, kh, kw) ? 1 : 0; }
 
-int orp_conv_split_multi(const orp_conv_level* levels_host, int nlevels, int batch, int c_in, int c_out,
-                         const float* weight_a_packed, const float* weight_b_packed, const float* bias_a, const float* bias_b,
-                         int relu, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
-                         int out_layout, int nprod, void* stream) {
+static int conv_split_impl(const orp_conv_level* levels_host, const float* const* weights_host, const float* const* biases_host,
+                           int nlevels, int batch, int c_in, int c_out, const float* weight_a_packed, const float* weight_b_packed,
+                           const float* bias_a, const float* bias_b, int relu, int kh, int kw, int stride_h, int stride_w,
+                           int pad_h, int pad_w, int dil_h, int dil_w, int out_layout, int nprod, void* stream) {
   if (!levels_host || nlevels <= 0 || nlevels > orp_split::kMaxLevels || batch <= 0 || !weight_a_packed) return ORP_EINVAL;
   if (!orp_split::shape_ok(c_in, c_out, kh, kw) || (nprod != 6 && nprod != 9) || (out_layout != 0 && out_layout != 1))
     return ORP_EINVAL;
@@ -83,6 +83,12 @@ int orp_conv_split_multi(const orp_conv_level* levels_host, int nlevels, int bat
     orp_split::Level& S = A.lv[i];
     S.x[0] = lv.input_a; S.x[1] = nconv == 2 ? lv.input_b : lv.input_a;
     S.off = nullptr; S.mask = nullptr;
+    S.planes = nullptr; S.bias = nullptr;
+    if (weights_host) {                                                   // a layer of its own for this level
+      if (!weights_host[i]) return ORP_EINVAL;
+      S.planes = reinterpret_cast<const uint16_t*>(weights_host[i] + plane_off);
+      S.bias = biases_host ? biases_host[i] : nullptr;
+    }
     S.out[0] = lv.output_a; S.out[1] = nconv == 2 ? lv.output_b : lv.output_a;
     S.H = lv.height; S.W = lv.width;
     S.Ho = out_dim(lv.height, pad_h, dil_h, kh, stride_h);
@@ -92,6 +98,24 @@ int orp_conv_split_multi(const orp_conv_level* levels_host, int nlevels, int bat
   OrpProfScope prof(ORP_PROF_CONV_SPLIT, (hipStream_t)stream);
   const hipError_t e = orp_split::launch(A, (hipStream_t)stream);
   return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_conv_split_multi(const orp_conv_level* levels_host, int nlevels, int batch, int c_in, int c_out,
+                         const float* weight_a_packed, const float* weight_b_packed, const float* bias_a, const float* bias_b,
+                         int relu, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                         int out_layout, int nprod, void* stream) {
+  return conv_split_impl(levels_host, nullptr, nullptr, nlevels, batch, c_in, c_out, weight_a_packed, weight_b_packed, bias_a,
+                         bias_b, relu, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, out_layout, nprod, stream);
+}
+
+int orp_conv_split_multi_ex(const orp_conv_level* levels_host, const float* const* weights_packed_host,
+                            const float* const* biases_host, int nlevels, int batch, int c_in, int c_out, int relu, int kh, int kw,
+                            int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int out_layout, int nprod,
+                            void* stream) {
+  if (!weights_packed_host || nlevels <= 0) return ORP_EINVAL;
+  return conv_split_impl(levels_host, weights_packed_host, biases_host, nlevels, batch, c_in, c_out, weights_packed_host[0],
+                         nullptr, nullptr, nullptr, relu, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, out_layout,
+                         nprod, stream);
 }
 
 int orp_nchw_to_nhwc_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, void* stream) {

@@ -1153,6 +1153,7 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
       orp_split::Level& S = A.lv[i];
       S.x[0] = D.x; S.x[1] = D.x2; S.off = D.off; S.mask = D.mask; S.out[0] = D.out; S.out[1] = D.out2;
       S.H = D.H; S.W = D.W; S.Ho = D.Ho; S.Wo = D.Wo;
+      S.planes = nullptr; S.bias = nullptr;
     }
     OrpProfScope prof(ORP_PROF_DCN_FWD, st);
     const hipError_t se = orp_split::launch(A, st);

@@ -85,6 +85,8 @@ struct LevelK {
   float* out[2];
   int H, W, Ho, Wo;
   int tile0;
+  const uint16_t* planes;         // this level's own layer (or nullptr: FwdS::planes / bias)
+  const float* bias;
 };
 struct FwdS {
   LevelK lv[kMaxLevels];
@@ -282,7 +284,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   const int n_wave = blockIdx.y * 256 + wave * 32;
   const int mrow = lane & 31, kg = lane >> 5;
   const bool live = n_wave < P.Cout;                      // c_out % 64 == 0 -> ... % 32 == 0: a wave is live or idle as a whole
-  const uint16_t* wp = (conv ? P.planes[1] : P.planes[0]) + ((size_t)kg * P.Cout + (live ? n_wave : 0) + mrow) * 8;
+  const uint16_t* wp = (L.planes ? L.planes : conv ? P.planes[1] : P.planes[0]) + ((size_t)kg * P.Cout + (live ? n_wave : 0) + mrow) * 8;
   const size_t wblk = (size_t)2 * P.Cout * 8;             // elements per 16-channel block
   auto load_b = [&](int tap, int cb, int j, bf8 (&b)[3]) {
     const uint16_t* a = wp + ((size_t)tap * (P.Cin / 16) + cb * NCH + j) * wblk;
@@ -407,7 +409,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) acc[mt] += side[mt];
   }
-  const float* bias = conv ? P.bias[1] : P.bias[0];
+  const float* bias = L.planes ? L.bias : conv ? P.bias[1] : P.bias[0];
   float* outp = conv ? L.out[1] : L.out[0];
   auto finish = [&](float v, int ch) { if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
 #pragma unroll
@@ -510,6 +512,7 @@ hipError_t launch(const Args& a, hipStream_t st) {
     D.x[0] = a.lv[i].x[0]; D.x[1] = a.lv[i].x[1]; D.off = a.lv[i].off; D.mask = a.lv[i].mask;
     D.out[0] = a.lv[i].out[0]; D.out[1] = a.lv[i].out[1];
     D.H = a.lv[i].H; D.W = a.lv[i].W; D.Ho = a.lv[i].Ho; D.Wo = a.lv[i].Wo;
+    D.planes = a.nconv == 1 ? a.lv[i].planes : nullptr; D.bias = a.lv[i].bias;
     D.tile0 = tiles;
     tiles += (int)(((long)a.B * D.Ho * D.Wo + 32 * MT - 1) / (32 * MT));
   }

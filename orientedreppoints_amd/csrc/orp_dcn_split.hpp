@@ -15,6 +15,8 @@ struct Level {
   const float* mask;    // DCNv2 modulation [B, taps, Ho, Wo] or nullptr
   float* out[2];        // NCHW [B, Cout, Ho, Wo] or NHWC [B, Ho, Wo, Cout]
   int H, W, Ho, Wo;
+  const uint16_t* planes;   // nullptr, or this level's own weight planes / bias (single-layer launches: a different layer per
+  const float* bias;        // level, e.g. the FPN's output convolutions) instead of Args::planes[0] / bias[0]
 };
 
 struct Args {

@@ -61,6 +61,30 @@ class FPN(nn.Module):
                    and isinstance(m.conv, nn.Conv2d) and m.conv.bias is None
                    and m.norm.num_groups == mods[0].norm.num_groups and m.norm.eps == mods[0].norm.eps for m in mods)
 
+    def _split_ok(self, laterals):
+        """The output convolutions take the channels-last bf16-split path: library split mode on (ORP_DCN_SPLIT != 0),
+        `split_convs` not switched off (attribute, or ORP_FPN_SPLIT=0 for A/B timing), stride-1 'same' convolutions of one
+        shape that `orp_conv_split_multi_ex` takes, GroupNorm shapes the channels-last kernels take."""
+        import os
+        from .. import _lib
+        from ..mmdet_ops.fused_norm import conv_split_ok
+        on = getattr(self, 'split_convs', None)
+        if on is None:
+            on = os.environ.get('ORP_FPN_SPLIT', '1') == '1'
+        used = len(self.lateral_convs)
+        if not on or _lib.lib().orp_dcn_get_split_mode() == 0 or used > 8:
+            return False
+        c0 = self.fpn_convs[0].conv
+        for fc in self.fpn_convs[:used]:
+            c = fc.conv
+            if not (conv_split_ok(c, laterals[0]) and tuple(c.stride) == (1, 1) and tuple(c.weight.shape) == tuple(c0.weight.shape)
+                    and c.padding == c0.padding and c.dilation == c0.dilation and
+                    2 * c.padding[0] == c.dilation[0] * (c.weight.size(2) - 1) and
+                    2 * c.padding[1] == c.dilation[1] * (c.weight.size(3) - 1)):
+                return False
+        C, G = c0.weight.size(0), self.fpn_convs[0].norm.num_groups
+        return 1024 % C == 0 and C % G == 0 and (C // G) % 4 == 0 and min(min(t.size(2), t.size(3)) for t in laterals) > 1
+
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
         used = len(self.lateral_convs)
@@ -84,6 +108,14 @@ class FPN(nn.Module):
         if train:
             outs = group_norm_act_train([self.fpn_convs[i].conv(laterals[i]) for i in range(used)],
                                         [fc.norm for fc in self.fpn_convs[:used]], relu=False)
+        elif fused and self._split_ok(laterals):
+            # the output convolutions of all levels in ONE launch on the bf16 matrix pipe (csrc/orp_conv_split.hip: fp32 in /
+            # out, operands split exactly into three bf16 pieces), a layer of its own per level; channels-last from here on --
+            # the layout the head's towers read (their own transposition launch goes away)
+            from ..mmdet_ops.fused_norm import conv_split_multi, group_norm_act_multi_cl, to_channels_last_multi
+            outs = group_norm_act_multi_cl(conv_split_multi(to_channels_last_multi(laterals),
+                                                            [fc.conv for fc in self.fpn_convs[:used]]),
+                                           [fc.norm for fc in self.fpn_convs[:used]], relu=False)
         elif fused:
             outs = group_norm_act_multi(conv3x3_multi(laterals, [fc.conv for fc in self.fpn_convs[:used]]),
                                         [fc.norm for fc in self.fpn_convs[:used]], relu=False, inplace=True)

@@ -420,6 +420,14 @@ def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=Fals
     from .deform_conv import _packed_weight
     L = _lib.lib()
     pair = xs_b is not None
+    per_level = None
+    if isinstance(conv_a, (list, tuple)):                  # one layer per tensor (the FPN's output convolutions)
+        per_level = list(conv_a)
+        conv_a = per_level[0]
+        if pair or len(per_level) != len(xs_a) or any(
+                tuple(c.weight.shape) != tuple(conv_a.weight.shape) or c.stride != conv_a.stride or c.padding != conv_a.padding
+                or c.dilation != conv_a.dilation for c in per_level):
+            raise ValueError("conv_split_multi: one module per tensor, equal shapes / strides / paddings / dilations, no second layer")
     w = conv_a.weight
     cout, cin, kh, kw = w.shape
     if pair and (tuple(conv_b.weight.shape) != tuple(w.shape) or conv_b.stride != conv_a.stride or conv_b.padding != conv_a.padding
@@ -451,6 +459,20 @@ def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=Fals
         ob = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=xa.device, memory_format=fmt) if pair else None
         keep += [xa, xb]; outs_a.append(oa); outs_b.append(ob)
         levels[i] = _ConvLevel(xa.data_ptr(), xb.data_ptr() if pair else None, oa.data_ptr(), ob.data_ptr() if pair else None, H, W)
+    if per_level is not None:
+        wts = (ctypes.c_void_p * n)()
+        bs = (ctypes.c_void_p * n)()
+        for i, c in enumerate(per_level):
+            pk = _packed_weight(c.weight)
+            bi = c.bias.detach().float().contiguous() if (bias and c.bias is not None) else None
+            keep += [pk, bi]
+            wts[i] = pk.data_ptr()
+            bs[i] = bi.data_ptr() if bi is not None else None
+        with torch.cuda.device(x0.device):
+            rc = L.orp_conv_split_multi_ex(levels, wts, bs, n, B, cin, cout, 1 if relu else 0, kh, kw, st[0], st[1], pd[0], pd[1],
+                                           dl[0], dl[1], 1 if out_channels_last else 0, int(nprod), _lib.stream_of(x0))
+        _lib.check(rc, "orp_conv_split_multi_ex")
+        return outs_a
     pa = _packed_weight(conv_a.weight)
     pb = _packed_weight(conv_b.weight) if pair else None
     ba = conv_a.bias.detach().float().contiguous() if (bias and conv_a.bias is not None) else None

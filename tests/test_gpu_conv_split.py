@@ -236,3 +236,39 @@ def test_conv_split_at_a_head_level_vs_float64_and_the_library(dev):
     # the same order as the library's own fp32 convolution at this shape (measured 8.8e-7 against 7.7e-7; 2.0e-6 before the
     # small partial products got their own accumulator set)
     assert e6 <= 1.5 * e_lib + 5e-8
+
+
+def test_fpn_output_convolutions_one_layer_per_level(dev):
+    """FPN.forward at inference (mmdet/models/necks/fpn.py:118-175): the output convolutions of all levels -- a different
+    ConvModule per level -- as one orp_conv_split_multi_ex launch, channels-last results; against the module-by-module path
+    (stock ConvModules) and the library-convolution path; B = 1 and 2, odd sizes."""
+    from orientedreppoints_amd.dota_configs import r50_model
+    from orientedreppoints_amd.mmdet_models import ConfigDict
+    from orientedreppoints_amd.mmdet_models.registry import build_neck
+    torch.manual_seed(13)
+    neck = build_neck(ConfigDict(r50_model['neck'])).to(dev).eval()
+    with torch.no_grad():
+        for m in list(neck.lateral_convs) + list(neck.fpn_convs):
+            m.conv.weight.normal_(0, 0.03)
+            if getattr(m, 'norm', None) is not None:
+                m.norm.weight.uniform_(0.5, 1.5); m.norm.bias.normal_(0, 0.2)
+        for B, sizes in ((1, (64, 32, 16, 8)), (2, (44, 22, 11, 6))):
+            inputs = [torch.randn(B, c, n, n, device=dev) for c, n in zip(neck.in_channels, sizes)]
+            neck.split_convs = True
+            got = neck(inputs)
+            neck.split_convs = False
+            lib = neck(inputs)
+            # module by module: what ConvModule.forward does (conv -> norm), the reference's statement order
+            used = len(neck.lateral_convs)
+            lats = [lc(inputs[i + neck.start_level]) for i, lc in enumerate(neck.lateral_convs)]
+            for i in range(used - 1, 0, -1):
+                lats[i - 1] = lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[2:], mode='nearest')
+            want = [neck.fpn_convs[i](lats[i]) for i in range(used)]
+            assert len(got) == len(lib) == neck.num_outs
+            for i in range(used):
+                assert got[i].shape == want[i].shape
+                scale = max(1.0, float(want[i].abs().max()))
+                assert float((got[i] - want[i]).abs().max()) <= 1e-4 * scale
+                assert float((got[i] - lib[i]).abs().max()) <= 1e-4 * scale
+            for i in range(used, neck.num_outs):                 # the extra levels do not depend on the output convolutions here
+                assert float((got[i] - lib[i]).abs().max()) <= 1e-4 * max(1.0, float(lib[i].abs().max()))
