@@ -898,7 +898,7 @@ def main():
                 elapsed = p_elapsed
 
     prof = {name: read_prof(slot) for name, slot in
-            (('nms_mask', 0), ('nms_sweep', 1), ('nms_rank_prepare', 2), ('dcn_fwd', 3), ('minarearect', 4))}
+            (('nms_mask', 0), ('nms_sweep', 1), ('nms_rank_prepare', 2), ('dcn_fwd', 3), ('minarearect', 4), ('conv_split', 12))}
     if rank != 0:
         if distributed:
             dist.destroy_process_group()
@@ -1007,6 +1007,26 @@ def main():
                              'socket power cap (2.14 GHz instead of 2.4; a register-operand microbenchmark of the instruction '
                              'sustains 1.7-2.0 PFLOP/s there: tests/checks/mfma_rate_bf16.hip, clock_under_split.sh)'
                              % (mode, mode), **common)
+    # the head's tower / FPN output convolutions on the same kernel (PLAIN instantiation, csrc/orp_conv_split.hip): per image
+    # 3 pair launches (both towers' layer k) + the init branch's convolution over all five levels + the FPN's three output
+    # convolutions in one launch; HIP events inside the library, summed over the step's launches
+    cs_ms, cs_n = prof['conv_split']
+    if roof is not None and cs_n > 0:
+        mode = int(_lib.lib().orp_dcn_get_split_mode()) or 6
+        npos3 = args.batch * sum((IMG // s_) ** 2 for s_ in (8, 16, 32))
+        layers_all, layers_fpn = 7, 1                      # 256 -> 256 3x3 layers over all five levels / over the first three
+        cflops = 2.0 * cout * cin * 9 * (layers_all * npos + layers_fpn * npos3)
+        per_step = cs_n / float(dcn_n)                     # one DeformConv pair launch per step
+        us_step = cs_ms * 1e3 / dcn_n
+        roof['tower_and_fpn_convolutions'] = dict(
+            kernel='dcn_fwd_split_kernel<MT 3, %d products, PLAIN (no offsets)>' % mode, launches_per_step=per_step,
+            us_per_step=us_step, algorithmic_flops_per_step=cflops, algorithmic_tflops=cflops / (us_step * 1e-6) / 1e12,
+            achieved=mode * cflops / (us_step * 1e-6) / 1e12, peak=BF16_MFMA_PEAK_TFLOPS,
+            frac=mode * cflops / (us_step * 1e-6) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+            note='the same bf16-split kernel without offsets: the head\'s seven 256->256 3x3 tower convolutions (the two towers\' '
+                 'layer k as grid halves of one launch) and the FPN\'s three output convolutions (a layer per level), channels-'
+                 'last; the library (Winograd + small-level kernel) took 246 us per layer, ORP_TOWER_SPLIT=0 / ORP_FPN_SPLIT=0 '
+                 'switch back')
     # ---- the rotated-IoU + NMS stage (HBM is the formal bound, the work is fp32 VALU) --------------------------------
     mask_ms, mask_n = prof['nms_mask']
     nms = None

@@ -20,7 +20,9 @@ for d in dirs:
             k = r['Kernel_Name']
             key = ('dcn_bwd_scatter' if 'dcn_bwd_scatter' in k else
                    'dcn_bwd_input' if 'dcn_bwd_input' in k else 'dcn_bwd_weight' if 'dcn_bwd_weight' in k else
-                   'dcn_fwd_half' if 'dcn_fwd_half' in k else 'dcn_fwd_split' if 'dcn_fwd_split' in k else
+                   'dcn_fwd_half' if 'dcn_fwd_half' in k else
+                   # dcn_fwd_split_kernel<MT, products, nchw, PLAIN>: PLAIN = the tower / FPN convolutions (no offsets)
+                   'conv_split_pair' if ('dcn_fwd_split' in k and ', true>' in k) else 'dcn_fwd_split' if 'dcn_fwd_split' in k else
                    'dcn_fwd_pair' if 'dcn_fwd_mfma2' in k else 'nms_mask' if 'nms_mask' in k
                    else 'nms_sweep' if 'nms_sweep' in k else 'nms_rankprep' if 'nms_rankprep' in k else None)
             if key is None:
@@ -54,7 +56,7 @@ for k, c in agg.items():
     if k.startswith('dcn_bwd'):
         e['batch'] = 2
         e['img'] = 1024
-    if k.startswith('dcn_fwd'):
+    if k.startswith('dcn_fwd') or k.startswith('conv_split'):
         e['batch'] = 1
         e['img'] = 1024
     out[k] = e

@@ -13,7 +13,7 @@ if not f:
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     k = r['Kernel_Name'][:60]
-    if 'dcn_fwd' in k or 'dcn_bwd' in k or 'nms_' in k or 'convex' in k or 'minarearect' in k or 'chamfer' in k or 'assign' in k:
+    if 'dcn_fwd' in k or 'conv_split' in k or 'dcn_bwd' in k or 'nms_' in k or 'convex' in k or 'minarearect' in k or 'chamfer' in k or 'assign' in k:
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, c in agg.items():
     print(k, {n: sum(v) / len(v) for n, v in c.items()}, 'launches', max(len(v) for v in c.values()))

@@ -21,6 +21,14 @@ if which in ('dcn', 'all'):
         for _ in range(iters):
             deform_conv_forward_pair(xs, xs2, offs, w, w2, 1, 1, 1, relu=True)  # the head's launch: both layers, all levels
     _lib.lib().orp_dcn_set_split_mode(-1)
+    # the towers' layer k of both towers as one launch (the same kernel without offsets), channels-last as in the head
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv_split_multi
+    ca, cb = torch.nn.Conv2d(256, 256, 3, padding=1, bias=False).to(dev), torch.nn.Conv2d(256, 256, 3, padding=1, bias=False).to(dev)
+    cl = [x.contiguous(memory_format=torch.channels_last) for x in xs]
+    cl2 = [x.contiguous(memory_format=torch.channels_last) for x in xs2]
+    with torch.no_grad():
+        for _ in range(iters):
+            conv_split_multi(cl, ca, cl2, cb)
     hx, ho, hw = [x.half() for x in xs], [o.half() for o in offs], w.half()
     for _ in range(iters):
         deform_conv_forward_multi(hx, ho, hw, 1, 1, 1)                          # fp16 path
