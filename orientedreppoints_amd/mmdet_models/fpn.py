@@ -106,8 +106,13 @@ class FPN(nn.Module):
             laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
                                                               mode='nearest')
         if train:
-            outs = group_norm_act_train([self.fpn_convs[i].conv(laterals[i]) for i in range(used)],
-                                        [fc.norm for fc in self.fpn_convs[:used]], relu=False)
+            from ..mmdet_ops.fused_norm import conv_split_train, conv_split_train_ok
+            out_convs = [fc.conv for fc in self.fpn_convs[:used]]
+            if used <= 8 and conv_split_train_ok(out_convs, laterals[0]):     # one node, a layer per level (bf16-split kernel)
+                conv_outs = conv_split_train(laterals, out_convs)
+            else:
+                conv_outs = [c(l) for c, l in zip(out_convs, laterals)]
+            outs = group_norm_act_train(conv_outs, [fc.norm for fc in self.fpn_convs[:used]], relu=False)
         elif fused and self._split_ok(laterals):
             # the output convolutions of all levels in ONE launch on the bf16 matrix pipe (csrc/orp_conv_split.hip: fp32 in /
             # out, operands split exactly into three bf16 pieces), a layer of its own per level; channels-last from here on --

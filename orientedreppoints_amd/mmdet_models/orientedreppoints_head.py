@@ -239,6 +239,18 @@ class OrientedRepPointsHead(nn.Module):
             cur = group_norm_act_train([m.conv(x) for x in cur], m.norm, relu=True)
         return cur
 
+    def _towers_train_pair(self, feats):
+        """Both towers with autograd, layer by layer: conv_split_train (one node for the ten tensors) -> GroupNorm + ReLU (one
+        node for the ten tensors)."""
+        from ..mmdet_ops.fused_norm import conv_split_train, group_norm_act_train
+        n = len(feats)
+        a_cur = b_cur = list(feats)
+        for a, b in zip(self.cls_convs, self.reg_convs):
+            outs = conv_split_train(a_cur + b_cur, [a.conv] * n + [b.conv] * n)
+            ys = group_norm_act_train(outs, [a.norm] * n + [b.norm] * n, relu=True)
+            a_cur, b_cur = ys[:n], ys[n:]
+        return a_cur, b_cur
+
     def forward_train_multi(self, feats):
         """Training forward with the two DeformConvs of ALL levels as one autograd node (one pair launch forward, the MFMA
         backward over all levels at once); per level the same operations as forward_single, in the same order."""
@@ -246,12 +258,26 @@ class OrientedRepPointsHead(nn.Module):
         dcn_base_offset = self._base_offset_on(feats[0])
         cls_feats, pts_feats, inits, offsets = [], [], [], []
         fused_gn = self._fused_towers_ok(feats)
+        hid = None
         if fused_gn:
-            cls_all, pts_all = self._tower_train(self.cls_convs, feats), self._tower_train(self.reg_convs, feats)
+            from ..mmdet_ops.fused_norm import conv_split_train, conv_split_train_ok
+            tower_convs = [m.conv for m in list(self.cls_convs) + list(self.reg_convs)]
+            if len(self.cls_convs) == len(self.reg_convs) and len(feats) <= 8 and conv_split_train_ok(tower_convs, feats[0]):
+                # the two towers' layer k over all levels: ONE convolution node on the bf16-split kernel (forward and
+                # grad_input; grad_weight stays on the library), then the GroupNorm + ReLU node of both towers' tensors
+                cls_all, pts_all = self._towers_train_pair(feats)
+            else:
+                cls_all, pts_all = self._tower_train(self.cls_convs, feats), self._tower_train(self.reg_convs, feats)
+            pc = self.reppoints_pts_init_conv
+            if conv_split_train_ok([pc], feats[0], allow_bias=True):
+                hid = conv_split_train(pts_all, pc)
+                if pc.bias is not None:
+                    hid = [h + pc.bias.view(1, -1, 1, 1) for h in hid]
         for i, x in enumerate(feats):
             if fused_gn:
                 cls_feat, pts_feat = cls_all[i], pts_all[i]
-                pts_out_init = self.reppoints_pts_init_out(self.relu(self.reppoints_pts_init_conv(pts_feat)))
+                init_mid = hid[i] if hid is not None else self.reppoints_pts_init_conv(pts_feat)
+                pts_out_init = self.reppoints_pts_init_out(self.relu(init_mid))
             else:
                 cls_feat, pts_feat, pts_out_init = self._towers(x)
             grad_mul = (1 - self.gradient_mul) * pts_out_init.detach() + self.gradient_mul * pts_out_init

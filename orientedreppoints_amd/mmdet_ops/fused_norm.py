@@ -411,28 +411,21 @@ def conv_split_ok(conv, x=None):
     return ok
 
 
-def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=False, out_channels_last=True, nprod=None):
-    """[conv_a(x) for x in xs_a] (and [conv_b(x) for x in xs_b]: two layers of equal shape in ONE launch -- the two towers'
-    layer k) over all FPN levels, `orp_conv_split_multi`: fp32 on the bf16 matrix pipe with every operand split exactly
-    into three bf16 pieces, fp32 accumulation.  xs_*: channels-last fp32 CUDA tensors (logical [B,C,H,W]); bias=True adds the
-    modules' biases in the epilogue, relu fuses the activation; outputs channels-last or NCHW.  Inference only.
-    nprod: 6 | 9 partial products (None: the library's DeformConv split mode, 6 when that is off)."""
+def conv_split_weights(xs_a, weights_a, xs_b=None, weight_b=None, biases_a=None, bias_b=None, stride=(1, 1), padding=(1, 1),
+                       dilation=(1, 1), relu=False, out_channels_last=True, nprod=None, cache_pack=True):
+    """The launch behind conv_split_multi, on tensors: weights_a = one [Cout,Cin,kh,kw] weight for all of xs_a, or a list with
+    one weight per tensor (then no second layer); cache_pack=False re-packs the weights on every call (training: the
+    optimizer writes them between calls)."""
     from .deform_conv import _packed_weight
     L = _lib.lib()
     pair = xs_b is not None
-    per_level = None
-    if isinstance(conv_a, (list, tuple)):                  # one layer per tensor (the FPN's output convolutions)
-        per_level = list(conv_a)
-        conv_a = per_level[0]
-        if pair or len(per_level) != len(xs_a) or any(
-                tuple(c.weight.shape) != tuple(conv_a.weight.shape) or c.stride != conv_a.stride or c.padding != conv_a.padding
-                or c.dilation != conv_a.dilation for c in per_level):
-            raise ValueError("conv_split_multi: one module per tensor, equal shapes / strides / paddings / dilations, no second layer")
-    w = conv_a.weight
+    per_level = list(weights_a) if isinstance(weights_a, (list, tuple)) else None
+    w = per_level[0] if per_level is not None else weights_a
     cout, cin, kh, kw = w.shape
-    if pair and (tuple(conv_b.weight.shape) != tuple(w.shape) or conv_b.stride != conv_a.stride or conv_b.padding != conv_a.padding
-                 or conv_b.dilation != conv_a.dilation or len(xs_b) != len(xs_a)):
-        raise ValueError("conv_split_multi: the two layers must have equal shapes / strides / paddings / dilations")
+    if per_level is not None and (pair or len(per_level) != len(xs_a) or any(tuple(t.shape) != tuple(w.shape) for t in per_level)):
+        raise ValueError("conv_split: one weight per tensor, equal shapes, no second layer")
+    if pair and (tuple(weight_b.shape) != tuple(w.shape) or len(xs_b) != len(xs_a)):
+        raise ValueError("conv_split: the two layers must have equal shapes")
     if nprod is None:
         nprod = L.orp_dcn_get_split_mode() or 6
     x0 = xs_a[0]
@@ -440,7 +433,7 @@ def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=Fals
     n = len(xs_a)
     levels = (_ConvLevel * n)()
     keep, outs_a, outs_b = [], [], []
-    st, pd, dl = conv_a.stride, conv_a.padding, conv_a.dilation
+    st, pd, dl = tuple(stride), tuple(padding), tuple(dilation)
     fmt = torch.channels_last if out_channels_last else torch.contiguous_format
     for i in range(n):
         xa = xs_a[i].detach()
@@ -449,9 +442,9 @@ def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=Fals
             if x is None:
                 continue
             if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.size(0) == B and x.size(1) == cin and _is_cl(x)):
-                raise ValueError("conv_split_multi expects channels-last fp32 CUDA [B,%d,H,W] tensors" % cin)
+                raise ValueError("conv_split expects channels-last fp32 CUDA [B,%d,H,W] tensors" % cin)
             if xb is not None and x.shape != xa.shape:
-                raise ValueError("conv_split_multi: the two layers' inputs must have equal shapes")
+                raise ValueError("conv_split: the two layers' inputs must have equal shapes")
         H, W = xa.size(2), xa.size(3)
         ho = (H + 2 * pd[0] - (dl[0] * (kh - 1) + 1)) // st[0] + 1
         wo = (W + 2 * pd[1] - (dl[1] * (kw - 1) + 1)) // st[1] + 1
@@ -459,12 +452,15 @@ def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=Fals
         ob = torch.empty((B, cout, ho, wo), dtype=torch.float32, device=xa.device, memory_format=fmt) if pair else None
         keep += [xa, xb]; outs_a.append(oa); outs_b.append(ob)
         levels[i] = _ConvLevel(xa.data_ptr(), xb.data_ptr() if pair else None, oa.data_ptr(), ob.data_ptr() if pair else None, H, W)
+
+    def f32(t):
+        return t.detach().float().contiguous() if t is not None else None
     if per_level is not None:
         wts = (ctypes.c_void_p * n)()
         bs = (ctypes.c_void_p * n)()
-        for i, c in enumerate(per_level):
-            pk = _packed_weight(c.weight)
-            bi = c.bias.detach().float().contiguous() if (bias and c.bias is not None) else None
+        for i, wt in enumerate(per_level):
+            pk = _packed_weight(wt, cache_pack)
+            bi = f32(biases_a[i]) if biases_a is not None else None
             keep += [pk, bi]
             wts[i] = pk.data_ptr()
             bs[i] = bi.data_ptr() if bi is not None else None
@@ -473,16 +469,138 @@ def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=Fals
                                            dl[0], dl[1], 1 if out_channels_last else 0, int(nprod), _lib.stream_of(x0))
         _lib.check(rc, "orp_conv_split_multi_ex")
         return outs_a
-    pa = _packed_weight(conv_a.weight)
-    pb = _packed_weight(conv_b.weight) if pair else None
-    ba = conv_a.bias.detach().float().contiguous() if (bias and conv_a.bias is not None) else None
-    bb = conv_b.bias.detach().float().contiguous() if (pair and bias and conv_b.bias is not None) else None
+    pa = _packed_weight(w, cache_pack)
+    pb = _packed_weight(weight_b, cache_pack) if pair else None
+    ba, bb = f32(biases_a), f32(bias_b) if pair else None
     with torch.cuda.device(x0.device):
         rc = L.orp_conv_split_multi(levels, n, B, cin, cout, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(ba), _lib.ptr(bb),
                                     1 if relu else 0, kh, kw, st[0], st[1], pd[0], pd[1], dl[0], dl[1],
                                     1 if out_channels_last else 0, int(nprod), _lib.stream_of(x0))
     _lib.check(rc, "orp_conv_split_multi")
     return (outs_a, outs_b) if pair else outs_a
+
+
+def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=False, out_channels_last=True, nprod=None):
+    """[conv_a(x) for x in xs_a] (and [conv_b(x) for x in xs_b]: two layers of equal shape in ONE launch -- the two towers'
+    layer k) over all FPN levels, `orp_conv_split_multi`: fp32 on the bf16 matrix pipe with every operand split exactly
+    into three bf16 pieces, fp32 accumulation.  xs_*: channels-last fp32 CUDA tensors (logical [B,C,H,W]); conv_a: one
+    nn.Conv2d for all tensors, or a list with one per tensor (the FPN's output convolutions; no second layer then); bias=True
+    adds the modules' biases in the epilogue, relu fuses the activation; outputs channels-last or NCHW.  No autograd
+    (training: conv_split_train).  nprod: 6 | 9 partial products (None: the library's DeformConv split mode, 6 when off)."""
+    per_level = list(conv_a) if isinstance(conv_a, (list, tuple)) else None
+    c0 = per_level[0] if per_level is not None else conv_a
+    mods = (per_level or [c0]) + ([conv_b] if conv_b is not None else [])
+    if any(c.stride != c0.stride or c.padding != c0.padding or c.dilation != c0.dilation for c in mods):
+        raise ValueError("conv_split_multi: equal strides / paddings / dilations")
+    if per_level is not None:
+        return conv_split_weights(xs_a, [c.weight for c in per_level], None, None,
+                                  [c.bias for c in per_level] if bias else None, None, c0.stride, c0.padding, c0.dilation,
+                                  relu, out_channels_last, nprod)
+    return conv_split_weights(xs_a, c0.weight, xs_b, conv_b.weight if conv_b is not None else None,
+                              c0.bias if bias else None, conv_b.bias if (bias and conv_b is not None) else None,
+                              c0.stride, c0.padding, c0.dilation, relu, out_channels_last, nprod)
+
+
+class _ConvSplitTrain(torch.autograd.Function):
+    """ys = [conv(x, W_k)] for the levels of one tower layer (or of the two towers' layer k, or of the FPN's output
+    convolutions with a weight per level) as ONE autograd node on the bf16-split kernel.  forward: inputs transposed to
+    channels-last in one launch, one convolution launch writing NCHW.  backward: grad_input = the same kernel on the
+    transposed grad_outputs with the flipped, transposed weights (stride 1: correlation with W[o][c][kh-1-i][kw-1-j] as
+    [c][o], padding dil*(k-1) - pad); grad_weight = the library's weight-gradient kernel per level on the channels-last
+    tensors (torch.ops.aten.convolution_backward), summed over the levels that share a weight."""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        n, nw, groups, padding, dilation = meta             # n inputs, nw weights, groups[i] = weight index of input i
+        ws, xs = tensors[:nw], tensors[nw:]
+        def key(x):                                           # the towers' first layer reads the same FPN output twice
+            return (x.data_ptr(), tuple(x.shape), tuple(x.stride()))
+        seen = {}
+        for x in xs:
+            seen.setdefault(key(x), len(seen))
+        uniq = [None] * len(seen)
+        for x in xs:
+            uniq[seen[key(x)]] = x
+        uniq_cl = to_channels_last_multi([u.detach().float() for u in uniq])
+        cl = [uniq_cl[seen[key(x)]] for x in xs]
+        outs = _ConvSplitTrain._run(cl, ws, groups, padding, dilation, nw)
+        ctx.meta = meta
+        ctx.save_for_backward(*ws, *cl)
+        return tuple(outs)
+
+    @staticmethod
+    def _run(cl, ws, groups, padding, dilation, nw):
+        """one launch: a single weight, two weights (pair: first / second half of the tensors), or one weight per tensor"""
+        n = len(cl)
+        if nw == 1:
+            return conv_split_weights(cl, ws[0], padding=padding, dilation=dilation, out_channels_last=False, cache_pack=False)
+        if nw == 2 and n % 2 == 0 and list(groups) == [0] * (n // 2) + [1] * (n // 2):
+            a, b = conv_split_weights(cl[:n // 2], ws[0], cl[n // 2:], ws[1], padding=padding, dilation=dilation,
+                                      out_channels_last=False, cache_pack=False)
+            return a + b
+        return conv_split_weights(cl, [ws[g] for g in groups], padding=padding, dilation=dilation, out_channels_last=False,
+                                  cache_pack=False)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n, nw, groups, padding, dilation = ctx.meta
+        saved = ctx.saved_tensors
+        ws, cl = saved[:nw], saved[nw:]
+        kh, kw = ws[0].size(2), ws[0].size(3)
+        g_cl = to_channels_last_multi([g.detach().float() for g in grads])
+        gxs = [None] * n
+        if any(ctx.needs_input_grad[1 + nw:]):
+            wt = [w.detach().flip(2, 3).transpose(0, 1).contiguous() for w in ws]
+            pad_t = (dilation[0] * (kh - 1) - padding[0], dilation[1] * (kw - 1) - padding[1])
+            gxs = _ConvSplitTrain._run(g_cl, wt, groups, pad_t, dilation, nw)
+        gws = [None] * nw
+        for k in range(nw):
+            if not ctx.needs_input_grad[1 + k]:
+                continue
+            acc = None
+            for i in range(n):
+                if groups[i] != k:
+                    continue
+                gw = torch.ops.aten.convolution_backward(g_cl[i], cl[i], ws[k], None, [1, 1], list(padding), list(dilation), False,
+                                                         [0, 0], 1, [False, True, False])[1]
+                acc = gw if acc is None else acc + gw
+            gws[k] = acc
+        return (None, *gws, *gxs)
+
+
+def conv_split_train_ok(convs, x, allow_bias=False):
+    """the modules' convolutions can run as a conv_split_train node: split mode on (ORP_TRAIN_SPLIT=0 switches the training
+    route off for A/B timing), no autocast, stride 1, fp32 nn.Conv2d of one shape that `orp_conv_split_multi` takes (bias-free
+    unless the caller adds the bias itself), fp32 CUDA input"""
+    import os
+    if os.environ.get('ORP_TRAIN_SPLIT', '1') != '1' or _lib.lib().orp_dcn_get_split_mode() == 0 or torch.is_autocast_enabled():
+        return False
+    c0 = convs[0]
+    for c in convs:
+        if not (conv_split_ok(c, x) and (allow_bias or c.bias is None) and tuple(c.stride) == (1, 1) and tuple(c.weight.shape) == tuple(c0.weight.shape)
+                and c.padding == c0.padding and c.dilation == c0.dilation and c.weight.size(0) % 64 == 0 and c.weight.size(1) % 64 == 0
+                and c.dilation[0] * (c.weight.size(2) - 1) >= c.padding[0] and c.dilation[1] * (c.weight.size(3) - 1) >= c.padding[1]):
+            return False
+    return True
+
+
+def conv_split_train(xs, convs):
+    """[convs[i](x_i)] with autograd as one node; xs: NCHW fp32 CUDA tensors (up to 8 per distinct layer in a pair / single
+    launch, see _ConvSplitTrain._run), convs: one module, or a list with one module per tensor (tensors sharing a module are
+    one layer).  Layouts a launch takes: all tensors one layer; first half / second half two layers (the two towers' layer
+    k); a layer per tensor (the FPN)."""
+    convs = list(convs) if isinstance(convs, (list, tuple)) else [convs] * len(xs)
+    order, groups = {}, []
+    for c in convs:
+        if id(c) not in order:
+            order[id(c)] = len(order)
+        groups.append(order[id(c)])
+    mods = [None] * len(order)
+    for c in convs:
+        mods[order[id(c)]] = c
+    c0 = mods[0]
+    meta = (len(xs), len(mods), tuple(groups), tuple(c0.padding), tuple(c0.dilation))
+    return list(_ConvSplitTrain.apply(meta, *[m.weight for m in mods], *xs))
 
 
 def group_norm_act_multi_cl(xs, gn, relu=True, inplace=True):

@@ -272,3 +272,61 @@ def test_fpn_output_convolutions_one_layer_per_level(dev):
                 assert float((got[i] - lib[i]).abs().max()) <= 1e-4 * scale
             for i in range(used, neck.num_outs):                 # the extra levels do not depend on the output convolutions here
                 assert float((got[i] - lib[i]).abs().max()) <= 1e-4 * max(1.0, float(lib[i].abs().max()))
+
+
+def test_conv_split_train_gradients_vs_float64(dev):
+    """conv_split_train: one autograd node for the levels of a tower layer (one weight), the two towers' layer k (two
+    weights, first / second half of the tensors, the first layer reading the SAME tensors twice) and the FPN's output
+    convolutions (a weight per tensor): outputs, grad_input and grad_weight against torch's float64 convolution on the CPU
+    (grad_input = the same kernel with the flipped, transposed weights; grad_weight = the library's kernel per level)."""
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv_split_train, conv_split_train_ok
+    torch.manual_seed(17)
+    shapes = [(12, 10), (6, 5), (3, 3)]
+    B, C = 2, 128
+    convs = [nn.Conv2d(C, C, 3, padding=1, bias=False).to(dev) for _ in range(3)]
+    with torch.no_grad():
+        for c in convs:
+            c.weight.normal_(0, 0.04)
+    assert conv_split_train_ok(convs, torch.zeros(1, C, 4, 4, device=dev))
+
+    def reference(xs, mods, gos):
+        ws = {id(m): m.weight.detach().double().cpu().requires_grad_(True) for m in mods}
+        xr = {}
+        outs = []
+        for x, m in zip(xs, mods):
+            xd = xr.setdefault(id(x), x.detach().double().cpu().requires_grad_(True))
+            outs.append(F.conv2d(xd, ws[id(m)], padding=1))
+        loss = sum((o * g.double().cpu()).sum() for o, g in zip(outs, gos))
+        loss.backward()
+        return outs, xr, ws
+
+    def check(xs, mods):
+        xs_g = {}
+        ins = []
+        for x in xs:
+            ins.append(xs_g.setdefault(id(x), x.clone().requires_grad_(True)))
+        for m in mods:
+            m.weight.grad = None
+        outs = conv_split_train(ins, mods)
+        gos = [torch.randn_like(o) for o in outs]
+        sum((o * g).sum() for o, g in zip(outs, gos)).backward()
+        r_outs, r_x, r_w = reference(xs, mods, gos)
+        for o, r in zip(outs, r_outs):
+            assert o.is_contiguous() and _rel(o, r.detach()) <= 1e-5
+        for x in {id(x): x for x in xs}.values():
+            assert _rel(xs_g[id(x)].grad, r_x[id(x)].grad) <= 1e-5
+        for m in {id(m): m for m in mods}.values():
+            assert _rel(m.weight.grad, r_w[id(m)].grad) <= 1e-4
+
+    xs = [torch.randn(B, C, h, w, device=dev) for h, w in shapes]
+    check(xs, [convs[0]] * 3)                                        # one layer, all levels
+    check(xs + xs, [convs[0]] * 3 + [convs[1]] * 3)                  # two layers reading the same tensors (towers' layer 0)
+    ys = [torch.randn(B, C, h, w, device=dev) for h, w in shapes]
+    check(xs + ys, [convs[0]] * 3 + [convs[1]] * 3)                  # two layers, own inputs
+    check(xs, convs)                                                 # a layer per tensor (FPN)
+    # no gradient wanted for the inputs: still the weights'
+    for c in convs:
+        c.weight.grad = None
+    outs = conv_split_train([x.detach() for x in xs], convs[0])
+    sum(o.sum() for o in outs).backward()
+    assert convs[0].weight.grad is not None
