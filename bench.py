@@ -968,7 +968,7 @@ def main():
         avg_s = dcn_ms / dcn_n * 1e-3
         flops = layers * 2.0 * npos * cout * cin * 9
         alg_bytes = 4.0 * (layers * (npos * cin + 9 * cin * cout + npos * cout) + npos * 18)
-        mode = int(_lib.lib().orp_dcn_get_split_mode())          # 0 = exact-fp32 MFMA, 6 / 9 = bf16-split products per multiply
+        mode = int(_lib.lib().orp_dcn_get_split_mode())          # 0 = exact-fp32 MFMA, 6 / 9 = products of three bf16 pieces, 3 = two fp16 pieces
         pmc, pmc_note = load_pmc()
         d = pmc.get('dcn_fwd_split' if mode else 'dcn_fwd_pair', {}) if pmc else {}
         traffic = d.get('hbm_bytes_per_launch') if d and args.batch == d.get('batch') and IMG == d.get('img', 1024) else None
@@ -977,7 +977,7 @@ def main():
         # the SAME pair launch in the other arithmetic mode, on the same shapes (random feature maps), HIP events inside the
         # library around the kernel: so that both the figure of the instruction actually issued and the exact-fp32 figure
         # are in the line whichever mode the timed loops ran in
-        modes_us = dcn_pair_modes_us(dev, args.batch, IMG, (0, 6, 9))
+        modes_us = dcn_pair_modes_us(dev, args.batch, IMG, (0, 3, 6, 9))
         exact_us = modes_us.get(0)
         exact = dict(kernel='dcn_fwd_mfma2_kernel<3, nchw, 2 layers, tap-granular split>' if ksplit
                      else 'dcn_fwd_mfma2_kernel<3, nchw, 2 layers>', instruction='v_mfma_f32_32x32x2_f32',
@@ -995,18 +995,32 @@ def main():
                              'tests/checks/mfma_rate.hip); one launch per image = cls + refine DeformConv over all levels', **common)
         else:
             issued = mode * flops / avg_s / 1e12
+            f16 = mode == 3
+            by_mode = {str(k): (k * flops / (v * 1e-6) / 1e12 / BF16_MFMA_PEAK_TFLOPS) for k, v in modes_us.items() if k and v}
             roof = dict(kernel='dcn_fwd_split_kernel<MT 3, %d products, nchw, 2 layers as grid halves>' % mode, bound='mfma',
                         achieved=issued, peak=BF16_MFMA_PEAK_TFLOPS, frac=issued / BF16_MFMA_PEAK_TFLOPS,
-                        instruction='v_mfma_f32_32x32x16_bf16', products_per_fp32_multiply=mode,
+                        instruction='v_mfma_f32_32x32x16_f16' if f16 else 'v_mfma_f32_32x32x16_bf16',
+                        products_per_fp32_multiply=mode, frac_by_mode_back_to_back=by_mode,
                         frac_of_fp32_mfma_peak_equivalent=flops / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, exact_fp32=exact,
-                        note='fp32 tensors, fp32 accumulation; every fp32 operand split EXACTLY into three bf16 pieces and the '
-                             'product formed from %d partial products on the bf16 matrix pipe (csrc/orp_dcn_split.hip). '
-                             '`achieved` counts the bf16 MFMA flops actually issued (%d x the algorithmic fp32 flops) against '
-                             'the 2.5 PFLOP/s dense bf16 peak; `algorithmic_tflops` is the fp32-equivalent rate (the exact-'
-                             'fp32 MFMA kernel, kept as `exact_fp32`, cannot exceed 157.3). The kernel runs at the 1.4 kW '
-                             'socket power cap (2.14 GHz instead of 2.4; a register-operand microbenchmark of the instruction '
-                             'sustains 1.7-2.0 PFLOP/s there: tests/checks/mfma_rate_bf16.hip, clock_under_split.sh)'
-                             % (mode, mode), **common)
+                        note=('fp32 tensors, fp32 accumulation; every fp32 operand carried as TWO fp16 pieces (11 + 11 significant bits, '
+                              '|v - (hi + lo)| <= 2^-22 |v|, after an exact power-of-two range scaling from max |x| of the launch\'s '
+                              'inputs), the product formed from hi*hi + hi*lo + lo*hi on the 16-bit matrix pipe, each exact in the fp32 '
+                              'accumulator (csrc/orp_dcn_split.hip; error vs the fp64 oracle below the exact-fp32 kernel\'s own, '
+                              'tests/test_gpu_dcn_split.py). `achieved` counts the MFMA flops actually issued (3 x the algorithmic fp32 '
+                              'flops) against the 2.5 PFLOP/s dense peak: with half the matrix work of the six-product mode (three '
+                              'bf16 pieces, operands exact; `frac_by_mode_back_to_back`) the launch is no longer bound by the matrix '
+                              'pipe alone -- 55 us of it are outside the K loop (range pre-pass, coefficient tables, 45 MB of output '
+                              'stores) -- so `frac` is LOWER than in that mode while the launch is faster; `algorithmic_tflops` / '
+                              '`frac_of_fp32_mfma_peak_equivalent` are the fp32-equivalent rate (the exact-fp32 MFMA kernel, kept as '
+                              '`exact_fp32`, cannot exceed 157.3 TFLOP/s)') if f16 else
+                             ('fp32 tensors, fp32 accumulation; every fp32 operand split EXACTLY into three bf16 pieces and the '
+                              'product formed from %d partial products on the bf16 matrix pipe (csrc/orp_dcn_split.hip). '
+                              '`achieved` counts the bf16 MFMA flops actually issued (%d x the algorithmic fp32 flops) against '
+                              'the 2.5 PFLOP/s dense bf16 peak; `algorithmic_tflops` is the fp32-equivalent rate (the exact-'
+                              'fp32 MFMA kernel, kept as `exact_fp32`, cannot exceed 157.3). The kernel runs at the 1.4 kW '
+                              'socket power cap (2.14 GHz instead of 2.4; a register-operand microbenchmark of the instruction '
+                              'sustains 1.7-2.0 PFLOP/s there: tests/checks/mfma_rate_bf16.hip, clock_under_split.sh)'
+                              % (mode, mode)), **common)
     # the head's tower / FPN output convolutions on the same kernel (PLAIN instantiation, csrc/orp_conv_split.hip): per image
     # 3 pair launches (both towers' layer k) + the init branch's convolution over all five levels + the FPN's three output
     # convolutions in one launch; HIP events inside the library, summed over the step's launches
@@ -1020,6 +1034,7 @@ def main():
         us_step = cs_ms * 1e3 / dcn_n
         roof['tower_and_fpn_convolutions'] = dict(
             kernel='dcn_fwd_split_kernel<MT 3, %d products, PLAIN (no offsets)>' % mode, launches_per_step=per_step,
+            instruction='v_mfma_f32_32x32x16_f16' if mode == 3 else 'v_mfma_f32_32x32x16_bf16',
             us_per_step=us_step, algorithmic_flops_per_step=cflops, algorithmic_tflops=cflops / (us_step * 1e-6) / 1e12,
             achieved=mode * cflops / (us_step * 1e-6) / 1e12, peak=BF16_MFMA_PEAK_TFLOPS,
             frac=mode * cflops / (us_step * 1e-6) / 1e12 / BF16_MFMA_PEAK_TFLOPS,

@@ -473,7 +473,9 @@ int orp_conv3x3_small_multi_strided(const orp_norm_level* levels_host, const flo
  *   reg_convs, :107 reppoints_pts_init_conv; mmdet/ops/conv_module.py:130-140 `self.conv(x)`) -- kh x kw convolution of ALL FPN
  *   levels, ONE layer (weight_b_packed NULL) or TWO layers of equal shape (the two towers' layer k: grid halves of one
  *   launch), fp32 in / fp32 out / fp32 accumulation on the bf16 matrix pipe with every operand split exactly into three bf16
- *   pieces (nprod = 6 or 9 partial products; the DeformConv forward's kernel without offsets, orp_dcn_set_split_mode).
+ *   pieces (nprod = 6 or 9 partial products; the DeformConv forward's kernel without offsets, orp_dcn_set_split_mode), or
+ *   (nprod = 3) into two fp16 pieces after an exact power-of-two range scaling (products hi*hi, hi*lo, lo*hi; max |x| of the
+ *   inputs is taken by a pre-pass into `workspace`, >= 256 bytes of device memory, which nprod = 6 / 9 do not need).
  *   input_* : channels-last [B, H, W, Cin]; output_* : [B, Cout, Ho, Wo] (out_layout 0) or [B, Ho, Wo, Cout] (1);
  *   weight_*_packed: orp_dcn_pack_weight of the [Cout, Cin, kh, kw] weight; bias_* [Cout] or NULL; relu fused.
  *   orp_conv_split_ok: Cin % 64 == 0, Cout % 64 == 0, kh * kw <= 9.
@@ -484,14 +486,14 @@ int orp_conv_split_ok(int c_in, int c_out, int kh, int kw);
 int orp_conv_split_multi(const orp_conv_level* levels_host, int nlevels, int batch, int c_in, int c_out,
                          const float* weight_a_packed, const float* weight_b_packed, const float* bias_a, const float* bias_b,
                          int relu, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
-                         int out_layout, int nprod, void* stream);
+                         int out_layout, int nprod, void* workspace, size_t workspace_bytes, void* stream);
 /* one layer PER LEVEL (the FPN's output convolutions, mmdet/models/necks/fpn.py:150-153 `self.fpn_convs[i](laterals[i])`):
  * weights_packed_host[i] / biases_host[i] (biases_host or its entries may be NULL) belong to levels_host[i]; input_b / output_b
  * are ignored */
 int orp_conv_split_multi_ex(const orp_conv_level* levels_host, const float* const* weights_packed_host,
                             const float* const* biases_host, int nlevels, int batch, int c_in, int c_out, int relu, int kh, int kw,
                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int out_layout, int nprod,
-                            void* stream);
+                            void* workspace, size_t workspace_bytes, void* stream);
 int orp_nchw_to_nhwc_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -61,18 +61,23 @@ int orp_conv_split_ok(int c_in, int c_out, int kh, int kw) { return orp_split::s
 static int conv_split_impl(const orp_conv_level* levels_host, const float* const* weights_host, const float* const* biases_host,
                            int nlevels, int batch, int c_in, int c_out, const float* weight_a_packed, const float* weight_b_packed,
                            const float* bias_a, const float* bias_b, int relu, int kh, int kw, int stride_h, int stride_w,
-                           int pad_h, int pad_w, int dil_h, int dil_w, int out_layout, int nprod, void* stream) {
+                           int pad_h, int pad_w, int dil_h, int dil_w, int out_layout, int nprod, void* workspace,
+                           size_t workspace_bytes, void* stream) {
   if (!levels_host || nlevels <= 0 || nlevels > orp_split::kMaxLevels || batch <= 0 || !weight_a_packed) return ORP_EINVAL;
-  if (!orp_split::shape_ok(c_in, c_out, kh, kw) || (nprod != 6 && nprod != 9) || (out_layout != 0 && out_layout != 1))
+  if (!orp_split::shape_ok(c_in, c_out, kh, kw) || (nprod != 3 && nprod != 6 && nprod != 9) || (out_layout != 0 && out_layout != 1))
     return ORP_EINVAL;
+  if (nprod == 3 && (!workspace || workspace_bytes < 256)) return ORP_EWORKSPACE;      // max |x| of the inputs lives there
   if (stride_h <= 0 || stride_w <= 0 || dil_h <= 0 || dil_w <= 0 || pad_h < 0 || pad_w < 0) return ORP_EINVAL;
   const int nconv = weight_b_packed ? 2 : 1;
   orp_split::Args A;
   A.nlev = nlevels; A.B = batch; A.Cin = c_in; A.Cout = c_out;
   A.kh = kh; A.kw = kw; A.sh = stride_h; A.sw = stride_w; A.ph = pad_h; A.pw = pad_w; A.dh = dil_h; A.dw = dil_w;
-  const size_t plane_off = (size_t)2 * kh * kw * c_in * c_out;          // orp_dcn_pack_weight: the planes follow the fp32 packings
-  A.planes[0] = reinterpret_cast<const uint16_t*>(weight_a_packed + plane_off);
-  A.planes[1] = nconv == 2 ? reinterpret_cast<const uint16_t*>(weight_b_packed + plane_off) : A.planes[0];
+  const int taps = kh * kw;                                             // orp_dcn_pack_weight: the planes follow the fp32 packings
+  A.planes[0] = orp_split::planes_of(weight_a_packed, c_out, c_in, taps, nprod);
+  A.planes[1] = nconv == 2 ? orp_split::planes_of(weight_b_packed, c_out, c_in, taps, nprod) : A.planes[0];
+  A.wscale[0] = orp_split::wscale_of(weight_a_packed, c_out, c_in, taps);
+  A.wscale[1] = nconv == 2 ? orp_split::wscale_of(weight_b_packed, c_out, c_in, taps) : A.wscale[0];
+  A.scratch = nprod == 3 ? reinterpret_cast<unsigned*>(workspace) : nullptr;
   A.bias[0] = bias_a; A.bias[1] = nconv == 2 ? bias_b : bias_a;
   A.relu = relu ? 1 : 0; A.nconv = nconv; A.out_nchw = out_layout == 0 ? 1 : 0; A.nprod = nprod;
   for (int i = 0; i < nlevels; i++) {
@@ -83,10 +88,11 @@ static int conv_split_impl(const orp_conv_level* levels_host, const float* const
     orp_split::Level& S = A.lv[i];
     S.x[0] = lv.input_a; S.x[1] = nconv == 2 ? lv.input_b : lv.input_a;
     S.off = nullptr; S.mask = nullptr;
-    S.planes = nullptr; S.bias = nullptr;
+    S.planes = nullptr; S.bias = nullptr; S.wscale = nullptr;
     if (weights_host) {                                                   // a layer of its own for this level
       if (!weights_host[i]) return ORP_EINVAL;
-      S.planes = reinterpret_cast<const uint16_t*>(weights_host[i] + plane_off);
+      S.planes = orp_split::planes_of(weights_host[i], c_out, c_in, taps, nprod);
+      S.wscale = orp_split::wscale_of(weights_host[i], c_out, c_in, taps);
       S.bias = biases_host ? biases_host[i] : nullptr;
     }
     S.out[0] = lv.output_a; S.out[1] = nconv == 2 ? lv.output_b : lv.output_a;
@@ -103,19 +109,20 @@ static int conv_split_impl(const orp_conv_level* levels_host, const float* const
 int orp_conv_split_multi(const orp_conv_level* levels_host, int nlevels, int batch, int c_in, int c_out,
                          const float* weight_a_packed, const float* weight_b_packed, const float* bias_a, const float* bias_b,
                          int relu, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
-                         int out_layout, int nprod, void* stream) {
+                         int out_layout, int nprod, void* workspace, size_t workspace_bytes, void* stream) {
   return conv_split_impl(levels_host, nullptr, nullptr, nlevels, batch, c_in, c_out, weight_a_packed, weight_b_packed, bias_a,
-                         bias_b, relu, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, out_layout, nprod, stream);
+                         bias_b, relu, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, out_layout, nprod, workspace,
+                         workspace_bytes, stream);
 }
 
 int orp_conv_split_multi_ex(const orp_conv_level* levels_host, const float* const* weights_packed_host,
                             const float* const* biases_host, int nlevels, int batch, int c_in, int c_out, int relu, int kh, int kw,
                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int out_layout, int nprod,
-                            void* stream) {
+                            void* workspace, size_t workspace_bytes, void* stream) {
   if (!weights_packed_host || nlevels <= 0) return ORP_EINVAL;
   return conv_split_impl(levels_host, weights_packed_host, biases_host, nlevels, batch, c_in, c_out, weights_packed_host[0],
                          nullptr, nullptr, nullptr, relu, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, out_layout,
-                         nprod, stream);
+                         nprod, workspace, workspace_bytes, stream);
 }
 
 int orp_nchw_to_nhwc_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, void* stream) {

@@ -994,21 +994,25 @@ size_t orp_dcn_packed_weight_floats(int c_out, int c_in, int kh, int kw) {
   return 2 * n + (orp_split::shape_ok(c_in, c_out, kh, kw) ? (orp_split::plane_elems(c_out, c_in, kh * kw) + 1) / 2 : 0);
 }
 
-// fp32-by-bf16-splitting path (orp_dcn_split.hip): 0 = off (exact fp32 MFMA), 6 / 9 = partial products per operand pair.
-// Default 6 since round 4 (its error against the fp64-accumulated oracle is below the exact-fp32 path's own on every test
-// shape, tests/test_gpu_dcn_split.py; 483 -> 333 us for the head's pair launch); the environment overrides it
-// (ORP_DCN_SPLIT = 0 | 1 (= 6) | 6 | 9), orp_dcn_set_split_mode() overrides both.
+// fp32-by-splitting path (orp_dcn_split.hip): 0 = off (exact fp32 MFMA); 6 / 9 = partial products of three bf16 pieces per
+// operand pair (operands represented exactly); 3 = two fp16 pieces per operand (11 + 11 bits: 2^-22 relative, after an exact
+// power-of-two range scaling from max |x| of the launch's inputs), products hi*hi, hi*lo, lo*hi -- needs scratch in the
+// workspace and no modulation mask, else the call runs as mode 6.
+// Default 3 since round 4: on every test shape its error against the fp64-accumulated oracle is below the exact-fp32 path's
+// own (three accumulator roundings per 16 channels instead of eight: tests/test_gpu_dcn_split.py prints all four modes), the
+// head's pair launch takes 483 (mode 0) -> 333 (6) -> 255 us (3).  The environment overrides it (ORP_DCN_SPLIT = 0 | 3 |
+// 6 (or 1) | 9), orp_dcn_set_split_mode() overrides both.
 static int g_split_mode = -1;
 static int split_mode() {
   if (g_split_mode < 0) {
     const char* e = getenv("ORP_DCN_SPLIT");
-    const int v = e ? atoi(e) : 6;
-    g_split_mode = v == 9 ? 9 : (v == 1 || v == 6) ? 6 : 0;
+    const int v = e ? atoi(e) : 3;
+    g_split_mode = v == 9 ? 9 : v == 3 ? 3 : (v == 1 || v == 6) ? 6 : 0;
   }
   return g_split_mode;
 }
 int orp_dcn_set_split_mode(int mode) {
-  if (mode != 0 && mode != 6 && mode != 9 && mode != -1) return ORP_EINVAL;
+  if (mode != 0 && mode != 3 && mode != 6 && mode != 9 && mode != -1) return ORP_EINVAL;
   g_split_mode = mode;                                   // -1: back to the environment's choice
   return ORP_OK;
 }
@@ -1143,17 +1147,23 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
     orp_split::Args A;
     A.nlev = nlevels; A.B = batch; A.Cin = c_in; A.Cout = c_out;
     A.kh = kh; A.kw = kw; A.sh = stride_h; A.sw = stride_w; A.ph = pad_h; A.pw = pad_w; A.dh = dil_h; A.dw = dil_w;
-    const size_t plane_off = (size_t)2 * kh * kw * c_in * c_out;
-    A.planes[0] = reinterpret_cast<const uint16_t*>(weight_packed + plane_off);
-    A.planes[1] = weight2_packed ? reinterpret_cast<const uint16_t*>(weight2_packed + plane_off) : A.planes[0];
+    int mode = split_mode();
+    char* scratch = reinterpret_cast<char*>(align256_(reinterpret_cast<size_t>(wsp)));
+    if (mode == 3 && (masks_host || !workspace || scratch + 256 > ws_end)) mode = 6;
+    const int taps_ = kh * kw;
+    A.planes[0] = orp_split::planes_of(weight_packed, c_out, c_in, taps_, mode);
+    A.planes[1] = weight2_packed ? orp_split::planes_of(weight2_packed, c_out, c_in, taps_, mode) : A.planes[0];
+    A.wscale[0] = orp_split::wscale_of(weight_packed, c_out, c_in, taps_);
+    A.wscale[1] = weight2_packed ? orp_split::wscale_of(weight2_packed, c_out, c_in, taps_) : A.wscale[0];
+    A.scratch = mode == 3 ? reinterpret_cast<unsigned*>(scratch) : nullptr;
     A.bias[0] = bias; A.bias[1] = bias2;
-    A.relu = relu ? 1 : 0; A.nconv = nconv; A.out_nchw = out_layout == 0 ? 1 : 0; A.nprod = split_mode();
+    A.relu = relu ? 1 : 0; A.nconv = nconv; A.out_nchw = out_layout == 0 ? 1 : 0; A.nprod = mode;
     for (int i = 0; i < nlevels; i++) {
       const LevelDesc& D = P.lv[i];
       orp_split::Level& S = A.lv[i];
       S.x[0] = D.x; S.x[1] = D.x2; S.off = D.off; S.mask = D.mask; S.out[0] = D.out; S.out[1] = D.out2;
       S.H = D.H; S.W = D.W; S.Ho = D.Ho; S.Wo = D.Wo;
-      S.planes = nullptr; S.bias = nullptr;
+      S.planes = nullptr; S.bias = nullptr; S.wscale = nullptr;
     }
     OrpProfScope prof(ORP_PROF_DCN_FWD, st);
     const hipError_t se = orp_split::launch(A, st);

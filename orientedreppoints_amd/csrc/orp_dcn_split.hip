@@ -62,6 +62,9 @@
 #ifndef ORP_DCNS_SIDE_ACC
 #define ORP_DCNS_SIDE_ACC 1          // PLAIN instantiation: second accumulator set for the small partial products (see Products)
 #endif
+#ifndef ORP_DCNS_CC
+#define ORP_DCNS_CC 0                // dev aid: number of trailing chunks that carry the combine (0: the rule in the kernel)
+#endif
 #ifndef ORP_DCNS_INTERLEAVE
 #define ORP_DCNS_INTERLEAVE 4        // VALU instructions of the combine pinned behind every MFMA of the chunk that carries it (0: scheduler's choice)
 #endif
@@ -70,7 +73,9 @@ namespace orp_split {
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));     // one MFMA operand: 8 k-values (of either 16-bit format: see F16)
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int kTapsMax = 9;
 constexpr int CBS = 64;            // input channels per phase
@@ -85,8 +90,9 @@ struct LevelK {
   float* out[2];
   int H, W, Ho, Wo;
   int tile0;
-  const uint16_t* planes;         // this level's own layer (or nullptr: FwdS::planes / bias)
+  const uint16_t* planes;         // this level's own layer (or nullptr: FwdS::planes / bias / wscale)
   const float* bias;
+  const float* wscale;
 };
 struct FwdS {
   LevelK lv[kMaxLevels];
@@ -96,6 +102,8 @@ struct FwdS {
   const float* bias[2];
   int relu, nconv;
   size_t plane_stride;            // elements between two planes of a layer
+  const float* wscale[2];         // F16: the power of two the layer's weights were multiplied by at pack time (device scalar)
+  const unsigned* amax;           // F16: [2] bits of max |x| over the inputs of layer 0 / 1 (device, written by absmax_kernel)
 };
 
 // w [o][c][tap] fp32 -> three bf16 planes [pl][tap][c/16][kg][o][8]  (kg = (c % 16) / 8, e = c % 8), exact truncation split
@@ -119,6 +127,64 @@ __global__ void pack_planes_kernel(const float* __restrict__ w, int cout, int ci
   }
 }
 
+// max |x| over up to kAbsMaxT tensors, as float bits (monotonic for non-negative values), into out[slot of the tensor]
+constexpr int kAbsMaxT = 2 * kMaxLevels;
+struct AbsMaxArgs {
+  const float* x[kAbsMaxT];
+  size_t n[kAbsMaxT];
+  int slot[kAbsMaxT];
+  int bx0[kAbsMaxT + 1];
+  int count;
+};
+__global__ void __launch_bounds__(256)
+absmax_kernel(const AbsMaxArgs A, unsigned* __restrict__ out) {
+  __shared__ unsigned red[4];
+  int t = 0;
+#pragma unroll 1
+  for (int i = 1; i < A.count; i++) if ((int)blockIdx.x >= A.bx0[i]) t = i;
+  const float* x = A.x[t];
+  const size_t n = A.n[t];
+  const int nb = A.bx0[t + 1] - A.bx0[t], b = (int)blockIdx.x - A.bx0[t];
+  unsigned m = 0u;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)b * 256 + threadIdx.x; i < n4; i += (size_t)nb * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
+            max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+  }
+  if (b == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(x[(n4 << 2) + threadIdx.x]) & 0x7fffffffu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out + A.slot[t], max(max(red[0], red[1]), max(red[2], red[3])));
+}
+
+// w [o][c][tap] fp32 -> two fp16 planes [pl][tap][c/16][kg][o][8] of w * 2^k, k from amax = max |w| (float bits) so that the
+// largest magnitude lands in [2^14, 2^15); wscale[0] = 2^k
+__global__ void pack_planes16_kernel(const float* __restrict__ w, int cout, int cin, int taps, const unsigned* __restrict__ amax,
+                                     uint16_t* __restrict__ planes, float* __restrict__ wscale) {
+  const unsigned am = *amax;
+  int k = am == 0u ? 0 : 14 - ((int)((am >> 23) & 0xffu) - 127);
+  k = k < -100 ? -100 : k > 100 ? 100 : k;
+  const float sc = __uint_as_float((unsigned)(127 + k) << 23);
+  if (blockIdx.x == 0 && threadIdx.x == 0) wscale[0] = sc;
+  const long total = (long)cout * cin * taps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7);
+    long r = i >> 3;
+    const int o = (int)(r % cout); r /= cout;
+    const int kg = (int)(r & 1); r >>= 1;
+    const int cblk = (int)(r % (cin / 16)), tap = (int)(r / (cin / 16));
+    const int c = cblk * 16 + kg * 8 + e;
+    const float v = w[((long)o * cin + c) * taps + tap] * sc;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    planes[i] = __builtin_bit_cast(uint16_t, hi);
+    planes[total + i] = __builtin_bit_cast(uint16_t, lo);
+  }
+}
+
 // two fp32 values whose low 16 bits are zero (or may be dropped) -> one dword of two bf16: (a >> 16) | (b & 0xffff0000)
 __device__ __forceinline__ unsigned pack_hi16(float a, float b) {
   return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
@@ -128,28 +194,37 @@ __device__ __forceinline__ unsigned pack_hi16(float a, float b) {
 // loop indexes registers with compile-time constants (a constexpr array would be materialised in scratch memory)
 __device__ __forceinline__ constexpr int prod_a(int t) { const int tab[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}; return tab[t]; }
 __device__ __forceinline__ constexpr int prod_b(int t) { const int tab[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}; return tab[t]; }
+// F16 (two fp16 pieces, 0 = hi, 1 = lo): lo * hi, hi * lo, hi * hi
+__device__ __forceinline__ constexpr int prod_a16(int t) { const int tab[3] = {1, 0, 0}; return tab[t]; }
+__device__ __forceinline__ constexpr int prod_b16(int t) { const int tab[3] = {0, 1, 0}; return tab[t]; }
 
 // SIDE: the small partial products (everything but hi * hi) go to a second accumulator set that is added once in the
-// epilogue -- the main chain then rounds once per 16 channels at the output's magnitude instead of 6 (9) times, and the
-// roundings of the side chain happen 2^-8 further down (PLAIN instantiation: the registers are there)
-template <int T, int TEND, int MT, bool OUT_NCHW, bool SIDE>
+// epilogue -- the main chain then rounds once per 16 channels at the output's magnitude instead of 3 (6, 9) times, and the
+// roundings of the side chain happen 2^-8 (2^-11) further down (PLAIN instantiation: the registers are there)
+template <int T, int TEND, int MT, bool OUT_NCHW, bool SIDE, bool F16>
 struct Products {
   static __device__ __forceinline__ void run(floatx16 (&acc)[MT], floatx16 (&side)[SIDE ? MT : 1], const bf8 (&a)[MT][3],
                                              const bf8 (&b)[3]) {
-    constexpr int pa = prod_a(T), pb = prod_b(T);
-    constexpr bool to_side = SIDE && T != 8;
+    constexpr int pa = F16 ? prod_a16(T) : prod_a(T), pb = F16 ? prod_b16(T) : prod_b(T);
+    constexpr bool to_side = SIDE && T != TEND - 1;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
       if (ORP_DCNS_DBG & 4) { acc[mt][0] += (float)a[mt][pa][0] * (float)b[pb][0]; continue; }
       floatx16& d = to_side ? side[mt] : acc[mt];
-      if (OUT_NCHW) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[pb], a[mt][pa], d, 0, 0, 0);   // D[channel][position]
-      else          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][pa], b[pb], d, 0, 0, 0);   // D[position][channel]
+      if (F16) {
+        const h8 av = __builtin_bit_cast(h8, a[mt][pa]), bv = __builtin_bit_cast(h8, b[pb]);
+        if (OUT_NCHW) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, d, 0, 0, 0);
+        else          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, d, 0, 0, 0);
+      } else {
+        if (OUT_NCHW) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[pb], a[mt][pa], d, 0, 0, 0);   // D[channel][position]
+        else          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][pa], b[pb], d, 0, 0, 0);   // D[position][channel]
+      }
     }
-    Products<T + 1, TEND, MT, OUT_NCHW, SIDE>::run(acc, side, a, b);
+    Products<T + 1, TEND, MT, OUT_NCHW, SIDE, F16>::run(acc, side, a, b);
   }
 };
-template <int TEND, int MT, bool OUT_NCHW, bool SIDE>
-struct Products<TEND, TEND, MT, OUT_NCHW, SIDE> {
+template <int TEND, int MT, bool OUT_NCHW, bool SIDE, bool F16>
+struct Products<TEND, TEND, MT, OUT_NCHW, SIDE, F16> {
   static __device__ __forceinline__ void run(floatx16 (&)[MT], floatx16 (&)[SIDE ? MT : 1], const bf8 (&)[MT][3], const bf8 (&)[3]) {}
 };
 
@@ -160,9 +235,16 @@ __global__ void __launch_bounds__(kThreadsS)
 dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   constexpr int BMS = 32 * MT;
   constexpr int PLANE = BMS * ASTRS;                                          // elements of one plane of one buffer
+  // NPROD = 3: TWO fp16 pieces per operand (11 + 11 significant bits: |v - (hi + lo)| <= 2^-22 |v|), products hi*hi, hi*lo,
+  // lo*hi, each exact in the fp32 accumulator; the dropped lo*lo <= 2^-22 |v w|.  fp16 has 5 exponent bits, so both operands
+  // are first multiplied by a power of two that puts their tensor's largest magnitude at 2^14..2^15 (exact; the weights at
+  // pack time, the samples here from amax = max |x| over the launch's inputs) and the sum is scaled back in the epilogue.
+  // Measured representation error 8e-8 of the output scale against 5e-7 .. 9e-7 of the fp32 accumulation itself.
+  constexpr bool F16 = NPROD == 3;
+  constexpr int NPL = F16 ? 2 : 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint16_t* sA = reinterpret_cast<uint16_t*>(smem);                           // [2 buffers][3 planes][BMS][ASTRS]
-  float4* sCw = reinterpret_cast<float4*>(sA + 2 * 3 * PLANE);                // [BMS * taps] bilinear weights
+  uint16_t* sA = reinterpret_cast<uint16_t*>(smem);                           // [2 buffers][NPL planes][BMS][ASTRS]
+  float4* sCw = reinterpret_cast<float4*>(sA + 2 * NPL * PLANE);              // [BMS * taps] bilinear weights
   int4* sCi = reinterpret_cast<int4*>(sCw + BMS * kTapsMax);                  // [BMS * taps] pixel indices
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -185,6 +267,15 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   const long npos = (long)P.B * HoWo;
   const long p0 = (long)(tile - L.tile0) * BMS;
   const float* xin = conv ? L.x[1] : L.x[0];
+  float sx = 1.f, osc = 1.f;                                                  // F16: sample scale 2^k, output scale 1 / (sx * sw)
+  if (F16) {
+    const unsigned am = P.amax[conv];
+    int k = am == 0u ? 0 : 14 - ((int)((am >> 23) & 0xffu) - 127);
+    k = k < -100 ? -100 : k > 100 ? 100 : k;
+    sx = __uint_as_float((unsigned)(127 + k) << 23);
+    const float sw = *(L.planes ? L.wscale : conv ? P.wscale[1] : P.wscale[0]);
+    osc = 1.f / (sx * sw);
+  }
 
   // ---- bilinear coefficient table, one entry per (position, tap): deformable_im2col_bilinear (:84-115) hoisted out of the
   //      channel loop; a sample outside (-1, H) x (-1, W) has weight 0 (:229); DCNv2 folds the modulation scalar in (:620) ----
@@ -267,6 +358,20 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       s[2] = bil(v[0].z, v[1].z, v[2].z, v[3].z);
       s[3] = bil(v[0].w, v[1].w, v[2].w, v[3].w);
     }
+    uint16_t* dst = sA + (size_t)buf * NPL * PLANE + (size_t)m * ASTRS + c4;
+    if (F16) {
+      _Float16 h[4], l[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float sv = s[i] * sx;                                             // exact (power of two)
+        h[i] = (_Float16)sv;                                                    // round to nearest
+        l[i] = (_Float16)(sv - (float)h[i]);                                    // the residual is exact in fp32
+      }
+      const h2 h01 = {h[0], h[1]}, h23 = {h[2], h[3]}, l01 = {l[0], l[1]}, l23 = {l[2], l[3]};
+      *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+      *reinterpret_cast<uint2*>(dst + PLANE) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+      return;
+    }
     float hi[4], mid[4], lo[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -275,7 +380,6 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       mid[i] = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
       lo[i] = r1 - mid[i];                                                     // exact, <= 8 significant bits
     }
-    uint16_t* dst = sA + (size_t)buf * 3 * PLANE + (size_t)m * ASTRS + c4;
     *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]));
     *reinterpret_cast<uint2*>(dst + PLANE) = make_uint2(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]));
     *reinterpret_cast<uint2*>(dst + 2 * PLANE) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
@@ -289,7 +393,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   auto load_b = [&](int tap, int cb, int j, bf8 (&b)[3]) {
     const uint16_t* a = wp + ((size_t)tap * (P.Cin / 16) + cb * NCH + j) * wblk;
 #pragma unroll
-    for (int pl = 0; pl < 3; pl++) b[pl] = *reinterpret_cast<const bf8*>(a + (size_t)pl * P.plane_stride);
+    for (int pl = 0; pl < NPL; pl++) b[pl] = *reinterpret_cast<const bf8*>(a + (size_t)pl * P.plane_stride);
   };
 
   // ---- prologue: weight ring and A tile of phase 0 -------------------------------------------------------------------------
@@ -325,7 +429,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-      for (int pl = 0; pl < 3; pl++)
+      for (int pl = 0; pl < NPL; pl++)
         if (!(ORP_DCNS_DBG & 16)) a[mt][pl] = *reinterpret_cast<const bf8*>(abase + (size_t)pl * PLANE + (size_t)mt * 32 * ASTRS + j * 16);
   };
 
@@ -339,7 +443,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     // (the scheduler would otherwise SINK these loads down to their use to save registers -- measured in the ISA: the
     //  gathers ended up between the last MFMAs with s_waitcnt vmcnt(0) right behind them; the barriers pin the pipeline)
     __builtin_amdgcn_sched_barrier(0);
-    const uint16_t* abase = sA + (size_t)cur * 3 * PLANE + (size_t)mrow * ASTRS + 8 * kg;
+    const uint16_t* abase = sA + (size_t)cur * NPL * PLANE + (size_t)mrow * ASTRS + 8 * kg;
     // (2) the phase: the A fragments of chunk j + 1 are read from LDS BEFORE the MFMAs of chunk j are issued (a second
     //     register set), the weight registers of chunk j are refilled for the next phase right after use
     bf8 a[2][MT][3];
@@ -366,9 +470,16 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       //     (nobody reads it before the barrier below; everybody finished reading it before the barrier that ended the
       //     previous phase): ~70 VALU per row group that the scheduler can place in the shadow of the region's MFMAs
       //     (a 32-cycle MFMA leaves ~5 issue slots) instead of a VALU-only tail during which the matrix pipe idles
-      const bool with_combine = ORP_DCNS_COMBINE_IN_LAST && j >= NCH - MT;       // row group j - (NCH - MT) rides in chunk j
-      if (with_combine) combine_store(tap_n, j - (NCH - MT), g[j - (NCH - MT)], cur ^ 1);
-      Products<9 - NPROD, 9, MT, OUT_NCHW, SIDE>::run(acc, side, a[j & 1], bq[j]);
+      //     The row groups ride in the LAST CC chunks, one each (CC = MT).  (All of them in the last chunk, so that the
+      //     gathers have three chunks to land instead of one, measured no faster with fp16 pieces: 211 vs 200 us.)
+      constexpr int CC = (ORP_DCNS_CC > 0) ? (ORP_DCNS_CC < MT ? ORP_DCNS_CC : MT) : MT;
+      const bool with_combine = ORP_DCNS_COMBINE_IN_LAST && j >= NCH - CC;
+      if (with_combine) {
+#pragma unroll
+        for (int r = 0; r < MT; r++)
+          if (r * CC / MT == j - (NCH - CC)) combine_store(tap_n, r, g[r], cur ^ 1);
+      }
+      Products<F16 ? 0 : 9 - NPROD, F16 ? 3 : 9, MT, OUT_NCHW, SIDE, F16>::run(acc, side, a[j & 1], bq[j]);
 #if ORP_DCNS_DRAIN & 2
       __builtin_amdgcn_sched_barrier(0);
       { float t_; 
@@ -383,11 +494,12 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       if (!(ORP_DCNS_DBG & 2)) load_b(tap_n, cb_n, j, bq[j]);
 #endif
       if (with_combine && ORP_DCNS_INTERLEAVE > 0) {
-        // pin the interleave: one MFMA, then ORP_DCNS_INTERLEAVE VALU of the combine in its 32-cycle shadow, ...
+        // pin the interleave: one MFMA, then the chunk's share of the combine's VALU in its 32-cycle shadow, ...
+        constexpr int kGroups = (MT + CC - 1) / CC;
 #pragma unroll
         for (int i = 0; i < NPROD * MT; i++) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, ORP_DCNS_INTERLEAVE, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, ORP_DCNS_INTERLEAVE * kGroups, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -411,7 +523,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   }
   const float* bias = L.planes ? L.bias : conv ? P.bias[1] : P.bias[0];
   float* outp = conv ? L.out[1] : L.out[0];
-  auto finish = [&](float v, int ch) { if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
+  auto finish = [&](float v, int ch) { if (F16) v *= osc; if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
 #pragma unroll
   for (int mt = 0; mt < MT; mt++) {
     if (OUT_NCHW) {
@@ -436,8 +548,8 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   }
 }
 
-template <int MT>
-constexpr size_t split_smem() { return (size_t)2 * 3 * 32 * MT * ASTRS * 2 + (sizeof(float4) + sizeof(int4)) * 32 * MT * kTapsMax; }
+template <int MT, int NPL>
+constexpr size_t split_smem() { return (size_t)2 * NPL * 32 * MT * ASTRS * 2 + (sizeof(float4) + sizeof(int4)) * 32 * MT * kTapsMax; }
 
 template <int MT, int NPROD, bool OUT_NCHW, bool PLAIN>
 hipError_t launch_one(const FwdS& P, int tiles, int nblk_n, hipStream_t st) {
@@ -446,7 +558,8 @@ hipError_t launch_one(const FwdS& P, int tiles, int nblk_n, hipStream_t st) {
   // ORP_DCNS_DRAIN that configuration produced wrong rows (see there), with it both residencies are bit-stable under soak
   // (tests/checks/soak_dcn_split.py) and the shared one is 1-2 % faster on multi-round launches.
   static const int pad_env = getenv("ORP_DCNS_PAD_LDS") ? atoi(getenv("ORP_DCNS_PAD_LDS")) : 0;
-  const size_t smem = split_smem<MT>() < (size_t)pad_env * 1024 ? (size_t)pad_env * 1024 : split_smem<MT>();
+  constexpr size_t need = split_smem<MT, NPROD == 3 ? 2 : 3>();
+  const size_t smem = need < (size_t)pad_env * 1024 ? (size_t)pad_env * 1024 : need;
   struct Tag {};
   hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_split_kernel<MT, NPROD, OUT_NCHW, PLAIN>), smem);
   if (e != hipSuccess) return e;
@@ -474,12 +587,35 @@ bool shape_ok(int c_in, int c_out, int kh, int kw) {
   return kh * kw <= kTapsMax && c_in % CBS == 0 && c_in >= CBS && c_out % 64 == 0 && c_out >= 64;
 }
 
-size_t plane_elems(int c_out, int c_in, int taps) { return (size_t)3 * c_out * c_in * taps; }
+// one layer's planes in uint16_t elements: three bf16 planes, then two fp16 planes, then 8 elements that hold the fp16
+// planes' scale (a float) and the weights' max |w| (float bits): [3N bf16][2N fp16][scale, amax, pad]
+size_t plane_elems(int c_out, int c_in, int taps) { return (size_t)5 * c_out * c_in * taps + 8; }
+
+const uint16_t* planes_of(const float* packed, int c_out, int c_in, int taps, int nprod) {
+  const size_t n = (size_t)c_out * c_in * taps;
+  const uint16_t* base = reinterpret_cast<const uint16_t*>(packed + 2 * n);
+  return nprod == 3 ? base + 3 * n : base;
+}
+const float* wscale_of(const float* packed, int c_out, int c_in, int taps) {
+  const size_t n = (size_t)c_out * c_in * taps;
+  return reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(packed + 2 * n) + 5 * n);
+}
 
 hipError_t pack_planes(const float* weight, int c_out, int c_in, int taps, uint16_t* planes, hipStream_t st) {
   const long total = (long)c_out * c_in * taps;
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_planes_kernel, dim3(blocks), dim3(256), 0, st, weight, c_out, c_in, taps, planes);
+  // the fp16 planes: max |w| -> scale -> two planes
+  float* tail = reinterpret_cast<float*>(planes + 5 * total);              // [0] scale, [1] max |w| bits
+  unsigned* amax = reinterpret_cast<unsigned*>(tail + 1);
+  hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned), st);
+  if (e != hipSuccess) return e;
+  AbsMaxArgs M;
+  long nb = (total / 4 + 256 * 8 - 1) / (256 * 8); if (nb < 1) nb = 1; if (nb > 512) nb = 512;
+  for (int i = 0; i < kAbsMaxT; i++) { M.x[i] = weight; M.n[i] = i == 0 ? (size_t)total : 0; M.slot[i] = 0; M.bx0[i] = i == 0 ? 0 : (int)nb; }
+  M.bx0[kAbsMaxT] = (int)nb; M.count = 1;
+  hipLaunchKernelGGL(absmax_kernel, dim3((int)nb), dim3(256), 0, st, M, amax);
+  hipLaunchKernelGGL(pack_planes16_kernel, dim3(blocks), dim3(256), 0, st, weight, c_out, c_in, taps, amax, planes + 3 * total, tail);
   return hipGetLastError();
 }
 
@@ -512,7 +648,7 @@ hipError_t launch(const Args& a, hipStream_t st) {
     D.x[0] = a.lv[i].x[0]; D.x[1] = a.lv[i].x[1]; D.off = a.lv[i].off; D.mask = a.lv[i].mask;
     D.out[0] = a.lv[i].out[0]; D.out[1] = a.lv[i].out[1];
     D.H = a.lv[i].H; D.W = a.lv[i].W; D.Ho = a.lv[i].Ho; D.Wo = a.lv[i].Wo;
-    D.planes = a.nconv == 1 ? a.lv[i].planes : nullptr; D.bias = a.lv[i].bias;
+    D.planes = a.nconv == 1 ? a.lv[i].planes : nullptr; D.bias = a.lv[i].bias; D.wscale = a.lv[i].wscale;
     D.tile0 = tiles;
     tiles += (int)(((long)a.B * D.Ho * D.Wo + 32 * MT - 1) / (32 * MT));
   }
@@ -521,6 +657,31 @@ hipError_t launch(const Args& a, hipStream_t st) {
   bool plain = a.lv[0].off == nullptr;                   // no offsets anywhere: the ordinary convolution
   for (int i = 0; i < a.nlev; i++)
     if ((a.lv[i].off == nullptr) != plain || (plain && a.lv[i].mask)) return hipErrorInvalidValue;
+  if (a.nprod == 3) {
+    // fp16 pieces: max |x| of the launch's inputs first (one slot per layer; a pair launch reading the same tensors
+    // twice gets the same value in both), into the caller's scratch
+    if (!a.scratch || !a.wscale[0] || (a.nconv == 2 && !a.wscale[1])) return hipErrorInvalidValue;
+    for (int i = 0; i < a.nlev; i++) if (a.lv[i].mask) return hipErrorInvalidValue;     // a modulation scalar has no known range
+    AbsMaxArgs M;
+    int bx = 0, cnt = 0;
+    for (int cv = 0; cv < a.nconv; cv++)
+      for (int i = 0; i < a.nlev; i++) {
+        M.x[cnt] = a.lv[i].x[cv]; M.n[cnt] = (size_t)a.B * a.lv[i].H * a.lv[i].W * a.Cin; M.slot[cnt] = cv; M.bx0[cnt] = bx;
+        long nb = (long)((M.n[cnt] / 4 + 256 * 8 - 1) / (256 * 8)); if (nb < 1) nb = 1; if (nb > 512) nb = 512;
+        bx += (int)nb; cnt++;
+      }
+    for (int i = cnt; i <= kAbsMaxT; i++) M.bx0[i] = bx;
+    for (int i = cnt; i < kAbsMaxT; i++) { M.x[i] = M.x[0]; M.n[i] = 0; M.slot[i] = 0; }
+    M.count = cnt;
+    hipError_t e = hipMemsetAsync(a.scratch, 0, 2 * sizeof(unsigned), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(absmax_kernel, dim3(bx), dim3(256), 0, st, M, a.scratch);
+    P.amax = a.scratch;
+    P.wscale[0] = a.wscale[0]; P.wscale[1] = a.nconv == 2 ? a.wscale[1] : a.wscale[0];
+    return plain ? launch_m<3, true>(MT, P, tiles, nblk_n, a.out_nchw != 0, st)
+                 : launch_m<3, false>(MT, P, tiles, nblk_n, a.out_nchw != 0, st);
+  }
+  P.amax = nullptr; P.wscale[0] = P.wscale[1] = nullptr;
   if (plain)
     return a.nprod == 9 ? launch_m<9, true>(MT, P, tiles, nblk_n, a.out_nchw != 0, st)
                         : launch_m<6, true>(MT, P, tiles, nblk_n, a.out_nchw != 0, st);

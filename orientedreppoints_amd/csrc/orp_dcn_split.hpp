@@ -17,22 +17,29 @@ struct Level {
   int H, W, Ho, Wo;
   const uint16_t* planes;   // nullptr, or this level's own weight planes / bias (single-layer launches: a different layer per
   const float* bias;        // level, e.g. the FPN's output convolutions) instead of Args::planes[0] / bias[0]
+  const float* wscale;      //   ... and (nprod == 3) the scale of its fp16 planes
 };
 
 struct Args {
   Level lv[kMaxLevels];
   int nlev, B, Cin, Cout;
   int kh, kw, sh, sw, ph, pw, dh, dw;
-  const uint16_t* planes[2];   // per layer: [3 planes hi|mid|lo][tap][Cin/16][2][Cout][8] bf16 (pack_planes)
+  const uint16_t* planes[2];   // per layer: planes_of(packed, ..., nprod): [3 planes hi|mid|lo] bf16 or [2 planes hi|lo] fp16,
+                               // each [tap][Cin/16][2][Cout][8] (pack_planes)
   const float* bias[2];        // [Cout] or nullptr
   int relu, nconv, out_nchw;
-  int nprod;                   // 6 or 9 partial products per (a, w) pair
+  int nprod;                   // 6 or 9 partial products of three bf16 pieces; 3 = two fp16 pieces (hi*hi, hi*lo, lo*hi)
+  const float* wscale[2];      // nprod == 3: wscale_of(packed, ...) per layer (device scalar: the planes' power-of-two scale)
+  unsigned* scratch;           // nprod == 3: >= 8 bytes of device memory of the caller's (max |x| of the inputs, per layer)
 };
 
 // cin % 64 == 0, cout % 64 == 0, taps <= 9
 bool shape_ok(int c_in, int c_out, int kh, int kw);
-// number of uint16_t elements of one layer's planes
+// number of uint16_t elements of one layer's planes (bf16 planes + fp16 planes + the fp16 planes' scale)
 size_t plane_elems(int c_out, int c_in, int taps);
+// within the buffer orp_dcn_pack_weight fills (2 N floats of fp32 packings first): the plane set of a mode, the fp16 scale
+const uint16_t* planes_of(const float* packed, int c_out, int c_in, int taps, int nprod);
+const float* wscale_of(const float* packed, int c_out, int c_in, int taps);
 hipError_t pack_planes(const float* weight /* [o][c][tap] */, int c_out, int c_in, int taps, uint16_t* planes, hipStream_t st);
 hipError_t launch(const Args& a, hipStream_t st);
 

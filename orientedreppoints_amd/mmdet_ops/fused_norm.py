@@ -455,6 +455,7 @@ def conv_split_weights(xs_a, weights_a, xs_b=None, weight_b=None, biases_a=None,
 
     def f32(t):
         return t.detach().float().contiguous() if t is not None else None
+    ws = _lib.workspace(x0.device, 256)                    # nprod = 3: max |x| of the inputs (a pre-pass writes it there)
     if per_level is not None:
         wts = (ctypes.c_void_p * n)()
         bs = (ctypes.c_void_p * n)()
@@ -466,7 +467,8 @@ def conv_split_weights(xs_a, weights_a, xs_b=None, weight_b=None, biases_a=None,
             bs[i] = bi.data_ptr() if bi is not None else None
         with torch.cuda.device(x0.device):
             rc = L.orp_conv_split_multi_ex(levels, wts, bs, n, B, cin, cout, 1 if relu else 0, kh, kw, st[0], st[1], pd[0], pd[1],
-                                           dl[0], dl[1], 1 if out_channels_last else 0, int(nprod), _lib.stream_of(x0))
+                                           dl[0], dl[1], 1 if out_channels_last else 0, int(nprod), _lib.ptr(ws), ws.numel(),
+                                           _lib.stream_of(x0))
         _lib.check(rc, "orp_conv_split_multi_ex")
         return outs_a
     pa = _packed_weight(w, cache_pack)
@@ -475,7 +477,7 @@ def conv_split_weights(xs_a, weights_a, xs_b=None, weight_b=None, biases_a=None,
     with torch.cuda.device(x0.device):
         rc = L.orp_conv_split_multi(levels, n, B, cin, cout, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(ba), _lib.ptr(bb),
                                     1 if relu else 0, kh, kw, st[0], st[1], pd[0], pd[1], dl[0], dl[1],
-                                    1 if out_channels_last else 0, int(nprod), _lib.stream_of(x0))
+                                    1 if out_channels_last else 0, int(nprod), _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
     _lib.check(rc, "orp_conv_split_multi")
     return (outs_a, outs_b) if pair else outs_a
 

@@ -21,7 +21,7 @@ while time.time() - t0 < 6.0:
 print("calls %d, %.1f us per call" % (n, (time.time() - t0) / n * 1e6))
 PY
 sample() { for i in 1 2 3; do sleep 1; /opt/rocm/bin/rocm-smi -d 0 --showclocks --showpower 2>/dev/null | grep -E "sclk|Power \(W\)|Socket" | tr '\n' ' '; echo; done; }
-for m in 0 6 9; do
+for m in 0 3 6 9; do
   echo "== pair launch loop, ORP_DCN_SPLIT=$m"
   ORP_DCN_SPLIT=$m python /tmp/dcn_loop.py & pid=$!
   sleep 2.5; sample; wait $pid

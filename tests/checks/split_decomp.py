@@ -1,4 +1,4 @@
-"""Development aid (GPU box): the bf16-split DeformConv forward at the configs[1] shapes under the ORP_DCNS_DBG timing switches
+"""Development aid (GPU box): the split DeformConv forward (and the same kernel as a convolution) at the configs[1] shapes under the ORP_DCNS_DBG timing switches (MODES=3,6,... selects the arithmetic modes)
 (variant libraries from tools/build_variant.py; each in a fresh process):  python tests/checks/split_decomp.py d1,d2,d4,d8"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,7 +33,15 @@ for mode in [int(m) for m in os.environ.get("MODES", "0,6,9").split(",")]:
     torch.cuda.synchronize(); prof(3)
     for _ in range(20): deform_conv_forward_pair(xs, xs2, offs, w, w2, 1, 1, 1, relu=True)
     torch.cuda.synchronize(); us2 = prof(3)
-    out.append("mode %%d: single %%.1f us, pair %%.1f us (%%.1f TF/s fp32-equivalent)" %% (mode, us1, us2, 4.0 * npos * 256 * 2304 / us2 / 1e6))
+    # the same kernel without offsets (the towers' layer k of both towers): orp_conv_split_multi, slot 12
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv_split_weights
+    us3 = float("nan")
+    if mode:
+        for _ in range(3): conv_split_weights(xs, w, xs2, w2, nprod=mode)
+        torch.cuda.synchronize(); prof(12)
+        for _ in range(20): conv_split_weights(xs, w, xs2, w2, nprod=mode)
+        torch.cuda.synchronize(); us3 = prof(12)
+    out.append("mode %%d: single %%.1f us, pair %%.1f us (%%.1f TF/s fp32-equivalent), convolution pair %%.1f us" %% (mode, us1, us2, 4.0 * npos * 256 * 2304 / us2 / 1e6, us3))
 print("  " + " | ".join(out))
 ''' % ROOT
 names = sys.argv[1].split(',') if len(sys.argv) > 1 and sys.argv[1] else []

@@ -7,7 +7,7 @@ from orientedreppoints_amd.mmdet_ops import deform_conv_forward_pair
 
 from orientedreppoints_amd import _lib
 dev = torch.device("cuda:0")
-MODE = _lib.lib().orp_dcn_get_split_mode()        # ORP_DCN_SPLIT = 0 (exact fp32 MFMA) | 6 | 9 (bf16-split products)
+MODE = _lib.lib().orp_dcn_get_split_mode()        # ORP_DCN_SPLIT = 0 (exact fp32 MFMA) | 6 | 9 (bf16-split products) | 3 (two fp16 pieces)
 torch.manual_seed(0)
 w1, w2 = torch.randn(256, 256, 3, 3, device=dev) * 0.02, torch.randn(256, 256, 3, 3, device=dev) * 0.02
 for size, B in ((1024, 1), (1024, 2), (1536, 1)):

@@ -41,7 +41,7 @@ with torch.no_grad():
         flop = 2 * B * sum(f.size(2) * f.size(3) for f in feats) * 256 * 256 * 9
         t = timed(lambda: to_channels_last_multi(feats))
         print("   to_channels_last_multi: %.1f us" % t)
-        for nprod in (6, 9):
+        for nprod in (3, 6, 9):
             t = timed(lambda: conv_split_multi(cl, a.conv, cl, b.conv, nprod=nprod))
             print("   pair convolution, %d products: %.1f us = %.1f TFLOP/s fp32-equivalent (%.0f TFLOP/s bf16 issued)"
                   % (nprod, t, 2 * flop / t / 1e6, 2 * flop * nprod / t / 1e6))

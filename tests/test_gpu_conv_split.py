@@ -60,7 +60,7 @@ def test_conv_split_vs_oracle_and_float64(dev, oracle, B, C, H, W, Cout):
     with torch.no_grad():
         lib = F.conv2d(x.to(dev), conv.weight, padding=1)
         errs['library'] = _rel(lib, want64)
-        for nprod in (9, 6):
+        for nprod in (9, 6, 3):
             got = conv_split_multi([_cl(x.to(dev))], conv, nprod=nprod)[0]
             assert got.shape == want64.shape and got.is_contiguous(memory_format=torch.channels_last)
             errs[nprod] = _rel(got, want64)
@@ -69,10 +69,11 @@ def test_conv_split_vs_oracle_and_float64(dev, oracle, B, C, H, W, Cout):
             assert nchw.is_contiguous() and torch.equal(nchw, got.contiguous()), "NCHW / NHWC outputs: same bits"
             assert torch.equal(conv_split_multi([_cl(x.to(dev))], conv, nprod=nprod)[0], got)
     conftest.REPORT.append("3x3 convolution %dx%dx%dx%d -> %d, max |err| / max |out| vs float64: library fp32 %.2e, split 9 products "
-                           "%.2e, split 6 products %.2e" % (B, C, H, W, Cout, errs['library'], errs[9], errs[6]))
+                           "%.2e, split 6 products %.2e, two fp16 pieces / 3 products %.2e"
+                           % (B, C, H, W, Cout, errs['library'], errs[9], errs[6], errs[3]))
     # what remains is the fp32 accumulator's rounding (one per 16-channel MFMA and product, in a chain over K = 9 Cin): the
     # same figure the DeformConv forward has on both of its paths (test_gpu_dcn_split.py); six products lose nothing to nine
-    assert errs[6] <= errs[9] + 5e-8
+    assert errs[6] <= errs[9] + 5e-8 and errs[3] <= 2.0 * max(errs[9], errs['library']) + 1e-7
 
 
 def test_conv_split_pair_levels_bias_relu_strides(dev):
@@ -118,7 +119,7 @@ def test_conv_split_is_exact_on_integers_and_rejects_bad_arguments(dev):
     with torch.no_grad():
         m.weight.copy_(torch.randint(-4, 5, (64, 64, 3, 3), generator=g).float())
         want = F.conv2d(x.double(), m.weight.double(), padding=1)
-        for nprod in (9, 6):
+        for nprod in (9, 6, 3):
             assert torch.equal(conv_split_multi([_cl(x)], m, nprod=nprod)[0].double(), want)
         assert conv_split_ok(m, x)
         assert not conv_split_ok(nn.Conv2d(48, 64, 3, padding=1).to(dev))
@@ -230,9 +231,17 @@ def test_conv_split_at_a_head_level_vs_float64_and_the_library(dev):
         e_lib = _rel(F.conv2d(x.to(dev), conv.weight, padding=1), want)
         e6 = _rel(conv_split_multi([_cl(x.to(dev))], conv, nprod=6)[0], want)
         e9 = _rel(conv_split_multi([_cl(x.to(dev))], conv, nprod=9)[0], want)
+        e3 = _rel(conv_split_multi([_cl(x.to(dev))], conv, nprod=3)[0], want)
+        # inputs spanning 2^40: the range scaling must hold (no overflow to inf, small values keep their absolute precision)
+        xw = x * torch.exp2(torch.randint(-30, 11, x.shape).float())
+        want_w = F.conv2d(xw.double(), conv.weight.detach().cpu().double(), padding=1)
+        e3w = _rel(conv_split_multi([_cl(xw.to(dev))], conv, nprod=3)[0], want_w)
+        e6w = _rel(conv_split_multi([_cl(xw.to(dev))], conv, nprod=6)[0], want_w)
     conftest.REPORT.append("3x3 convolution 1x256x64x64 -> 256, max |err| / max |out| vs float64: library fp32 %.2e, split 9 products "
-                           "%.2e, split 6 products %.2e" % (e_lib, e9, e6))
-    assert e6 <= 1e-5 and e9 <= 1e-5
+                           "%.2e, split 6 products %.2e, two fp16 pieces %.2e; inputs spanning 2^40: 6 products %.2e, fp16 pieces %.2e"
+                           % (e_lib, e9, e6, e3, e6w, e3w))
+    assert e6 <= 1e-5 and e9 <= 1e-5 and e3 <= 1e-5 and e3w <= 1e-5
+    assert e3 <= 1.5 * e_lib + 5e-8
     # the same order as the library's own fp32 convolution at this shape (measured 8.8e-7 against 7.7e-7; 2.0e-6 before the
     # small partial products got their own accumulator set)
     assert e6 <= 1.5 * e_lib + 5e-8

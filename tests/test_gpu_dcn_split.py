@@ -43,7 +43,7 @@ def split(dev):
     from orientedreppoints_amd import _lib
     L = _lib.lib()
 
-    def set_mode(m):
+    def set_mode(m):                        # 0 exact fp32 MFMA | 6, 9 products of three bf16 pieces | 3 two fp16 pieces
         assert L.orp_dcn_set_split_mode(int(m)) == 0
         assert L.orp_dcn_get_split_mode() == int(m)
     yield set_mode
@@ -57,7 +57,7 @@ def test_split_forward_vs_oracle_and_error_gate(dev, oracle, split, B, C, H, W, 
     x, off, w = _case(7 + C + H, B, C, H, W, Cout)
     want = oracle.dcn_forward(x, off, w, stride=1, pad=1, dil=1)
     errs = {}
-    for mode in (0, 9, 6):
+    for mode in (0, 9, 6, 3):
         split(mode)
         got = deform_conv(_t(x, dev), _t(off, dev), _t(w, dev), 1, 1, 1, 1, 1, 64)
         assert got.shape == want.shape and got.is_contiguous()
@@ -70,11 +70,13 @@ def test_split_forward_vs_oracle_and_error_gate(dev, oracle, split, B, C, H, W, 
         again = deform_conv(_t(x, dev), _t(off, dev), _t(w, dev), 1, 1, 1, 1, 1, 64)
         assert torch.equal(again, got)
     conftest.REPORT.append("DeformConv forward %dx%dx%dx%d -> %d, max |err| / max |out| vs the fp64-accumulated oracle: exact-fp32 MFMA "
-                           "%.2e, split 9 products %.2e, split 6 products %.2e" % (B, C, H, W, Cout, errs[0], errs[9], errs[6]))
+                           "%.2e, split 9 products %.2e, split 6 products %.2e, two fp16 pieces / 3 products %.2e"
+                           % (B, C, H, W, Cout, errs[0], errs[9], errs[6], errs[3]))
     # the gate: no worse than the exact-fp32 path's own accumulation error (+ 5e-8: half an fp32 ulp of the output scale,
     # the resolution of the comparison itself)
     assert errs[9] <= errs[0] + 5e-8
     assert errs[6] <= errs[0] + 5e-8
+    assert errs[3] <= errs[0] + 5e-8
 
 
 def test_split_modulated_bias_relu_multi_level(dev, oracle, split):
@@ -86,7 +88,7 @@ def test_split_modulated_bias_relu_multi_level(dev, oracle, split):
     w = cases[0][2]
     masks = [rng.uniform(0, 1, size=(2, 9, h, ww)).astype(np.float32) for h, ww in shapes]
     bias = rng.normal(size=(64,)).astype(np.float32)
-    for mode in (9, 6):
+    for mode in (9, 6, 3):                  # (3: a modulated launch has no known sample range -- it runs as mode 6)
         split(mode)
         outs = deform_conv_forward_multi([_t(c[0], dev) for c in cases], [_t(c[1], dev) for c in cases], _t(w, dev), 1, 1, 1,
                                          masks=[_t(m, dev) for m in masks], bias=_t(bias, dev), relu=True)
@@ -107,7 +109,7 @@ def test_split_pair_launch_at_head_shapes(dev, oracle, split):
         w1, w2 = torch.randn(256, 256, 3, 3, device=dev) * 0.02, torch.randn(256, 256, 3, 3, device=dev) * 0.02
         split(0)
         ea, eb = deform_conv_forward_pair(fa, fb, of, w1, w2, 1, 1, 1, relu=True)
-        for mode in (9, 6):
+        for mode in (9, 6, 3):
             split(mode)
             pa, pb = deform_conv_forward_pair(fa, fb, of, w1, w2, 1, 1, 1, relu=True)
             sa = deform_conv_forward_multi(fa, of, w1, 1, 1, 1, relu=True)
@@ -136,7 +138,7 @@ def test_split_pieces_are_exact(dev, split):
     w = torch.randint(-4, 5, (64, 64, 3, 3), generator=g).float().to(dev)
     off = torch.zeros(1, 18, 12, 12, device=dev)
     want = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
-    for mode in (9, 6):
+    for mode in (9, 6, 3):
         split(mode)
         got = deform_conv(x, off, w, 1, 1, 1, 1, 1, 64)
         assert torch.equal(got.double(), want)

@@ -22,10 +22,11 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[0, 6], ids=["exact_fp32_mfma", "bf16_split_6"])
+@pytest.fixture(params=[0, 6, 3], ids=["exact_fp32_mfma", "bf16_split_6", "fp16_split_3"])
 def dcn_mode(request, dev):
-    """The two arithmetic modes of the fp32 DeformConv forward entry points: 0 = exact-fp32 MFMA (csrc/orp_dcn.hip, incl. its
-    tap-granular split of multi-round launches), 6 = the library default, the bf16-split products of csrc/orp_dcn_split.hip."""
+    """The arithmetic modes of the fp32 DeformConv forward entry points: 0 = exact-fp32 MFMA (csrc/orp_dcn.hip, incl. its
+    tap-granular split of multi-round launches), 6 = products of three bf16 pieces, 3 = the library default, two fp16 pieces
+    per operand (csrc/orp_dcn_split.hip)."""
     from orientedreppoints_amd import _lib
     L = _lib.lib()
     assert L.orp_dcn_set_split_mode(request.param) == 0
