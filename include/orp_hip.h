@@ -180,6 +180,14 @@ int orp_dcn_forward_pair(const orp_dcn_level* levels_a, const orp_dcn_level* lev
  * written (levels_a[i].output / levels_b[i].output are ignored).  heads->weight_*_packed: orp_dcn_head_packed_floats()
  * floats from orp_dcn_pack_head_weight ([k,256] -> [256][20]); heads->levels[i]: NCHW outputs [B,k_a,Ho,Wo] / [B,k_b,Ho,Wo]
  * and the optional residual of the second head.  k <= 20.  The partial sums of the eight waves are added in a fixed order. */
+/* the same with an upper bound of max |x| of the channels-last inputs from their producer (see orp_conv_split_multi):
+ * layers a / b read amax_in[0] / amax_in[amax_stride]; used in the two-fp16-pieces mode with in_layout 1 only */
+int orp_dcn_forward_pair_amax(const orp_dcn_level* levels_a, const orp_dcn_level* levels_b, const float* const* masks_host,
+                              int nlevels, int batch, int c_in, int c_out, const float* weight_a_packed,
+                              const float* weight_b_packed, const float* bias_a, const float* bias_b, int relu, int kh, int kw,
+                              int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout,
+                              int out_layout, void* workspace, size_t workspace_bytes, const uint32_t* amax_in, int amax_stride,
+                              void* stream);
 typedef struct { float* output_a; float* output_b; const float* residual_b; } orp_dcn_head_level;
 typedef struct { const float* weight_a_packed; const float* bias_a; int k_a; const float* weight_b_packed; const float* bias_b;
                  int k_b; const orp_dcn_head_level* levels; } orp_dcn_heads;
@@ -408,6 +416,12 @@ size_t orp_groupnorm_cl_workspace_bytes(const orp_norm_level* levels_host, int n
 int orp_groupnorm_act_multi_cl(const orp_norm_level* levels, const float* const* gammas_host, const float* const* betas_host,
                                int nlevels, int batch, int channels, int groups, float eps, int relu, void* workspace,
                                size_t workspace_bytes, void* stream);
+/* ... leaving an upper bound of max |y| over the tensors of every slot in amax_out[slot] (float bits; zeroed here): from the
+ * statistics pass, (max |x| + |mean|) rstd max |gamma| + max |beta| per group -- the range the fp16-pieces convolution that
+ * reads y scales by (orp_conv_split_multi amax_in, orp_dcn_forward_pair_amax) without a pass of its own */
+int orp_groupnorm_act_multi_cl_amax(const orp_norm_level* levels, const float* const* gammas_host, const float* const* betas_host,
+                                    int nlevels, int batch, int channels, int groups, float eps, int relu, const int* slots_host,
+                                    uint32_t* amax_out, int nslots, void* workspace, size_t workspace_bytes, void* stream);
 /* training: the same launch pair, additionally storing (mean, rstd) of every (image, group) in
  * stats [sum over tensors of batch * groups][2] (tensor i's rows follow tensor i-1's), and the backward:
  *   grad_inputs[i] = d loss / d x_i given grad_outputs[i] = d loss / d y_i (dy masked where y <= 0 when relu),
@@ -475,7 +489,10 @@ int orp_conv3x3_small_multi_strided(const orp_norm_level* levels_host, const flo
  *   launch), fp32 in / fp32 out / fp32 accumulation on the bf16 matrix pipe with every operand split exactly into three bf16
  *   pieces (nprod = 6 or 9 partial products; the DeformConv forward's kernel without offsets, orp_dcn_set_split_mode), or
  *   (nprod = 3) into two fp16 pieces after an exact power-of-two range scaling (products hi*hi, hi*lo, lo*hi; max |x| of the
- *   inputs is taken by a pre-pass into `workspace`, >= 256 bytes of device memory, which nprod = 6 / 9 do not need).
+ *   inputs is taken by a pre-pass into `workspace`, >= 256 bytes of device memory, which nprod = 6 / 9 do not need -- or,
+ *   amax_in != NULL, the producer of the inputs left an UPPER BOUND of it there as float bits (device memory;
+ *   orp_groupnorm_act_multi_cl_amax, orp_nchw_to_nhwc_multi_amax): layer a reads amax_in[0], layer b amax_in[amax_stride],
+ *   amax_stride 0 or 1; no pre-pass then).
  *   input_* : channels-last [B, H, W, Cin]; output_* : [B, Cout, Ho, Wo] (out_layout 0) or [B, Ho, Wo, Cout] (1);
  *   weight_*_packed: orp_dcn_pack_weight of the [Cout, Cin, kh, kw] weight; bias_* [Cout] or NULL; relu fused.
  *   orp_conv_split_ok: Cin % 64 == 0, Cout % 64 == 0, kh * kw <= 9.
@@ -486,15 +503,20 @@ int orp_conv_split_ok(int c_in, int c_out, int kh, int kw);
 int orp_conv_split_multi(const orp_conv_level* levels_host, int nlevels, int batch, int c_in, int c_out,
                          const float* weight_a_packed, const float* weight_b_packed, const float* bias_a, const float* bias_b,
                          int relu, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
-                         int out_layout, int nprod, void* workspace, size_t workspace_bytes, void* stream);
+                         int out_layout, int nprod, void* workspace, size_t workspace_bytes, const uint32_t* amax_in,
+                         int amax_stride, void* stream);
 /* one layer PER LEVEL (the FPN's output convolutions, mmdet/models/necks/fpn.py:150-153 `self.fpn_convs[i](laterals[i])`):
  * weights_packed_host[i] / biases_host[i] (biases_host or its entries may be NULL) belong to levels_host[i]; input_b / output_b
  * are ignored */
 int orp_conv_split_multi_ex(const orp_conv_level* levels_host, const float* const* weights_packed_host,
                             const float* const* biases_host, int nlevels, int batch, int c_in, int c_out, int relu, int kh, int kw,
                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int out_layout, int nprod,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            void* workspace, size_t workspace_bytes, const uint32_t* amax_in, void* stream);
 int orp_nchw_to_nhwc_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, void* stream);
+/* ... leaving max |x| of the tensors of every slot (slots_host[i] in [0, nslots)) in amax_out[slot] as float bits, by
+ * atomicMax; reset != 0 zeroes amax_out first (0: accumulate into what another producer left there) */
+int orp_nchw_to_nhwc_multi_amax(const orp_norm_level* levels_host, int nlevels, int batch, int channels, const int* slots_host,
+                                uint32_t* amax_out, int nslots, int reset, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Fused test-time post-processing around the rotated NMS: replaces the tensor-op chains of

@@ -111,8 +111,11 @@ _SIGNATURES = {
     "orp_conv3x3_small_workspace_bytes": (ctypes.c_size_t, [_vp, _vp, _i, _i, _i]),
     "orp_conv3x3_small_multi_strided": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
     "orp_conv_split_ok": (_i, [_i, _i, _i, _i]),
-    "orp_conv_split_multi": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp]),
-    "orp_conv_split_multi_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, _i] + [_i] * 11 + [_vp, _sz, _vp]),
+    "orp_conv_split_multi": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp, _i, _vp]),
+    "orp_conv_split_multi_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, _i] + [_i] * 11 + [_vp, _sz, _vp, _vp]),
+    "orp_nchw_to_nhwc_multi_amax": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "orp_groupnorm_act_multi_cl_amax": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "orp_dcn_forward_pair_amax": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp, _i, _vp]),
     "orp_nchw_to_nhwc_multi": (_i, [_vp, _i, _i, _i, _vp]),
     "orp_groupnorm_cl_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "orp_groupnorm_act_multi_cl": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),

@@ -25,6 +25,8 @@ struct TrLevels {
   int hw[kMaxT];
   int bx0[kMaxT + 1];
   int nlev;
+  int slot[kMaxT];                  // amax != nullptr: the slot tensor i's max |x| goes to
+  unsigned* amax;                   // nullptr, or [nslots] float bits, zeroed by the entry (atomicMax per workgroup)
 };
 
 // [B][C][HW] -> [B][HW][C] through a 32 x 33 LDS tile, every tensor of the launch back to back along blockIdx.x
@@ -39,14 +41,25 @@ to_channels_last_kernel(const TrLevels T, int C) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const float* src = T.in[l] + (size_t)b * C * HW;
   float* dst = T.out[l] + (size_t)b * C * HW;
+  unsigned m = 0u;
   for (int r = ty; r < 32; r += 8) {
     const int c = c0 + r, p = p0 + tx;
-    tile[r][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.f;
+    const float v = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.f;
+    tile[r][tx] = v;
+    m = max(m, __float_as_uint(v) & 0x7fffffffu);
   }
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
     const int p = p0 + r, c = c0 + tx;
     if (p < HW && c < C) dst[(size_t)p * C + c] = tile[tx][r];
+  }
+  if (T.amax) {                                      // max |x| of the tensors of a slot: what the fp16-pieces convolution scales by
+    __shared__ unsigned red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(T.amax + T.slot[l], max(max(red[0], red[1]), max(red[2], red[3])));
   }
 }
 
@@ -62,11 +75,12 @@ static int conv_split_impl(const orp_conv_level* levels_host, const float* const
                            int nlevels, int batch, int c_in, int c_out, const float* weight_a_packed, const float* weight_b_packed,
                            const float* bias_a, const float* bias_b, int relu, int kh, int kw, int stride_h, int stride_w,
                            int pad_h, int pad_w, int dil_h, int dil_w, int out_layout, int nprod, void* workspace,
-                           size_t workspace_bytes, void* stream) {
+                           size_t workspace_bytes, const uint32_t* amax_in, int amax_stride, void* stream) {
   if (!levels_host || nlevels <= 0 || nlevels > orp_split::kMaxLevels || batch <= 0 || !weight_a_packed) return ORP_EINVAL;
   if (!orp_split::shape_ok(c_in, c_out, kh, kw) || (nprod != 3 && nprod != 6 && nprod != 9) || (out_layout != 0 && out_layout != 1))
     return ORP_EINVAL;
-  if (nprod == 3 && (!workspace || workspace_bytes < 256)) return ORP_EWORKSPACE;      // max |x| of the inputs lives there
+  if (nprod == 3 && !amax_in && (!workspace || workspace_bytes < 256)) return ORP_EWORKSPACE;   // max |x| of the inputs lives there
+  if (amax_in && amax_stride != 0 && amax_stride != 1) return ORP_EINVAL;
   if (stride_h <= 0 || stride_w <= 0 || dil_h <= 0 || dil_w <= 0 || pad_h < 0 || pad_w < 0) return ORP_EINVAL;
   const int nconv = weight_b_packed ? 2 : 1;
   orp_split::Args A;
@@ -78,6 +92,7 @@ static int conv_split_impl(const orp_conv_level* levels_host, const float* const
   A.wscale[0] = orp_split::wscale_of(weight_a_packed, c_out, c_in, taps);
   A.wscale[1] = nconv == 2 ? orp_split::wscale_of(weight_b_packed, c_out, c_in, taps) : A.wscale[0];
   A.scratch = nprod == 3 ? reinterpret_cast<unsigned*>(workspace) : nullptr;
+  A.amax_in = nprod == 3 ? amax_in : nullptr; A.amax_stride = amax_stride;
   A.bias[0] = bias_a; A.bias[1] = nconv == 2 ? bias_b : bias_a;
   A.relu = relu ? 1 : 0; A.nconv = nconv; A.out_nchw = out_layout == 0 ? 1 : 0; A.nprod = nprod;
   for (int i = 0; i < nlevels; i++) {
@@ -109,38 +124,57 @@ static int conv_split_impl(const orp_conv_level* levels_host, const float* const
 int orp_conv_split_multi(const orp_conv_level* levels_host, int nlevels, int batch, int c_in, int c_out,
                          const float* weight_a_packed, const float* weight_b_packed, const float* bias_a, const float* bias_b,
                          int relu, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
-                         int out_layout, int nprod, void* workspace, size_t workspace_bytes, void* stream) {
+                         int out_layout, int nprod, void* workspace, size_t workspace_bytes, const uint32_t* amax_in,
+                         int amax_stride, void* stream) {
   return conv_split_impl(levels_host, nullptr, nullptr, nlevels, batch, c_in, c_out, weight_a_packed, weight_b_packed, bias_a,
                          bias_b, relu, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, out_layout, nprod, workspace,
-                         workspace_bytes, stream);
+                         workspace_bytes, amax_in, amax_stride, stream);
 }
 
 int orp_conv_split_multi_ex(const orp_conv_level* levels_host, const float* const* weights_packed_host,
                             const float* const* biases_host, int nlevels, int batch, int c_in, int c_out, int relu, int kh, int kw,
                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int out_layout, int nprod,
-                            void* workspace, size_t workspace_bytes, void* stream) {
+                            void* workspace, size_t workspace_bytes, const uint32_t* amax_in, void* stream) {
   if (!weights_packed_host || nlevels <= 0) return ORP_EINVAL;
   return conv_split_impl(levels_host, weights_packed_host, biases_host, nlevels, batch, c_in, c_out, weights_packed_host[0],
                          nullptr, nullptr, nullptr, relu, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, out_layout,
-                         nprod, workspace, workspace_bytes, stream);
+                         nprod, workspace, workspace_bytes, amax_in, 0, stream);
 }
 
-int orp_nchw_to_nhwc_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, void* stream) {
+static int to_cl_impl(const orp_norm_level* levels_host, int nlevels, int batch, int channels, const int* slots_host,
+                      uint32_t* amax_out, int nslots, int reset, void* stream) {
   if (!levels_host || nlevels <= 0 || nlevels > kMaxT || batch <= 0 || batch > 65535 || channels <= 0) return ORP_EINVAL;
+  if (amax_out && (!slots_host || nslots <= 0)) return ORP_EINVAL;
   TrLevels T;
   int bx = 0;
   for (int i = 0; i < nlevels; i++) {
     const orp_norm_level& lv = levels_host[i];
     if (!lv.input || !lv.output || lv.input == lv.output || lv.height <= 0 || lv.width <= 0) return ORP_EINVAL;
+    if (amax_out && (slots_host[i] < 0 || slots_host[i] >= nslots)) return ORP_EINVAL;
     T.in[i] = lv.input; T.out[i] = lv.output; T.hw[i] = lv.height * lv.width; T.bx0[i] = bx;
+    T.slot[i] = amax_out ? slots_host[i] : 0;
     bx += (T.hw[i] + 31) / 32;
   }
-  T.nlev = nlevels;
+  T.nlev = nlevels; T.amax = amax_out;
   for (int i = nlevels; i <= kMaxT; i++) T.bx0[i] = bx;
-  for (int i = nlevels; i < kMaxT; i++) { T.in[i] = T.in[0]; T.out[i] = T.out[0]; T.hw[i] = 0; }
+  for (int i = nlevels; i < kMaxT; i++) { T.in[i] = T.in[0]; T.out[i] = T.out[0]; T.hw[i] = 0; T.slot[i] = 0; }
+  if (amax_out && reset) {
+    const hipError_t me = hipMemsetAsync(amax_out, 0, sizeof(uint32_t) * nslots, (hipStream_t)stream);
+    if (me != hipSuccess) return (int)me;
+  }
   hipLaunchKernelGGL(to_channels_last_kernel, dim3(bx, (channels + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, T, channels);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_nchw_to_nhwc_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, void* stream) {
+  return to_cl_impl(levels_host, nlevels, batch, channels, nullptr, nullptr, 0, 0, stream);
+}
+
+int orp_nchw_to_nhwc_multi_amax(const orp_norm_level* levels_host, int nlevels, int batch, int channels, const int* slots_host,
+                                uint32_t* amax_out, int nslots, int reset, void* stream) {
+  if (!amax_out) return ORP_EINVAL;
+  return to_cl_impl(levels_host, nlevels, batch, channels, slots_host, amax_out, nslots, reset, stream);
 }
 
 }  // extern "C"

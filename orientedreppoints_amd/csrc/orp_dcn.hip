@@ -1048,7 +1048,8 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
                             const float* weight_packed, const float* weight2_packed, const float* bias, const float* bias2,
                             int relu, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h,
                             int dil_w, int in_layout, int out_layout, void* workspace, size_t workspace_bytes,
-                            void* stream, const orp_dcn_heads* heads = nullptr) {
+                            void* stream, const orp_dcn_heads* heads = nullptr, const uint32_t* amax_in = nullptr,
+                            int amax_stride = 0) {
   const int nconv = levels2_host ? 2 : 1;
   if (heads && (nconv != 2 || c_in != 256 || c_out != 256 || out_layout != 0 || !heads->weight_a_packed ||
                 !heads->weight_b_packed || !heads->levels || heads->k_a <= 0 || heads->k_a > KH || heads->k_b <= 0 ||
@@ -1149,13 +1150,17 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
     A.kh = kh; A.kw = kw; A.sh = stride_h; A.sw = stride_w; A.ph = pad_h; A.pw = pad_w; A.dh = dil_h; A.dw = dil_w;
     int mode = split_mode();
     char* scratch = reinterpret_cast<char*>(align256_(reinterpret_cast<size_t>(wsp)));
-    if (mode == 3 && (masks_host || !workspace || scratch + 256 > ws_end)) mode = 6;
+    // (amax_in: the producer of the channels-last inputs left an upper bound of max |x| -- no pre-pass, no scratch; it only
+    //  describes the tensors as handed over, so not with in_layout 0 where this call transposes copies of its own)
+    const bool have_amax = amax_in && in_layout == 1;
+    if (mode == 3 && (masks_host || (!have_amax && (!workspace || scratch + 256 > ws_end)))) mode = 6;
     const int taps_ = kh * kw;
     A.planes[0] = orp_split::planes_of(weight_packed, c_out, c_in, taps_, mode);
     A.planes[1] = weight2_packed ? orp_split::planes_of(weight2_packed, c_out, c_in, taps_, mode) : A.planes[0];
     A.wscale[0] = orp_split::wscale_of(weight_packed, c_out, c_in, taps_);
     A.wscale[1] = weight2_packed ? orp_split::wscale_of(weight2_packed, c_out, c_in, taps_) : A.wscale[0];
-    A.scratch = mode == 3 ? reinterpret_cast<unsigned*>(scratch) : nullptr;
+    A.scratch = (mode == 3 && !have_amax) ? reinterpret_cast<unsigned*>(scratch) : nullptr;
+    A.amax_in = (mode == 3 && have_amax) ? amax_in : nullptr; A.amax_stride = amax_stride;
     A.bias[0] = bias; A.bias[1] = bias2;
     A.relu = relu ? 1 : 0; A.nconv = nconv; A.out_nchw = out_layout == 0 ? 1 : 0; A.nprod = mode;
     for (int i = 0; i < nlevels; i++) {
@@ -1259,6 +1264,19 @@ int orp_dcn_forward_pair(const orp_dcn_level* levels_a, const orp_dcn_level* lev
   return dcn_forward_impl(levels_a, levels_b, masks_host, nlevels, batch, c_in, c_out, weight_a_packed, weight_b_packed,
                           bias_a, bias_b, relu, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, in_layout,
                           out_layout, workspace, workspace_bytes, stream);
+}
+
+int orp_dcn_forward_pair_amax(const orp_dcn_level* levels_a, const orp_dcn_level* levels_b, const float* const* masks_host,
+                              int nlevels, int batch, int c_in, int c_out, const float* weight_a_packed,
+                              const float* weight_b_packed, const float* bias_a, const float* bias_b, int relu, int kh, int kw,
+                              int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int in_layout,
+                              int out_layout, void* workspace, size_t workspace_bytes, const uint32_t* amax_in, int amax_stride,
+                              void* stream) {
+  if (!levels_b) return ORP_EINVAL;
+  if (c_in % CB != 0 || (amax_in && amax_stride != 0 && amax_stride != 1)) return ORP_EINVAL;
+  return dcn_forward_impl(levels_a, levels_b, masks_host, nlevels, batch, c_in, c_out, weight_a_packed, weight_b_packed,
+                          bias_a, bias_b, relu, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, in_layout,
+                          out_layout, workspace, workspace_bytes, stream, nullptr, amax_in, amax_stride);
 }
 
 size_t orp_dcn_head_packed_floats(void) { return (size_t)256 * KH; }

@@ -103,7 +103,8 @@ struct FwdS {
   int relu, nconv;
   size_t plane_stride;            // elements between two planes of a layer
   const float* wscale[2];         // F16: the power of two the layer's weights were multiplied by at pack time (device scalar)
-  const unsigned* amax;           // F16: [2] bits of max |x| over the inputs of layer 0 / 1 (device, written by absmax_kernel)
+  const unsigned* amax;           // F16: bits of (a bound of) max |x| over the inputs of layer cv at amax[cv * amax_stride]
+  int amax_stride;
 };
 
 // w [o][c][tap] fp32 -> three bf16 planes [pl][tap][c/16][kg][o][8]  (kg = (c % 16) / 8, e = c % 8), exact truncation split
@@ -269,7 +270,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   const float* xin = conv ? L.x[1] : L.x[0];
   float sx = 1.f, osc = 1.f;                                                  // F16: sample scale 2^k, output scale 1 / (sx * sw)
   if (F16) {
-    const unsigned am = P.amax[conv];
+    const unsigned am = P.amax[conv * P.amax_stride];
     int k = am == 0u ? 0 : 14 - ((int)((am >> 23) & 0xffu) - 127);
     k = k < -100 ? -100 : k > 100 ? 100 : k;
     sx = __uint_as_float((unsigned)(127 + k) << 23);
@@ -660,28 +661,32 @@ hipError_t launch(const Args& a, hipStream_t st) {
   if (a.nprod == 3) {
     // fp16 pieces: max |x| of the launch's inputs first (one slot per layer; a pair launch reading the same tensors
     // twice gets the same value in both), into the caller's scratch
-    if (!a.scratch || !a.wscale[0] || (a.nconv == 2 && !a.wscale[1])) return hipErrorInvalidValue;
+    if ((!a.scratch && !a.amax_in) || !a.wscale[0] || (a.nconv == 2 && !a.wscale[1])) return hipErrorInvalidValue;
     for (int i = 0; i < a.nlev; i++) if (a.lv[i].mask) return hipErrorInvalidValue;     // a modulation scalar has no known range
-    AbsMaxArgs M;
-    int bx = 0, cnt = 0;
-    for (int cv = 0; cv < a.nconv; cv++)
-      for (int i = 0; i < a.nlev; i++) {
-        M.x[cnt] = a.lv[i].x[cv]; M.n[cnt] = (size_t)a.B * a.lv[i].H * a.lv[i].W * a.Cin; M.slot[cnt] = cv; M.bx0[cnt] = bx;
-        long nb = (long)((M.n[cnt] / 4 + 256 * 8 - 1) / (256 * 8)); if (nb < 1) nb = 1; if (nb > 512) nb = 512;
-        bx += (int)nb; cnt++;
-      }
-    for (int i = cnt; i <= kAbsMaxT; i++) M.bx0[i] = bx;
-    for (int i = cnt; i < kAbsMaxT; i++) { M.x[i] = M.x[0]; M.n[i] = 0; M.slot[i] = 0; }
-    M.count = cnt;
-    hipError_t e = hipMemsetAsync(a.scratch, 0, 2 * sizeof(unsigned), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(absmax_kernel, dim3(bx), dim3(256), 0, st, M, a.scratch);
-    P.amax = a.scratch;
+    if (a.amax_in) {                                       // the producer of the inputs left the bound: no pre-pass
+      P.amax = a.amax_in; P.amax_stride = a.amax_stride;
+    } else {
+      AbsMaxArgs M;
+      int bx = 0, cnt = 0;
+      for (int cv = 0; cv < a.nconv; cv++)
+        for (int i = 0; i < a.nlev; i++) {
+          M.x[cnt] = a.lv[i].x[cv]; M.n[cnt] = (size_t)a.B * a.lv[i].H * a.lv[i].W * a.Cin; M.slot[cnt] = cv; M.bx0[cnt] = bx;
+          long nb = (long)((M.n[cnt] / 4 + 256 * 8 - 1) / (256 * 8)); if (nb < 1) nb = 1; if (nb > 512) nb = 512;
+          bx += (int)nb; cnt++;
+        }
+      for (int i = cnt; i <= kAbsMaxT; i++) M.bx0[i] = bx;
+      for (int i = cnt; i < kAbsMaxT; i++) { M.x[i] = M.x[0]; M.n[i] = 0; M.slot[i] = 0; }
+      M.count = cnt;
+      hipError_t e = hipMemsetAsync(a.scratch, 0, 2 * sizeof(unsigned), st);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(absmax_kernel, dim3(bx), dim3(256), 0, st, M, a.scratch);
+      P.amax = a.scratch; P.amax_stride = 1;
+    }
     P.wscale[0] = a.wscale[0]; P.wscale[1] = a.nconv == 2 ? a.wscale[1] : a.wscale[0];
     return plain ? launch_m<3, true>(MT, P, tiles, nblk_n, a.out_nchw != 0, st)
                  : launch_m<3, false>(MT, P, tiles, nblk_n, a.out_nchw != 0, st);
   }
-  P.amax = nullptr; P.wscale[0] = P.wscale[1] = nullptr;
+  P.amax = nullptr; P.amax_stride = 0; P.wscale[0] = P.wscale[1] = nullptr;
   if (plain)
     return a.nprod == 9 ? launch_m<9, true>(MT, P, tiles, nblk_n, a.out_nchw != 0, st)
                         : launch_m<6, true>(MT, P, tiles, nblk_n, a.out_nchw != 0, st);

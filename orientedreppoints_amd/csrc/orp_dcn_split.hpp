@@ -31,6 +31,8 @@ struct Args {
   int nprod;                   // 6 or 9 partial products of three bf16 pieces; 3 = two fp16 pieces (hi*hi, hi*lo, lo*hi)
   const float* wscale[2];      // nprod == 3: wscale_of(packed, ...) per layer (device scalar: the planes' power-of-two scale)
   unsigned* scratch;           // nprod == 3: >= 8 bytes of device memory of the caller's (max |x| of the inputs, per layer)
+  const unsigned* amax_in;     // nprod == 3: nullptr (a pre-pass over the inputs fills `scratch`), or float bits of an upper bound of
+  int amax_stride;             //   max |x| the producer of the inputs left: layer cv reads amax_in[cv * amax_stride]
 };
 
 // cin % 64 == 0, cout % 64 == 0, taps <= 9

@@ -440,6 +440,11 @@ struct GnClParams {
   float eps; int relu;
   float2* partial;        // [total_chunks][G] (mean, M2)
   float2* stats;          // [nlev][B][G] (mean, rstd)
+  // optional: an upper bound of max |y| over the tensors of a slot, as float bits (what the fp16-pieces convolution that reads
+  // y scales its samples by -- orp_conv_split_multi's amax_in -- so that it needs no pass of its own over y)
+  float* pmax;            // [total_chunks][G] max |x| of the chunk's group (same layout as partial), or nullptr
+  unsigned* amax;         // [nslots], zeroed by the entry
+  int slot[kGnMaxLevels];
 };
 
 struct ClGeom { int lvl, b, p0, np; };
@@ -465,6 +470,16 @@ __device__ __forceinline__ float group_total(float v, float* sh, int tpc, int tg
   float s = 0.f;
   for (int rep = 0; rep < kThreads / tpc; rep++)
     for (int j = 0; j < tg; j++) s += sh[rep * tpc + grp * tg + j];
+  return s;
+}
+
+__device__ __forceinline__ float group_max(float v, float* sh, int tpc, int tg, int grp) {
+  __syncthreads();
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int rep = 0; rep < kThreads / tpc; rep++)
+    for (int j = 0; j < tg; j++) s = fmaxf(s, sh[rep * tpc + grp * tg + j]);
   return s;
 }
 
@@ -500,8 +515,15 @@ gn_cl_stats_kernel(const GnClParams P) {
   }
   m2 = group_total(m2, sh, tpc, tg, grp);
   // partials of one (tensor, image, group) are contiguous over the image's chunks: [tensor][image][group][chunk]
-  if (threadIdx.x < tpc && threadIdx.x % tg == 0)
-    P.partial[(size_t)L.chunk0 * P.G + ((size_t)g.b * P.G + grp) * L.cpi + g.p0 / (kChunk / P.C)] = make_float2(mean, m2);
+  const size_t slot_ = (size_t)L.chunk0 * P.G + ((size_t)g.b * P.G + grp) * L.cpi + g.p0 / (kChunk / P.C);
+  if (threadIdx.x < tpc && threadIdx.x % tg == 0) P.partial[slot_] = make_float2(mean, m2);
+  if (P.pmax) {                                            // (block-uniform)
+    float am = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) am = fmaxf(am, fabsf(v[q]));          // (elements past the chunk's end were loaded as 0)
+    am = group_max(am, sh, tpc, tg, grp);
+    if (threadIdx.x < tpc && threadIdx.x % tg == 0) P.pmax[slot_] = am;
+  }
 }
 
 // one workgroup per (tensor, image, group)
@@ -527,7 +549,26 @@ gn_cl_merge_kernel(const GnClParams P) {
     m2 += pk.y + (float)nk * d * d;
   }
   const float var = block_sum(m2, red) / total;
-  if (threadIdx.x == 0) P.stats[((size_t)lvl * P.B + b) * P.G + grp] = make_float2(mean, rsqrtf(var + P.eps));
+  const float rstd = rsqrtf(var + P.eps);
+  if (threadIdx.x == 0) P.stats[((size_t)lvl * P.B + b) * P.G + grp] = make_float2(mean, rstd);
+  if (P.pmax) {
+    // |y| = |(x - mean) rstd gamma_c + beta_c| <= (max |x| + |mean|) rstd max |gamma| + max |beta| over the group's channels
+    const float* pm = P.pmax + (size_t)L.chunk0 * P.G + ((size_t)b * P.G + grp) * L.cpi;
+    float xm = 0.f;
+    for (int k = threadIdx.x; k < L.cpi; k += kThreads) xm = fmaxf(xm, pm[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) xm = fmaxf(xm, __shfl_xor(xm, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = xm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      xm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      float gm = 0.f, bm = 0.f;
+      for (int c = grp * cg; c < (grp + 1) * cg; c++) { gm = fmaxf(gm, fabsf(L.gamma[c])); bm = fmaxf(bm, fabsf(L.beta[c])); }
+      const float bound = (xm + fabsf(mean)) * rstd * gm + bm;
+      atomicMax(P.amax + P.slot[lvl], __float_as_uint(bound * 1.0001f));          // (a hair above the rounding of the bound itself)
+    }
+  }
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -673,31 +714,60 @@ size_t orp_groupnorm_cl_workspace_bytes(const orp_norm_level* levels, int nlevel
   GnClParams P;
   const int chunks = fill_cl(levels, nlevels, batch, channels, groups, P);
   if (chunks <= 0) return 0;
-  return gn_cl_stat_offset(chunks, groups) + sizeof(float2) * (size_t)nlevels * batch * groups;
+  // partials | (mean, rstd) per (tensor, image, group) | per-chunk group maxima of the _amax entry
+  return ((gn_cl_stat_offset(chunks, groups) + sizeof(float2) * (size_t)nlevels * batch * groups + 255) & ~(size_t)255) +
+         sizeof(float) * (size_t)chunks * groups;
 }
 
-int orp_groupnorm_act_multi_cl(const orp_norm_level* levels, const float* const* gammas_host, const float* const* betas_host,
-                               int nlevels, int batch, int channels, int groups, float eps, int relu, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+static int gn_cl_impl(const orp_norm_level* levels, const float* const* gammas_host, const float* const* betas_host,
+                      int nlevels, int batch, int channels, int groups, float eps, int relu, const int* slots_host,
+                      uint32_t* amax_out, int nslots, void* workspace, size_t workspace_bytes, void* stream) {
   GnClParams P;
   const int chunks = fill_cl(levels, nlevels, batch, channels, groups, P);
   if (chunks == -2) return ORP_ETOOBIG;
   if (chunks <= 0 || !gammas_host || !betas_host) return ORP_EINVAL;
-  const size_t need = gn_cl_stat_offset(chunks, groups) + sizeof(float2) * (size_t)nlevels * batch * groups;
+  if (amax_out && (!slots_host || nslots <= 0)) return ORP_EINVAL;
+  const size_t stat_off = gn_cl_stat_offset(chunks, groups);
+  const size_t pmax_off = (stat_off + sizeof(float2) * (size_t)nlevels * batch * groups + 255) & ~(size_t)255;
+  const size_t need = amax_out ? pmax_off + sizeof(float) * (size_t)chunks * groups : pmax_off;
   if (!workspace || workspace_bytes < need) return ORP_EWORKSPACE;
   for (int i = 0; i < nlevels; i++) {
     if (!gammas_host[i] || !betas_host[i]) return ORP_EINVAL;
+    if (amax_out && (slots_host[i] < 0 || slots_host[i] >= nslots)) return ORP_EINVAL;
     P.lv[i].gamma = gammas_host[i]; P.lv[i].beta = betas_host[i];
+    P.slot[i] = amax_out ? slots_host[i] : 0;
   }
+  for (int i = nlevels; i < kGnMaxLevels; i++) P.slot[i] = 0;
   P.eps = eps; P.relu = relu;
   P.partial = reinterpret_cast<float2*>(workspace);
-  P.stats = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + gn_cl_stat_offset(chunks, groups));
+  P.stats = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + stat_off);
+  P.pmax = amax_out ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pmax_off) : nullptr;
+  P.amax = amax_out;
   hipStream_t st = (hipStream_t)stream;
+  if (amax_out) {
+    const hipError_t me = hipMemsetAsync(amax_out, 0, sizeof(uint32_t) * nslots, st);
+    if (me != hipSuccess) return (int)me;
+  }
   hipLaunchKernelGGL(gn_cl_stats_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
   hipLaunchKernelGGL(gn_cl_merge_kernel, dim3(groups, batch, nlevels), dim3(kThreads), 0, st, P);
   hipLaunchKernelGGL(gn_cl_apply_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_groupnorm_act_multi_cl(const orp_norm_level* levels, const float* const* gammas_host, const float* const* betas_host,
+                               int nlevels, int batch, int channels, int groups, float eps, int relu, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  return gn_cl_impl(levels, gammas_host, betas_host, nlevels, batch, channels, groups, eps, relu, nullptr, nullptr, 0, workspace,
+                    workspace_bytes, stream);
+}
+
+int orp_groupnorm_act_multi_cl_amax(const orp_norm_level* levels, const float* const* gammas_host, const float* const* betas_host,
+                                    int nlevels, int batch, int channels, int groups, float eps, int relu, const int* slots_host,
+                                    uint32_t* amax_out, int nslots, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!amax_out) return ORP_EINVAL;
+  return gn_cl_impl(levels, gammas_host, betas_host, nlevels, batch, channels, groups, eps, relu, slots_host, amax_out, nslots,
+                    workspace, workspace_bytes, stream);
 }
 
 int orp_groupnorm_act_multi_train(const orp_norm_level* levels, const float* const* gammas_host,

@@ -7,6 +7,12 @@ from .layers import ConvModule, xavier_init
 from .registry import NECKS
 
 
+class FpnOutputs(tuple):
+    """The neck's outputs: a tuple of per-level tensors, plus `orp_amax` -- None, or an int32 CUDA tensor holding (float bits)
+    an upper bound of max |x| over the channels-last levels, left by their normalisation for the head's first tower layer."""
+    orp_amax = None
+
+
 @NECKS.register_module
 class FPN(nn.Module):
 
@@ -89,6 +95,7 @@ class FPN(nn.Module):
         assert len(inputs) == len(self.in_channels)
         used = len(self.lateral_convs)
         fused = self._fused_ok(inputs)
+        split_amax = None
         train = fused and torch.is_grad_enabled()     # autograd: the same launch pairs as one node per normalisation layer
         if train:
             from ..mmdet_ops.fused_norm import group_norm_act_train
@@ -117,10 +124,13 @@ class FPN(nn.Module):
             # the output convolutions of all levels in ONE launch on the bf16 matrix pipe (csrc/orp_conv_split.hip: fp32 in /
             # out, operands split exactly into three bf16 pieces), a layer of its own per level; channels-last from here on --
             # the layout the head's towers read (their own transposition launch goes away)
-            from ..mmdet_ops.fused_norm import conv_split_multi, group_norm_act_multi_cl, to_channels_last_multi
-            outs = group_norm_act_multi_cl(conv_split_multi(to_channels_last_multi(laterals),
-                                                            [fc.conv for fc in self.fpn_convs[:used]]),
-                                           [fc.norm for fc in self.fpn_convs[:used]], relu=False)
+            from ..mmdet_ops.fused_norm import Amax, conv_split_multi, group_norm_act_multi_cl, to_channels_last_multi
+            # (ranges for the fp16-pieces arithmetic ride along on the device: the transposition leaves max |x| of the
+            #  laterals, the normalisation a bound of its outputs' for the head's first tower layer -- FpnOutputs.orp_amax)
+            cl, bits = to_channels_last_multi(laterals, amax_slots=[0] * used)
+            conv = conv_split_multi(cl, [fc.conv for fc in self.fpn_convs[:used]], amax=Amax(bits, 0) if bits is not None else None)
+            outs, split_amax = group_norm_act_multi_cl(conv, [fc.norm for fc in self.fpn_convs[:used]], relu=False,
+                                                       amax_slots=[0] * used)
         elif fused:
             outs = group_norm_act_multi(conv3x3_multi(laterals, [fc.conv for fc in self.fpn_convs[:used]]),
                                         [fc.norm for fc in self.fpn_convs[:used]], relu=False, inplace=True)
@@ -141,7 +151,9 @@ class FPN(nn.Module):
                         outs.append(extra(self.fpn_convs[i], F.relu(outs[-1])))
                     else:
                         outs.append(extra(self.fpn_convs[i], outs[-1]))
-        return tuple(outs)
+        res = FpnOutputs(outs)
+        res.orp_amax = split_amax        # None, or the device-side range of the channels-last outputs (the first `used` levels)
+        return res
 
     @staticmethod
     def _extra_fused(m, x):

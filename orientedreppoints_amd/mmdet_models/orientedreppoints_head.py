@@ -193,19 +193,40 @@ class OrientedRepPointsHead(nn.Module):
 
     def _towers_split(self, feats):
         """Both towers and the init branch's 3x3 convolution, channels-last (see forward).  Returns (classification tower
-        output, regression tower output) as channels-last tensors -- what the DeformConv pair launch gathers from -- and
-        relu(reppoints_pts_init_conv(.)) NCHW for the 1x1 output convolution."""
-        from ..mmdet_ops.fused_norm import conv_split_multi, group_norm_act_multi_cl, to_channels_last_multi
+        output, regression tower output) as channels-last tensors -- what the DeformConv pair launch gathers from --,
+        relu(reppoints_pts_init_conv(.)) NCHW for the 1x1 output convolution, and the towers' outputs' range (`Amax`)."""
+        from ..mmdet_ops.fused_norm import Amax, conv_split_multi, group_norm_act_multi_cl, to_channels_last_multi
         n = len(feats)
-        cls_cur = reg_cur = to_channels_last_multi(list(feats))
+        # ranges for the fp16-pieces mode ride along (Amax: upper bounds of max |x| per tensor set, left on the device by the
+        # producers -- the FPN's normalisation, the transposition of the extra levels, each tower layer's normalisation), so
+        # that no convolution needs a pass of its own over its inputs; any gap in the chain just means that pre-pass runs
+        fpn_bits = getattr(feats, 'orp_amax', None)         # mmdet_models/fpn.py FpnOutputs: the bound of its channels-last outputs
+        cur = list(feats)
+        todo = [i for i, f in enumerate(cur) if not f.is_contiguous(memory_format=torch.channels_last)]
+        am = None
+        if not todo:
+            am = Amax(fpn_bits, 0) if fpn_bits is not None else None
+        elif len(todo) == n:
+            cur, bits = to_channels_last_multi(cur, amax_slots=[0] * n)
+            am = Amax(bits, 0) if bits is not None else None
+        elif fpn_bits is not None:                           # the extra levels: transposed here, their maxima merged into the slot
+            conv, bits = to_channels_last_multi([cur[i] for i in todo], amax_into=(fpn_bits, [0] * len(todo)))
+            for k, i in enumerate(todo):
+                cur[i] = conv[k]
+            am = Amax(fpn_bits, 0) if bits is not None else None
+        else:
+            cur = to_channels_last_multi(cur)
+        cls_cur = reg_cur = cur
         for a, b in zip(self.cls_convs, self.reg_convs):
-            oa, ob = conv_split_multi(cls_cur, a.conv, reg_cur, b.conv)
-            both = group_norm_act_multi_cl(oa + ob, [a.norm] * n + [b.norm] * n, relu=True)
+            oa, ob = conv_split_multi(cls_cur, a.conv, reg_cur, b.conv, amax=am)
+            both, bits = group_norm_act_multi_cl(oa + ob, [a.norm] * n + [b.norm] * n, relu=True, amax_slots=[0] * n + [1] * n)
+            am = Amax(bits, 1)
             cls_cur, reg_cur = both[:n], both[n:]
-        hid = conv_split_multi(reg_cur, self.reppoints_pts_init_conv, bias=True, relu=True, out_channels_last=False)
-        return cls_cur, reg_cur, hid
+        hid = conv_split_multi(reg_cur, self.reppoints_pts_init_conv, bias=True, relu=True, out_channels_last=False,
+                               amax=Amax(am.bits[1:], 0))
+        return cls_cur, reg_cur, hid, am                     # am: the range of (cls_cur, reg_cur) for the DeformConv pair launch
 
-    def _dcn_pair(self, cls_feats, pts_feats, offsets, out_channels_last=None):
+    def _dcn_pair(self, cls_feats, pts_feats, offsets, out_channels_last=None, amax=None):
         a, b = self.reppoints_cls_conv, self.reppoints_pts_refine_conv
         from ..mmdet_ops.deform_conv import deform_conv_forward_pair, fast_path_ok
         same = (a.stride == b.stride and a.padding == b.padding and a.dilation == b.dilation and
@@ -213,7 +234,7 @@ class OrientedRepPointsHead(nn.Module):
         if same and cls_feats[0].is_cuda and fast_path_ok(a.weight, a.groups, a.deformable_groups) and \
                 fast_path_ok(b.weight, b.groups, b.deformable_groups):
             return deform_conv_forward_pair(cls_feats, pts_feats, offsets, a.weight, b.weight, a.stride, a.padding,
-                                            a.dilation, relu=True, out_channels_last=out_channels_last)
+                                            a.dilation, relu=True, out_channels_last=out_channels_last, amax=amax)
         assert out_channels_last is None
         return a.forward_multi(cls_feats, offsets, relu=True), b.forward_multi(pts_feats, offsets, relu=True)
 
@@ -340,7 +361,7 @@ class OrientedRepPointsHead(nn.Module):
                 # towers' layer k = ONE launch over all levels, GroupNorm+ReLU of both towers' ten tensors in one launch
                 # triple, the init branch's 3x3 convolution with bias + ReLU in its epilogue -- 10 launches for what were
                 # 2 x 3 x (5 convolutions + 2) + 6; no second stream
-                cls_feats, pts_dcn_in, hid = self._towers_split(feats)
+                cls_feats, pts_dcn_in, hid, dcn_amax = self._towers_split(feats)
             else:
                 if side is not None:
                     with torch.cuda.stream(side):
@@ -388,7 +409,8 @@ class OrientedRepPointsHead(nn.Module):
                 return cls_outs, inits, refines, list(feats)
         # both DeformConvs take the same offsets: ONE launch for the two layers and all levels, ReLU fused in the epilogue
         if fused and hand:
-            dcn_cls, dcn_pts = self._dcn_pair(cls_feats, pts_dcn_in, offsets, out_channels_last=False)
+            dcn_cls, dcn_pts = self._dcn_pair(cls_feats, pts_dcn_in, offsets, out_channels_last=False,
+                                              amax=dcn_amax if split else None)
         else:
             dcn_cls, dcn_pts = self._dcn_pair(cls_feats, pts_feats, offsets)
         if fused and one_by_one:

@@ -209,13 +209,14 @@ def deform_conv_forward_multi_half(inputs, offsets, weight, stride, padding, dil
 
 
 def deform_conv_forward_pair(inputs_a, inputs_b, offsets, weight_a, weight_b, stride, padding, dilation, masks=None,
-                             bias_a=None, bias_b=None, relu=False, cache_pack=True, out_channels_last=None):
+                             bias_a=None, bias_b=None, relu=False, cache_pack=True, out_channels_last=None, amax=None):
     """Two DeformConv layers with the SAME offsets (the head's cls / refine pair) over a list of feature maps in ONE
     launch (`orp_dcn_forward_pair`): the bilinear coefficient table of every tile is built once for both layers.
     fp32, no autograd.  Returns (outs_a, outs_b).  Falls back to two `deform_conv_forward_multi` launches when the
     channel count is not a multiple of 256.  Outputs follow the inputs' memory format unless `out_channels_last` says
     otherwise (the head hands the towers' last layer over channels-last -- no transposition launch -- and wants NCHW
-    outputs for its 1x1 convolutions)."""
+    outputs for its 1x1 convolutions).  amax: a `fused_norm.Amax` from the producer of channels-last inputs (slot 0: inputs_a,
+    slot `stride`: inputs_b) -- the fp16-pieces mode then skips its range pre-pass."""
     L = _lib.lib()
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     x0 = inputs_a[0]
@@ -262,10 +263,16 @@ def deform_conv_forward_pair(inputs_a, inputs_b, offsets, weight_a, weight_b, st
     nbytes = 2 * L.orp_dcn_forward_workspace_bytes(lev_a, n, B, cin, layout)
     ws = _lib.workspace(x0.device, nbytes)
     with torch.cuda.device(x0.device):
-        rc = L.orp_dcn_forward_pair(lev_a, lev_b, mask_ptrs, n, B, cin, cout, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(ba),
-                                    _lib.ptr(bb), 1 if relu else 0, kh, kw, stride[0], stride[1], padding[0], padding[1],
-                                    dilation[0], dilation[1], layout, 1 if out_cl else 0, _lib.ptr(ws), ws.numel(),
-                                    _lib.stream_of(x0))
+        if amax is not None and nhwc:
+            rc = L.orp_dcn_forward_pair_amax(lev_a, lev_b, mask_ptrs, n, B, cin, cout, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(ba),
+                                             _lib.ptr(bb), 1 if relu else 0, kh, kw, stride[0], stride[1], padding[0],
+                                             padding[1], dilation[0], dilation[1], layout, 1 if out_cl else 0, _lib.ptr(ws),
+                                             ws.numel(), amax.bits.data_ptr(), int(amax.stride), _lib.stream_of(x0))
+        else:
+            rc = L.orp_dcn_forward_pair(lev_a, lev_b, mask_ptrs, n, B, cin, cout, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(ba),
+                                        _lib.ptr(bb), 1 if relu else 0, kh, kw, stride[0], stride[1], padding[0], padding[1],
+                                        dilation[0], dilation[1], layout, 1 if out_cl else 0, _lib.ptr(ws), ws.numel(),
+                                        _lib.stream_of(x0))
     _lib.check(rc, "orp_dcn_forward_pair")
     return outs_a, outs_b
 

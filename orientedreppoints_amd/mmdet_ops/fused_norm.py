@@ -374,14 +374,29 @@ def _is_cl(x):
     return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
 
 
-def to_channels_last_multi(xs):
+class Amax(object):
+    """Device-side range hand-over between a producer and the fp16-pieces convolution that reads its outputs: `bits` is an int32
+    CUDA tensor of float bits (upper bounds of max |x| per slot, written by atomicMax), `stride` 0 = both layers of a pair
+    launch read slot 0, 1 = layer b reads slot 1.  None anywhere in the chain simply means the convolution takes the maximum
+    itself (a pre-pass over its inputs)."""
+    __slots__ = ('bits', 'stride')
+
+    def __init__(self, bits, stride=0):
+        self.bits, self.stride = bits, stride
+
+
+def to_channels_last_multi(xs, amax_slots=None, amax_into=None):
     """[x in channels-last memory for x in xs] -- NCHW-contiguous fp32 CUDA tensors [B,C,H,W] with equal B and C, ONE launch
-    (`orp_nchw_to_nhwc_multi`); tensors that already are channels-last pass through."""
+    (`orp_nchw_to_nhwc_multi`); tensors that already are channels-last pass through.
+    amax_slots (one slot index per tensor): also returns an int32 tensor with max |x| per slot as float bits, or None when a
+    tensor passed through untouched (its range is not known here); amax_into = (bits tensor, slots): accumulate into an
+    existing one instead (all tensors of xs must then be converted here or the result is None again)."""
     L = _lib.lib()
     todo = [i for i, x in enumerate(xs) if not _is_cl(x)]
     outs = list(xs)
+    want_amax = amax_slots is not None or amax_into is not None
     if not todo:
-        return outs
+        return (outs, None) if want_amax else outs
     x0 = xs[todo[0]]
     B, C = x0.size(0), x0.size(1)
     levels = (_NormLevel * len(todo))()
@@ -394,10 +409,22 @@ def to_channels_last_multi(xs):
         y = torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         keep.append(x); outs[i] = y
         levels[k] = _NormLevel(x.data_ptr(), y.data_ptr(), x.size(2), x.size(3))
+    if want_amax and len(todo) == len(xs):
+        if amax_into is not None:
+            bits, slots_all, reset = amax_into[0], amax_into[1], 0
+        else:
+            slots_all, reset = list(amax_slots), 1
+            bits = torch.empty(max(slots_all) + 1, dtype=torch.int32, device=x0.device)
+        slots = (ctypes.c_int * len(todo))(*[int(slots_all[i]) for i in todo])
+        with torch.cuda.device(x0.device):
+            rc = L.orp_nchw_to_nhwc_multi_amax(levels, len(todo), B, C, slots, bits.data_ptr(), bits.numel(), reset,
+                                               _lib.stream_of(x0))
+        _lib.check(rc, "orp_nchw_to_nhwc_multi_amax")
+        return outs, bits
     with torch.cuda.device(x0.device):
         rc = L.orp_nchw_to_nhwc_multi(levels, len(todo), B, C, _lib.stream_of(x0))
     _lib.check(rc, "orp_nchw_to_nhwc_multi")
-    return outs
+    return (outs, None) if want_amax else outs
 
 
 def conv_split_ok(conv, x=None):
@@ -412,10 +439,11 @@ def conv_split_ok(conv, x=None):
 
 
 def conv_split_weights(xs_a, weights_a, xs_b=None, weight_b=None, biases_a=None, bias_b=None, stride=(1, 1), padding=(1, 1),
-                       dilation=(1, 1), relu=False, out_channels_last=True, nprod=None, cache_pack=True):
+                       dilation=(1, 1), relu=False, out_channels_last=True, nprod=None, cache_pack=True, amax=None):
     """The launch behind conv_split_multi, on tensors: weights_a = one [Cout,Cin,kh,kw] weight for all of xs_a, or a list with
     one weight per tensor (then no second layer); cache_pack=False re-packs the weights on every call (training: the
-    optimizer writes them between calls)."""
+    optimizer writes them between calls); amax: an `Amax` from the producer of the inputs (fp16-pieces mode: no range
+    pre-pass), or None."""
     from .deform_conv import _packed_weight
     L = _lib.lib()
     pair = xs_b is not None
@@ -456,6 +484,9 @@ def conv_split_weights(xs_a, weights_a, xs_b=None, weight_b=None, biases_a=None,
     def f32(t):
         return t.detach().float().contiguous() if t is not None else None
     ws = _lib.workspace(x0.device, 256)                    # nprod = 3: max |x| of the inputs (a pre-pass writes it there)
+    am_ptr = amax.bits.data_ptr() if amax is not None else None
+    am_stride = int(amax.stride) if amax is not None else 0
+    keep.append(amax.bits if amax is not None else None)
     if per_level is not None:
         wts = (ctypes.c_void_p * n)()
         bs = (ctypes.c_void_p * n)()
@@ -468,7 +499,7 @@ def conv_split_weights(xs_a, weights_a, xs_b=None, weight_b=None, biases_a=None,
         with torch.cuda.device(x0.device):
             rc = L.orp_conv_split_multi_ex(levels, wts, bs, n, B, cin, cout, 1 if relu else 0, kh, kw, st[0], st[1], pd[0], pd[1],
                                            dl[0], dl[1], 1 if out_channels_last else 0, int(nprod), _lib.ptr(ws), ws.numel(),
-                                           _lib.stream_of(x0))
+                                           am_ptr, _lib.stream_of(x0))
         _lib.check(rc, "orp_conv_split_multi_ex")
         return outs_a
     pa = _packed_weight(w, cache_pack)
@@ -477,12 +508,13 @@ def conv_split_weights(xs_a, weights_a, xs_b=None, weight_b=None, biases_a=None,
     with torch.cuda.device(x0.device):
         rc = L.orp_conv_split_multi(levels, n, B, cin, cout, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(ba), _lib.ptr(bb),
                                     1 if relu else 0, kh, kw, st[0], st[1], pd[0], pd[1], dl[0], dl[1],
-                                    1 if out_channels_last else 0, int(nprod), _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
+                                    1 if out_channels_last else 0, int(nprod), _lib.ptr(ws), ws.numel(), am_ptr, am_stride,
+                                    _lib.stream_of(x0))
     _lib.check(rc, "orp_conv_split_multi")
     return (outs_a, outs_b) if pair else outs_a
 
 
-def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=False, out_channels_last=True, nprod=None):
+def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=False, out_channels_last=True, nprod=None, amax=None):
     """[conv_a(x) for x in xs_a] (and [conv_b(x) for x in xs_b]: two layers of equal shape in ONE launch -- the two towers'
     layer k) over all FPN levels, `orp_conv_split_multi`: fp32 on the bf16 matrix pipe with every operand split exactly
     into three bf16 pieces, fp32 accumulation.  xs_*: channels-last fp32 CUDA tensors (logical [B,C,H,W]); conv_a: one
@@ -497,10 +529,10 @@ def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=Fals
     if per_level is not None:
         return conv_split_weights(xs_a, [c.weight for c in per_level], None, None,
                                   [c.bias for c in per_level] if bias else None, None, c0.stride, c0.padding, c0.dilation,
-                                  relu, out_channels_last, nprod)
+                                  relu, out_channels_last, nprod, amax=amax)
     return conv_split_weights(xs_a, c0.weight, xs_b, conv_b.weight if conv_b is not None else None,
                               c0.bias if bias else None, conv_b.bias if (bias and conv_b is not None) else None,
-                              c0.stride, c0.padding, c0.dilation, relu, out_channels_last, nprod)
+                              c0.stride, c0.padding, c0.dilation, relu, out_channels_last, nprod, amax=amax)
 
 
 class _ConvSplitTrain(torch.autograd.Function):
@@ -605,10 +637,11 @@ def conv_split_train(xs, convs):
     return list(_ConvSplitTrain.apply(meta, *[m.weight for m in mods], *xs))
 
 
-def group_norm_act_multi_cl(xs, gn, relu=True, inplace=True):
+def group_norm_act_multi_cl(xs, gn, relu=True, inplace=True, amax_slots=None):
     """[GroupNorm(+ReLU)(x) for x in xs] for CHANNELS-LAST fp32 CUDA tensors (logical [B,C,H,W], memory [B,H,W,C]; up to 16:
     both towers' levels), results channels-last -- `orp_groupnorm_act_multi_cl`, three launches for all tensors.  gn: one
-    nn.GroupNorm or a list with one per tensor (equal num_groups / eps)."""
+    nn.GroupNorm or a list with one per tensor (equal num_groups / eps).  amax_slots (a slot index per tensor): returns
+    (outs, int32 tensor of float bits: an upper bound of max |y| per slot, from the statistics pass) for `Amax`."""
     L = _lib.lib()
     x0 = xs[0]
     B, C = x0.size(0), x0.size(1)
@@ -639,6 +672,14 @@ def group_norm_act_multi_cl(xs, gn, relu=True, inplace=True):
         gam[i], bet[i] = ptrs
     nbytes = L.orp_groupnorm_cl_workspace_bytes(levels, len(xs), B, C, G)
     ws = _lib.workspace(x0.device, nbytes)
+    if amax_slots is not None:
+        slots = (ctypes.c_int * len(xs))(*[int(v) for v in amax_slots])
+        bits = torch.empty(max(int(v) for v in amax_slots) + 1, dtype=torch.int32, device=x0.device)
+        with torch.cuda.device(x0.device):
+            rc = L.orp_groupnorm_act_multi_cl_amax(levels, gam, bet, len(xs), B, C, G, float(gns[0].eps), 1 if relu else 0, slots,
+                                                   bits.data_ptr(), bits.numel(), _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
+        _lib.check(rc, "orp_groupnorm_act_multi_cl_amax")
+        return outs, bits
     with torch.cuda.device(x0.device):
         rc = L.orp_groupnorm_act_multi_cl(levels, gam, bet, len(xs), B, C, G, float(gns[0].eps), 1 if relu else 0,
                                           _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))

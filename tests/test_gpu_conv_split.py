@@ -339,3 +339,37 @@ def test_conv_split_train_gradients_vs_float64(dev):
     outs = conv_split_train([x.detach() for x in xs], convs[0])
     sum(o.sum() for o in outs).backward()
     assert convs[0].weight.grad is not None
+
+
+def test_range_hand_over_between_producers_and_the_fp16_pieces_convolution(dev):
+    """The fp16-pieces mode scales its samples by a power of two taken from max |x| of the inputs.  Producers can leave that on
+    the device (`Amax`): the transposition the exact maximum per slot, the channels-last GroupNorm an upper bound from its
+    statistics pass -- never below the true maximum, and not wastefully above it; a convolution run with such a bound gives the
+    float64 result to the same tolerance as with its own pre-pass."""
+    from orientedreppoints_amd.mmdet_ops.fused_norm import (Amax, conv_split_multi, group_norm_act_multi_cl,
+                                                          to_channels_last_multi)
+    torch.manual_seed(23)
+    xs = [torch.randn(2, 256, h, w, device=dev) * (1.0 + 3.0 * i) for i, (h, w) in enumerate(((20, 24), (7, 9), (3, 3), (16, 16)))]
+    cl, bits = to_channels_last_multi(xs, amax_slots=[0, 0, 1, 1])
+    got = bits.view(torch.float32).cpu()
+    assert float(got[0]) == max(float(xs[0].abs().max()), float(xs[1].abs().max()))
+    assert float(got[1]) == max(float(xs[2].abs().max()), float(xs[3].abs().max()))
+    more = [torch.randn(2, 256, 5, 5, device=dev) * 100.0]
+    _, bits2 = to_channels_last_multi(more, amax_into=(bits, [0]))                 # merged into slot 0, nothing reset
+    assert bits2 is bits and float(bits.view(torch.float32)[0]) == float(more[0].abs().max())
+    gn = nn.GroupNorm(32, 256).to(dev)
+    with torch.no_grad():
+        gn.weight.uniform_(0.2, 2.0); gn.bias.normal_(0, 0.5)
+        for relu in (True, False):
+            ys, b = group_norm_act_multi_cl([t.clone() for t in cl], gn, relu=relu, amax_slots=[0, 1, 1, 0])
+            bound = b.view(torch.float32).cpu()
+            for slot, idx in ((0, (0, 3)), (1, (1, 2))):
+                true = max(float(ys[i].abs().max()) for i in idx)
+                assert true <= float(bound[slot]) <= 8.0 * true, (relu, slot, true, float(bound[slot]))
+        conv = _conv(256, 256, 3, dev, seed=3, std=0.03)
+        ys, b = group_norm_act_multi_cl([t.clone() for t in cl], gn, relu=True, amax_slots=[0] * 4)
+        with_bound = conv_split_multi(ys, conv, nprod=3, amax=Amax(b, 0))
+        own = conv_split_multi(ys, conv, nprod=3)
+        for y, u, v in zip(ys, with_bound, own):
+            want = F.conv2d(y.double().cpu(), conv.weight.double().cpu(), padding=1)
+            assert _rel(u, want) <= 2e-6 and _rel(v, want) <= 2e-6
