@@ -555,25 +555,34 @@ class _ConvSplitTrain(torch.autograd.Function):
         uniq = [None] * len(seen)
         for x in xs:
             uniq[seen[key(x)]] = x
-        uniq_cl = to_channels_last_multi([u.detach().float() for u in uniq])
+        # the transposition also leaves max |x| (fp16-pieces mode: no range pre-pass in the convolution): one slot per layer
+        # of a pair launch -- or one for everything when the two layers read the same tensors
+        pair = nw == 2 and n % 2 == 0 and list(groups) == [0] * (n // 2) + [1] * (n // 2)
+        split_slots = pair and len(uniq) == n
+        slots = [(1 if (split_slots and i >= n // 2) else 0) for i in range(len(uniq))]
+        uniq_cl, bits = to_channels_last_multi([u.detach().float() for u in uniq], amax_slots=slots)
         cl = [uniq_cl[seen[key(x)]] for x in xs]
-        outs = _ConvSplitTrain._run(cl, ws, groups, padding, dilation, nw)
+        amax = Amax(bits, 1 if split_slots else 0) if bits is not None else None
+        outs = _ConvSplitTrain._run(cl, ws, groups, padding, dilation, nw, amax)
         ctx.meta = meta
         ctx.save_for_backward(*ws, *cl)
         return tuple(outs)
 
     @staticmethod
-    def _run(cl, ws, groups, padding, dilation, nw):
+    def _run(cl, ws, groups, padding, dilation, nw, amax=None):
         """one launch: a single weight, two weights (pair: first / second half of the tensors), or one weight per tensor"""
         n = len(cl)
         if nw == 1:
-            return conv_split_weights(cl, ws[0], padding=padding, dilation=dilation, out_channels_last=False, cache_pack=False)
+            return conv_split_weights(cl, ws[0], padding=padding, dilation=dilation, out_channels_last=False, cache_pack=False,
+                                      amax=amax)
         if nw == 2 and n % 2 == 0 and list(groups) == [0] * (n // 2) + [1] * (n // 2):
             a, b = conv_split_weights(cl[:n // 2], ws[0], cl[n // 2:], ws[1], padding=padding, dilation=dilation,
-                                      out_channels_last=False, cache_pack=False)
+                                      out_channels_last=False, cache_pack=False, amax=amax)
             return a + b
+        if amax is not None and amax.stride != 0:
+            amax = None                                      # (a layer per tensor reads one slot for all of them)
         return conv_split_weights(cl, [ws[g] for g in groups], padding=padding, dilation=dilation, out_channels_last=False,
-                                  cache_pack=False)
+                                  cache_pack=False, amax=amax)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -581,12 +590,15 @@ class _ConvSplitTrain(torch.autograd.Function):
         saved = ctx.saved_tensors
         ws, cl = saved[:nw], saved[nw:]
         kh, kw = ws[0].size(2), ws[0].size(3)
-        g_cl = to_channels_last_multi([g.detach().float() for g in grads])
+        pair = nw == 2 and n % 2 == 0 and list(groups) == [0] * (n // 2) + [1] * (n // 2)
+        g_cl, bits = to_channels_last_multi([g.detach().float() for g in grads],
+                                            amax_slots=[(1 if (pair and i >= n // 2) else 0) for i in range(n)])
         gxs = [None] * n
         if any(ctx.needs_input_grad[1 + nw:]):
             wt = [w.detach().flip(2, 3).transpose(0, 1).contiguous() for w in ws]
             pad_t = (dilation[0] * (kh - 1) - padding[0], dilation[1] * (kw - 1) - padding[1])
-            gxs = _ConvSplitTrain._run(g_cl, wt, groups, pad_t, dilation, nw)
+            gxs = _ConvSplitTrain._run(g_cl, wt, groups, pad_t, dilation, nw,
+                                       Amax(bits, 1 if pair else 0) if bits is not None else None)
         gws = [None] * nw
         for k in range(nw):
             if not ctx.needs_input_grad[1 + k]:
