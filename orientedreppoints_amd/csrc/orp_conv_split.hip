@@ -59,7 +59,13 @@ to_channels_last_kernel(const TrLevels T, int C) {
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(T.amax + T.slot[l], max(max(red[0], red[1]), max(red[2], red[3])));
+    if (threadIdx.x == 0) {
+      // thousands of workgroups, one address: the atomic only where it would change the value (a contended atomicMax per
+      // workgroup serialised in the L2: 37 us instead of 9 for the FPN's three levels, 190 us at 2 x 1024^2)
+      const unsigned mx = max(max(red[0], red[1]), max(red[2], red[3]));
+      unsigned* dst_ = T.amax + T.slot[l];
+      if (mx > __atomic_load_n(dst_, __ATOMIC_RELAXED)) atomicMax(dst_, mx);
+    }
   }
 }
 

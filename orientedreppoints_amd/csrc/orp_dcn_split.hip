@@ -158,7 +158,10 @@ absmax_kernel(const AbsMaxArgs A, unsigned* __restrict__ out) {
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) atomicMax(out + A.slot[t], max(max(red[0], red[1]), max(red[2], red[3])));
+  if (threadIdx.x == 0) {                                  // (the atomic only where it would change the value: one address)
+    const unsigned mx = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (mx > __atomic_load_n(out + A.slot[t], __ATOMIC_RELAXED)) atomicMax(out + A.slot[t], mx);
+  }
 }
 
 // w [o][c][tap] fp32 -> two fp16 planes [pl][tap][c/16][kg][o][8] of w * 2^k, k from amax = max |w| (float bits) so that the
