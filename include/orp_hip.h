@@ -518,6 +518,20 @@ int orp_nchw_to_nhwc_multi(const orp_norm_level* levels_host, int nlevels, int b
 int orp_nchw_to_nhwc_multi_amax(const orp_norm_level* levels_host, int nlevels, int batch, int channels, const int* slots_host,
                                 uint32_t* amax_out, int nslots, int reset, void* stream);
 
+/* orp_conv_wgrad_split: the weight gradient of those convolutions in training (what autograd runs behind ConvModule.conv,
+ *   mmdet/ops/conv_module.py:130-140): grad_weight [Cout, Cin, kh, kw] = sum over all levels, images and positions of
+ *   grad_output[b, o, p] * input[b, c, p + shift(tap)], stride 1, 'same' padding, Cin = Cout = 256 (orp_conv_wgrad_split_ok).
+ *   levels_host[i] = {input, grad_output, height, width}, both NCHW fp32 -- positions are the contraction axis and contiguous
+ *   per channel row, so no transposition.  fp16-pieces arithmetic (two pieces per operand after a power-of-two range scaling,
+ *   fp32 accumulation); amax_x / amax_g: device scalars (float bits of an upper bound of max |input| / max |grad_output| over
+ *   all levels) from the producers, or NULL (both are then taken by a pre-pass).  Fixed summation order: deterministic. */
+typedef struct { const float* input; const float* grad_output; int height; int width; } orp_wgrad_level;
+int orp_conv_wgrad_split_ok(int c_in, int c_out, int kh, int kw);
+size_t orp_conv_wgrad_split_workspace_bytes(const orp_wgrad_level* levels_host, int nlevels, int batch, int kh, int kw);
+int orp_conv_wgrad_split(const orp_wgrad_level* levels_host, int nlevels, int batch, int c_in, int c_out, int kh, int kw,
+                         int pad_h, int pad_w, int dil_h, int dil_w, const uint32_t* amax_x, const uint32_t* amax_g,
+                         float* grad_weight, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Fused test-time post-processing around the rotated NMS: replaces the tensor-op chains of
  * get_bboxes_single (orientedreppoints_head.py:707-779), multiclass_rnms (bbox_nms.py:93-182) and rbbox2result
@@ -559,7 +573,7 @@ int orp_pp_pack(const int64_t* keep, const int32_t* num_keep, const float* dets,
  * Built-in kernel timing (measurement aid for bench.py): when enabled every instrumented launch is bracketed by
  * a HIP event pair recorded on the launch stream.  Slots: 0 nms mask, 1 nms sweep, 2 nms sort, 3 dcn forward,
  * 4 minaerarect, 5 convex_iou, 6 convex_giou, 7 iou matrix, 8 dcn backward (9 / 10 / 11: its input-gradient GEMM, scatter,
- * weight-gradient parts), 12 orp_conv_split_multi.
+ * weight-gradient parts), 12 orp_conv_split_multi, 13 orp_conv_wgrad_split.
  * orp_profile_read synchronises on the recorded events and returns their summed duration and count.
  * ------------------------------------------------------------------------------------------------------- */
 int orp_profile_enable(int on);

@@ -113,6 +113,9 @@ _SIGNATURES = {
     "orp_conv_split_ok": (_i, [_i, _i, _i, _i]),
     "orp_conv_split_multi": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp, _i, _vp]),
     "orp_conv_split_multi_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, _i] + [_i] * 11 + [_vp, _sz, _vp, _vp]),
+    "orp_conv_wgrad_split_ok": (_i, [_i, _i, _i, _i]),
+    "orp_conv_wgrad_split_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "orp_conv_wgrad_split": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "orp_nchw_to_nhwc_multi_amax": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "orp_groupnorm_act_multi_cl_amax": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "orp_dcn_forward_pair_amax": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _sz, _vp, _i, _vp]),

@@ -37,6 +37,7 @@ SOURCES = [
     ("orp_dcn.hip", []),
     ("orp_dcn_split.hip", ["-ffp-contract=off"]),    # the bilinear combine is the reference's unfused float expression
     ("orp_conv_split.hip", []),
+    ("orp_conv_wgrad.hip", []),
     ("orp_dcn_half.hip", []),
     ("orp_dcn_bwd.hip", []),
     ("orp_dcn_bwd_mfma.hip", []),

@@ -1,0 +1,315 @@
+// orp_conv_wgrad.hip -- weight gradient of the head's 256 -> 256 3x3 tower / FPN convolutions, all FPN levels in one launch
+// (gfx950), on the 16-bit matrix pipe with the fp16-pieces arithmetic of orp_dcn_split.hip.
+//
+//   dW[o][c][tap] = sum over images and positions p of  G[b][o][p] * X[b][c][p + shift(tap)]        (zero outside the map)
+//
+// (torch.nn.functional.conv2d's backward for the weight, what autograd runs behind ConvModule.conv,
+// mmdet/ops/conv_module.py:130-140, for the layers of mmdet/models/anchor_heads/orientedreppoints_head.py:91-113 and
+// mmdet/models/necks/fpn.py:150-153).  The contraction runs over POSITIONS, and in NCHW -- the layout both tensors have in
+// training -- positions are the contiguous axis of every channel row: a lane's eight k-values of an MFMA operand are eight
+// consecutive floats of one row, no transposition anywhere (the forward kernel contracts over channels and reads
+// channels-last for the same reason).  The library's kernel for these shapes (igemm_wrw_gtcx35_nhwc_fp32, exact-fp32 MFMA,
+// after transposing both tensors) took 0.64 ms per layer at 2 x 1024^2, 6 ms of a 33 ms training step.
+//
+// Workgroup = one tap x one slice of the position chunks, 8 waves, output tile 256 (o) x 256 (c) in registers (wave: 64 x 128 =
+// 2 x 4 accumulators).  K runs in steps of 32 positions of one image of one level: the 256 G rows and the 256 (shifted) X rows of
+// the step are fetched once by the workgroup (8 consecutive floats per item, 4 items per thread), scaled by the tensors'
+// power-of-two range factors, split into two fp16 pieces (hi = fp16(v), lo = fp16(v - hi): 2^-22 relative) and written to LDS
+// as [operand][piece][row][32 positions]; every wave then reads its fragments with one 16-byte LDS read per lane and issues
+// hi*hi + hi*lo + lo*hi.  The next step's global loads are in flight during the MFMAs (registers), two barriers per step.
+// Partial tiles per (slice, tap) go to the workspace and are summed in slice order by a second launch: deterministic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orp_hip.h"
+#include "orp_prof.hpp"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int kMaxLv = 8;
+constexpr int CH = 256;                 // Cin = Cout = 256
+constexpr int KS = 32;                  // positions per K step
+constexpr int RS = 40;                  // LDS row stride in halfs (80 B: 64 B of payload + pad)
+constexpr int kThreadsW = 512;
+constexpr int kTapsMaxW = 9;
+
+struct WLevel {
+  const float* x;                       // [B][CH][H][W]
+  const float* g;                       // [B][CH][H][W] (stride 1, 'same' padding: the output has the input's size)
+  int H, W;
+  int chunk0;                           // first K step of this level; steps of one image are consecutive
+  int cpi;                              // steps per image = ceil(H*W / KS)
+};
+struct WParams {
+  WLevel lv[kMaxLv];
+  int nlev, B;
+  int kh, kw, ph, pw, dh, dw;
+  int total_chunks, nsplit;
+  const unsigned* amax_x;               // float bits of (a bound of) max |x| / max |g| over all levels (device scalars)
+  const unsigned* amax_g;
+  float* partial;                       // [nsplit][taps][CH (o)][CH (c)]
+};
+
+struct Item { float v[8]; };
+
+__global__ void __launch_bounds__(kThreadsW)
+conv_wgrad_split_kernel(const WParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  _Float16* sT = reinterpret_cast<_Float16*>(smem);        // [operand: 0 = G, 1 = X][piece][CH rows][RS]
+  constexpr int PL = CH * RS;                               // halfs per (operand, piece) plane
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tap = blockIdx.y, taps = P.kh * P.kw;
+  const int ki = tap / P.kw, kj = tap - ki * P.kw;
+  const int sh_h = ki * P.dh - P.ph, sh_w = kj * P.dw - P.pw;           // the tap's shift of the input position
+  const int per = (P.total_chunks + P.nsplit - 1) / P.nsplit;
+  const int c_begin = blockIdx.x * per;
+  const int c_end = min(c_begin + per, P.total_chunks);
+
+  // range factors (powers of two): the tensor's largest magnitude lands in [2^14, 2^15)
+  auto scale_of = [](unsigned am) {
+    int k = am == 0u ? 0 : 14 - ((int)((am >> 23) & 0xffu) - 127);
+    k = k < -100 ? -100 : k > 100 ? 100 : k;
+    return __uint_as_float((unsigned)(127 + k) << 23);
+  };
+  const float sx = scale_of(*P.amax_x), sg = scale_of(*P.amax_g);
+
+  // this thread's four items of a step: item u = (row r = (tid >> 2) + 128 * u of the 512 rows [G 0..255 | X 256..511],
+  // octet q = tid & 3): eight consecutive positions of one channel row
+  const int q = tid & 3;
+  auto fetch = [&](int chunk, Item (&it)[4]) {
+    int l = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.nlev; i++) if (chunk >= P.lv[i].chunk0) l = i;
+    const WLevel& L = P.lv[l];
+    const int id = chunk - L.chunk0;
+    const int b = id / L.cpi, p0 = (id - b * L.cpi) * KS + q * 8;
+    const int HW = L.H * L.W;
+    const int h0 = p0 / L.W, w0 = p0 - h0 * L.W;             // one division per step; the eight positions walk on from here
+    const bool vec = (HW & 3) == 0 && p0 + 8 <= HW;          // G rows: two aligned 16-byte loads
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = (tid >> 2) + 128 * u;
+      const bool is_x = r >= CH;                             // (u < 2: a G row, u >= 2: an X row -- uniform per u)
+      const float* row = (is_x ? L.x : L.g) + ((size_t)b * CH + (r & (CH - 1))) * HW;
+      if (!is_x) {
+        if (vec) {
+          const float4 a = *reinterpret_cast<const float4*>(row + p0), c = *reinterpret_cast<const float4*>(row + p0 + 4);
+          it[u].v[0] = a.x; it[u].v[1] = a.y; it[u].v[2] = a.z; it[u].v[3] = a.w;
+          it[u].v[4] = c.x; it[u].v[5] = c.y; it[u].v[6] = c.z; it[u].v[7] = c.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; e++) it[u].v[e] = (p0 + e < HW) ? row[p0 + e] : 0.f;
+        }
+      } else {
+        int h = h0, w = w0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int hs = h + sh_h, ws = w + sh_w;
+          const bool ok = p0 + e < HW && hs >= 0 && hs < L.H && ws >= 0 && ws < L.W;
+          it[u].v[e] = ok ? row[hs * L.W + ws] : 0.f;
+          if (++w == L.W) { w = 0; h++; }
+        }
+      }
+    }
+  };
+  auto stash = [&](const Item (&it)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = (tid >> 2) + 128 * u;
+      const bool is_x = r >= CH;
+      const float sc = is_x ? sx : sg;
+      h8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float sv = it[u].v[e] * sc;                                 // exact
+        hi[e] = (_Float16)sv;
+        lo[e] = (_Float16)(sv - (float)hi[e]);                            // the residual is exact in fp32
+      }
+      _Float16* dst = sT + (size_t)(is_x ? 2 : 0) * PL + (size_t)(r & (CH - 1)) * RS + q * 8;
+      *reinterpret_cast<h8*>(dst) = hi;
+      *reinterpret_cast<h8*>(dst + PL) = lo;
+    }
+  };
+
+  floatx16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[a][c] = floatx16{0};
+  const int m = lane & 31, kg = lane >> 5;
+  const int wo = wave >> 1, wc = wave & 1;                  // o rows [64 wo, +64), c columns [128 wc, +128)
+
+  if (c_begin < c_end) {
+    Item it[4];
+    fetch(c_begin, it);
+    stash(it);
+    __syncthreads();
+#pragma unroll 1
+    for (int chunk = c_begin; chunk < c_end; chunk++) {
+      const bool more = chunk + 1 < c_end;
+      if (more) fetch(chunk + 1, it);                       // in flight during the MFMAs below
+#pragma unroll
+      for (int j = 0; j < KS / 16; j++) {
+        h8 ga[2][2], xb[4][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int pl = 0; pl < 2; pl++)
+            ga[a][pl] = *reinterpret_cast<const h8*>(sT + (size_t)pl * PL + (size_t)(wo * 64 + a * 32 + m) * RS + j * 16 + kg * 8);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+          for (int pl = 0; pl < 2; pl++)
+            xb[c][pl] = *reinterpret_cast<const h8*>(sT + (size_t)(2 + pl) * PL + (size_t)(wc * 128 + c * 32 + m) * RS + j * 16 + kg * 8);
+        // smallest products first; eight independent accumulators between two MFMAs into the same one
+#pragma unroll
+        for (int pr = 0; pr < 3; pr++)
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+              acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[a][pr == 0 ? 1 : 0], xb[c][pr == 1 ? 1 : 0], acc[a][c], 0, 0, 0);
+      }
+      if (more) {
+        __syncthreads();                                    // every wave is past its last read of this step
+        stash(it);
+        __syncthreads();
+      }
+    }
+  }
+
+  const float osc = 1.f / (sx * sg);
+  float* outp = P.partial + ((size_t)blockIdx.x * taps + tap) * CH * CH;
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int o = wo * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        outp[(size_t)o * CH + wc * 128 + c * 32 + m] = acc[a][c][r] * osc;
+      }
+}
+
+// dW[o][c][tap] = sum over slices, in slice order, of partial[slice][tap][o][c]
+__global__ void __launch_bounds__(256)
+conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int taps, float* __restrict__ dw) {
+  const int total = CH * CH * taps;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int tap = i % taps, oc = i / taps;                 // dw is [o][c][tap]
+    float s = 0.f;
+    for (int z = 0; z < nsplit; z++) s += partial[((size_t)z * taps + tap) * CH * CH + oc];
+    dw[i] = s;
+  }
+}
+
+// max |x| over the levels of x (slot 0) and of g (slot 1), float bits
+struct WAbs { const float* p[2 * kMaxLv]; size_t n[2 * kMaxLv]; int slot[2 * kMaxLv]; int bx0[2 * kMaxLv + 1]; int count; };
+__global__ void __launch_bounds__(256)
+wgrad_absmax_kernel(const WAbs A, unsigned* __restrict__ out) {
+  __shared__ unsigned red[4];
+  int t = 0;
+#pragma unroll 1
+  for (int i = 1; i < A.count; i++) if ((int)blockIdx.x >= A.bx0[i]) t = i;
+  const float* x = A.p[t];
+  const size_t n = A.n[t];
+  const int nb = A.bx0[t + 1] - A.bx0[t], b = (int)blockIdx.x - A.bx0[t];
+  unsigned mx = 0u;
+  for (size_t i = (size_t)b * 256 + threadIdx.x; i < n; i += (size_t)nb * 256) mx = max(mx, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned v = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (v > __atomic_load_n(out + A.slot[t], __ATOMIC_RELAXED)) atomicMax(out + A.slot[t], v);
+  }
+}
+
+inline int pick_nsplit(int total_chunks, int taps) {
+  int ns = 252 / taps;                                        // one workgroup per CU, one round (9 taps: 28 slices)
+  if (ns > total_chunks) ns = total_chunks;
+  return ns < 1 ? 1 : ns;
+}
+inline size_t align256w(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+int orp_conv_wgrad_split_ok(int c_in, int c_out, int kh, int kw) { return (c_in == CH && c_out == CH && kh * kw <= kTapsMaxW && kh > 0 && kw > 0) ? 1 : 0; }
+
+size_t orp_conv_wgrad_split_workspace_bytes(const orp_wgrad_level* levels_host, int nlevels, int batch, int kh, int kw) {
+  if (!levels_host || nlevels <= 0 || nlevels > kMaxLv || batch <= 0) return 0;
+  long chunks = 0;
+  for (int i = 0; i < nlevels; i++) chunks += (long)batch * (((long)levels_host[i].height * levels_host[i].width + KS - 1) / KS);
+  const int ns = pick_nsplit((int)chunks, kh * kw);
+  return 256 + align256w(sizeof(float) * (size_t)ns * kh * kw * CH * CH);
+}
+
+int orp_conv_wgrad_split(const orp_wgrad_level* levels_host, int nlevels, int batch, int c_in, int c_out, int kh, int kw,
+                         int pad_h, int pad_w, int dil_h, int dil_w, const uint32_t* amax_x, const uint32_t* amax_g,
+                         float* grad_weight, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!levels_host || nlevels <= 0 || nlevels > kMaxLv || batch <= 0 || !grad_weight) return ORP_EINVAL;
+  if (!orp_conv_wgrad_split_ok(c_in, c_out, kh, kw) || dil_h <= 0 || dil_w <= 0) return ORP_EINVAL;
+  if (2 * pad_h != dil_h * (kh - 1) || 2 * pad_w != dil_w * (kw - 1)) return ORP_EINVAL;      // 'same' convolutions, stride 1
+  const size_t need = orp_conv_wgrad_split_workspace_bytes(levels_host, nlevels, batch, kh, kw);
+  if (!workspace || workspace_bytes < need) return ORP_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  WParams P;
+  P.nlev = nlevels; P.B = batch; P.kh = kh; P.kw = kw; P.ph = pad_h; P.pw = pad_w; P.dh = dil_h; P.dw = dil_w;
+  long chunks = 0;
+  for (int i = 0; i < nlevels; i++) {
+    const orp_wgrad_level& lv = levels_host[i];
+    if (!lv.input || !lv.grad_output || lv.height <= 0 || lv.width <= 0) return ORP_EINVAL;
+    if ((long)lv.height * lv.width >= (1L << 30)) return ORP_ETOOBIG;
+    WLevel& L = P.lv[i];
+    L.x = lv.input; L.g = lv.grad_output; L.H = lv.height; L.W = lv.width;
+    L.cpi = (lv.height * lv.width + KS - 1) / KS; L.chunk0 = (int)chunks;
+    chunks += (long)batch * L.cpi;
+    if (chunks >= (1L << 30)) return ORP_ETOOBIG;
+  }
+  for (int i = nlevels; i < kMaxLv; i++) { P.lv[i] = P.lv[0]; P.lv[i].chunk0 = 0x7fffffff; }
+  P.total_chunks = (int)chunks;
+  P.nsplit = pick_nsplit(P.total_chunks, kh * kw);
+  unsigned* amax = reinterpret_cast<unsigned*>(workspace);
+  P.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 256);
+  OrpProfScope prof(ORP_PROF_CONV_WGRAD, st);
+  P.amax_x = amax_x; P.amax_g = amax_g;
+  if (!amax_x || !amax_g) {                                   // no producer left (both) ranges: take them here
+    hipError_t me = hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), st);
+    if (me != hipSuccess) return (int)me;
+    WAbs A;
+    int bx = 0, cnt = 0;
+    for (int s = 0; s < 2; s++)
+      for (int i = 0; i < nlevels; i++) {
+        A.p[cnt] = s ? levels_host[i].grad_output : levels_host[i].input;
+        A.n[cnt] = (size_t)batch * CH * levels_host[i].height * levels_host[i].width;
+        A.slot[cnt] = s; A.bx0[cnt] = bx;
+        long nb = (long)((A.n[cnt] + 256 * 16 - 1) / (256 * 16)); if (nb < 1) nb = 1; if (nb > 512) nb = 512;
+        bx += (int)nb; cnt++;
+      }
+    for (int i = cnt; i <= 2 * kMaxLv; i++) A.bx0[i] = bx;
+    for (int i = cnt; i < 2 * kMaxLv; i++) { A.p[i] = A.p[0]; A.n[i] = 0; A.slot[i] = 0; }
+    A.count = cnt;
+    hipLaunchKernelGGL(wgrad_absmax_kernel, dim3(bx), dim3(256), 0, st, A, amax);
+    P.amax_x = amax; P.amax_g = amax + 1;
+  }
+  const size_t smem = sizeof(_Float16) * 4 * CH * RS;         // 80 KB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (ae != hipSuccess) return (int)ae;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_wgrad_split_kernel, dim3(P.nsplit, kh * kw), dim3(kThreadsW), smem, st, P);
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(512), dim3(256), 0, st, P.partial, P.nsplit, kh * kw, grad_weight);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+}  // extern "C"

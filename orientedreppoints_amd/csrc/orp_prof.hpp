@@ -9,7 +9,7 @@ enum OrpProfSlot {
   ORP_PROF_NMS_MASK = 0, ORP_PROF_NMS_SWEEP = 1, ORP_PROF_NMS_SORT = 2, ORP_PROF_DCN_FWD = 3, ORP_PROF_MINAREARECT = 4,
   ORP_PROF_CONVEX_IOU = 5, ORP_PROF_CONVEX_GIOU = 6, ORP_PROF_IOU_MATRIX = 7, ORP_PROF_DCN_BWD = 8,
   ORP_PROF_DCN_BWD_INPUT = 9, ORP_PROF_DCN_BWD_SCATTER = 10, ORP_PROF_DCN_BWD_WEIGHT = 11,
-  ORP_PROF_CONV_SPLIT = 12, ORP_PROF_NSLOTS = 16
+  ORP_PROF_CONV_SPLIT = 12, ORP_PROF_CONV_WGRAD = 13, ORP_PROF_NSLOTS = 16
 };
 
 void orp_prof_begin(int slot, hipStream_t st);

@@ -535,6 +535,45 @@ def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=Fals
                               c0.stride, c0.padding, c0.dilation, relu, out_channels_last, nprod, amax=amax)
 
 
+class _WgradLevel(ctypes.Structure):
+    _fields_ = [("input", ctypes.c_void_p), ("grad_output", ctypes.c_void_p), ("height", ctypes.c_int), ("width", ctypes.c_int)]
+
+
+def conv_wgrad_split_ok(weight, padding, dilation):
+    cout, cin, kh, kw = weight.shape
+    return (bool(_lib.lib().orp_conv_wgrad_split_ok(cin, cout, kh, kw)) and weight.is_cuda and weight.dtype == torch.float32 and
+            2 * padding[0] == dilation[0] * (kh - 1) and 2 * padding[1] == dilation[1] * (kw - 1))
+
+
+def conv_wgrad_split(xs, grad_outs, weight_shape, padding=(1, 1), dilation=(1, 1), amax_x=None, amax_g=None):
+    """grad_weight [Cout,Cin,kh,kw] of a stride-1 'same' 256 -> 256 convolution summed over a list of (input, grad_output) pairs
+    (the FPN levels of one layer), `orp_conv_wgrad_split`: NCHW fp32 CUDA tensors, ONE launch, fixed summation order.
+    amax_x / amax_g: one-element int32 tensors (float bits of an upper bound of max |input| / max |grad_output|), or None."""
+    L = _lib.lib()
+    cout, cin, kh, kw = weight_shape
+    x0 = xs[0]
+    B = x0.size(0)
+    n = len(xs)
+    levels = (_WgradLevel * n)()
+    keep = []
+    for i in range(n):
+        x, g = xs[i].detach().float().contiguous(), grad_outs[i].detach().float().contiguous()
+        if not (x.is_cuda and x.dim() == 4 and x.size(0) == B and x.size(1) == cin and tuple(g.shape) == (B, cout, x.size(2), x.size(3))):
+            raise ValueError("conv_wgrad_split expects NCHW fp32 CUDA inputs [B,%d,H,W] and grad_outputs [B,%d,H,W]" % (cin, cout))
+        keep += [x, g]
+        levels[i] = _WgradLevel(x.data_ptr(), g.data_ptr(), x.size(2), x.size(3))
+    gw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x0.device)
+    nbytes = L.orp_conv_wgrad_split_workspace_bytes(levels, n, B, kh, kw)
+    ws = _lib.workspace(x0.device, nbytes)
+    have = amax_x is not None and amax_g is not None
+    with torch.cuda.device(x0.device):
+        rc = L.orp_conv_wgrad_split(levels, n, B, cin, cout, kh, kw, padding[0], padding[1], dilation[0], dilation[1],
+                                    amax_x.data_ptr() if have else None, amax_g.data_ptr() if have else None,
+                                    gw.data_ptr(), _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
+    _lib.check(rc, "orp_conv_wgrad_split")
+    return gw
+
+
 class _ConvSplitTrain(torch.autograd.Function):
     """ys = [conv(x, W_k)] for the levels of one tower layer (or of the two towers' layer k, or of the FPN's output
     convolutions with a weight per level) as ONE autograd node on the bf16-split kernel.  forward: inputs transposed to
@@ -565,7 +604,8 @@ class _ConvSplitTrain(torch.autograd.Function):
         amax = Amax(bits, 1 if split_slots else 0) if bits is not None else None
         outs = _ConvSplitTrain._run(cl, ws, groups, padding, dilation, nw, amax)
         ctx.meta = meta
-        ctx.save_for_backward(*ws, *cl)
+        ctx.x_bits = (bits, split_slots)                      # ranges of the inputs, for the weight-gradient kernel
+        ctx.save_for_backward(*ws, *cl, *[x.detach() for x in xs])
         return tuple(outs)
 
     @staticmethod
@@ -588,7 +628,7 @@ class _ConvSplitTrain(torch.autograd.Function):
     def backward(ctx, *grads):
         n, nw, groups, padding, dilation = ctx.meta
         saved = ctx.saved_tensors
-        ws, cl = saved[:nw], saved[nw:]
+        ws, cl, xs_nchw = saved[:nw], saved[nw:nw + n], saved[nw + n:]
         kh, kw = ws[0].size(2), ws[0].size(3)
         pair = nw == 2 and n % 2 == 0 and list(groups) == [0] * (n // 2) + [1] * (n // 2)
         g_cl, bits = to_channels_last_multi([g.detach().float() for g in grads],
@@ -603,10 +643,18 @@ class _ConvSplitTrain(torch.autograd.Function):
         for k in range(nw):
             if not ctx.needs_input_grad[1 + k]:
                 continue
+            idx = [i for i in range(n) if groups[i] == k]
+            if len(idx) <= 8 and conv_wgrad_split_ok(ws[k], padding, dilation):
+                # one launch for the layer's levels, straight from the NCHW tensors (positions = the contraction axis)
+                xb, x_split = ctx.x_bits
+                sx = 1 if (x_split and idx[0] >= n // 2) else 0
+                sg = 1 if (pair and idx[0] >= n // 2) else 0
+                have = xb is not None and bits is not None
+                gws[k] = conv_wgrad_split([xs_nchw[i] for i in idx], [grads[i] for i in idx], tuple(ws[k].shape), padding, dilation,
+                                          xb[sx:sx + 1] if have else None, bits[sg:sg + 1] if have else None)
+                continue
             acc = None
-            for i in range(n):
-                if groups[i] != k:
-                    continue
+            for i in idx:
                 gw = torch.ops.aten.convolution_backward(g_cl[i], cl[i], ws[k], None, [1, 1], list(padding), list(dilation), False,
                                                          [0, 0], 1, [False, True, False])[1]
                 acc = gw if acc is None else acc + gw

@@ -373,3 +373,41 @@ def test_range_hand_over_between_producers_and_the_fp16_pieces_convolution(dev):
         for y, u, v in zip(ys, with_bound, own):
             want = F.conv2d(y.double().cpu(), conv.weight.double().cpu(), padding=1)
             assert _rel(u, want) <= 2e-6 and _rel(v, want) <= 2e-6
+
+
+def test_conv_weight_gradient_kernel_vs_float64(dev):
+    """orp_conv_wgrad_split: grad_weight of a 256 -> 256 stride-1 'same' convolution over several levels in one launch, NCHW
+    tensors, fp16-pieces arithmetic -- against torch's float64 weight gradient on the CPU; 3x3, dilated 3x3 and 1x1 kernels,
+    odd sizes, B = 1 and 2, with the ranges taken by the kernel's own pre-pass and handed in; bitwise reproducible; and
+    through conv_split_train (the autograd node) for 256-channel layers."""
+    import conftest
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv_split_train, conv_wgrad_split
+    torch.manual_seed(29)
+    shapes = [(20, 24), (7, 9), (3, 3), (1, 2)]
+    worst = 0.0
+    for B in (1, 2):
+        for k, pad, dil in ((3, 1, 1), (3, 2, 2), (1, 0, 1)):
+            xs = [torch.randn(B, 256, h, w, device=dev) * (1.0 + i) for i, (h, w) in enumerate(shapes)]
+            gs = [torch.randn(B, 256, h, w, device=dev) * 0.01 * (1.0 + i) for i, (h, w) in enumerate(shapes)]
+            want = sum(torch.nn.grad.conv2d_weight(x.double().cpu(), (256, 256, k, k), g.double().cpu(), padding=pad, dilation=dil)
+                       for x, g in zip(xs, gs))
+            got = conv_wgrad_split(xs, gs, (256, 256, k, k), (pad, pad), (dil, dil))
+            assert got.shape == want.shape
+            worst = max(worst, _rel(got, want))
+            assert _rel(got, want) <= 1e-5, (B, k, pad, dil)
+            assert torch.equal(conv_wgrad_split(xs, gs, (256, 256, k, k), (pad, pad), (dil, dil)), got)
+            ax = torch.tensor([max(float(x.abs().max()) for x in xs) * 3.0], device=dev).view(torch.int32)   # a loose bound
+            ag = torch.tensor([max(float(g.abs().max()) for g in gs)], device=dev).view(torch.int32)
+            assert _rel(conv_wgrad_split(xs, gs, (256, 256, k, k), (pad, pad), (dil, dil), ax, ag), want) <= 1e-5
+    conftest.REPORT.append("convolution weight gradient (256 -> 256, 4 levels), max |err| / max |grad| vs float64: %.2e" % worst)
+    # through the autograd node: two 256-channel layers on their own inputs (pair layout)
+    convs = [nn.Conv2d(256, 256, 3, padding=1, bias=False).to(dev) for _ in range(2)]
+    xa = [torch.randn(2, 256, h, w, device=dev).requires_grad_(True) for h, w in shapes[:3]]
+    xb = [torch.randn(2, 256, h, w, device=dev).requires_grad_(True) for h, w in shapes[:3]]
+    outs = conv_split_train(xa + xb, [convs[0]] * 3 + [convs[1]] * 3)
+    gos = [torch.randn_like(o) for o in outs]
+    sum((o * g).sum() for o, g in zip(outs, gos)).backward()
+    for c, xs_, gg in ((convs[0], xa, gos[:3]), (convs[1], xb, gos[3:])):
+        want = sum(torch.nn.grad.conv2d_weight(x.detach().double().cpu(), (256, 256, 3, 3), g.double().cpu(), padding=1)
+                   for x, g in zip(xs_, gg))
+        assert _rel(c.weight.grad, want) <= 1e-5
