@@ -16,13 +16,18 @@
 // the step are fetched once by the workgroup (8 consecutive floats per item, 4 items per thread), scaled by the tensors'
 // power-of-two range factors, split into two fp16 pieces (hi = fp16(v), lo = fp16(v - hi): 2^-22 relative) and written to LDS
 // as [operand][piece][row][32 positions]; every wave then reads its fragments with one 16-byte LDS read per lane and issues
-// hi*hi + hi*lo + lo*hi.  The next step's global loads are in flight during the MFMAs (registers), two barriers per step.
+// hi*hi + hi*lo + lo*hi.  LDS is double buffered (2 x 80 KB): the next step's rows are converted and written in the shadow of
+// this step's MFMAs, the step after that is in flight from memory; one barrier per step.
 // Partial tiles per (slice, tap) go to the workspace and are summed in slice order by a second launch: deterministic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/orp_hip.h"
 #include "orp_prof.hpp"
+
+#ifndef ORP_WG_DBG
+#define ORP_WG_DBG 0      // dev aid (timing only, wrong results): 1 = no fetches after the first, 2 = no MFMA, 4 = no conversion / LDS writes
+#endif
 
 namespace {
 
@@ -54,6 +59,7 @@ struct WParams {
 };
 
 struct Item { float v[8]; };
+struct __attribute__((packed, aligned(4))) F4u { float v[4]; };     // a 16-byte load at 4-byte alignment
 
 __global__ void __launch_bounds__(kThreadsW)
 conv_wgrad_split_kernel(const WParams P) {
@@ -61,11 +67,13 @@ conv_wgrad_split_kernel(const WParams P) {
   _Float16* sT = reinterpret_cast<_Float16*>(smem);        // [operand: 0 = G, 1 = X][piece][CH rows][RS]
   constexpr int PL = CH * RS;                               // halfs per (operand, piece) plane
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tap = blockIdx.y, taps = P.kh * P.kw;
+  // (Measured and dropped: all `taps` workgroups of a slice on one XCD so that they share its L2 -- 285 us with the 24 slices
+  //  that fill the XCDs evenly against 257 us for the plain grid of 28 slices; the rows are L2 / MALL resident either way.)
+  const int taps = P.kh * P.kw, tap = blockIdx.y, slice = blockIdx.x;
   const int ki = tap / P.kw, kj = tap - ki * P.kw;
   const int sh_h = ki * P.dh - P.ph, sh_w = kj * P.dw - P.pw;           // the tap's shift of the input position
   const int per = (P.total_chunks + P.nsplit - 1) / P.nsplit;
-  const int c_begin = blockIdx.x * per;
+  const int c_begin = slice * per;
   const int c_end = min(c_begin + per, P.total_chunks);
 
   // range factors (powers of two): the tensor's largest magnitude lands in [2^14, 2^15)
@@ -79,7 +87,7 @@ conv_wgrad_split_kernel(const WParams P) {
   // this thread's four items of a step: item u = (row r = (tid >> 2) + 128 * u of the 512 rows [G 0..255 | X 256..511],
   // octet q = tid & 3): eight consecutive positions of one channel row
   const int q = tid & 3;
-  auto fetch = [&](int chunk, Item (&it)[4]) {
+  auto fetch = [&](int chunk, Item (&it)[4], int u0, int u1) {
     int l = 0;
 #pragma unroll 1
     for (int i = 1; i < P.nlev; i++) if (chunk >= P.lv[i].chunk0) l = i;
@@ -89,8 +97,10 @@ conv_wgrad_split_kernel(const WParams P) {
     const int HW = L.H * L.W;
     const int h0 = p0 / L.W, w0 = p0 - h0 * L.W;             // one division per step; the eight positions walk on from here
     const bool vec = (HW & 3) == 0 && p0 + 8 <= HW;          // G rows: two aligned 16-byte loads
+    // (16-byte loads wherever possible: the L1 serves one line per clock and every load instruction of a wave touches 16 rows
+    //  here -- position-by-position loads of the shifted rows cost 427 us for the launch against 257)
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = u0; u < u1; u++) {
       const int r = (tid >> 2) + 128 * u;
       const bool is_x = r >= CH;                             // (u < 2: a G row, u >= 2: an X row -- uniform per u)
       const float* row = (is_x ? L.x : L.g) + ((size_t)b * CH + (r & (CH - 1))) * HW;
@@ -104,20 +114,30 @@ conv_wgrad_split_kernel(const WParams P) {
           for (int e = 0; e < 8; e++) it[u].v[e] = (p0 + e < HW) ? row[p0 + e] : 0.f;
         }
       } else {
-        int h = h0, w = w0;
+        // the shifted run: eight consecutive floats of the same input row whenever the octet neither wraps nor touches the
+        // border (two 16-byte loads, 4-byte aligned); else position by position (row starts / ends, map borders, the tail)
+        const int hs0 = h0 + sh_h, ws0 = w0 + sh_w;
+        if (p0 + 8 <= HW && w0 + 8 <= L.W && hs0 >= 0 && hs0 < L.H && ws0 >= 0 && ws0 + 8 <= L.W) {
+          const F4u a = *reinterpret_cast<const F4u*>(row + hs0 * L.W + ws0), c = *reinterpret_cast<const F4u*>(row + hs0 * L.W + ws0 + 4);
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const int hs = h + sh_h, ws = w + sh_w;
-          const bool ok = p0 + e < HW && hs >= 0 && hs < L.H && ws >= 0 && ws < L.W;
-          it[u].v[e] = ok ? row[hs * L.W + ws] : 0.f;
-          if (++w == L.W) { w = 0; h++; }
+          for (int e = 0; e < 4; e++) { it[u].v[e] = a.v[e]; it[u].v[4 + e] = c.v[e]; }
+        } else {
+          int h = h0, w = w0;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const int hs = h + sh_h, ws = w + sh_w;
+            const bool ok = p0 + e < HW && hs >= 0 && hs < L.H && ws >= 0 && ws < L.W;
+            it[u].v[e] = ok ? row[hs * L.W + ws] : 0.f;
+            if (++w == L.W) { w = 0; h++; }
+          }
         }
       }
     }
   };
-  auto stash = [&](const Item (&it)[4]) {
+  constexpr int BUF = 4 * PL;                               // halfs per LDS buffer (G hi | G lo | X hi | X lo)
+  auto stash = [&](const Item (&it)[4], int buf, int u0, int u1) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = u0; u < u1; u++) {
       const int r = (tid >> 2) + 128 * u;
       const bool is_x = r >= CH;
       const float sc = is_x ? sx : sg;
@@ -128,7 +148,7 @@ conv_wgrad_split_kernel(const WParams P) {
         hi[e] = (_Float16)sv;
         lo[e] = (_Float16)(sv - (float)hi[e]);                            // the residual is exact in fp32
       }
-      _Float16* dst = sT + (size_t)(is_x ? 2 : 0) * PL + (size_t)(r & (CH - 1)) * RS + q * 8;
+      _Float16* dst = sT + (size_t)buf * BUF + (size_t)(is_x ? 2 : 0) * PL + (size_t)(r & (CH - 1)) * RS + q * 8;
       *reinterpret_cast<h8*>(dst) = hi;
       *reinterpret_cast<h8*>(dst + PL) = lo;
     }
@@ -143,14 +163,19 @@ conv_wgrad_split_kernel(const WParams P) {
   const int wo = wave >> 1, wc = wave & 1;                  // o rows [64 wo, +64), c columns [128 wc, +128)
 
   if (c_begin < c_end) {
+    // LDS double buffered: while the waves contract step t out of buffer t & 1, the rows of step t + 1 (fetched one step
+    // earlier, in registers) are converted and written to the other buffer in the shadow of the MFMAs (one MFMA : four VALU),
+    // then the rows of step t + 2 are requested; ONE barrier per step
     Item it[4];
-    fetch(c_begin, it);
-    stash(it);
+    fetch(c_begin, it, 0, 4);
+    stash(it, 0, 0, 4);
+    if (c_begin + 1 < c_end) fetch(c_begin + 1, it, 0, 4);
     __syncthreads();
 #pragma unroll 1
     for (int chunk = c_begin; chunk < c_end; chunk++) {
-      const bool more = chunk + 1 < c_end;
-      if (more) fetch(chunk + 1, it);                       // in flight during the MFMAs below
+      const int cur = (chunk - c_begin) & 1;
+      const bool more = chunk + 1 < c_end, more2 = chunk + 2 < c_end;
+      const _Float16* sB = sT + (size_t)cur * BUF;
 #pragma unroll
       for (int j = 0; j < KS / 16; j++) {
         h8 ga[2][2], xb[4][2];
@@ -158,12 +183,17 @@ conv_wgrad_split_kernel(const WParams P) {
         for (int a = 0; a < 2; a++)
 #pragma unroll
           for (int pl = 0; pl < 2; pl++)
-            ga[a][pl] = *reinterpret_cast<const h8*>(sT + (size_t)pl * PL + (size_t)(wo * 64 + a * 32 + m) * RS + j * 16 + kg * 8);
+            ga[a][pl] = *reinterpret_cast<const h8*>(sB + (size_t)pl * PL + (size_t)(wo * 64 + a * 32 + m) * RS + j * 16 + kg * 8);
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
           for (int pl = 0; pl < 2; pl++)
-            xb[c][pl] = *reinterpret_cast<const h8*>(sT + (size_t)(2 + pl) * PL + (size_t)(wc * 128 + c * 32 + m) * RS + j * 16 + kg * 8);
+            xb[c][pl] = *reinterpret_cast<const h8*>(sB + (size_t)(2 + pl) * PL + (size_t)(wc * 128 + c * 32 + m) * RS + j * 16 + kg * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        // half of the next step's rows per 16-position chunk, converted in the shadow of the chunk's MFMAs (1 MFMA : 4 VALU).
+        // (Converting first and re-arming the registers with the step after next right away -- a whole step for the loads to
+        //  land instead of a barrier -- measured slower: 281 us against 257.)
+        if (more && !(ORP_WG_DBG & 4)) stash(it, cur ^ 1, 2 * j, 2 * j + 2);
         // smallest products first; eight independent accumulators between two MFMAs into the same one
 #pragma unroll
         for (int pr = 0; pr < 3; pr++)
@@ -171,18 +201,22 @@ conv_wgrad_split_kernel(const WParams P) {
           for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int c = 0; c < 4; c++)
-              acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[a][pr == 0 ? 1 : 0], xb[c][pr == 1 ? 1 : 0], acc[a][c], 0, 0, 0);
+              if (ORP_WG_DBG & 2) acc[a][c][0] += (float)ga[a][pr == 0 ? 1 : 0][0] * (float)xb[c][pr == 1 ? 1 : 0][0];
+              else acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[a][pr == 0 ? 1 : 0], xb[c][pr == 1 ? 1 : 0], acc[a][c], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 24; i++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (more) {
-        __syncthreads();                                    // every wave is past its last read of this step
-        stash(it);
-        __syncthreads();
-      }
+      if (more2 && !(ORP_WG_DBG & 1)) fetch(chunk + 2, it, 0, 4);           // lands during the next step
+      __syncthreads();
     }
   }
 
   const float osc = 1.f / (sx * sg);
-  float* outp = P.partial + ((size_t)blockIdx.x * taps + tap) * CH * CH;
+  float* outp = P.partial + ((size_t)slice * taps + tap) * CH * CH;
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -194,16 +228,16 @@ conv_wgrad_split_kernel(const WParams P) {
       }
 }
 
-// dW[o][c][tap] = sum over slices, in slice order, of partial[slice][tap][o][c]
+// dW[o][c][tap] = sum over slices, in slice order, of partial[slice][tap][o][c]: one thread per (tap, o, c), consecutive
+// threads read consecutive floats of every partial image
 __global__ void __launch_bounds__(256)
 conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int taps, float* __restrict__ dw) {
-  const int total = CH * CH * taps;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int tap = i % taps, oc = i / taps;                 // dw is [o][c][tap]
-    float s = 0.f;
-    for (int z = 0; z < nsplit; z++) s += partial[((size_t)z * taps + tap) * CH * CH + oc];
-    dw[i] = s;
-  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= taps * CH * CH) return;
+  const int tap = i / (CH * CH), oc = i - tap * (CH * CH);
+  float s = 0.f;
+  for (int z = 0; z < nsplit; z++) s += partial[((size_t)z * taps + tap) * CH * CH + oc];
+  dw[(size_t)oc * taps + tap] = s;
 }
 
 // max |x| over the levels of x (slot 0) and of g (slot 1), float bits
@@ -298,7 +332,7 @@ int orp_conv_wgrad_split(const orp_wgrad_level* levels_host, int nlevels, int ba
     hipLaunchKernelGGL(wgrad_absmax_kernel, dim3(bx), dim3(256), 0, st, A, amax);
     P.amax_x = amax; P.amax_g = amax + 1;
   }
-  const size_t smem = sizeof(_Float16) * 4 * CH * RS;         // 80 KB
+  const size_t smem = sizeof(_Float16) * 2 * 4 * CH * RS;     // two buffers of 80 KB: all of a CU's LDS
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel),
@@ -307,7 +341,7 @@ int orp_conv_wgrad_split(const orp_wgrad_level* levels_host, int nlevels, int ba
     attr_set = true;
   }
   hipLaunchKernelGGL(conv_wgrad_split_kernel, dim3(P.nsplit, kh * kw), dim3(kThreadsW), smem, st, P);
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(512), dim3(256), 0, st, P.partial, P.nsplit, kh * kw, grad_weight);
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(kh * kw * CH * CH / 256), dim3(256), 0, st, P.partial, P.nsplit, kh * kw, grad_weight);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }
