@@ -97,8 +97,8 @@ conv_wgrad_split_kernel(const WParams P) {
     const int HW = L.H * L.W;
     const int h0 = p0 / L.W, w0 = p0 - h0 * L.W;             // one division per step; the eight positions walk on from here
     const bool vec = (HW & 3) == 0 && p0 + 8 <= HW;          // G rows: two aligned 16-byte loads
-    // (16-byte loads wherever possible: the L1 serves one line per clock and every load instruction of a wave touches 16 rows
-    //  here -- position-by-position loads of the shifted rows cost 427 us for the launch against 257)
+    // (16-byte loads wherever possible: position-by-position loads of the shifted rows cost 427 us for the launch against 257;
+    //  eight lanes per row with one 16-byte load each -- half the cache lines per load instruction -- measured the same, 269)
 #pragma unroll
     for (int u = u0; u < u1; u++) {
       const int r = (tid >> 2) + 128 * u;
