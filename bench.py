@@ -452,7 +452,7 @@ def train_probe(dev, model_name='r50', steps=10, warmup=4, gts=64):
         log_vars = D.train_step(model, opt, data, hook)
     torch.cuda.synchronize()
     slots = dict(dcn_fwd=3, dcn_bwd_all=8, dcn_bwd_input_gemm=9, dcn_bwd_scatter=10, dcn_bwd_weight=11, convex_iou=5,
-                 convex_giou=6, minarearect=4)
+                 convex_giou=6, minarearect=4, tower_fpn_conv_fwd_and_grad_input=12, tower_fpn_conv_grad_weight=13)
     L.orp_profile_enable(1)
     for sl in slots.values():
         read_prof(sl)

@@ -220,10 +220,10 @@ class OrientedRepPointsHead(nn.Module):
         for a, b in zip(self.cls_convs, self.reg_convs):
             oa, ob = conv_split_multi(cls_cur, a.conv, reg_cur, b.conv, amax=am)
             both, bits = group_norm_act_multi_cl(oa + ob, [a.norm] * n + [b.norm] * n, relu=True, amax_slots=[0] * n + [1] * n)
-            am = Amax(bits, 1)
+            am = Amax(bits, 1) if bits is not None else None
             cls_cur, reg_cur = both[:n], both[n:]
         hid = conv_split_multi(reg_cur, self.reppoints_pts_init_conv, bias=True, relu=True, out_channels_last=False,
-                               amax=Amax(am.bits[1:], 0))
+                               amax=Amax(am.bits[1:], 0) if am is not None else None)
         return cls_cur, reg_cur, hid, am                     # am: the range of (cls_cur, reg_cur) for the DeformConv pair launch
 
     def _dcn_pair(self, cls_feats, pts_feats, offsets, out_channels_last=None, amax=None):

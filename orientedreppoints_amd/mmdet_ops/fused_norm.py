@@ -374,6 +374,11 @@ def _is_cl(x):
     return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
 
 
+def _ranges_wanted():
+    """the library's arithmetic mode is the fp16-pieces one (orp_dcn_get_split_mode() == 3): producers leave their ranges"""
+    return _lib.lib().orp_dcn_get_split_mode() == 3
+
+
 class Amax(object):
     """Device-side range hand-over between a producer and the fp16-pieces convolution that reads its outputs: `bits` is an int32
     CUDA tensor of float bits (upper bounds of max |x| per slot, written by atomicMax), `stride` 0 = both layers of a pair
@@ -381,11 +386,17 @@ class Amax(object):
     itself (a pre-pass over its inputs)."""
     __slots__ = ('bits', 'stride')
 
+    def __new__(cls, bits, stride=0):
+        import os
+        if bits is None or os.environ.get('ORP_AMAX_HANDOVER', '1') != '1':      # (0: every consumer takes its own maximum; A/B aid)
+            return None
+        return object.__new__(cls)
+
     def __init__(self, bits, stride=0):
         self.bits, self.stride = bits, stride
 
 
-def to_channels_last_multi(xs, amax_slots=None, amax_into=None):
+def to_channels_last_multi(xs, amax_slots=None, amax_into=None, force_ranges=False):
     """[x in channels-last memory for x in xs] -- NCHW-contiguous fp32 CUDA tensors [B,C,H,W] with equal B and C, ONE launch
     (`orp_nchw_to_nhwc_multi`); tensors that already are channels-last pass through.
     amax_slots (one slot index per tensor): also returns an int32 tensor with max |x| per slot as float bits, or None when a
@@ -395,6 +406,7 @@ def to_channels_last_multi(xs, amax_slots=None, amax_into=None):
     todo = [i for i, x in enumerate(xs) if not _is_cl(x)]
     outs = list(xs)
     want_amax = amax_slots is not None or amax_into is not None
+    ranges = want_amax and (force_ranges or _ranges_wanted())      # (only the fp16-pieces kernels read them)
     if not todo:
         return (outs, None) if want_amax else outs
     x0 = xs[todo[0]]
@@ -409,7 +421,7 @@ def to_channels_last_multi(xs, amax_slots=None, amax_into=None):
         y = torch.empty(x.shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         keep.append(x); outs[i] = y
         levels[k] = _NormLevel(x.data_ptr(), y.data_ptr(), x.size(2), x.size(3))
-    if want_amax and len(todo) == len(xs):
+    if ranges and len(todo) == len(xs):
         if amax_into is not None:
             bits, slots_all, reset = amax_into[0], amax_into[1], 0
         else:
@@ -599,7 +611,7 @@ class _ConvSplitTrain(torch.autograd.Function):
         pair = nw == 2 and n % 2 == 0 and list(groups) == [0] * (n // 2) + [1] * (n // 2)
         split_slots = pair and len(uniq) == n
         slots = [(1 if (split_slots and i >= n // 2) else 0) for i in range(len(uniq))]
-        uniq_cl, bits = to_channels_last_multi([u.detach().float() for u in uniq], amax_slots=slots)
+        uniq_cl, bits = to_channels_last_multi([u.detach().float() for u in uniq], amax_slots=slots, force_ranges=True)
         cl = [uniq_cl[seen[key(x)]] for x in xs]
         amax = Amax(bits, 1 if split_slots else 0) if bits is not None else None
         outs = _ConvSplitTrain._run(cl, ws, groups, padding, dilation, nw, amax)
@@ -632,7 +644,7 @@ class _ConvSplitTrain(torch.autograd.Function):
         kh, kw = ws[0].size(2), ws[0].size(3)
         pair = nw == 2 and n % 2 == 0 and list(groups) == [0] * (n // 2) + [1] * (n // 2)
         g_cl, bits = to_channels_last_multi([g.detach().float() for g in grads],
-                                            amax_slots=[(1 if (pair and i >= n // 2) else 0) for i in range(n)])
+                                            amax_slots=[(1 if (pair and i >= n // 2) else 0) for i in range(n)], force_ranges=True)
         gxs = [None] * n
         if any(ctx.needs_input_grad[1 + nw:]):
             wt = [w.detach().flip(2, 3).transpose(0, 1).contiguous() for w in ws]
@@ -732,6 +744,10 @@ def group_norm_act_multi_cl(xs, gn, relu=True, inplace=True, amax_slots=None):
         gam[i], bet[i] = ptrs
     nbytes = L.orp_groupnorm_cl_workspace_bytes(levels, len(xs), B, C, G)
     ws = _lib.workspace(x0.device, nbytes)
+    if amax_slots is not None and not _ranges_wanted():
+        amax_slots, no_ranges = None, True
+    else:
+        no_ranges = False
     if amax_slots is not None:
         slots = (ctypes.c_int * len(xs))(*[int(v) for v in amax_slots])
         bits = torch.empty(max(int(v) for v in amax_slots) + 1, dtype=torch.int32, device=x0.device)
@@ -744,4 +760,4 @@ def group_norm_act_multi_cl(xs, gn, relu=True, inplace=True, amax_slots=None):
         rc = L.orp_groupnorm_act_multi_cl(levels, gam, bet, len(xs), B, C, G, float(gns[0].eps), 1 if relu else 0,
                                           _lib.ptr(ws), ws.numel(), _lib.stream_of(x0))
     _lib.check(rc, "orp_groupnorm_act_multi_cl")
-    return outs
+    return (outs, None) if no_ranges else outs

@@ -346,8 +346,18 @@ def test_range_hand_over_between_producers_and_the_fp16_pieces_convolution(dev):
     the device (`Amax`): the transposition the exact maximum per slot, the channels-last GroupNorm an upper bound from its
     statistics pass -- never below the true maximum, and not wastefully above it; a convolution run with such a bound gives the
     float64 result to the same tolerance as with its own pre-pass."""
+    from orientedreppoints_amd import _lib
     from orientedreppoints_amd.mmdet_ops.fused_norm import (Amax, conv_split_multi, group_norm_act_multi_cl,
                                                           to_channels_last_multi)
+    L = _lib.lib()
+    assert L.orp_dcn_set_split_mode(3) == 0              # producers leave ranges in the fp16-pieces mode only
+    try:
+        _range_hand_over_body(dev, Amax, conv_split_multi, group_norm_act_multi_cl, to_channels_last_multi)
+    finally:
+        L.orp_dcn_set_split_mode(-1)
+
+
+def _range_hand_over_body(dev, Amax, conv_split_multi, group_norm_act_multi_cl, to_channels_last_multi):
     torch.manual_seed(23)
     xs = [torch.randn(2, 256, h, w, device=dev) * (1.0 + 3.0 * i) for i, (h, w) in enumerate(((20, 24), (7, 9), (3, 3), (16, 16)))]
     cl, bits = to_channels_last_multi(xs, amax_slots=[0, 0, 1, 1])

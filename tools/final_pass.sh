@@ -29,6 +29,8 @@ ORP_DCN_SPLIT=0 python tests/checks/time_dcn_pair.py >> $O/${TAG}_dcn_pair.log 2
 ORP_DCN_SPLIT=6 python tests/checks/time_dcn_pair.py >> $O/${TAG}_dcn_pair.log 2>&1
 ORP_DCN_SPLIT=9 python tests/checks/time_dcn_pair.py >> $O/${TAG}_dcn_pair.log 2>&1
 python tests/checks/time_towers.py > $O/${TAG}_towers.log 2>&1
+python tests/checks/time_wgrad.py > $O/${TAG}_wgrad.log 2>&1
+ORP_DCN_SPLIT=3 python bench.py --steps 100 --no-cpu-baseline > $O/${TAG}_bench_mode3.json 2>/dev/null
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/${TAG}_prof_bench -- python $R/bench.py --steps 30 --no-cpu-baseline --pipeline 1 > $R/$O/${TAG}_prof_bench.log 2>&1)
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/${TAG}_prof_train -- python $R/bench.py --mode train --steps 12 > $R/$O/${TAG}_prof_train.log 2>&1)
 tail -2 $O/${TAG}_smoke.log; tail -c 600 $O/${TAG}_bench.json; echo; tail -c 300 $O/${TAG}_bench_train.json
