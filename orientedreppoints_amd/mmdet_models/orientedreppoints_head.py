@@ -169,7 +169,13 @@ class OrientedRepPointsHead(nn.Module):
         from ..mmdet_ops.fused_norm import conv_split_ok
         on = getattr(self, 'split_towers', None)
         if on is None:
-            on = os.environ.get('ORP_TOWER_SPLIT', '1') == '1'
+            # automatic: on (ORP_TOWER_SPLIT=0 switches it off), for pyramids whose smallest level is at least 8 x 8 -- every
+            # 1024^2 / 1536^2 input.  Below that (the 256^2 images of the graph tests: levels down to 2 x 2) captured-graph
+            # replays of this path disagreed with the eager call in about one suite run out of four, values off beyond the
+            # tolerance, while every operator-level comparison, the soak under concurrent streams and five eager-interleaved
+            # replays at 1024^2 were bit-identical: not understood, so small pyramids keep the round-3 towers
+            # unless `split_towers = True` asks for this path explicitly
+            on = os.environ.get('ORP_TOWER_SPLIT', '1') == '1' and min(min(f.size(2), f.size(3)) for f in feats) >= 8
         if not on or _lib.lib().orp_dcn_get_split_mode() == 0 or len(self.cls_convs) != len(self.reg_convs) or len(feats) > 8:
             return False
         x = feats[0]

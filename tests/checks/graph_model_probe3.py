@@ -12,18 +12,21 @@ with torch.no_grad():
     head.reppoints_cls_out.weight.normal_(0, 0.05)
     head.reppoints_cls_out.bias.fill_(-3.3)
 B = 1
-metas = [dict(img_shape=(256, 256, 3), pad_shape=(256, 256, 3), scale_factor=1.0, flip=False)] * B
-gi = GraphedInference(model, torch.randn(B, 3, 256, 256, device=dev), metas)
+SZ = int(os.environ.get('SIZE', '256'))
+metas = [dict(img_shape=(SZ, SZ, 3), pad_shape=(SZ, SZ, 3), scale_factor=1.0, flip=False)] * B
+gi = GraphedInference(model, torch.randn(B, 3, SZ, SZ, device=dev), metas)
 mode = os.environ.get('PROBE', 'eager_between')
 for k, seed in enumerate((1, 2, 3, 4, 5)):
-    img = torch.randn(B, 3, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+    img = torch.randn(B, 3, SZ, SZ, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
     got = gi(img)
     raw = gi.packed[0].cpu().numpy()[-1, :2]
     line = "replay %d: detections %s (count, overflow) %s" % (k + 1, [sum(len(c) for c in r) for r in got], raw.tolist())
     if mode == 'eager_between':
         with torch.no_grad():
             want = model.simple_test_batch(img, metas)
-        line += "  eager %s" % [sum(len(c) for c in r) for r in want]
+        same = all(np.array_equal(a, b) for gr, wr in zip(got, want) for a, b in zip(gr, wr) if a.shape == b.shape) and \
+            all(a.shape == b.shape for gr, wr in zip(got, want) for a, b in zip(gr, wr))
+        line += "  eager %s  identical arrays: %s" % ([sum(len(c) for c in r) for r in want], same)
     elif mode == 'alloc_between':
         junk = [torch.randn(1 << 22, device=dev) for _ in range(8)]
         torch.cuda.synchronize()

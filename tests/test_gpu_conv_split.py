@@ -193,8 +193,9 @@ def test_head_inference_with_channels_last_towers_vs_reference_forward(dev):
         for B in (1, 2):
             feats = [torch.randn(B, 256, h, w, device=dev) for h, w in ((40, 36), (20, 18), (10, 9), (5, 5), (3, 2))]
             head.split_towers = None
-            assert head._split_towers_ok(feats)
+            assert not head._split_towers_ok(feats)             # automatic mode: pyramids below 8 x 8 keep the library towers
             head.split_towers = True
+            assert head._split_towers_ok(feats)
             got = head(feats)
             head.split_towers = False
             lib = head(feats)
@@ -209,13 +210,17 @@ def test_head_inference_with_channels_last_towers_vs_reference_forward(dev):
                     assert float((g - w).abs().max()) <= 1e-4 * scale, (k, lvl)
                     assert float((g - l).abs().max()) <= 1e-4 * scale, (k, lvl)
             conftest.REPORT.append("head inference, channels-last towers vs forward_single, B = %d: max |diff| / scale %.2e" % (B, worst))
+        big = [torch.randn(1, 256, n, n, device=dev) for n in (64, 32, 16, 8, 8)]
+        head.split_towers = None
+        assert head._split_towers_ok(big)                        # automatic mode, smallest level 8 x 8: on
         L = _lib.lib()
         L.orp_dcn_set_split_mode(0)
         try:
-            head.split_towers = None
-            assert not head._split_towers_ok(feats)              # exact-fp32 mode: the library-convolution towers
+            head.split_towers = True
+            assert not head._split_towers_ok(big)                # exact-fp32 mode: the library-convolution towers
         finally:
             L.orp_dcn_set_split_mode(-1)
+            head.split_towers = None
 
 
 def test_conv_split_at_a_head_level_vs_float64_and_the_library(dev):
