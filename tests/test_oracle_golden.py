@@ -105,3 +105,23 @@ def test_box_iou_rotated(oracle, golden_dir):
     assert np.max(np.abs(got - g["iou"])) <= 1e-6
     assert abs(float(g["unit"][0, 0]) - 0.8223) < 1e-4       # SURVEY 8c check value for 10x10 boxes offset by 0.5
     assert (got > 0.1).sum() > 20
+
+
+def test_deform_conv_oracle_with_zero_offsets_is_the_convolution(oracle):
+    """The checker tests/test_gpu_conv_split.py holds the tower / FPN convolutions against: the oracle's DeformConv forward
+    (deform_conv_cuda_kernel.cu:84-115 samples, contracted in double) with ZERO offsets must be the ordinary convolution --
+    restated here position by position in float64 numpy; odd sizes, padding 1 and 2 (dilated), batch 2."""
+    rng = np.random.RandomState(3)
+    for (B, C, H, W, Co, pad, dil) in ((2, 6, 5, 7, 4, 1, 1), (1, 3, 6, 4, 5, 2, 2)):
+        x = rng.normal(size=(B, C, H, W)).astype(np.float32)
+        w = rng.normal(size=(Co, C, 3, 3)).astype(np.float32)
+        got = oracle.dcn_forward(x, np.zeros((B, 18, H, W), np.float32), w, stride=1, pad=pad, dil=dil)
+        xp = np.zeros((B, C, H + 2 * pad, W + 2 * pad), np.float64)
+        xp[:, :, pad:pad + H, pad:pad + W] = x
+        want = np.zeros((B, Co, H, W), np.float64)
+        for i in range(3):
+            for j in range(3):
+                patch = xp[:, :, i * dil:i * dil + H, j * dil:j * dil + W]
+                want += np.einsum('bchw,oc->bohw', patch, w[:, :, i, j].astype(np.float64))
+        assert got.shape == want.shape
+        assert float(np.abs(got - want).max()) <= 1e-6 * max(1.0, float(np.abs(want).max()))
