@@ -577,6 +577,11 @@ int orp_pp_pack(const int64_t* keep, const int32_t* num_keep, const float* dets,
  * orp_profile_read synchronises on the recorded events and returns their summed duration and count.
  * ------------------------------------------------------------------------------------------------------- */
 int orp_profile_enable(int on);
+/* Development aid (tests/checks/graph_bitwise.py): while `log` is non-NULL every fp16-pieces launch (nprod = 3) of
+ * orp_conv_split_multi(_ex) / orp_dcn_forward_pair(_amax) leaves, in launch order, four words in device memory at
+ * log + 4 * k (k < capacity_launches): the range word layer a / layer b actually READ and the scale of their weight planes.
+ * Returns the number of launches logged since the previous call; NULL switches the log off.  No reference counterpart. */
+int orp_debug_amax_log(uint32_t* log, int capacity_launches);
 int orp_profile_read(int slot, double* total_ms, int* count, int reset);
 
 #ifdef __cplusplus

@@ -122,6 +122,7 @@ _SIGNATURES = {
     "orp_nchw_to_nhwc_multi": (_i, [_vp, _i, _i, _i, _vp]),
     "orp_groupnorm_cl_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "orp_groupnorm_act_multi_cl": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
+    "orp_debug_amax_log": (_i, [_vp, _i]),
 }
 
 _lib = None

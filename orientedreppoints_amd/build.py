@@ -14,9 +14,18 @@ LIB = os.path.join(CSRC, "liborp_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
+# -packed-fp32-ops: NO packed fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in any kernel of this library.
+# Measured on MI355X (tests/checks/mfma_refill_victim.hip, a self-contained reproducer): while other waves keep the
+# matrix pipe busy with dense bf16 / f16 MFMAs, a v_pk_mul_f32 returns a wrong low half in lanes 48..63 -- 5.6e6 wrong results in
+# 5e10, none for the same arithmetic as two v_mul_f32.  Every wrong-result anomaly of rounds 4 / 5 (wrong rows of the tile-height-1
+# DeformConv launch, rows of the fp16-pieces build, a rotated-NMS keep count off by one next to another stream's convolutions) was
+# this instruction in compiler-generated code; the scalar forms cost at most one VALU instruction per pair.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result", "-Wno-unused-value",
           "-Wno-bitwise-instead-of-logical"]   # predicates are combined with & / | on purpose (no short-circuit branches)
+if os.environ.get("ORP_PACKED_FP32", "0") != "1":   # ORP_PACKED_FP32=1: dev aid (build_variants with the packed forms)
+    COMMON = COMMON + NO_PACKED_FP32
 # (source, extra flags)
 SOURCES = [
     ("orp_nms.hip", ["-ffp-contract=off"]),
@@ -78,7 +87,14 @@ def _compile(src, extra):
         extra = extra + ['-DORP_BUILD_ID="%s"' % build_id()]
     if _stale(obj, deps):
         cmd = [HIPCC] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
-        subprocess.check_call(cmd, cwd=CSRC)
+        r = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, universal_newlines=True)
+        # (the host half of the compilation does not know the device feature of NO_PACKED_FP32 and says so once per function)
+        err = "\n".join(l for l in r.stderr.splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in l)
+        if err.strip():
+            import sys
+            sys.stderr.write(err + "\n")
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
     return obj
 
 

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "../../include/orp_hip.h"
+#include "orp_launch.hpp"
 
 namespace {
 
@@ -281,12 +282,12 @@ int orp_point_assign(const float* points, int n, const float* gts, int k, float 
   if (n < 0 || k < 0 || pos_num < 1 || (!gt_inds && n > 0)) return ORP_EINVAL;
   if (n == 0) return ORP_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (k == 0) { hipError_t e = hipMemsetAsync(gt_inds, 0, sizeof(int64_t) * (size_t)n, st); return e == hipSuccess ? ORP_OK : (int)e; }
+  if (k == 0) { hipError_t e = orp::fill_async(gt_inds, 0, sizeof(int64_t) * (size_t)n, st); return e == hipSuccess ? ORP_OK : (int)e; }
   if (!points || !gts) return ORP_EINVAL;
   if (!workspace || workspace_bytes < orp_point_assign_workspace_bytes(n)) return ORP_EWORKSPACE;
   u64* best = reinterpret_cast<u64*>(workspace);
   int* minmax = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + align256(sizeof(u64) * (size_t)n));
-  hipError_t e = hipMemsetAsync(best, 0xff, sizeof(u64) * (size_t)n, st);
+  hipError_t e = orp::fill_async(best, 0xff, sizeof(u64) * (size_t)n, st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(init_minmax_kernel, dim3(1), dim3(1), 0, st, minmax);
   hipLaunchKernelGGL(level_minmax_kernel, dim3(64), dim3(kThreads), 0, st, points, n, minmax);
@@ -305,8 +306,8 @@ int orp_max_iou_assign(const float* overlaps_nk, int n, int k, float pos_iou_thr
   if (n == 0) return ORP_OK;
   hipStream_t st = (hipStream_t)stream;
   if (k == 0) {      // no gt: everything background, max_overlaps = 0 (max_iou_assigner.py:103-118)
-    hipError_t e = hipMemsetAsync(gt_inds, 0, sizeof(int64_t) * (size_t)n, st);
-    if (e == hipSuccess && max_overlaps) e = hipMemsetAsync(max_overlaps, 0, sizeof(float) * (size_t)n, st);
+    hipError_t e = orp::fill_async(gt_inds, 0, sizeof(int64_t) * (size_t)n, st);
+    if (e == hipSuccess && max_overlaps) e = orp::fill_async(max_overlaps, 0, sizeof(float) * (size_t)n, st);
     return e == hipSuccess ? ORP_OK : (int)e;
   }
   if (!overlaps_nk) return ORP_EINVAL;
@@ -344,7 +345,7 @@ int orp_apaa_select(const float* quality, const int64_t* pos_gt_inds, const int3
   if (p == 0) return ORP_OK;
   if (!quality || !pos_gt_inds || !pos_level || !keep) return ORP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(keep, 0, (size_t)p, st);
+  hipError_t e = orp::fill_async(keep, 0, (size_t)p, st);
   if (e != hipSuccess) return (int)e;
   if (num_gt == 0) return ORP_OK;
   hipLaunchKernelGGL(apaa_select_kernel, dim3(num_gt), dim3(kThreads), 0, st, quality, pos_gt_inds, pos_level, p,

@@ -11,10 +11,12 @@
 // NCHW out, bias / ReLU in the epilogue; the two towers' layer k are the two grid halves of ONE launch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/orp_hip.h"
 #include "orp_dcn_split.hpp"
 #include "orp_prof.hpp"
+#include "orp_launch.hpp"
 
 namespace {
 
@@ -165,13 +167,15 @@ static int to_cl_impl(const orp_norm_level* levels_host, int nlevels, int batch,
   for (int i = nlevels; i <= kMaxT; i++) T.bx0[i] = bx;
   for (int i = nlevels; i < kMaxT; i++) { T.in[i] = T.in[0]; T.out[i] = T.out[0]; T.hw[i] = 0; T.slot[i] = 0; }
   if (amax_out && reset) {
-    const hipError_t me = hipMemsetAsync(amax_out, 0, sizeof(uint32_t) * nslots, (hipStream_t)stream);
+    const hipError_t me = orp::fill_async(amax_out, 0, sizeof(unsigned) * (size_t)(nslots), (hipStream_t)stream);
     if (me != hipSuccess) return (int)me;
   }
   hipLaunchKernelGGL(to_channels_last_kernel, dim3(bx, (channels + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, T, channels);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }
+
+int orp_debug_amax_log(uint32_t* log, int capacity_launches) { return orp_split::set_amax_log(log, capacity_launches); }
 
 int orp_nchw_to_nhwc_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, void* stream) {
   return to_cl_impl(levels_host, nlevels, batch, channels, nullptr, nullptr, 0, 0, stream);

@@ -24,6 +24,7 @@
 
 #include "../../include/orp_hip.h"
 #include "orp_prof.hpp"
+#include "orp_launch.hpp"
 
 #ifndef ORP_WG_DBG
 #define ORP_WG_DBG 0      // dev aid (timing only, wrong results): 1 = no fetches after the first, 2 = no MFMA, 4 = no conversion / LDS writes
@@ -314,7 +315,7 @@ int orp_conv_wgrad_split(const orp_wgrad_level* levels_host, int nlevels, int ba
   OrpProfScope prof(ORP_PROF_CONV_WGRAD, st);
   P.amax_x = amax_x; P.amax_g = amax_g;
   if (!amax_x || !amax_g) {                                   // no producer left (both) ranges: take them here
-    hipError_t me = hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), st);
+    hipError_t me = orp::fill_async(amax, 0, 2 * sizeof(unsigned), st);
     if (me != hipSuccess) return (int)me;
     WAbs A;
     int bx = 0, cnt = 0;

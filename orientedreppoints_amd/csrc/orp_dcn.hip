@@ -1204,7 +1204,7 @@ static int dcn_forward_impl(const orp_dcn_level* levels_host, const orp_dcn_leve
       P.ks_scratch = reinterpret_cast<float*>(wsp);
       P.ks_flags = reinterpret_cast<int*>(wsp + align256_((size_t)nwg * kKsSlotBytes));
       P.ks_nwg = nwg; P.ks_total = tiles * taps;
-      const hipError_t me = hipMemsetAsync(P.ks_flags, 0, sizeof(int) * nwg, st);
+      const hipError_t me = orp::fill_async(P.ks_flags, 0, sizeof(int) * nwg, st);
       if (me != hipSuccess) return (int)me;
       use_ks = true;
     }

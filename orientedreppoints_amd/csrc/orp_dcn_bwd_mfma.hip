@@ -1033,7 +1033,7 @@ int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float*
   TO.in_code = 0; TO.out_code = io_dtype;                   // grad_input leaves in the I/O type
 
   OrpProfScope prof(ORP_PROF_DCN_BWD, st);
-  hipError_t e = hipMemsetAsync(flags, 0, sizeof(int) * (size_t)pl.total_chunks, st);
+  hipError_t e = orp::fill_async(flags, 0, sizeof(int) * (size_t)pl.total_chunks, st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(transpose_set_kernel, dim3(tin, batch), dim3(256), 0, st, TI);
   hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, st, flags, pl.total_chunks, const_cast<int*>(P.active));
@@ -1053,13 +1053,13 @@ int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float*
     P.sorted_vals = reinterpret_cast<unsigned*>(ws + pl.vals_out_off);
     if (use_atomics) {
       P.G = nullptr;
-      e = hipMemsetAsync(ws + pl.gx_begin, 0, pl.gx_bytes, st);
+      e = orp::fill_async(ws + pl.gx_begin, 0, pl.gx_bytes, st);
       if (e != hipSuccess) return (int)e;
       for (int i = 0; i < nlevels; i++) {                            // grad_offset of the chunks that are skipped is zero
-        e = hipMemsetAsync(levels_host[i].grad_offset, 0, sizeof(float) * (size_t)batch * 2 * taps * pl.Ho[i] * pl.Wo[i], st);
+        e = orp::fill_async(levels_host[i].grad_offset, 0, sizeof(float) * (size_t)batch * 2 * taps * pl.Ho[i] * pl.Wo[i], st);
         if (e != hipSuccess) return (int)e;
         if (P.lv[i].gmask) {
-          e = hipMemsetAsync(P.lv[i].gmask, 0, sizeof(float) * (size_t)batch * taps * pl.Ho[i] * pl.Wo[i], st);
+          e = orp::fill_async(P.lv[i].gmask, 0, sizeof(float) * (size_t)batch * taps * pl.Ho[i] * pl.Wo[i], st);
           if (e != hipSuccess) return (int)e;
         }
       }

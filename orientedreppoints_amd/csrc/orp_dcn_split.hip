@@ -59,6 +59,15 @@
 // 1 = drain before the A-fragment prefetch instead, 3 = both, 0 = none (dev aid).
 #define ORP_DCNS_DRAIN 2
 #endif
+#ifndef ORP_DCNS_OWN_SIMD
+#define ORP_DCNS_OWN_SIMD 1          // 0: dev aid (the instantiations of tile height 1 / 2 then share their SIMDs with other waves)
+#endif
+#ifndef ORP_DCNS_TABLE_SELECTS
+#define ORP_DCNS_TABLE_SELECTS 0     // dev aid: 1 = the coefficient table's border conditions as selects (round 4; wrong rows under co-residency)
+#endif
+#ifndef ORP_DCNS_TRACE
+#define ORP_DCNS_TRACE 0             // dev aid (tests/checks/split_trace.py): 1 = every workgroup dumps its coefficient table, 2 = also a hash of every A-tile row of every phase, into the orp_debug_amax_log buffer
+#endif
 #ifndef ORP_DCNS_SIDE_ACC
 #define ORP_DCNS_SIDE_ACC 1          // PLAIN instantiation: second accumulator set for the small partial products (see Products)
 #endif
@@ -105,6 +114,7 @@ struct FwdS {
   const float* wscale[2];         // F16: the power of two the layer's weights were multiplied by at pack time (device scalar)
   const unsigned* amax;           // F16: bits of (a bound of) max |x| over the inputs of layer cv at amax[cv * amax_stride]
   int amax_stride;
+  unsigned* dbg;                  // dev aid (orp_debug_amax_log): the first tile of layer cv leaves [cv] = the range word it READ, [2 + cv] = its weight scale
 };
 
 // w [o][c][tap] fp32 -> three bf16 planes [pl][tap][c/16][kg][o][8]  (kg = (c % 16) / 8, e = c % 8), exact truncation split
@@ -251,6 +261,12 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   float4* sCw = reinterpret_cast<float4*>(sA + 2 * NPL * PLANE);              // [BMS * taps] bilinear weights
   int4* sCi = reinterpret_cast<int4*>(sCw + BMS * kTapsMax);                  // [BMS * taps] pixel indices
 
+#if ORP_DCNS_OWN_SIMD
+  // the kernel claims the whole register budget of its waves (256 VGPRs: two waves fill a SIMD's file), whatever the tile height
+  // needs: no wave of another workgroup -- of this kernel or of any other stream's -- runs on a SIMD beside a wave that is in the
+  // MFMA loop (what such neighbours suffered)
+  asm volatile("" ::: "v255");
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int taps = P.kh * P.kw;
   int tile, conv;
@@ -279,6 +295,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     sx = __uint_as_float((unsigned)(127 + k) << 23);
     const float sw = *(L.planes ? L.wscale : conv ? P.wscale[1] : P.wscale[0]);
     osc = 1.f / (sx * sw);
+    if (P.dbg && tile == 0 && blockIdx.y == 0 && tid == 0) { P.dbg[conv] = am; P.dbg[2 + conv] = __float_as_uint(sw); }
   }
 
   // ---- bilinear coefficient table, one entry per (position, tap): deformable_im2col_bilinear (:84-115) hoisted out of the
@@ -303,15 +320,33 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       const float w_im = (float)(wo * P.sw - P.pw + kj * P.dw) + ob[HoWo];
       if (h_im > -1.f && w_im > -1.f && h_im < (float)L.H && w_im < (float)L.W) {
         const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-        const int h_high = h_low + 1, w_high = w_low + 1;
         const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
         const float hh = 1.f - lh, hw_ = 1.f - lw;
+#if ORP_DCNS_TABLE_SELECTS
+        // (the first formulation, kept as a dev aid: its lane-mask code is where the wrong rows of round 4 came from -- see below)
+        const int h_high = h_low + 1, w_high = w_low + 1;
         const bool t_ok = h_low >= 0, b_ok = h_high <= L.H - 1, l_ok = w_low >= 0, r_ok = w_high <= L.W - 1;
         const int hl = t_ok ? h_low : 0, hhg = b_ok ? h_high : L.H - 1, wl = l_ok ? w_low : 0, whg = r_ok ? w_high : L.W - 1;
         w.x = (t_ok && l_ok) ? hh * hw_ : 0.f;
         w.y = (t_ok && r_ok) ? hh * lw : 0.f;
         w.z = (b_ok && l_ok) ? lh * hw_ : 0.f;
         w.w = (b_ok && r_ok) ? lh * lw : 0.f;
+#else
+        // The four border conditions as 0 / 1 FACTORS and min / max clamps -- no lane masks.  h_low is in [-1, H - 1] here, so
+        // t_ok = (h_low >= 0) = min(h_low + 1, 1), b_ok = (h_low + 1 <= H - 1) = min(H - 1 - h_low, 1), likewise l_ok / r_ok; a
+        // product times 1.f is the product, times 0.f is +0 (the products are >= 0): the same bits as the selects of the
+        // reference (deform_conv_cuda_kernel.cu:84-115).  Why: the compiler turned the selects into v_cmp_*_e64 -> s_and_b64 ->
+        // v_cndmask chains between packed-fp32 instructions, and with a second workgroup of this kernel in its K loop on the
+        // same CU the mask of w.z arrived with its last lane quarter (lanes 48..63) stale -- w.z = 0 in 16 consecutive table
+        // entries, i.e. three wrong A rows in all channels (tests/checks/split_trace.py, sgpr_mask_probe.hip).
+        const float t_ok = (float)min(h_low + 1, 1), b_ok = (float)min(L.H - 1 - h_low, 1);
+        const float l_ok = (float)min(w_low + 1, 1), r_ok = (float)min(L.W - 1 - w_low, 1);
+        const int hl = max(h_low, 0), hhg = min(h_low + 1, L.H - 1), wl = max(w_low, 0), whg = min(w_low + 1, L.W - 1);
+        w.x = (hh * hw_) * (t_ok * l_ok);
+        w.y = (hh * lw) * (t_ok * r_ok);
+        w.z = (lh * hw_) * (b_ok * l_ok);
+        w.w = (lh * lw) * (b_ok * r_ok);
+#endif
         const int base = b * L.H;
         ix.x = (base + hl) * L.W + wl;
         ix.y = (base + hl) * L.W + whg;
@@ -326,6 +361,16 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     sCw[e] = w; sCi[e] = ix;
   }
   __syncthreads();
+#if ORP_DCNS_TRACE
+  const int trace_wg = conv * total_tiles + tile;
+  if (P.dbg && !PLAIN)                                    // (the DeformConv instantiation only: a PLAIN neighbour stream does not write)
+    for (int e = tid; e < BMS * taps; e += kThreadsS) {
+      unsigned* t = P.dbg + 16 + ((size_t)trace_wg * BMS * kTapsMax + e) * 8;
+      const float4 w = sCw[e]; const int4 ix = sCi[e];
+      t[0] = __float_as_uint(w.x); t[1] = __float_as_uint(w.y); t[2] = __float_as_uint(w.z); t[3] = __float_as_uint(w.w);
+      t[4] = ix.x; t[5] = ix.y; t[6] = ix.z; t[7] = ix.w;
+    }
+#endif
 
   const int ncb = P.Cin / CBS;
   const int nphase = taps * ncb;
@@ -440,6 +485,20 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
 #pragma unroll 1
   for (int phase = 0; phase < nphase; phase++) {
     const int cur = phase & 1;
+#if ORP_DCNS_TRACE >= 2
+    if (P.dbg && !PLAIN) {   // hash of every row of the buffer this phase reads, as the readers see it (16 threads per row)
+      const int r = tid >> 4, sub = tid & 15;
+      if (r < BMS) {
+        unsigned h = 0;
+        for (int pl = 0; pl < NPL; pl++) {
+          const uint16_t* src = sA + (size_t)cur * NPL * PLANE + (size_t)pl * PLANE + (size_t)r * ASTRS + sub * 4;
+          for (int i = 0; i < 4; i++) h = h * 0x9E3779B1u + src[i] + 1u;
+        }
+        for (int o = 8; o > 0; o >>= 1) h = h * 31u + (unsigned)__shfl_down((int)h, o, 16);
+        if (sub == 0) P.dbg[16 + (size_t)(1 << 20) + ((size_t)trace_wg * 128 + phase) * BMS + r] = h;
+      }
+    }
+#endif
     // (1) the gathers of the next phase's rows go out first: a whole phase of matrix work to land
     float4 g[MT][4];
 #pragma unroll
@@ -490,6 +549,8 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) asm volatile("v_mov_b32 %0, %1" : "=v"(t_) : "v"(acc[mt][15])); }
       __builtin_amdgcn_sched_barrier(0);
+#elif ORP_DCNS_DRAIN & 4
+      __builtin_amdgcn_sched_barrier(0);                  // the fence alone: the chunk's MFMAs stay together, its refills behind them
 #endif
 #if ORP_DCNS_REFILL_LAG
       // the registers of chunk j - 1 are refilled one chunk LATER, behind the MFMAs of chunk j (chunk NCH - 1: after the loop)
@@ -612,7 +673,7 @@ hipError_t pack_planes(const float* weight, int c_out, int c_in, int taps, uint1
   // the fp16 planes: max |w| -> scale -> two planes
   float* tail = reinterpret_cast<float*>(planes + 5 * total);              // [0] scale, [1] max |w| bits
   unsigned* amax = reinterpret_cast<unsigned*>(tail + 1);
-  hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned), st);
+  hipError_t e = orp::fill_async(amax, 0, sizeof(unsigned), st);
   if (e != hipSuccess) return e;
   AbsMaxArgs M;
   long nb = (total / 4 + 256 * 8 - 1) / (256 * 8); if (nb < 1) nb = 1; if (nb > 512) nb = 512;
@@ -623,8 +684,24 @@ hipError_t pack_planes(const float* weight, int c_out, int c_in, int taps, uint1
   return hipGetLastError();
 }
 
+// dev aid: a log of what the fp16-pieces launches read as their range words (4 words per launch, in launch order; baked into a
+// captured graph's kernel nodes like every other argument, so a replay writes the slots its capture was given)
+static unsigned* g_amax_log = nullptr;
+static int g_amax_log_cap = 0, g_amax_log_next = 0;
+int set_amax_log(unsigned* log, int capacity_launches) {
+  const int used = g_amax_log_next;
+  g_amax_log = log; g_amax_log_cap = log ? capacity_launches : 0; g_amax_log_next = 0;
+  return used;
+}
+
 hipError_t launch(const Args& a, hipStream_t st) {
   FwdS P;
+  P.dbg = nullptr;
+#if ORP_DCNS_TRACE
+  P.dbg = g_amax_log;                                     // the trace buffer (>= 16 + 2^20 + 2^20 words), every launch from its start
+#else
+  if (a.nprod == 3 && g_amax_log && g_amax_log_next < g_amax_log_cap) P.dbg = g_amax_log + 4 * (g_amax_log_next++);
+#endif
   P.nlev = a.nlev; P.B = a.B; P.Cin = a.Cin; P.Cout = a.Cout;
   P.kh = a.kh; P.kw = a.kw; P.sh = a.sh; P.sw = a.sw; P.ph = a.ph; P.pw = a.pw; P.dh = a.dh; P.dw = a.dw;
   P.planes[0] = a.planes[0]; P.planes[1] = a.planes[1]; P.bias[0] = a.bias[0]; P.bias[1] = a.bias[1];
@@ -680,7 +757,7 @@ hipError_t launch(const Args& a, hipStream_t st) {
       for (int i = cnt; i <= kAbsMaxT; i++) M.bx0[i] = bx;
       for (int i = cnt; i < kAbsMaxT; i++) { M.x[i] = M.x[0]; M.n[i] = 0; M.slot[i] = 0; }
       M.count = cnt;
-      hipError_t e = hipMemsetAsync(a.scratch, 0, 2 * sizeof(unsigned), st);
+      hipError_t e = orp::fill_async(a.scratch, 0, sizeof(unsigned) * (size_t)(2), st);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(absmax_kernel, dim3(bx), dim3(256), 0, st, M, a.scratch);
       P.amax = a.scratch; P.amax_stride = 1;

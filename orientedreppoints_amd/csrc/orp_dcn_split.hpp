@@ -44,5 +44,7 @@ const uint16_t* planes_of(const float* packed, int c_out, int c_in, int taps, in
 const float* wscale_of(const float* packed, int c_out, int c_in, int taps);
 hipError_t pack_planes(const float* weight /* [o][c][tap] */, int c_out, int c_in, int taps, uint16_t* planes, hipStream_t st);
 hipError_t launch(const Args& a, hipStream_t st);
+// dev aid (orp_debug_amax_log): returns the number of launches logged since the previous call
+int set_amax_log(unsigned* log, int capacity_launches);
 
 }  // namespace orp_split

@@ -969,7 +969,7 @@ int launch_nms(const float* dets, int n_total, const int32_t* seg_off_dev, int n
     hipLaunchKernelGGL(set_single_segment_kernel, dim3(1), dim3(1), 0, st, seg, n_total);
   }
   if (n_total == 0) {
-    hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int32_t) * (size_t)nseg, st);
+    hipError_t e = orp::fill_async(num_keep, 0, sizeof(int32_t) * (size_t)nseg, st);
     return e == hipSuccess ? ORP_OK : (int)e;
   }
   // ---- stage 1: visiting order + per-box records ----------------------------------------------------------------------
@@ -1129,7 +1129,7 @@ int orp_poly_nms_f64(const double* dets_sorted, int n, double iou_thr, int64_t* 
   if (n > ORP_NMS_MAX_BOXES) return ORP_ETOOBIG;
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) {
-    hipError_t e0 = hipMemsetAsync(num_keep, 0, sizeof(int32_t), st);
+    hipError_t e0 = orp::fill_async(num_keep, 0, sizeof(int32_t), st);
     return e0 == hipSuccess ? ORP_OK : (int)e0;
   }
   if (!workspace || workspace_bytes < orp_poly_nms_f64_workspace_bytes(n)) return ORP_EWORKSPACE;

@@ -19,8 +19,10 @@
 //               bias / ReLU / `+ pts_out_init` / `- dcn_base_offset` passes around the head's output convolutions.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/orp_hip.h"
+#include "orp_launch.hpp"
 
 namespace {
 
@@ -189,7 +191,7 @@ struct GnNhwc {
 __global__ void __launch_bounds__(kThreads)
 gn_apply_nhwc_kernel(const GnParams P, const GnNhwc T) {
   __shared__ float tile[32][33];
-  __shared__ float2 sStat[8];                     // (mean, rstd) of the tile's groups (32 channels / (C / G) <= 8 groups)
+  __shared__ float2 sStat[32];                    // (mean, rstd) of the tile's groups (32 channels / (C / G) <= 32 groups)
   int lvl = 0;
 #pragma unroll 1
   for (int i = 1; i < P.nlev; i++) if ((int)blockIdx.x >= T.bx0[i]) lvl = i;
@@ -745,7 +747,7 @@ static int gn_cl_impl(const orp_norm_level* levels, const float* const* gammas_h
   P.amax = amax_out;
   hipStream_t st = (hipStream_t)stream;
   if (amax_out) {
-    const hipError_t me = hipMemsetAsync(amax_out, 0, sizeof(uint32_t) * nslots, st);
+    const hipError_t me = orp::fill_async(amax_out, 0, sizeof(unsigned) * (size_t)(nslots), st);
     if (me != hipSuccess) return (int)me;
   }
   hipLaunchKernelGGL(gn_cl_stats_kernel, dim3(chunks), dim3(kThreads), 0, st, P);

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "../../include/orp_hip.h"
+#include "orp_launch.hpp"
 
 namespace {
 
@@ -506,7 +507,7 @@ int orp_pp_compact(const float* sig_all, const int64_t* cand, int m0, int n, int
   unsigned* max_ord = reinterpret_cast<unsigned*>(scratch);
   unsigned* bits = max_ord + 64;
   // ordered encoding of -inf = ~0xff800000 = 0x007fffff
-  hipError_t e = hipMemsetAsync(max_ord, 0, sizeof(unsigned), st);     // 0 < f2ord(x) for every float x: "no box yet"
+  hipError_t e = orp::fill_async(max_ord, 0, sizeof(unsigned), st);     // 0 < f2ord(x) for every float x: "no box yet"
   if (e != hipSuccess) return (int)e;
   if (m0 > 0)
     hipLaunchKernelGGL(pp_flags_kernel, dim3((m0 + 255) / 256), dim3(256), 0, st, sig_all, cand, m0, n, num_classes, boxes,

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "../../include/orp_hip.h"
+#include "orp_launch.hpp"
 
 namespace {
 
@@ -204,7 +205,7 @@ int orp_pointset_target(const int64_t* gt_inds, const uint8_t* valid, int batch,
     return ORP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (counts) {
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * 2 * (size_t)(batch > 0 ? batch : 1), st);
+    hipError_t e = orp::fill_async(counts, 0, sizeof(int32_t) * 2 * (size_t)(batch > 0 ? batch : 1), st);
     if (e != hipSuccess) return (int)e;
   }
   const long total = (long)batch * n;
@@ -249,7 +250,7 @@ int orp_gather_levels_backward(const orp_level_desc* levels_host, int nlevels, i
   hipStream_t st = (hipStream_t)stream;
   for (int i = 0; i < nlevels; i++) {
     if (!levels_host[i].grad) return ORP_EINVAL;
-    hipError_t e = hipMemsetAsync(levels_host[i].grad, 0, sizeof(float) * (size_t)batch * channels * T.hw[i], st);
+    hipError_t e = orp::fill_async(levels_host[i].grad, 0, sizeof(float) * (size_t)batch * channels * T.hw[i], st);
     if (e != hipSuccess) return (int)e;
   }
   if (p == 0) return ORP_OK;

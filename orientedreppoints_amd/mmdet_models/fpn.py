@@ -76,9 +76,7 @@ class FPN(nn.Module):
         from ..mmdet_ops.fused_norm import conv_split_ok
         on = getattr(self, 'split_convs', None)
         if on is None:
-            # automatic: on (ORP_FPN_SPLIT=0: off) when the smallest lateral is at least 32 x 32, i.e. the pyramid's extra
-            # levels stay >= 8 x 8 (the head's rule for its towers, see OrientedRepPointsHead._split_towers_ok)
-            on = os.environ.get('ORP_FPN_SPLIT', '1') == '1' and min(min(t.size(2), t.size(3)) for t in laterals) >= 32
+            on = os.environ.get('ORP_FPN_SPLIT', '1') == '1'      # automatic: on at every input size (ORP_FPN_SPLIT=0: off, A/B timing)
         used = len(self.lateral_convs)
         if not on or _lib.lib().orp_dcn_get_split_mode() == 0 or used > 8:
             return False

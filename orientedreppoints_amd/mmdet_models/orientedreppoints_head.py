@@ -141,6 +141,15 @@ class OrientedRepPointsHead(nn.Module):
                 return False
         return True
 
+    def _nhwc_norm_ok(self, channels):
+        """the towers' last GroupNorm has a shape `orp_groupnorm_act_multi_nhwc` takes (32-channel tiles of whole groups);
+        otherwise the hand-over is off and the NCHW normalisation + transposition route runs"""
+        for m in (self.cls_convs[-1], self.reg_convs[-1]) if len(self.cls_convs) and len(self.reg_convs) else ():
+            g = m.norm.num_groups
+            if channels % 32 != 0 or channels % g != 0 or 32 % (channels // g) != 0:
+                return False
+        return bool(len(self.cls_convs) and len(self.reg_convs))
+
     @staticmethod
     def _conv_nobias(m, x):
         return F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
@@ -169,13 +178,11 @@ class OrientedRepPointsHead(nn.Module):
         from ..mmdet_ops.fused_norm import conv_split_ok
         on = getattr(self, 'split_towers', None)
         if on is None:
-            # automatic: on (ORP_TOWER_SPLIT=0 switches it off), for pyramids whose smallest level is at least 8 x 8 -- every
-            # 1024^2 / 1536^2 input.  Below that (the 256^2 images of the graph tests: levels down to 2 x 2) captured-graph
-            # replays of this path disagreed with the eager call in about one suite run out of four, values off beyond the
-            # tolerance, while every operator-level comparison, the soak under concurrent streams and five eager-interleaved
-            # replays at 1024^2 were bit-identical: not understood, so small pyramids keep the round-3 towers
-            # unless `split_towers = True` asks for this path explicitly
-            on = os.environ.get('ORP_TOWER_SPLIT', '1') == '1' and min(min(f.size(2), f.size(3)) for f in feats) >= 8
+            # automatic: on at every input size, as the reference runs its towers at every size (head :91-113, :148-171);
+            # ORP_TOWER_SPLIT=0 switches the path off (A/B timing).  (Round 4 kept pyramids below 8 x 8 off this path because
+            # graph replays there disagreed with eager: that was packed-fp32 VALU code of ANY kernel miscomputing next to dense
+            # MFMAs -- DESIGN.md 4.5 --, fixed in the library's build, not a property of this path.)
+            on = os.environ.get('ORP_TOWER_SPLIT', '1') == '1'
         if not on or _lib.lib().orp_dcn_get_split_mode() == 0 or len(self.cls_convs) != len(self.reg_convs) or len(feats) > 8:
             return False
         x = feats[0]
@@ -296,7 +303,7 @@ class OrientedRepPointsHead(nn.Module):
             else:
                 cls_all, pts_all = self._tower_train(self.cls_convs, feats), self._tower_train(self.reg_convs, feats)
             pc = self.reppoints_pts_init_conv
-            if conv_split_train_ok([pc], feats[0], allow_bias=True):
+            if len(feats) <= 8 and conv_split_train_ok([pc], feats[0], allow_bias=True):     # (orp_split::kMaxLevels tensors per launch)
                 hid = conv_split_train(pts_all, pc)
                 if pc.bias is not None:
                     hid = [h + pc.bias.view(1, -1, 1, 1) for h in hid]
@@ -349,7 +356,7 @@ class OrientedRepPointsHead(nn.Module):
             hand = bool(hand) and not getattr(self, 'fuse_output_convs', False) and a_.weight.size(1) % 256 == 0 and \
                 tuple(a_.weight.shape) == tuple(b_.weight.shape) and a_.stride == b_.stride and a_.padding == b_.padding and \
                 a_.dilation == b_.dilation and a_.groups == 1 and b_.groups == 1 and a_.deformable_groups == 1 and \
-                b_.deformable_groups == 1 and min(min(f.size(2), f.size(3)) for f in feats) > 1
+                b_.deformable_groups == 1 and min(min(f.size(2), f.size(3)) for f in feats) > 1 and self._nhwc_norm_ok(feats[0].size(1))
             from ..mmdet_ops.fused_norm import bias_act_multi, conv3x3_multi
             split = hand and self._split_towers_ok(feats)
             side = None

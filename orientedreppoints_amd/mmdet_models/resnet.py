@@ -29,12 +29,15 @@ class Bottleneck(nn.Module):
         self.with_dcn = dcn is not None
         fallback_on_stride = False
         if self.with_dcn:
-            dcn = dict(dcn)
+            # as the reference does it (resnet.py:145-148): the flag is POPPED from the dict the backbone hands to every block
+            # of every stage, so only the first block built from it sees the flag -- which decides the set of
+            # conv2.conv_offset keys a reference-trained checkpoint has -- and a set flag means a plain conv2 whatever its stride
             fallback_on_stride = dcn.pop('fallback_on_stride', False)
+            dcn = dict(dcn)
             if 'modulated' in dcn:                                   # the older spelling of the same choice
                 dcn.setdefault('type', 'DCNv2' if dcn.pop('modulated') else 'DCN')
             dcn.setdefault('type', 'DCN')
-        use_dcn = self.with_dcn and not (fallback_on_stride and conv2_stride > 1)
+        use_dcn = self.with_dcn and not fallback_on_stride
         self.conv2 = build_conv_layer(dcn if use_dcn else None, planes, planes, kernel_size=3, stride=conv2_stride,
                                       padding=dilation, dilation=dilation, bias=False)
         self.conv2_is_dcn = use_dcn

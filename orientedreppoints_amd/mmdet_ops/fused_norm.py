@@ -617,8 +617,19 @@ class _ConvSplitTrain(torch.autograd.Function):
         outs = _ConvSplitTrain._run(cl, ws, groups, padding, dilation, nw, amax)
         ctx.meta = meta
         ctx.x_bits = (bits, split_slots)                      # ranges of the inputs, for the weight-gradient kernel
-        ctx.save_for_backward(*ws, *cl, *[x.detach() for x in xs])
+        # the weight gradient reads ONE copy of the inputs: NCHW for the layers that take orp_conv_wgrad_split, channels-last for
+        # the library's kernel -- only what the chosen routes need is kept (both copies doubled the saved activations)
+        routes = [_ConvSplitTrain._wgrad_split_route(ws[k], [i for i in range(n) if groups[i] == k], padding, dilation) for k in range(nw)]
+        ctx.routes = tuple(routes)
+        keep_cl = cl if not all(routes) else []
+        keep_x = [x.detach() for x in xs] if any(routes) else []
+        ctx.kept = (len(keep_cl), len(keep_x))
+        ctx.save_for_backward(*ws, *keep_cl, *keep_x)
         return tuple(outs)
+
+    @staticmethod
+    def _wgrad_split_route(w, idx, padding, dilation):
+        return len(idx) <= 8 and conv_wgrad_split_ok(w, padding, dilation)
 
     @staticmethod
     def _run(cl, ws, groups, padding, dilation, nw, amax=None):
@@ -640,7 +651,8 @@ class _ConvSplitTrain(torch.autograd.Function):
     def backward(ctx, *grads):
         n, nw, groups, padding, dilation = ctx.meta
         saved = ctx.saved_tensors
-        ws, cl, xs_nchw = saved[:nw], saved[nw:nw + n], saved[nw + n:]
+        ncl, nx = ctx.kept
+        ws, cl, xs_nchw = saved[:nw], saved[nw:nw + ncl], saved[nw + ncl:nw + ncl + nx]
         kh, kw = ws[0].size(2), ws[0].size(3)
         pair = nw == 2 and n % 2 == 0 and list(groups) == [0] * (n // 2) + [1] * (n // 2)
         g_cl, bits = to_channels_last_multi([g.detach().float() for g in grads],
@@ -656,7 +668,7 @@ class _ConvSplitTrain(torch.autograd.Function):
             if not ctx.needs_input_grad[1 + k]:
                 continue
             idx = [i for i in range(n) if groups[i] == k]
-            if len(idx) <= 8 and conv_wgrad_split_ok(ws[k], padding, dilation):
+            if ctx.routes[k]:
                 # one launch for the layer's levels, straight from the NCHW tensors (positions = the contraction axis)
                 xb, x_split = ctx.x_bits
                 sx = 1 if (x_split and idx[0] >= n // 2) else 0

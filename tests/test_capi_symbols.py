@@ -37,3 +37,33 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 src = open(os.path.join(dp, f), errors="replace").read()
                 assert "orp_oracle" not in src and "liborp_oracle" not in src and "libref_orp" not in src, f
+
+
+def test_device_code_has_no_packed_fp32_instructions():
+    """The built library's gfx950 code objects contain no v_pk_*_f32 instruction.  Why this is a test: on MI355X a packed fp32
+    multiply returns a wrong low half in lanes 48..63 while other waves of the CU issue dense bf16 / f16 MFMAs
+    (tests/checks/mfma_refill_victim.hip: 5.6e6 wrong results in 5e10, none for the scalar form); compiler-generated packed
+    code in this library's kernels was the cause of every wrong-result anomaly of rounds 4 and 5.  build.py
+    compiles every kernel with the packed-fp32 feature off; this checks the binary that ships."""
+    import shutil
+    import subprocess
+    import tempfile
+    from orientedreppoints_amd import build, _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        import pytest
+        pytest.skip("llvm-objdump not found")
+    build.build_hip()
+    with tempfile.TemporaryDirectory() as tmp:
+        so = os.path.join(tmp, "liborp_hip.so")
+        shutil.copy(_lib.LIB_PATH, so)
+        subprocess.run([objdump, "--offloading", so], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        bundles = [f for f in os.listdir(tmp) if f.endswith("gfx950")]
+        assert len(bundles) >= 10, "expected one gfx950 code object per kernel source"
+        mfma = packed = 0
+        for b in bundles:
+            asm = subprocess.run([objdump, "-d", os.path.join(tmp, b)], stdout=subprocess.PIPE, universal_newlines=True, check=True).stdout
+            mfma += asm.count("v_mfma_")
+            packed += len(re.findall(r"\bv_pk_(?:mul|add|fma)_f32\b", asm))
+        assert mfma > 1000                                  # (the disassembly really is this library's kernels)
+        assert packed == 0, "%d packed fp32 instructions in the device code" % packed

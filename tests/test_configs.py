@@ -80,3 +80,7 @@ def test_dcn_conv_types_and_resnet_stage_with_dcn():
     net = build_backbone(dict(type='ResNet', depth=50, dcn=dict(type='DCN', fallback_on_stride=True),
                               stage_with_dcn=(False, True, True, True)))
     assert isinstance(net.layer2[0].conv2, torch.nn.Conv2d) and isinstance(net.layer2[1].conv2, DeformConvPack)
+    # the reference POPS the flag from the dict every block of every stage receives (resnet.py:145-148): only the first block
+    # built from it falls back; the stride-2 first blocks of the later stages are deformable -- the key set of its checkpoints
+    assert isinstance(net.layer3[0].conv2, DeformConvPack) and isinstance(net.layer4[0].conv2, DeformConvPack)
+    assert 'layer2.0.conv2.conv_offset.weight' not in net.state_dict() and 'layer3.0.conv2.conv_offset.weight' in net.state_dict()

@@ -428,32 +428,162 @@ def test_conv_weight_gradient_kernel_vs_float64(dev):
         assert _rel(c.weight.grad, want) <= 1e-5
 
 
-@pytest.mark.xfail(strict=False, reason="OPEN (DESIGN.md 4.4): in the opt-in fp16-pieces arithmetic a GraphedInference replay that follows "
-                                        "an eager call of the same model returns no detections; mechanism not understood, which is "
-                                        "why that arithmetic is not the default")
-def test_fp16_pieces_mode_graph_replay_after_an_eager_call(dev):
-    """The reproduction of the open issue, kept as an expected failure: towers forced onto the split path, library in the
-    fp16-pieces mode, replay / eager call / replay."""
-    from orientedreppoints_amd import _lib
+def _small_detector(dev):
     from orientedreppoints_amd.dota_configs import r50_model, test_cfg
-    from orientedreppoints_amd.mmdet_models import ConfigDict, GraphedInference, build_detector
-    L = _lib.lib()
+    from orientedreppoints_amd.mmdet_models import ConfigDict, build_detector
     torch.manual_seed(0)
     model = build_detector(ConfigDict(r50_model), train_cfg=None, test_cfg=ConfigDict(test_cfg)).to(dev).eval()
     with torch.no_grad():
         model.bbox_head.reppoints_cls_out.weight.normal_(0, 0.05)
         model.bbox_head.reppoints_cls_out.bias.fill_(-3.3)
-    model.bbox_head.split_towers = True
-    model.neck.split_convs = True
+    return model
+
+
+def test_fp16_pieces_mode_graph_replay_after_an_eager_call(dev):
+    """Round 4's open issue, now a regression test: fp16-pieces arithmetic, small pyramid (the automatic mode takes the split
+    path at every size), replay / eager call / replay.  The replays used to return no detections: the range words were zeroed
+    by hipMemsetAsync NODES, which wrote 0x80808080 in replays that followed eager work (tests/checks/graph_bitwise.py with
+    ORP_FILL=memset); every fill of the library is a kernel node now (csrc/orp_launch.hpp fill_async)."""
+    from orientedreppoints_amd import _lib
+    from orientedreppoints_amd.mmdet_models import GraphedInference
+    L = _lib.lib()
+    model = _small_detector(dev)
     metas = [dict(img_shape=(256, 256, 3), pad_shape=(256, 256, 3), scale_factor=1.0, flip=False)]
     assert L.orp_dcn_set_split_mode(3) == 0
     try:
         gi = GraphedInference(model, torch.randn(1, 3, 256, 256, device=dev), metas)
-        for seed in (1, 2, 3):
+        for seed in (1, 2, 3, 4):
             img = torch.randn(1, 3, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
             got = gi(img)
             with torch.no_grad():
                 want = model.simple_test_batch(img, metas)                 # the eager call in between
             assert sum(len(c) for r in got for c in r) == sum(len(c) for r in want for c in r) > 0
+            for gr, wr in zip(got, want):
+                for a, b in zip(gr, wr):
+                    assert a.shape == b.shape and np.array_equal(a, b)
+    finally:
+        L.orp_dcn_set_split_mode(-1)
+
+
+@pytest.mark.parametrize("mode", [6, 3])
+def test_concurrent_graph_replays_are_bitwise_the_eager_step_at_a_small_pyramid(dev, mode):
+    """256^2 images, two per call (pyramid down to 2 x 2: tile height 1, the workgroups that share a CU), three captured graphs
+    replayed CONCURRENTLY on their own streams, every replay's head outputs and detections compared BIT FOR BIT with the eager
+    step of its images.  What round 4 could not pass: replays next to other streams' kernels differed in a few positions of the
+    DeformConv output (all channels) and, rarely, in the rotated NMS's keep count -- packed-fp32 VALU instructions returning a
+    wrong low half in lanes 48..63 while other waves ran dense MFMAs (tests/checks/mfma_refill_victim.hip; DESIGN.md 4.5);
+    the library is built without those instructions (build.py NO_PACKED_FP32; tests/test_capi_symbols.py checks the binary)."""
+    from orientedreppoints_amd import _lib
+    from orientedreppoints_amd.mmdet_models import GraphedInference
+    L = _lib.lib()
+    model = _small_detector(dev)
+    head = model.bbox_head
+    head.tower_streams = False
+    det_flag = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    B, depth = 2, 3
+    metas = [dict(img_shape=(256, 256, 3), pad_shape=(256, 256, 3), scale_factor=1.0, flip=False)] * B
+    imgs = [torch.randn(B, 3, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(20 + i)) for i in range(5)]
+    target = [None]                                            # the buffer set the head's outputs are copied into (none: product path)
+
+    def hook(m, inp, out):
+        if target[0] is not None:
+            flat = list(out[0]) + list(out[1]) + list(out[2])
+            if not target[0]:
+                target[0].extend(torch.empty_like(t) for t in flat)
+            for b, t in zip(target[0], flat):
+                b.copy_(t)
+    handle = head.register_forward_hook(hook)
+    assert L.orp_dcn_set_split_mode(mode) == 0
+    try:
+        def eager(img, store):
+            target[0] = store
+            with torch.no_grad():
+                r = model.simple_test_batch(img, metas)
+            target[0] = None
+            return r
+        want, want_det, store = [], [], []
+        for im in imgs:
+            want_det.append(eager(im, store))
+            torch.cuda.synchronize()
+            want.append([t.clone() for t in store])
+        assert len({sum(len(c) for r in w for c in r) for w in want_det}) > 1
+        slots, sets = [], []
+        for d in range(depth):
+            s_ = []
+            eager(imgs[0], s_)                                 # (allocates this graph's buffers outside its capture)
+            target[0] = s_
+            slots.append(GraphedInference(model, imgs[0], metas)); sets.append(s_)
+            target[0] = None
+        streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        from orientedreppoints_amd.mmdet_models.core import rbbox2result_packed
+        rng = np.random.RandomState(3)
+        for it in range(120):
+            pick = [int(rng.randint(0, len(imgs))) for _ in range(depth)]
+            cur = torch.cuda.current_stream(dev)
+            for d in range(depth):
+                streams[d].wait_stream(cur)
+                with torch.cuda.stream(streams[d]):
+                    slots[d].static_img.copy_(imgs[pick[d]], non_blocking=True)
+                    slots[d].graph.replay()
+            torch.cuda.synchronize()
+            for d in range(depth):
+                for a, b in zip(sets[d], want[pick[d]]):
+                    assert torch.equal(a, b), "replay %d of graph %d: a head output differs from the eager step's" % (it, d)
+                res = [rbbox2result_packed(p, head.num_classes) for p in slots[d].packed]
+                for gr, wr in zip(res, want_det[pick[d]]):
+                    assert gr is not None
+                    for a, b in zip(gr, wr):
+                        assert a.shape == b.shape and np.array_equal(a, b), "replay %d of graph %d: detections differ" % (it, d)
+    finally:
+        L.orp_dcn_set_split_mode(-1)
+        handle.remove()
+        torch.backends.cudnn.deterministic = det_flag
+
+
+@pytest.mark.parametrize("mode", [6, 3])
+def test_deformconv_pair_at_tile_height_one_next_to_other_streams_every_launch_compared(dev, mode):
+    """The launch that produced round 4's wrong rows (small pyramid: tile height 1), 400 times next to a GEMM stream and a
+    stream of tower convolutions, EVERY result compared on the device with the first one (which is checked against the exact
+    fp32 kernel)."""
+    from orientedreppoints_amd import _lib
+    from orientedreppoints_amd.mmdet_ops import deform_conv_forward_pair
+    from orientedreppoints_amd.mmdet_ops.fused_norm import conv_split_multi
+    L = _lib.lib()
+    torch.manual_seed(5)
+    sizes = (32, 16, 8, 4, 2)
+    w1, w2 = torch.randn(256, 256, 3, 3, device=dev) * 0.02, torch.randn(256, 256, 3, 3, device=dev) * 0.02
+    conv = nn.Conv2d(256, 256, 3, padding=1, bias=False).to(dev)
+    side, third = torch.cuda.Stream(), torch.cuda.Stream()
+    g = torch.randn(2048, 2048, device=dev)
+    try:
+        with torch.no_grad():
+            for B in (1, 2):
+                fa = [torch.randn(B, 256, n, n, device=dev) for n in sizes]
+                fb = [torch.randn(B, 256, n, n, device=dev) for n in sizes]
+                of = [torch.randn(B, 18, n, n, device=dev) * 2 for n in sizes]
+                xa = [torch.randn(B, 256, n, n, device=dev).contiguous(memory_format=torch.channels_last) for n in sizes]
+
+                def run():
+                    r = deform_conv_forward_pair(fa, fb, of, w1, w2, 1, 1, 1, relu=False)
+                    return list(r[0]) + list(r[1])
+                L.orp_dcn_set_split_mode(0)
+                exact = [t.clone() for t in run()]
+                L.orp_dcn_set_split_mode(mode)
+                ref = [t.clone() for t in run()]
+                for x, y in zip(ref, exact):
+                    assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max())
+                nbad = torch.zeros((), dtype=torch.int64, device=dev)
+                for i in range(400):
+                    if i % 4 == 0:
+                        with torch.cuda.stream(side):
+                            g = (g @ g).clamp_(-1, 1)
+                    if i % 2 == 0:
+                        with torch.cuda.stream(third):
+                            conv_split_multi(xa, conv, xa, conv, nprod=6)
+                    out = run()
+                    nbad += torch.stack([(x != y).any() for x, y in zip(out, ref)]).any().to(torch.int64)
+                torch.cuda.synchronize()
+                assert int(nbad) == 0, "%d of 400 launches differ from the first one (B = %d)" % (int(nbad), B)
     finally:
         L.orp_dcn_set_split_mode(-1)

@@ -15,6 +15,8 @@ from orientedreppoints_amd import build as B  # noqa: E402
 
 def main():
     name, srcs, flags = sys.argv[1], sys.argv[2].split(","), sys.argv[3:]
+    if srcs == ["ALL"]:
+        srcs = [s_ for s_, _ in B.SOURCES]
     B.build_hip()
     out_dir = os.path.join(ROOT, "build_variants")
     os.makedirs(out_dir, exist_ok=True)
@@ -23,7 +25,11 @@ def main():
         base = os.path.splitext(src)[0]
         if src in srcs:
             obj = os.path.join(out_dir, "%s_%s.o" % (base, name))
-            subprocess.check_call([B.HIPCC] + B.COMMON + extra + flags + ["-c", os.path.join(B.CSRC, src), "-o", obj], cwd=B.CSRC)
+            r = subprocess.run([B.HIPCC] + B.COMMON + extra + flags + ["-c", os.path.join(B.CSRC, src), "-o", obj], cwd=B.CSRC,
+                               stderr=subprocess.PIPE, universal_newlines=True)
+            sys.stderr.write("\n".join(l for l in r.stderr.splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in l))
+            if r.returncode != 0:
+                raise SystemExit(r.returncode)
         else:
             obj = os.path.join(B.CSRC, base + ".o")
         objs.append(obj)
