@@ -998,19 +998,18 @@ size_t orp_dcn_packed_weight_floats(int c_out, int c_in, int kh, int kw) {
 // operand pair (operands represented exactly); 3 = two fp16 pieces per operand (11 + 11 bits: 2^-22 relative, after an exact
 // power-of-two range scaling from max |x| of the launch's inputs), products hi*hi, hi*lo, lo*hi -- needs scratch in the
 // workspace and no modulation mask, else the call runs as mode 6.
-// Default 6 (round 4): operands exact, error against the fp64-accumulated oracle below the exact-fp32 path's own on every test
-// shape (tests/test_gpu_dcn_split.py prints all four modes), the head's pair launch 483 (mode 0) -> 333 us.  Mode 3 is faster
-// still (255 us) and at least as accurate (three accumulator roundings per 16 channels instead of eight) and passes every
-// operator-level test, but is NOT the default: with the head's towers on it, a GraphedInference replay that followed an eager
-// call of the same model returned no detections in tests/test_gpu_parity.py::test_graphed_inference_equals_simple_test (256^2
-// images; head outputs bit-identical wherever they were observed, the anomaly disappears when any intermediate tensor is kept
-// alive -- not understood).  The environment overrides the default (ORP_DCN_SPLIT = 0 | 3 | 6 (or 1) | 9),
-// orp_dcn_set_split_mode() overrides both.
+// Default 3 (round 5): at least as accurate as mode 6 on every test shape (three accumulator roundings per 16 channels instead of
+// eight; error against the fp64-accumulated oracle below the exact-fp32 path's own, tests/test_gpu_dcn_split.py prints all four
+// modes) and half the matrix work: the head's pair launch 483 us (mode 0) -> 296 (mode 6) -> 192 (mode 3) inside the step.  Round 4
+// had to leave it opt-in: graph replays after an eager call lost their detections.  That was the range words being zeroed by
+// hipMemsetAsync NODES, which replayed with a wrong pattern (0x80808080 read back by the kernel behind them); every fill of this
+// library is a kernel node now (orp_launch.hpp fill_async; tests/test_gpu_conv_split.py::test_fp16_pieces_mode_graph_replay_...).
+// The environment overrides the default (ORP_DCN_SPLIT = 0 | 3 | 6 (or 1) | 9), orp_dcn_set_split_mode() overrides both.
 static int g_split_mode = -1;
 static int split_mode() {
   if (g_split_mode < 0) {
     const char* e = getenv("ORP_DCN_SPLIT");
-    const int v = e ? atoi(e) : 6;
+    const int v = e ? atoi(e) : 3;
     g_split_mode = v == 9 ? 9 : v == 3 ? 3 : (v == 1 || v == 6) ? 6 : 0;
   }
   return g_split_mode;

@@ -48,16 +48,15 @@
 #ifndef ORP_DCNS_REFILL_LAG
 #define ORP_DCNS_REFILL_LAG 0
 #endif
-#ifndef ORP_DCNS_DRAIN
-// 2 (default): before the weight registers of a chunk are refilled in place, the wave reads one element of every accumulator
-// -- a VALU read that cannot issue before the chain's last MFMA has written back, i.e. before every MFMA the wave has issued
-// so far has executed and read its operands.  Without it asynchronous register writes (the refill's VMEM return, the next
-// chunk's LDS return) overtook queued MFMAs whenever other waves kept the SIMD's matrix pipe backlogged: wrong rows with two
-// workgroups per CU (tests/checks/split_diag2.py) and with other streams' kernels beside it (PipelinedInference test); the
-// in-order-issue model ("an MFMA has read its operands once the next instruction issues") does not hold under that load.
-// Costs nothing measurable: the partner wave's MFMAs fill the pipe meanwhile (332 vs 352 us per pair launch).
-// 1 = drain before the A-fragment prefetch instead, 3 = both, 0 = none (dev aid).
-#define ORP_DCNS_DRAIN 2
+#ifndef ORP_DCNS_FENCE
+// 1 (default): a scheduling fence between the MFMAs of a chunk and the in-place refill of the chunk's weight registers -- the
+// MFMAs stay together, the refills go out behind them (measured +3 % on the pair launch against the scheduler's own mix).
+// History: round 4 had an inline-asm v_mov of one accumulator element here ("accumulator drain"), on the hypothesis that the
+// refill's VMEM return could overtake queued MFMAs.  tests/checks/mfma_war.hip settles it: 6.5e9 in-place refills right behind
+// their MFMAs, four waves per SIMD, every accumulator exact -- an issued MFMA has read its A / B operands --, and the v_mov
+// waited for nothing (it read a value two MFMAs old).  The wrong rows it seemed to cure were packed-fp32 VALU instructions of
+// the coefficient-table code miscomputing next to a second workgroup's MFMA loop; the v_mov only shifted that workgroup's timing.
+#define ORP_DCNS_FENCE 1
 #endif
 #ifndef ORP_DCNS_OWN_SIMD
 #define ORP_DCNS_OWN_SIMD 1          // 0: dev aid (the instantiations of tile height 1 / 2 then share their SIMDs with other waves)
@@ -521,12 +520,6 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     load_a(abase, 0, a[0]);
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
-#if ORP_DCNS_DRAIN & 1
-      { float t_; 
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) asm volatile("v_mov_b32 %0, %1" : "=v"(t_) : "v"(acc[mt][15])); }
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       if (j + 1 < NCH) load_a(abase, j + 1, a[(j + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
       // (3) the last chunk's scheduling region also holds the combine + split of the gathered rows into the OTHER buffer
@@ -543,14 +536,8 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
           if (r * CC / MT == j - (NCH - CC)) combine_store(tap_n, r, g[r], cur ^ 1);
       }
       Products<F16 ? 0 : 9 - NPROD, F16 ? 3 : 9, MT, OUT_NCHW, SIDE, F16>::run(acc, side, a[j & 1], bq[j]);
-#if ORP_DCNS_DRAIN & 2
-      __builtin_amdgcn_sched_barrier(0);
-      { float t_; 
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) asm volatile("v_mov_b32 %0, %1" : "=v"(t_) : "v"(acc[mt][15])); }
-      __builtin_amdgcn_sched_barrier(0);
-#elif ORP_DCNS_DRAIN & 4
-      __builtin_amdgcn_sched_barrier(0);                  // the fence alone: the chunk's MFMAs stay together, its refills behind them
+#if ORP_DCNS_FENCE
+      __builtin_amdgcn_sched_barrier(0);                  // the chunk's MFMAs stay together, its refills behind them
 #endif
 #if ORP_DCNS_REFILL_LAG
       // the registers of chunk j - 1 are refilled one chunk LATER, behind the MFMAs of chunk j (chunk NCH - 1: after the loop)
@@ -618,10 +605,7 @@ constexpr size_t split_smem() { return (size_t)2 * NPL * 32 * MT * ASTRS * 2 + (
 
 template <int MT, int NPROD, bool OUT_NCHW, bool PLAIN>
 hipError_t launch_one(const FwdS& P, int tiles, int nblk_n, hipStream_t st) {
-  // (dev aid) ORP_DCNS_PAD_LDS=<KB>: a floor under the LDS request, e.g. 84 = exactly one workgroup per CU.  The MT = 1
-  // instantiation (37 KB, 119 VGPRs) runs two workgroups = four waves per SIMD side by side; before the accumulator drain of
-  // ORP_DCNS_DRAIN that configuration produced wrong rows (see there), with it both residencies are bit-stable under soak
-  // (tests/checks/soak_dcn_split.py) and the shared one is 1-2 % faster on multi-round launches.
+  // (dev aid) ORP_DCNS_PAD_LDS=<KB>: a floor under the LDS request (with ORP_DCNS_OWN_SIMD the kernel is alone on its CU anyway)
   static const int pad_env = getenv("ORP_DCNS_PAD_LDS") ? atoi(getenv("ORP_DCNS_PAD_LDS")) : 0;
   constexpr size_t need = split_smem<MT, NPROD == 3 ? 2 : 3>();
   const size_t smem = need < (size_t)pad_env * 1024 ? (size_t)pad_env * 1024 : need;

@@ -193,9 +193,7 @@ def test_head_inference_with_channels_last_towers_vs_reference_forward(dev):
         for B in (1, 2):
             feats = [torch.randn(B, 256, h, w, device=dev) for h, w in ((40, 36), (20, 18), (10, 9), (5, 5), (3, 2))]
             head.split_towers = None
-            assert not head._split_towers_ok(feats)             # automatic mode: pyramids below 8 x 8 keep the library towers
-            head.split_towers = True
-            assert head._split_towers_ok(feats)
+            assert head._split_towers_ok(feats)                 # automatic mode: on at every pyramid size, down to 3 x 2 levels
             got = head(feats)
             head.split_towers = False
             lib = head(feats)
@@ -212,7 +210,7 @@ def test_head_inference_with_channels_last_towers_vs_reference_forward(dev):
             conftest.REPORT.append("head inference, channels-last towers vs forward_single, B = %d: max |diff| / scale %.2e" % (B, worst))
         big = [torch.randn(1, 256, n, n, device=dev) for n in (64, 32, 16, 8, 8)]
         head.split_towers = None
-        assert head._split_towers_ok(big)                        # automatic mode, smallest level 8 x 8: on
+        assert head._split_towers_ok(big)
         L = _lib.lib()
         L.orp_dcn_set_split_mode(0)
         try:
