@@ -512,6 +512,36 @@ int orp_conv_split_multi_ex(const orp_conv_level* levels_host, const float* cons
                             const float* const* biases_host, int nlevels, int batch, int c_in, int c_out, int relu, int kh, int kw,
                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int out_layout, int nprod,
                             void* workspace, size_t workspace_bytes, const uint32_t* amax_in, void* stream);
+/* The tower ConvModules are conv -> GroupNorm -> ReLU (mmdet/models/anchor_heads/orientedreppoints_head.py:91-113, applied per level
+ * by forward_single :148-158; mmdet/ops/conv_module.py:130-140 `conv`, `norm`, `activate`).  Fused around orp_conv_split_multi
+ * (inference): the normalisation's statistics come out of the convolution's own epilogue and its affine + ReLU are applied by the NEXT
+ * layer while it reads the tensor -- the normalised tensor of an inner layer never exists in HBM.
+ *   orp_conv_split_multi_gn   one or two layers ('same' stride-1 convolutions, no bias, channels-last in / out) over all levels.
+ *       coef_in (or NULL): [layer][level][image][c_in] pairs (a, b) from orp_conv_split_gn_finish of the previous layer; the inputs
+ *       are read as relu_in ? max(x a[c] + b[c], 0) : x a[c] + b[c] (c_in <= 512).  partials (out): per (layer, tile, group)
+ *       (mean, M2 about it, max |y|, count) of the RAW outputs, partial_floats >= orp_conv_split_gn_partial_floats(...); no tile
+ *       spans two images.  c_out / groups must divide 32.  amax_in / amax_stride / amax_count (nprod = 3): layer k scales its
+ *       samples by the maximum of the amax_count words at amax_in[k * amax_stride] (bound_out of the previous finish); with coef_in
+ *       and no amax_in the launch runs as nprod = 6.
+ *   orp_conv_split_gn_finish  merges the tiles' statistics per (tensor, image, group) in tile order (Chan et al.; one wave each) ->
+ *       coef_out [nlayers * nlevels][batch][channels] pairs (a = rstd gamma_c, b = beta_c - mean a); tensor i = layer * nlevels + level
+ *       takes gammas_host[i] / betas_host[i]; bound_out (or NULL): [nlayers][nlevels * batch * groups] float bits of upper bounds
+ *       of max |y| after the affine.  levels_host: the same levels as the launch that wrote `partials`.
+ *   orp_affine_act_multi_cl   y = relu?(x a[c] + b[c]) for nlevels channels-last tensors with coef [tensor][batch][channels] (the last
+ *       layer's normalisation, materialised; in place allowed); bound_in (or NULL): nsets x per_set words folded into slot_out[nsets].
+ * Statistics partition differently from orp_groupnorm_act_multi_cl (tiles instead of 16-position chunks): results agree to a few
+ * 1e-7 of scale, not bit for bit; every step is fixed-order (bitwise reproducible). */
+size_t orp_conv_split_gn_partial_floats(const orp_conv_level* levels_host, int nlevels, int batch, int groups, int nlayers);
+int orp_conv_split_multi_gn(const orp_conv_level* levels_host, int nlevels, int batch, int c_in, int c_out,
+                            const float* weight_a_packed, const float* weight_b_packed, int kh, int kw, int pad_h, int pad_w,
+                            int dil_h, int dil_w, int nprod, const float* coef_in, int relu_in, float* partials,
+                            size_t partial_floats, int groups, void* workspace, size_t workspace_bytes, const uint32_t* amax_in,
+                            int amax_stride, int amax_count, void* stream);
+int orp_conv_split_gn_finish(const orp_conv_level* levels_host, int nlevels, int batch, int channels, int groups, int nlayers,
+                             float eps, const float* const* gammas_host, const float* const* betas_host, const float* partials,
+                             float* coef_out, uint32_t* bound_out, void* stream);
+int orp_affine_act_multi_cl(const orp_norm_level* levels, int nlevels, int batch, int channels, const float* coef, int relu,
+                            const uint32_t* bound_in, int nsets, int per_set, uint32_t* slot_out, void* stream);
 int orp_nchw_to_nhwc_multi(const orp_norm_level* levels_host, int nlevels, int batch, int channels, void* stream);
 /* ... leaving max |x| of the tensors of every slot (slots_host[i] in [0, nslots)) in amax_out[slot] as float bits, by
  * atomicMax; reset != 0 zeroes amax_out first (0: accumulate into what another producer left there) */

@@ -123,6 +123,10 @@ _SIGNATURES = {
     "orp_groupnorm_cl_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "orp_groupnorm_act_multi_cl": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "orp_debug_amax_log": (_i, [_vp, _i]),
+    "orp_conv_split_gn_partial_floats": (_sz, [_vp, _i, _i, _i, _i]),
+    "orp_conv_split_multi_gn": (_i, [_vp, _i, _i, _i, _i, _vp, _vp] + [_i] * 7 + [_vp, _i, _vp, _sz, _i, _vp, _sz, _vp, _i, _i, _vp]),
+    "orp_conv_split_gn_finish": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "orp_affine_act_multi_cl": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
 }
 
 _lib = None

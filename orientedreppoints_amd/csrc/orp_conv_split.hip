@@ -79,16 +79,38 @@ extern "C" {
 
 int orp_conv_split_ok(int c_in, int c_out, int kh, int kw) { return orp_split::shape_ok(c_in, c_out, kh, kw) ? 1 : 0; }
 
+struct GnFuse {                      // orp_conv_split_multi_gn: GroupNorm around the launch (see include/orp_hip.h)
+  const float* coef_in; int relu_in; float* partials; size_t partial_floats; int groups; int amax_count;
+};
+
+static int fill_args(orp_split::Args& A, const orp_conv_level* levels_host, int nlevels, int batch, int c_in, int c_out, int nconv,
+                     int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w) {
+  A.nlev = nlevels; A.B = batch; A.Cin = c_in; A.Cout = c_out; A.nconv = nconv;
+  A.kh = kh; A.kw = kw; A.sh = stride_h; A.sw = stride_w; A.ph = pad_h; A.pw = pad_w; A.dh = dil_h; A.dw = dil_w;
+  for (int i = 0; i < nlevels; i++) {
+    const orp_conv_level& lv = levels_host[i];
+    if (lv.height <= 0 || lv.width <= 0) return ORP_EINVAL;
+    if ((long)batch * lv.height * lv.width >= (1L << 31)) return ORP_ETOOBIG;
+    orp_split::Level& S = A.lv[i];
+    S.off = nullptr; S.mask = nullptr; S.planes = nullptr; S.bias = nullptr; S.wscale = nullptr;
+    S.H = lv.height; S.W = lv.width;
+    S.Ho = out_dim(lv.height, pad_h, dil_h, kh, stride_h);
+    S.Wo = out_dim(lv.width, pad_w, dil_w, kw, stride_w);
+    if (S.Ho <= 0 || S.Wo <= 0) return ORP_EINVAL;
+  }
+  return ORP_OK;
+}
+
 static int conv_split_impl(const orp_conv_level* levels_host, const float* const* weights_host, const float* const* biases_host,
                            int nlevels, int batch, int c_in, int c_out, const float* weight_a_packed, const float* weight_b_packed,
                            const float* bias_a, const float* bias_b, int relu, int kh, int kw, int stride_h, int stride_w,
                            int pad_h, int pad_w, int dil_h, int dil_w, int out_layout, int nprod, void* workspace,
-                           size_t workspace_bytes, const uint32_t* amax_in, int amax_stride, void* stream) {
+                           size_t workspace_bytes, const uint32_t* amax_in, int amax_stride, void* stream, const GnFuse* gn = nullptr) {
   if (!levels_host || nlevels <= 0 || nlevels > orp_split::kMaxLevels || batch <= 0 || !weight_a_packed) return ORP_EINVAL;
   if (!orp_split::shape_ok(c_in, c_out, kh, kw) || (nprod != 3 && nprod != 6 && nprod != 9) || (out_layout != 0 && out_layout != 1))
     return ORP_EINVAL;
   if (nprod == 3 && !amax_in && (!workspace || workspace_bytes < 256)) return ORP_EWORKSPACE;   // max |x| of the inputs lives there
-  if (amax_in && amax_stride != 0 && amax_stride != 1) return ORP_EINVAL;
+  if (amax_in && amax_stride != 0 && amax_stride != 1 && !(gn && amax_stride >= gn->amax_count && gn->amax_count >= 1)) return ORP_EINVAL;
   if (stride_h <= 0 || stride_w <= 0 || dil_h <= 0 || dil_w <= 0 || pad_h < 0 || pad_w < 0) return ORP_EINVAL;
   const int nconv = weight_b_packed ? 2 : 1;
   orp_split::Args A;
@@ -103,6 +125,10 @@ static int conv_split_impl(const orp_conv_level* levels_host, const float* const
   A.amax_in = nprod == 3 ? amax_in : nullptr; A.amax_stride = amax_stride;
   A.bias[0] = bias_a; A.bias[1] = nconv == 2 ? bias_b : bias_a;
   A.relu = relu ? 1 : 0; A.nconv = nconv; A.out_nchw = out_layout == 0 ? 1 : 0; A.nprod = nprod;
+  if (gn) {
+    A.per_image = 1; A.coef_in = gn->coef_in; A.relu_in = gn->relu_in; A.gn_part = gn->partials; A.groups = gn->groups;
+    A.amax_count = gn->amax_count;
+  }
   for (int i = 0; i < nlevels; i++) {
     const orp_conv_level& lv = levels_host[i];
     if (!lv.input_a || !lv.output_a || lv.height <= 0 || lv.width <= 0) return ORP_EINVAL;
@@ -124,9 +150,71 @@ static int conv_split_impl(const orp_conv_level* levels_host, const float* const
     S.Wo = out_dim(lv.width, pad_w, dil_w, kw, stride_w);
     if (S.Ho <= 0 || S.Wo <= 0) return ORP_EINVAL;
   }
+  if (gn && gn->partials) {                                // room for [layer][tile][group] (mean, M2, max |y|, count)
+    const orp_split::Plan pl = orp_split::plan(A);
+    if (gn->partial_floats < (size_t)4 * nconv * pl.tiles * gn->groups) return ORP_EWORKSPACE;
+  }
   OrpProfScope prof(ORP_PROF_CONV_SPLIT, (hipStream_t)stream);
   const hipError_t e = orp_split::launch(A, (hipStream_t)stream);
   return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+// ---- GroupNorm fused around the tower convolutions: the merge of the tiles' statistics --------------------------------------------
+// one wave per (tensor, image, group): Chan et al.'s merge of the image's tile partials in two fixed-order passes (the weighted
+// mean, then M2 around it) -> the (a, b) of  y = x * a[c] + b[c]  for the group's channels, and an upper bound of max |y|
+struct GnFinish {
+  const float4* part;          // [nconv][tiles][G]
+  float2* coef;                // [tensor][B][C]
+  unsigned* bound;             // [nconv][nlev * B * G] float bits, or nullptr
+  const float* gamma[2 * orp_split::kMaxLevels];
+  const float* beta[2 * orp_split::kMaxLevels];
+  int tile0[orp_split::kMaxLevels], tpi[orp_split::kMaxLevels];
+  int nlev, tiles, B, C, G;
+  float eps;
+};
+__global__ void __launch_bounds__(64)
+conv_gn_finish_kernel(const GnFinish F) {
+  const int grp = blockIdx.x, b = blockIdx.y, tensor = blockIdx.z;
+  const int conv = tensor / F.nlev, lvl = tensor - conv * F.nlev;
+  const int cg = F.C / F.G, lane = threadIdx.x;
+  const float4* part = F.part + ((size_t)conv * F.tiles + F.tile0[lvl] + (size_t)b * F.tpi[lvl]) * F.G + grp;
+  auto wave_sum = [](float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  float sn = 0.f, sm = 0.f;
+  for (int t = lane; t < F.tpi[lvl]; t += 64) { const float4 p = part[(size_t)t * F.G]; sn += p.w; sm += p.w * p.x; }
+  const float total = wave_sum(sn);
+  const float mean = wave_sum(sm) / total;
+  float m2 = 0.f, mx = 0.f;
+  for (int t = lane; t < F.tpi[lvl]; t += 64) {
+    const float4 p = part[(size_t)t * F.G];
+    const float d = p.x - mean;
+    m2 += p.y + p.w * d * d;
+    mx = fmaxf(mx, p.z);
+  }
+  const float var = wave_sum(m2) / total;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const float rstd = rsqrtf(var + F.eps);
+  const float* gamma = F.gamma[tensor];
+  const float* beta = F.beta[tensor];
+  float gm = 0.f, bm = 0.f;
+  if (lane < cg) {
+    const int c = grp * cg + lane;
+    const float a = rstd * gamma[c];
+    F.coef[((size_t)tensor * F.B + b) * F.C + c] = make_float2(a, beta[c] - mean * a);
+    gm = fabsf(gamma[c]); bm = fabsf(beta[c]);
+  }
+  if (F.bound) {
+    // |y| = |(x - mean) rstd gamma_c + beta_c| <= (max |x| + |mean|) rstd max |gamma| + max |beta| over the group's channels
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { gm = fmaxf(gm, __shfl_xor(gm, o, 64)); bm = fmaxf(bm, __shfl_xor(bm, o, 64)); }
+    if (lane == 0)
+      F.bound[(size_t)conv * F.nlev * F.B * F.G + ((size_t)lvl * F.B + b) * F.G + grp] =
+          __float_as_uint(((mx + fabsf(mean)) * rstd * gm + bm) * 1.0001f);
+  }
 }
 
 int orp_conv_split_multi(const orp_conv_level* levels_host, int nlevels, int batch, int c_in, int c_out,
@@ -171,6 +259,53 @@ static int to_cl_impl(const orp_norm_level* levels_host, int nlevels, int batch,
     if (me != hipSuccess) return (int)me;
   }
   hipLaunchKernelGGL(to_channels_last_kernel, dim3(bx, (channels + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, T, channels);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+size_t orp_conv_split_gn_partial_floats(const orp_conv_level* levels_host, int nlevels, int batch, int groups, int nlayers) {
+  if (!levels_host || nlevels <= 0 || nlevels > orp_split::kMaxLevels || batch <= 0 || groups <= 0 || nlayers < 1 || nlayers > 2) return 0;
+  // (an upper bound that does not depend on the tile height the launch picks: tiles of 32 positions)
+  size_t tiles = 0;
+  for (int i = 0; i < nlevels; i++) tiles += (size_t)batch * (((size_t)levels_host[i].height * levels_host[i].width + 31) / 32);
+  return (size_t)4 * nlayers * tiles * groups;
+}
+
+int orp_conv_split_multi_gn(const orp_conv_level* levels_host, int nlevels, int batch, int c_in, int c_out,
+                            const float* weight_a_packed, const float* weight_b_packed, int kh, int kw, int pad_h, int pad_w,
+                            int dil_h, int dil_w, int nprod, const float* coef_in, int relu_in, float* partials,
+                            size_t partial_floats, int groups, void* workspace, size_t workspace_bytes, const uint32_t* amax_in,
+                            int amax_stride, int amax_count, void* stream) {
+  if (!partials || groups <= 0 || c_out % groups != 0 || 32 % (c_out / groups) != 0) return ORP_EINVAL;
+  if (2 * pad_h != dil_h * (kh - 1) || 2 * pad_w != dil_w * (kw - 1)) return ORP_EINVAL;       // 'same' convolutions: H x W in and out
+  if (coef_in && nprod == 3 && !amax_in) nprod = 6;        // (a range pre-pass would see the un-normalised inputs)
+  GnFuse gn{coef_in, relu_in ? 1 : 0, partials, partial_floats, groups, amax_in ? amax_count : 0};
+  return conv_split_impl(levels_host, nullptr, nullptr, nlevels, batch, c_in, c_out, weight_a_packed, weight_b_packed, nullptr,
+                         nullptr, 0, kh, kw, 1, 1, pad_h, pad_w, dil_h, dil_w, 1, nprod, workspace, workspace_bytes, amax_in,
+                         amax_stride, stream, &gn);
+}
+
+int orp_conv_split_gn_finish(const orp_conv_level* levels_host, int nlevels, int batch, int channels, int groups, int nlayers,
+                             float eps, const float* const* gammas_host, const float* const* betas_host, const float* partials,
+                             float* coef_out, uint32_t* bound_out, void* stream) {
+  if (!levels_host || nlevels <= 0 || nlevels > orp_split::kMaxLevels || batch <= 0 || batch > 65535 || nlayers < 1 || nlayers > 2 ||
+      !gammas_host || !betas_host || !partials || !coef_out || groups <= 0 || channels % groups != 0 || channels / groups > 64)
+    return ORP_EINVAL;
+  orp_split::Args A;                                        // the tile table of the launch that wrote the partials
+  const int rc = fill_args(A, levels_host, nlevels, batch, channels, channels, nlayers, 3, 3, 1, 1, 1, 1, 1, 1);
+  if (rc != ORP_OK) return rc;
+  A.per_image = 1;
+  const orp_split::Plan pl = orp_split::plan(A);
+  GnFinish F;
+  F.part = reinterpret_cast<const float4*>(partials); F.coef = reinterpret_cast<float2*>(coef_out); F.bound = bound_out;
+  F.nlev = nlevels; F.tiles = pl.tiles; F.B = batch; F.C = channels; F.G = groups; F.eps = eps;
+  for (int i = 0; i < orp_split::kMaxLevels; i++) { F.tile0[i] = pl.tile0[i]; F.tpi[i] = pl.tpi[i]; }
+  for (int i = 0; i < 2 * orp_split::kMaxLevels; i++) { F.gamma[i] = nullptr; F.beta[i] = nullptr; }
+  for (int i = 0; i < nlayers * nlevels; i++) {
+    if (!gammas_host[i] || !betas_host[i]) return ORP_EINVAL;
+    F.gamma[i] = gammas_host[i]; F.beta[i] = betas_host[i];
+  }
+  hipLaunchKernelGGL(conv_gn_finish_kernel, dim3(groups, batch, nlayers * nlevels), dim3(64), 0, (hipStream_t)stream, F);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }

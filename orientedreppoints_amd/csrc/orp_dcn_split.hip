@@ -98,6 +98,7 @@ struct LevelK {
   float* out[2];
   int H, W, Ho, Wo;
   int tile0;
+  int tpi;                        // 0: the level's positions of all images tiled back to back; > 0: tiles per IMAGE (no tile spans two images: GroupNorm statistics)
   const uint16_t* planes;         // this level's own layer (or nullptr: FwdS::planes / bias / wscale)
   const float* bias;
   const float* wscale;
@@ -111,8 +112,15 @@ struct FwdS {
   int relu, nconv;
   size_t plane_stride;            // elements between two planes of a layer
   const float* wscale[2];         // F16: the power of two the layer's weights were multiplied by at pack time (device scalar)
-  const unsigned* amax;           // F16: bits of (a bound of) max |x| over the inputs of layer cv at amax[cv * amax_stride]
-  int amax_stride;
+  const unsigned* amax;           // F16: bits of (bounds of) max |x| over the inputs of layer cv: the maximum of the amax_count words at amax[cv * amax_stride]
+  int amax_stride, amax_count;
+  // PLAIN, GroupNorm fused around the convolution (orp_conv_split_multi_gn): the INPUT tensors are read as relu?(x * a[c] + b[c]) with
+  // the (a, b) of the previous layer's normalisation, coef_in [layer][level][image][Cin] float2; the OUTPUT tiles leave their per-group
+  // (mean, M2 around it, max |y|, count) in gn_part [layer][tile][group] for orp_conv_split_gn_finish
+  const float2* coef_in;
+  int relu_in;
+  float4* gn_part;
+  int G;
   unsigned* dbg;                  // dev aid (orp_debug_amax_log): the first tile of layer cv leaves [cv] = the range word it READ, [2 + cv] = its weight scale
 };
 
@@ -284,11 +292,35 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   const LevelK L = P.lv[lvl];
   const int HoWo = L.Ho * L.Wo;
   const long npos = (long)P.B * HoWo;
-  const long p0 = (long)(tile - L.tile0) * BMS;
+  long p0, plim;                                                              // the tile's positions [p0, plim) of the level's B * HoWo
+  int img = 0;
+  if (L.tpi > 0) {                                                            // per-image tiles: the tile ends with its image
+    const int t_in = tile - L.tile0;
+    img = t_in / L.tpi;
+    const int pin = (t_in - img * L.tpi) * BMS;
+    p0 = (long)img * HoWo + pin;
+    plim = p0 + (HoWo - pin < BMS ? HoWo - pin : BMS);
+  } else {
+    p0 = (long)(tile - L.tile0) * BMS;
+    plim = p0 + BMS < npos ? p0 + BMS : npos;
+  }
   const float* xin = conv ? L.x[1] : L.x[0];
   float sx = 1.f, osc = 1.f;                                                  // F16: sample scale 2^k, output scale 1 / (sx * sw)
+  float* sAB = reinterpret_cast<float*>(sCi + BMS * kTapsMax);                 // [2][Cin] the input normalisation's (a[c]) then (b[c]) (coef_in only)
   if (F16) {
-    const unsigned am = P.amax[conv * P.amax_stride];
+    unsigned am = P.amax[conv * P.amax_stride];
+    if (P.amax_count > 1) {                                                   // (block-uniform) the producer left one bound per (tensor, image, group)
+      __shared__ unsigned red[kThreadsS / 64];
+      unsigned m_ = 0u;
+      for (int i = tid; i < P.amax_count; i += kThreadsS) m_ = max(m_, P.amax[conv * P.amax_stride + i]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m_ = max(m_, (unsigned)__shfl_xor((int)m_, o, 64));
+      if (lane == 0) red[wave] = m_;
+      __syncthreads();
+      am = red[0];
+#pragma unroll
+      for (int i = 1; i < kThreadsS / 64; i++) am = max(am, red[i]);
+    }
     int k = am == 0u ? 0 : 14 - ((int)((am >> 23) & 0xffu) - 127);
     k = k < -100 ? -100 : k > 100 ? 100 : k;
     sx = __uint_as_float((unsigned)(127 + k) << 23);
@@ -304,7 +336,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     const long p = p0 + m;
     float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
     int4 ix = make_int4(0, 0, 0, 0);
-    if (p < npos) {
+    if (p < plim) {
       const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
       const int ho = hw / L.Wo, wo = hw - ho * L.Wo;
       const int ki = tap / P.kw, kj = tap - ki * P.kw;
@@ -359,6 +391,11 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     }
     sCw[e] = w; sCi[e] = ix;
   }
+  const bool has_coef = PLAIN && P.coef_in != nullptr;                        // (block-uniform)
+  if (has_coef) {
+    const float2* cf = P.coef_in + ((size_t)(conv * P.nlev + lvl) * P.B + img) * P.Cin;
+    for (int c = tid; c < P.Cin; c += kThreadsS) { const float2 ab = cf[c]; sAB[c] = ab.x; sAB[P.Cin + c] = ab.y; }
+  }
   __syncthreads();
 #if ORP_DCNS_TRACE
   const int trace_wg = conv * total_tiles + tile;
@@ -386,7 +423,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     v[2] = *reinterpret_cast<const float4*>(base + (size_t)ix.z * P.Cin);
     v[3] = *reinterpret_cast<const float4*>(base + (size_t)ix.w * P.Cin);
   };
-  auto combine_store = [&](int tap, int g, const float4 (&v)[4], int buf) {
+  auto combine_store = [&](int tap, int cbk, int g, const float4 (&v)[4], int buf) {
     const int m = row_of(g);
     if (ORP_DCNS_DBG & 8) return;
     const float4 cw = sCw[m * taps + tap];
@@ -399,7 +436,14 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     float s[4];
     if (PLAIN) {
       const bool in = cw.x != 0.f;
-      s[0] = in ? v[0].x : 0.f; s[1] = in ? v[0].y : 0.f; s[2] = in ? v[0].z : 0.f; s[3] = in ? v[0].w : 0.f;
+      float4 x = v[0];
+      if (has_coef) {                                                         // the previous layer's GroupNorm (+ ReLU) on the way in
+        const float4 ca = *reinterpret_cast<const float4*>(sAB + cbk * CBS + c4);
+        const float4 cb_ = *reinterpret_cast<const float4*>(sAB + P.Cin + cbk * CBS + c4);
+        x.x = fmaf(x.x, ca.x, cb_.x); x.y = fmaf(x.y, ca.y, cb_.y); x.z = fmaf(x.z, ca.z, cb_.z); x.w = fmaf(x.w, ca.w, cb_.w);
+        if (P.relu_in) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+      }
+      s[0] = in ? x.x : 0.f; s[1] = in ? x.y : 0.f; s[2] = in ? x.z : 0.f; s[3] = in ? x.w : 0.f;   // (the padding of the NORMALISED tensor is 0)
     } else {
       s[0] = bil(v[0].x, v[1].x, v[2].x, v[3].x);
       s[1] = bil(v[0].y, v[1].y, v[2].y, v[3].y);
@@ -453,7 +497,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
 #pragma unroll
     for (int r = 0; r < MT; r++) gather_issue(0, 0, r, g[r]);
 #pragma unroll
-    for (int r = 0; r < MT; r++) combine_store(0, r, g[r], 0);
+    for (int r = 0; r < MT; r++) combine_store(0, 0, r, g[r], 0);
   }
   __syncthreads();
 
@@ -533,7 +577,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       if (with_combine) {
 #pragma unroll
         for (int r = 0; r < MT; r++)
-          if (r * CC / MT == j - (NCH - CC)) combine_store(tap_n, r, g[r], cur ^ 1);
+          if (r * CC / MT == j - (NCH - CC)) combine_store(tap_n, cb_n, r, g[r], cur ^ 1);
       }
       Products<F16 ? 0 : 9 - NPROD, F16 ? 3 : 9, MT, OUT_NCHW, SIDE, F16>::run(acc, side, a[j & 1], bq[j]);
 #if ORP_DCNS_FENCE
@@ -558,7 +602,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     }
     if (!ORP_DCNS_COMBINE_IN_LAST) {
 #pragma unroll
-      for (int r = 0; r < MT; r++) combine_store(tap_n, r, g[r], cur ^ 1);
+      for (int r = 0; r < MT; r++) combine_store(tap_n, cb_n, r, g[r], cur ^ 1);
     }
 #if ORP_DCNS_REFILL_LAG
     if (!(ORP_DCNS_DBG & 2)) load_b(tap_n, cb_n, NCH - 1, bq[NCH - 1]);
@@ -575,12 +619,51 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   }
   const float* bias = L.planes ? L.bias : conv ? P.bias[1] : P.bias[0];
   float* outp = conv ? L.out[1] : L.out[0];
-  auto finish = [&](float v, int ch) { if (F16) v *= osc; if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
+  bool scaled = false;
+  if (PLAIN && !OUT_NCHW && P.gn_part) {
+    // GroupNorm statistics of the tile while it is in registers: lane = channel (n_wave + lane % 32), its 16 * MT values = the
+    // rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) + 32 mt; a group = Cout / G consecutive channels = consecutive lanes of both
+    // half-waves.  Two passes (mean, then M2 around it), fixed shuffle order; orp_conv_split_gn_finish merges the tiles of an
+    // image (Chan et al.) in tile order.
+    if (F16) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) acc[mt] *= osc;
+      scaled = true;
+    }
+    const int cg = P.Cout / P.G, nrow = (int)(plim - p0);
+    auto row_ok = [&](int mt, int r) { return mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) < nrow; };
+    auto group_sum = [&](float v) {
+      for (int o = 1; o < cg; o <<= 1) v += __shfl_xor(v, o, 64);
+      return v + __shfl_xor(v, 32, 64);
+    };
+    float sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) sum += row_ok(mt, r) ? acc[mt][r] : 0.f;
+    const float cnt = (float)(nrow * cg);
+    const float mean = group_sum(sum) / cnt;
+    float m2 = 0.f, mx = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float d = acc[mt][r] - mean;
+        m2 += row_ok(mt, r) ? d * d : 0.f;
+        mx = fmaxf(mx, row_ok(mt, r) ? fabsf(acc[mt][r]) : 0.f);
+      }
+    m2 = group_sum(m2);
+    for (int o = 1; o < cg; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (lane < 32 && (lane & (cg - 1)) == 0)
+      P.gn_part[((size_t)conv * total_tiles + tile) * P.G + (n_wave + lane) / cg] = make_float4(mean, m2, mx, cnt);
+  }
+  auto finish = [&](float v, int ch) { if (F16 && !scaled) v *= osc; if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
 #pragma unroll
   for (int mt = 0; mt < MT; mt++) {
     if (OUT_NCHW) {
       const long p = p0 + mt * 32 + (lane & 31);
-      if (p < npos) {
+      if (p < plim) {
         const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
         float* ob = outp + (size_t)b * P.Cout * HoWo + hw;
 #pragma unroll
@@ -594,14 +677,17 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       for (int r = 0; r < 16; r++) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const long p = p0 + mt * 32 + m;
-        if (p < npos) outp[(size_t)p * P.Cout + n_wave + (lane & 31)] = finish(acc[mt][r], n_wave + (lane & 31));
+        if (p < plim) outp[(size_t)p * P.Cout + n_wave + (lane & 31)] = finish(acc[mt][r], n_wave + (lane & 31));
       }
     }
   }
 }
 
+constexpr int kCoefCinMax = 512;                                              // orp_conv_split_multi_gn: input channels of a layer that normalises on the way in
 template <int MT, int NPL>
-constexpr size_t split_smem() { return (size_t)2 * NPL * 32 * MT * ASTRS * 2 + (sizeof(float4) + sizeof(int4)) * 32 * MT * kTapsMax; }
+constexpr size_t split_smem() {
+  return (size_t)2 * NPL * 32 * MT * ASTRS * 2 + (sizeof(float4) + sizeof(int4)) * 32 * MT * kTapsMax + sizeof(float) * 2 * kCoefCinMax;
+}
 
 template <int MT, int NPROD, bool OUT_NCHW, bool PLAIN>
 hipError_t launch_one(const FwdS& P, int tiles, int nblk_n, hipStream_t st) {
@@ -668,6 +754,40 @@ hipError_t pack_planes(const float* weight, int c_out, int c_in, int taps, uint1
   return hipGetLastError();
 }
 
+Plan plan(const Args& a) {
+  Plan pl;
+  long npos_all = 0;
+  for (int i = 0; i < a.nlev; i++) npos_all += (long)a.B * a.lv[i].Ho * a.lv[i].Wo;
+  // tile height: rounds x height on 256 CUs (one layer) / 128 CUs per layer (pair: the grid halves run side by side), times
+  // what a 32-position unit costs at that height -- a shorter tile streams the layer's weight planes more often per position
+  // (measured per unit and round, pair launches at 1024^2 x 2 and 1536^2: MT = 1 1.30, MT = 2 1.09 of MT = 3;
+  // tests/checks/time_towers.py, time_dcn_pair.py with ORP_DCNS_MT)
+  const int cus = a.nconv == 2 ? 128 : 256;
+  int MT = 1;
+  long best = -1;
+  for (int mt = 1; mt <= 3; mt++) {
+    const long t = (npos_all + 32 * mt - 1) / (32 * mt) + a.nlev * (a.per_image ? a.B : 1);
+    const long cost = ((t + cus - 1) / cus) * mt * (mt == 1 ? 130 : mt == 2 ? 110 : 100);
+    if (best < 0 || cost < best) { best = cost; MT = mt; }
+  }
+  static const int force_mt = getenv("ORP_DCNS_MT") ? atoi(getenv("ORP_DCNS_MT")) : 0;
+  if (force_mt >= 1 && force_mt <= 3) MT = force_mt;
+  int tiles = 0;
+  for (int i = 0; i < kMaxLevels; i++) { pl.tile0[i] = 0x7fffffff; pl.tpi[i] = 0; }
+  for (int i = 0; i < a.nlev; i++) {
+    const long hw = (long)a.lv[i].Ho * a.lv[i].Wo;
+    pl.tile0[i] = tiles;
+    if (a.per_image) {
+      pl.tpi[i] = (int)((hw + 32 * MT - 1) / (32 * MT));
+      tiles += a.B * pl.tpi[i];
+    } else {
+      tiles += (int)((a.B * hw + 32 * MT - 1) / (32 * MT));
+    }
+  }
+  pl.MT = MT; pl.tiles = tiles;
+  return pl;
+}
+
 // dev aid: a log of what the fp16-pieces launches read as their range words (4 words per launch, in launch order; baked into a
 // captured graph's kernel nodes like every other argument, so a replay writes the slots its capture was given)
 static unsigned* g_amax_log = nullptr;
@@ -691,31 +811,23 @@ hipError_t launch(const Args& a, hipStream_t st) {
   P.planes[0] = a.planes[0]; P.planes[1] = a.planes[1]; P.bias[0] = a.bias[0]; P.bias[1] = a.bias[1];
   P.relu = a.relu; P.nconv = a.nconv;
   P.plane_stride = (size_t)a.Cout * a.Cin * a.kh * a.kw;
-  long npos_all = 0;
-  for (int i = 0; i < a.nlev; i++) npos_all += (long)a.B * a.lv[i].Ho * a.lv[i].Wo;
-  // tile height: rounds x height on 256 CUs (one layer) / 128 CUs per layer (pair: the grid halves run side by side), times
-  // what a 32-position unit costs at that height -- a shorter tile streams the layer's weight planes more often per position
-  // (measured per unit and round, pair launches at 1024^2 x 2 and 1536^2: MT = 1 1.30, MT = 2 1.09 of MT = 3;
-  // tests/checks/time_towers.py, time_dcn_pair.py with ORP_DCNS_MT)
-  const int cus = a.nconv == 2 ? 128 : 256;
-  int MT = 1;
-  long best = -1;
-  for (int mt = 1; mt <= 3; mt++) {
-    const long t = (npos_all + 32 * mt - 1) / (32 * mt) + a.nlev;
-    const long cost = ((t + cus - 1) / cus) * mt * (mt == 1 ? 130 : mt == 2 ? 110 : 100);
-    if (best < 0 || cost < best) { best = cost; MT = mt; }
-  }
-  static const int force_mt = getenv("ORP_DCNS_MT") ? atoi(getenv("ORP_DCNS_MT")) : 0;
-  if (force_mt >= 1 && force_mt <= 3) MT = force_mt;
-  int tiles = 0;
+  P.coef_in = reinterpret_cast<const float2*>(a.coef_in); P.relu_in = a.relu_in;
+  P.gn_part = reinterpret_cast<float4*>(a.gn_part); P.G = a.groups > 0 ? a.groups : 1;
+  P.amax_count = a.amax_count > 1 ? a.amax_count : 1;
+  if ((a.coef_in || a.gn_part) && (!a.per_image || a.lv[0].off != nullptr)) return hipErrorInvalidValue;
+  if (a.coef_in && (a.Cin > kCoefCinMax || (a.nprod == 3 && !a.amax_in))) return hipErrorInvalidValue;   // (a pre-pass would see the raw inputs)
+  if (a.gn_part && (a.out_nchw || a.groups <= 0 || a.Cout % a.groups != 0 || (32 % (a.Cout / a.groups)) != 0 || a.Cout / a.groups < 1 ||
+                    a.relu || a.bias[0] || a.bias[1]))
+    return hipErrorInvalidValue;
+  const Plan pl = plan(a);
+  const int MT = pl.MT, tiles = pl.tiles;
   for (int i = 0; i < a.nlev; i++) {
     LevelK& D = P.lv[i];
     D.x[0] = a.lv[i].x[0]; D.x[1] = a.lv[i].x[1]; D.off = a.lv[i].off; D.mask = a.lv[i].mask;
     D.out[0] = a.lv[i].out[0]; D.out[1] = a.lv[i].out[1];
     D.H = a.lv[i].H; D.W = a.lv[i].W; D.Ho = a.lv[i].Ho; D.Wo = a.lv[i].Wo;
     D.planes = a.nconv == 1 ? a.lv[i].planes : nullptr; D.bias = a.lv[i].bias; D.wscale = a.lv[i].wscale;
-    D.tile0 = tiles;
-    tiles += (int)(((long)a.B * D.Ho * D.Wo + 32 * MT - 1) / (32 * MT));
+    D.tile0 = pl.tile0[i]; D.tpi = pl.tpi[i];
   }
   for (int i = a.nlev; i < kMaxLevels; i++) { P.lv[i] = P.lv[0]; P.lv[i].tile0 = 0x7fffffff; }
   const int nblk_n = (a.Cout + 255) / 256;
@@ -730,6 +842,7 @@ hipError_t launch(const Args& a, hipStream_t st) {
     if (a.amax_in) {                                       // the producer of the inputs left the bound: no pre-pass
       P.amax = a.amax_in; P.amax_stride = a.amax_stride;
     } else {
+      P.amax_count = 1;
       AbsMaxArgs M;
       int bx = 0, cnt = 0;
       for (int cv = 0; cv < a.nconv; cv++)

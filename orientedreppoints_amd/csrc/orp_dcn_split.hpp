@@ -31,9 +31,22 @@ struct Args {
   int nprod;                   // 6 or 9 partial products of three bf16 pieces; 3 = two fp16 pieces (hi*hi, hi*lo, lo*hi)
   const float* wscale[2];      // nprod == 3: wscale_of(packed, ...) per layer (device scalar: the planes' power-of-two scale)
   unsigned* scratch;           // nprod == 3: >= 8 bytes of device memory of the caller's (max |x| of the inputs, per layer)
-  const unsigned* amax_in;     // nprod == 3: nullptr (a pre-pass over the inputs fills `scratch`), or float bits of an upper bound of
-  int amax_stride;             //   max |x| the producer of the inputs left: layer cv reads amax_in[cv * amax_stride]
+  const unsigned* amax_in;     // nprod == 3: nullptr (a pre-pass over the inputs fills `scratch`), or float bits of upper bounds of
+  int amax_stride;             //   max |x| the producer of the inputs left: layer cv takes the maximum of the amax_count words at
+  int amax_count = 0;          //   amax_in[cv * amax_stride] (0 / 1: one word)
+  // GroupNorm fused around a PLAIN launch (orp_conv_split_multi_gn): tiles never span two images; the inputs are read as
+  // relu?(x * a[c] + b[c]) (coef_in [layer][level][image][Cin] (a, b) pairs, or nullptr); every output tile leaves its per-group
+  // statistics in gn_part [layer][tile][group] (mean, M2, max |y|, count), or nullptr
+  int per_image = 0;
+  const float* coef_in = nullptr;
+  int relu_in = 0;
+  float* gn_part = nullptr;
+  int groups = 0;
 };
+
+// the tile table of a launch (what the kernel and orp_conv_split_gn_finish agree on)
+struct Plan { int MT, tiles; int tile0[kMaxLevels], tpi[kMaxLevels]; };
+Plan plan(const Args& a);
 
 // cin % 64 == 0, cout % 64 == 0, taps <= 9
 bool shape_ok(int c_in, int c_out, int kh, int kw);

@@ -597,6 +597,45 @@ gn_cl_apply_kernel(const GnClParams P) {
   }
 }
 
+// y = relu?(x * a[c] + b[c]) with per-(tensor, image, channel) coefficients (orp_conv_split_gn_finish): the LAST normalisation of a
+// tower, materialised for the consumers that cannot apply it on the fly; block 0 also folds the per-group bounds of max |y| into one
+// range word per tensor set
+__global__ void __launch_bounds__(kThreads)
+affine_cl_kernel(const GnClParams P, const float2* __restrict__ coef, const unsigned* __restrict__ bound_in, unsigned* __restrict__ slot_out,
+                 int nsets, int per_set) {
+  const ClGeom g = cl_locate(P, blockIdx.x);
+  const GnClLevel& L = P.lv[g.lvl];
+  const int n = g.np * P.C;
+  const size_t base = ((size_t)g.b * L.hw + g.p0) * P.C;
+  const int tpc = P.C >> 2;
+  const int c0 = (threadIdx.x % tpc) * 4;
+  const float2* cf = coef + ((size_t)g.lvl * P.B + g.b) * P.C + c0;
+  const float2 k0 = cf[0], k1 = cf[1], k2 = cf[2], k3 = cf[3];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int e = (threadIdx.x + q * kThreads) * 4;
+    if (e < n) {
+      float4 t = *reinterpret_cast<const float4*>(L.x + base + e);
+      t.x = fmaf(t.x, k0.x, k0.y); t.y = fmaf(t.y, k1.x, k1.y); t.z = fmaf(t.z, k2.x, k2.y); t.w = fmaf(t.w, k3.x, k3.y);
+      if (P.relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+      *reinterpret_cast<float4*>(L.y + base + e) = t;
+    }
+  }
+  if (blockIdx.x == 0 && bound_in && slot_out) {
+    __shared__ unsigned red[4];
+    for (int s_ = 0; s_ < nsets; s_++) {
+      unsigned m = 0u;
+      for (int i = threadIdx.x; i < per_set; i += kThreads) m = max(m, bound_in[(size_t)s_ * per_set + i]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+      __syncthreads();
+      if (threadIdx.x == 0) slot_out[s_] = max(max(red[0], red[1]), max(red[2], red[3]));
+    }
+  }
+}
+
 // fills P's levels; returns the number of chunks, -1 on bad arguments, -2 when a tensor is too large
 int fill_cl(const orp_norm_level* levels, int nlevels, int batch, int channels, int groups, GnClParams& P) {
   if (!levels || nlevels <= 0 || nlevels > kGnMaxLevels || batch <= 0 || batch > 65535 || channels <= 0 || groups <= 0 ||
@@ -754,6 +793,19 @@ static int gn_cl_impl(const orp_norm_level* levels, const float* const* gammas_h
   hipLaunchKernelGGL(gn_cl_merge_kernel, dim3(groups, batch, nlevels), dim3(kThreads), 0, st, P);
   hipLaunchKernelGGL(gn_cl_apply_kernel, dim3(chunks), dim3(kThreads), 0, st, P);
   hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+
+int orp_affine_act_multi_cl(const orp_norm_level* levels, int nlevels, int batch, int channels, const float* coef, int relu,
+                            const uint32_t* bound_in, int nsets, int per_set, uint32_t* slot_out, void* stream) {
+  GnClParams P;
+  const int chunks = fill_cl(levels, nlevels, batch, channels, 1, P);
+  if (chunks == -2) return ORP_ETOOBIG;
+  if (chunks <= 0 || !coef || (bound_in && (!slot_out || nsets <= 0 || per_set <= 0))) return ORP_EINVAL;
+  P.eps = 0.f; P.relu = relu ? 1 : 0; P.partial = nullptr; P.stats = nullptr; P.pmax = nullptr; P.amax = nullptr;
+  hipLaunchKernelGGL(affine_cl_kernel, dim3(chunks), dim3(kThreads), 0, (hipStream_t)stream, P, reinterpret_cast<const float2*>(coef),
+                     bound_in, slot_out, nsets, per_set);
+  const hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }
 

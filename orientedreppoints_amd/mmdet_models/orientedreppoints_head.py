@@ -230,11 +230,26 @@ class OrientedRepPointsHead(nn.Module):
         else:
             cur = to_channels_last_multi(cur)
         cls_cur = reg_cur = cur
-        for a, b in zip(self.cls_convs, self.reg_convs):
-            oa, ob = conv_split_multi(cls_cur, a.conv, reg_cur, b.conv, amax=am)
-            both, bits = group_norm_act_multi_cl(oa + ob, [a.norm] * n + [b.norm] * n, relu=True, amax_slots=[0] * n + [1] * n)
-            am = Amax(bits, 1) if bits is not None else None
-            cls_cur, reg_cur = both[:n], both[n:]
+        import os
+        from ..mmdet_ops.fused_norm import conv_split_gn, conv_split_gn_ok
+        fuse = getattr(self, 'fuse_tower_norm', None)          # None: automatic (ORP_TOWER_GN_FUSE=0 switches it off, A/B timing)
+        if fuse is None:
+            fuse = os.environ.get('ORP_TOWER_GN_FUSE', '1') == '1'
+        fuse = bool(fuse) and all(conv_split_gn_ok(a.conv, b.conv, a.norm, b.norm, cur[0]) for a, b in zip(self.cls_convs, self.reg_convs))
+        if fuse:
+            # conv -> GroupNorm -> ReLU with the normalisation fused AROUND the convolution launches: statistics from the
+            # convolution's epilogue, the affine + ReLU applied by the next layer as it reads (two launches per layer instead of
+            # four, the normalised tensors of the inner layers never reach HBM); the last layer's is materialised in place
+            coef, depth = None, len(self.cls_convs)
+            for k, (a, b) in enumerate(zip(self.cls_convs, self.reg_convs)):
+                cls_cur, reg_cur, coef, am = conv_split_gn(cls_cur, a.conv, reg_cur, b.conv, a.norm, b.norm, coef_in=coef, amax=am,
+                                                           materialize=(k == depth - 1))
+        else:
+            for a, b in zip(self.cls_convs, self.reg_convs):
+                oa, ob = conv_split_multi(cls_cur, a.conv, reg_cur, b.conv, amax=am)
+                both, bits = group_norm_act_multi_cl(oa + ob, [a.norm] * n + [b.norm] * n, relu=True, amax_slots=[0] * n + [1] * n)
+                am = Amax(bits, 1) if bits is not None else None
+                cls_cur, reg_cur = both[:n], both[n:]
         hid = conv_split_multi(reg_cur, self.reppoints_pts_init_conv, bias=True, relu=True, out_channels_last=False,
                                amax=Amax(am.bits[1:], 0) if am is not None else None)
         return cls_cur, reg_cur, hid, am                     # am: the range of (cls_cur, reg_cur) for the DeformConv pair launch

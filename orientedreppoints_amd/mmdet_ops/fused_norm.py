@@ -384,16 +384,17 @@ class Amax(object):
     CUDA tensor of float bits (upper bounds of max |x| per slot, written by atomicMax), `stride` 0 = both layers of a pair
     launch read slot 0, 1 = layer b reads slot 1.  None anywhere in the chain simply means the convolution takes the maximum
     itself (a pre-pass over its inputs)."""
-    __slots__ = ('bits', 'stride')
+    __slots__ = ('bits', 'stride', 'count')
 
-    def __new__(cls, bits, stride=0):
+    def __new__(cls, bits, stride=0, count=1):
         import os
         if bits is None or os.environ.get('ORP_AMAX_HANDOVER', '1') != '1':      # (0: every consumer takes its own maximum; A/B aid)
             return None
         return object.__new__(cls)
 
-    def __init__(self, bits, stride=0):
-        self.bits, self.stride = bits, stride
+    def __init__(self, bits, stride=0, count=1):
+        # count > 1 (conv_split_gn's hand-over): layer k's range is the maximum of `count` words at bits[k * stride]
+        self.bits, self.stride, self.count = bits, stride, count
 
 
 def to_channels_last_multi(xs, amax_slots=None, amax_into=None, force_ranges=False):
@@ -545,6 +546,94 @@ def conv_split_multi(xs_a, conv_a, xs_b=None, conv_b=None, bias=False, relu=Fals
     return conv_split_weights(xs_a, c0.weight, xs_b, conv_b.weight if conv_b is not None else None,
                               c0.bias if bias else None, conv_b.bias if (bias and conv_b is not None) else None,
                               c0.stride, c0.padding, c0.dilation, relu, out_channels_last, nprod, amax=amax)
+
+
+def conv_split_gn_ok(conv_a, conv_b, gn_a, gn_b, x):
+    """the two towers' layer k can run as `conv_split_gn`: stride-1 'same' bias-free convolutions of one shape that
+    orp_conv_split_multi takes, at most 512 input channels, affine GroupNorms with equal groups / eps whose group size divides 32"""
+    import torch.nn as nn
+    for c in (conv_a, conv_b):
+        if not (conv_split_ok(c, x) and c.bias is None and tuple(c.stride) == (1, 1) and c.weight.size(1) <= 512 and
+                tuple(c.weight.shape) == tuple(conv_a.weight.shape) and c.padding == conv_a.padding and c.dilation == conv_a.dilation and
+                2 * c.padding[0] == c.dilation[0] * (c.weight.size(2) - 1) and 2 * c.padding[1] == c.dilation[1] * (c.weight.size(3) - 1)):
+            return False
+    cout = conv_a.weight.size(0)
+    for g in (gn_a, gn_b):
+        if not (isinstance(g, nn.GroupNorm) and g.affine and g.num_groups == gn_a.num_groups and g.eps == gn_a.eps and
+                g.num_channels == cout and cout % g.num_groups == 0 and 32 % (cout // g.num_groups) == 0 and 1024 % cout == 0):
+            return False
+    return True
+
+
+def conv_split_gn(xs_a, conv_a, xs_b, conv_b, gn_a, gn_b, coef_in=None, amax=None, nprod=None, materialize=False):
+    """One layer of BOTH towers -- conv -> GroupNorm -> ReLU over all FPN levels (reference head :91-113, ConvModule) -- with the
+    normalisation fused AROUND the convolution launch (`orp_conv_split_multi_gn`): the statistics leave the convolution's epilogue
+    per tile, `orp_conv_split_gn_finish` merges them into per-(tensor, image, channel) coefficients (a, b), and the NEXT layer
+    applies relu(x a + b) while it reads.  xs_*: channels-last fp32 tensors; coef_in: the previous layer's coefficients (None: the
+    inputs are taken as they are).  Returns (outs_a, outs_b, coef, amax): RAW convolution outputs + their coefficients -- or, with
+    materialize=True (the towers' last layer), the normalised + ReLU'd outputs (in place) and coef None.  amax: `Amax` of the
+    normalised outputs for the fp16-pieces arithmetic (None in the other modes)."""
+    from .deform_conv import _packed_weight
+    L = _lib.lib()
+    n = len(xs_a)
+    w = conv_a.weight
+    cout, cin, kh, kw = w.shape
+    if nprod is None:
+        nprod = L.orp_dcn_get_split_mode() or 6
+    x0 = xs_a[0]
+    B = x0.size(0)
+    levels = (_ConvLevel * n)()
+    outs_a, outs_b, keep = [], [], []
+    for i in range(n):
+        xa, xb = xs_a[i].detach(), xs_b[i].detach()
+        for x in (xa, xb):
+            if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.size(0) == B and x.size(1) == cin and _is_cl(x) and
+                    x.shape == xa.shape):
+                raise ValueError("conv_split_gn expects channels-last fp32 CUDA [B,%d,H,W] tensors" % cin)
+        H, W = xa.size(2), xa.size(3)
+        oa = torch.empty((B, cout, H, W), dtype=torch.float32, device=xa.device, memory_format=torch.channels_last)
+        ob = torch.empty((B, cout, H, W), dtype=torch.float32, device=xa.device, memory_format=torch.channels_last)
+        keep += [xa, xb]; outs_a.append(oa); outs_b.append(ob)
+        levels[i] = _ConvLevel(xa.data_ptr(), xb.data_ptr(), oa.data_ptr(), ob.data_ptr(), H, W)
+    G = gn_a.num_groups
+    pf = int(L.orp_conv_split_gn_partial_floats(levels, n, B, G, 2))
+    partials = torch.empty((pf,), dtype=torch.float32, device=x0.device)
+    ws = _lib.workspace(x0.device, 256)
+    pa, pb = _packed_weight(conv_a.weight), _packed_weight(conv_b.weight)
+    am_ptr = amax.bits.data_ptr() if amax is not None else None
+    pd, dl = conv_a.padding, conv_a.dilation
+    with torch.cuda.device(x0.device):
+        rc = L.orp_conv_split_multi_gn(levels, n, B, cin, cout, _lib.ptr(pa), _lib.ptr(pb), kh, kw, pd[0], pd[1], dl[0], dl[1], int(nprod),
+                                       _lib.ptr(coef_in), 1, _lib.ptr(partials), pf, G, _lib.ptr(ws), ws.numel(), am_ptr,
+                                       int(amax.stride) if amax is not None else 0, int(amax.count) if amax is not None else 0,
+                                       _lib.stream_of(x0))
+    _lib.check(rc, "orp_conv_split_multi_gn")
+    coef = torch.empty((2 * n, B, cout, 2), dtype=torch.float32, device=x0.device)
+    ranges = _ranges_wanted()
+    per_set = n * B * G
+    bound = torch.empty((2, per_set), dtype=torch.int32, device=x0.device) if ranges else None
+    gam = (ctypes.c_void_p * (2 * n))()
+    bet = (ctypes.c_void_p * (2 * n))()
+    for k, g in enumerate((gn_a, gn_b)):
+        g_, b_ = g.weight.detach().float().contiguous(), g.bias.detach().float().contiguous()
+        keep += [g_, b_]
+        for i in range(n):
+            gam[k * n + i], bet[k * n + i] = g_.data_ptr(), b_.data_ptr()
+    with torch.cuda.device(x0.device):
+        rc = L.orp_conv_split_gn_finish(levels, n, B, cout, G, 2, float(gn_a.eps), gam, bet, _lib.ptr(partials), _lib.ptr(coef),
+                                        bound.data_ptr() if bound is not None else None, _lib.stream_of(x0))
+    _lib.check(rc, "orp_conv_split_gn_finish")
+    if not materialize:
+        return outs_a, outs_b, coef, (Amax(bound, per_set, per_set) if bound is not None else None)
+    nl = (_NormLevel * (2 * n))()
+    for i, t in enumerate(outs_a + outs_b):
+        nl[i] = _NormLevel(t.data_ptr(), t.data_ptr(), t.size(2), t.size(3))
+    slots = torch.empty((2,), dtype=torch.int32, device=x0.device) if bound is not None else None
+    with torch.cuda.device(x0.device):
+        rc = L.orp_affine_act_multi_cl(nl, 2 * n, B, cout, _lib.ptr(coef), 1, bound.data_ptr() if bound is not None else None, 2,
+                                       per_set, slots.data_ptr() if slots is not None else None, _lib.stream_of(x0))
+    _lib.check(rc, "orp_affine_act_multi_cl")
+    return outs_a, outs_b, None, (Amax(slots, 1) if slots is not None else None)
 
 
 class _WgradLevel(ctypes.Structure):

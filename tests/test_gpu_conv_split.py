@@ -426,6 +426,70 @@ def test_conv_weight_gradient_kernel_vs_float64(dev):
         assert _rel(c.weight.grad, want) <= 1e-5
 
 
+@pytest.mark.parametrize("mode", [6, 3])
+def test_tower_layers_with_groupnorm_fused_around_the_convolutions(dev, mode):
+    """conv -> GroupNorm -> ReLU -> conv -> GroupNorm -> ReLU of both towers over a five-level pyramid with the normalisation fused
+    around the convolution launches (`conv_split_gn`: statistics from the convolution's epilogue, affine + ReLU applied by the next
+    layer as it reads, the last one materialised) against the same modules in float64 on the CPU (reference head :91-113,
+    ConvModule: conv, norm, activate) and against the unfused path (`conv_split_multi` + `group_norm_act_multi_cl`); B = 1, 2 --
+    tiles never span two images --, levels down to 1 x 3; twice: the results are bitwise reproducible."""
+    import conftest
+    from orientedreppoints_amd import _lib
+    from orientedreppoints_amd.mmdet_ops.fused_norm import (Amax, conv_split_gn, conv_split_gn_ok, conv_split_multi, group_norm_act_multi_cl,
+                                                            to_channels_last_multi)
+    L = _lib.lib()
+    torch.manual_seed(31)
+    convs = [[_conv(256, 256, 3, dev, seed=40 + 2 * k + t, std=0.03) for t in range(2)] for k in range(2)]
+    gns = [[nn.GroupNorm(32, 256).to(dev) for t in range(2)] for k in range(2)]
+    with torch.no_grad():
+        for row in gns:
+            for g in row:
+                g.weight.uniform_(0.5, 1.5); g.bias.normal_(0, 0.2)
+    assert L.orp_dcn_set_split_mode(mode) == 0
+    worst = 0.0
+    try:
+        with torch.no_grad():
+            for B in (1, 2):
+                xs = [torch.randn(B, 256, h, w, device=dev) * (1.0 + 0.5 * i) for i, (h, w) in enumerate(((24, 20), (12, 10), (6, 5), (3, 3), (1, 3)))]
+                n = len(xs)
+                assert conv_split_gn_ok(convs[0][0], convs[0][1], gns[0][0], gns[0][1], xs[0])
+                cl, bits = to_channels_last_multi(xs, amax_slots=[0] * n)
+                am0 = Amax(bits, 0) if bits is not None else None
+
+                def fused():
+                    a, b, coef, am = conv_split_gn(cl, convs[0][0], cl, convs[0][1], gns[0][0], gns[0][1], amax=am0)
+                    assert coef is not None and tuple(coef.shape) == (2 * n, B, 256, 2)
+                    a, b, coef, am = conv_split_gn(a, convs[1][0], b, convs[1][1], gns[1][0], gns[1][1], coef_in=coef, amax=am, materialize=True)
+                    assert coef is None and (am is not None) == (mode == 3)
+                    return a + b
+                got = fused()
+                again = fused()
+                for x, y in zip(got, again):
+                    assert torch.equal(x, y)
+                # the unfused path
+                oa, ob = conv_split_multi(cl, convs[0][0], cl, convs[0][1], amax=am0)
+                both, bits1 = group_norm_act_multi_cl(oa + ob, [gns[0][0]] * n + [gns[0][1]] * n, relu=True, amax_slots=[0] * n + [1] * n)
+                oa, ob = conv_split_multi(both[:n], convs[1][0], both[n:], convs[1][1], amax=Amax(bits1, 1) if bits1 is not None else None)
+                unf, _ = group_norm_act_multi_cl(oa + ob, [gns[1][0]] * n + [gns[1][1]] * n, relu=True, amax_slots=[0] * n + [1] * n)
+                for t in range(2):
+                    for i in range(n):
+                        x64 = xs[i].double().cpu()
+                        for k in range(2):
+                            c, g = convs[k][t], gns[k][t]
+                            x64 = F.conv2d(x64, c.weight.detach().double().cpu(), padding=1)
+                            x64 = F.relu(F.group_norm(x64, 32, g.weight.detach().double().cpu(), g.bias.detach().double().cpu(), g.eps))
+                        gt = got[t * n + i]
+                        assert gt.shape == x64.shape and gt.is_contiguous(memory_format=torch.channels_last)
+                        scale = float(x64.abs().max())
+                        e = float((gt.double().cpu() - x64).abs().max()) / scale
+                        worst = max(worst, e)
+                        assert e <= 2e-5, (B, t, i, e)
+                        assert float((gt - unf[t * n + i]).abs().max()) <= 2e-5 * scale
+    finally:
+        L.orp_dcn_set_split_mode(-1)
+    conftest.REPORT.append("two tower layers with fused GroupNorm (mode %d), max |err| / max |out| vs float64 modules: %.2e" % (mode, worst))
+
+
 def _small_detector(dev):
     from orientedreppoints_amd.dota_configs import r50_model, test_cfg
     from orientedreppoints_amd.mmdet_models import ConfigDict, build_detector
