@@ -210,7 +210,12 @@ def cpu_baselines(dets_np, labels_np, thr, budget_s=6.0):
         except Exception as e:   # noqa: BLE001
             v['B1 per-class Pool(%d)' % cores] = 'failed: %s' % (str(e)[:120],)
     head = dt_ref if dt_ref is not None else dt_port
-    return dict(value=head * 1e6, unit='us/img (rotated-IoU + poly NMS stage)', cores=1,
+    b1 = next((x for k, x in v.items() if k.startswith('B1') and isinstance(x, dict)), None)
+    note = ("`value` is the reference's plain greedy loop on one core -- the SLOWEST CPU variant.  The realistic CPU figures for this "
+            "stage are B0' (the reference's own HBB-prefiltered loop, 1 core): %.0f us/img%s; the GPU stage should be read against "
+            "those, not against `value`" % (dt_fast * 1e6, (" and B1 (its per-class Pool(%d)): %.0f us/img" % (b1['cores'], b1['us_per_img']))
+                                              if b1 else ""))
+    return dict(value=head * 1e6, unit='us/img (rotated-IoU + poly NMS stage)', cores=1, note=note,
                 kind='reference' if dt_ref is not None else 'port',
                 sample='1 image, %d class-offset detections (the set multiclass_rnms hands to rnms), thr %.2f; every '
                        'variant repeated for <= %.0f s of CPU work' % (M, thr, budget_s),
@@ -475,6 +480,54 @@ def train_probe(dev, model_name='r50', steps=10, warmup=4, gts=64):
             'dcn_forward_mode': int(L.orp_dcn_get_split_mode()), 'hip_events': ev,
             'note': 'hot-path kernels are ~10 % of this step; ~30 ms is the library\'s convolution_backward (backbone / towers), '
                     'outside the hot path'}
+
+
+def quick_config(dev, model_name, batch, size, steps=10, warmup=3, depth=4):
+    """A compact line for another BASELINE configuration at its per-GPU load (rank 0, N = 1, after the headline loops): the same
+    measurement as the headline -- captured graphs, `depth` in flight for `value`, one at a time for `value_serial` -- with fewer
+    steps; every replay's detections are compared with the eager step's."""
+    import copy
+    from orientedreppoints_amd.mmdet_models import GraphedInference, PipelinedInference
+    torch.manual_seed(0)
+    model = build_detector(ConfigDict(MODELS[model_name]), train_cfg=None, test_cfg=ConfigDict(copy.deepcopy(TEST_CFG))).to(dev).eval()
+    g = torch.Generator(device='cpu').manual_seed(4321)
+    img = torch.randn(batch, 3, size, size, generator=g).to(dev)
+    metas = [dict(img_shape=(size, size, 3), pad_shape=(size, size, 3), scale_factor=1.0, flip=False) for _ in range(batch)]
+    calibrate_head(model, img[:1])
+    det_flag = torch.backends.cudnn.deterministic
+    try:
+        with torch.no_grad():
+            ref = model.simple_test_batch(img, metas)
+            same_ = lambda ra, rb: all(a.shape == b.shape and np.array_equal(a, b) for r, q in zip(ra, rb) for a, b in zip(r, q))   # noqa: E731
+            if not all(same_(ref, model.simple_test_batch(img, metas)) for _ in range(2)):
+                torch.backends.cudnn.deterministic = True       # (1536^2: the library's default solvers accumulate with atomics)
+                ref = model.simple_test_batch(img, metas)
+        gi = GraphedInference(model, img, metas)
+        for _ in range(warmup):
+            r = gi(img)
+        identical = same_(r, ref)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gi(img)
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t0) / steps * 1e3
+        del gi
+        pi = PipelinedInference(model, img, metas, depth=depth)
+        got = [r for r in (pi.submit(img) for _ in range(warmup + depth)) if r is not None] + pi.flush()
+        identical = identical and all(same_(g_, ref) for g_ in got)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = sum(pi.submit(img) is not None for _ in range(steps)) + len(pi.flush())
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        assert n == steps
+        return dict(workload='%s FPN inference, %dx%d, bs=%d/GPU' % (MODEL_LABEL[model_name], size, size, batch), value=batch / ms * 1e3,
+                    value_serial=batch / serial_ms * 1e3, unit='images/s', ms_per_step=ms, graph_replay_ms=serial_ms, steps=steps,
+                    images_in_flight=depth, detections=int(sum(sum(len(c) for c in r) for r in ref)),
+                    replays_identical_to_eager=bool(identical), library_deterministic_mode=bool(torch.backends.cudnn.deterministic))
+    finally:
+        torch.backends.cudnn.deterministic = det_flag
 
 
 def _free_port():
@@ -823,6 +876,7 @@ def main():
     # the eager loop above stays in the JSON (`eager_ms_per_step`) and provides the live HIP-event kernel timings.
     graph_ms = None
     pipe_ms = None
+    replays_identical = None
     eager_elapsed = elapsed
     if args.graph:
         ok = 1
@@ -869,6 +923,7 @@ def main():
                 got = [r for r in (pi.submit(img) for _ in range(args.warmup + args.pipeline)) if r is not None] + pi.flush()
                 if any(abs(int(sum(sum(len(c) for c in r) for r in g)) - ndet) > count_slack for g in got):
                     raise RuntimeError('pipelined replay returned a different detection count')
+                replays_identical = bool(step_reproducible and all(same(g, res) for g in got))
             except Exception as e:   # noqa: BLE001
                 pok = 0
                 pipe_ms = 'failed: %s' % (str(e)[:200],)
@@ -1042,6 +1097,11 @@ def main():
                  'layer k as grid halves of one launch) and the FPN\'s three output convolutions (a layer per level), channels-'
                  'last; the library (Winograd + small-level kernel) took 246 us per layer, ORP_TOWER_SPLIT=0 / ORP_FPN_SPLIT=0 '
                  'switch back')
+    if roof is not None:
+        tw = roof.get('tower_and_fpn_convolutions')
+        roof['dominant_by_time'] = ('tower_and_fpn_convolutions: %.0f us per step in %.0f launches (frac %.3f); the DeformConv pair launch '
+                                    'of the top-level fields: %.0f us' % (tw['us_per_step'], tw['launches_per_step'], tw['frac'],
+                                                                         roof['avg_launch_us'])) if tw else 'the DeformConv pair launch'
     # ---- the rotated-IoU + NMS stage (HBM is the formal bound, the work is fp32 VALU) --------------------------------
     mask_ms, mask_n = prof['nms_mask']
     nms = None
@@ -1091,6 +1151,15 @@ def main():
         except Exception as e:   # noqa: BLE001
             batched = 'failed: %s' % (str(e)[:200],)
 
+    other = None
+    if not args.no_cpu_baseline and world == 1 and (args.model, IMG, args.batch) == ('r50', 1024, 1):
+        # BASELINE configs[3] at its per-GPU load (R-101, two images per GPU) and the 1536^2 shapes of configs[4], compact
+        other = {}
+        for key, (mname, b_, sz) in (('configs[3] per-GPU load', ('r101', 2, 1024)), ('1536^2 patches', ('r50', 1, 1536))):
+            try:
+                other[key] = quick_config(dev, mname, b_, sz, depth=max(args.pipeline, 1))
+            except Exception as e:   # noqa: BLE001
+                other[key] = 'failed: %s' % (str(e)[:200],)
     train = None
     if not args.no_cpu_baseline and world == 1 and args.train_probe:
         try:
@@ -1121,7 +1190,11 @@ def main():
         'eager_ms_per_step': round(eager_elapsed / args.steps * 1e3, 4),
         'graph_replay_ms': graph_ms,
         'pipelined_ms_per_step': pipe_ms,
+        'replays_identical_to_eager': replays_identical,
+        'arithmetic': {0: 'exact fp32 MFMA', 3: 'fp32 as two fp16 pieces, 3 products (default)', 6: 'fp32 as three bf16 pieces, 6 products',
+                       9: 'fp32 as three bf16 pieces, 9 products'}.get(int(_lib.lib().orp_dcn_get_split_mode())),
         'roofline': roof, 'nms': nms, 'nms_batched_16_images': batched, 'per_op_us': per_op, 'train': train,
+        'other_configs': other,
         'cpu_baseline': cpu,
     }
     print(json.dumps(out))
