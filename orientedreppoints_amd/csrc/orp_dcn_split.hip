@@ -691,10 +691,7 @@ constexpr size_t split_smem() {
 
 template <int MT, int NPROD, bool OUT_NCHW, bool PLAIN>
 hipError_t launch_one(const FwdS& P, int tiles, int nblk_n, hipStream_t st) {
-  // (dev aid) ORP_DCNS_PAD_LDS=<KB>: a floor under the LDS request (with ORP_DCNS_OWN_SIMD the kernel is alone on its CU anyway)
-  static const int pad_env = getenv("ORP_DCNS_PAD_LDS") ? atoi(getenv("ORP_DCNS_PAD_LDS")) : 0;
-  constexpr size_t need = split_smem<MT, NPROD == 3 ? 2 : 3>();
-  const size_t smem = need < (size_t)pad_env * 1024 ? (size_t)pad_env * 1024 : need;
+  constexpr size_t smem = split_smem<MT, NPROD == 3 ? 2 : 3>();
   struct Tag {};
   hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_split_kernel<MT, NPROD, OUT_NCHW, PLAIN>), smem);
   if (e != hipSuccess) return e;

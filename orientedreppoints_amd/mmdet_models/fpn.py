@@ -71,12 +71,11 @@ class FPN(nn.Module):
         """The output convolutions take the channels-last bf16-split path: library split mode on (ORP_DCN_SPLIT != 0),
         `split_convs` not switched off (attribute, or ORP_FPN_SPLIT=0 for A/B timing), stride-1 'same' convolutions of one
         shape that `orp_conv_split_multi_ex` takes, GroupNorm shapes the channels-last kernels take."""
-        import os
-        from .. import _lib
+        from .. import _lib, switches
         from ..mmdet_ops.fused_norm import conv_split_ok
         on = getattr(self, 'split_convs', None)
         if on is None:
-            on = os.environ.get('ORP_FPN_SPLIT', '1') == '1'      # automatic: on at every input size (ORP_FPN_SPLIT=0: off, A/B timing)
+            on = switches.FPN_SPLIT                           # automatic: on at every input size (ORP_FPN_SPLIT=0: off, A/B timing)
         used = len(self.lateral_convs)
         if not on or _lib.lib().orp_dcn_get_split_mode() == 0 or used > 8:
             return False

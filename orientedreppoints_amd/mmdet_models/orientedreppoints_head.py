@@ -173,8 +173,7 @@ class OrientedRepPointsHead(nn.Module):
         """The channels-last tower path applies: library split mode on (ORP_DCN_SPLIT != 0), `split_towers` not switched off
         (attribute, or ORP_TOWER_SPLIT=0 for A/B timing), equal-depth towers of stride-1 convolutions of a shape
         `orp_conv_split_multi` takes, GroupNorm shapes the channels-last kernels take."""
-        import os
-        from .. import _lib
+        from .. import _lib, switches
         from ..mmdet_ops.fused_norm import conv_split_ok
         on = getattr(self, 'split_towers', None)
         if on is None:
@@ -182,7 +181,7 @@ class OrientedRepPointsHead(nn.Module):
             # ORP_TOWER_SPLIT=0 switches the path off (A/B timing).  (Round 4 kept pyramids below 8 x 8 off this path because
             # graph replays there disagreed with eager: that was packed-fp32 VALU code of ANY kernel miscomputing next to dense
             # MFMAs -- DESIGN.md 4.5 --, fixed in the library's build, not a property of this path.)
-            on = os.environ.get('ORP_TOWER_SPLIT', '1') == '1'
+            on = switches.TOWER_SPLIT
         if not on or _lib.lib().orp_dcn_get_split_mode() == 0 or len(self.cls_convs) != len(self.reg_convs) or len(feats) > 8:
             return False
         x = feats[0]
@@ -230,11 +229,11 @@ class OrientedRepPointsHead(nn.Module):
         else:
             cur = to_channels_last_multi(cur)
         cls_cur = reg_cur = cur
-        import os
+        from .. import switches
         from ..mmdet_ops.fused_norm import conv_split_gn, conv_split_gn_ok
         fuse = getattr(self, 'fuse_tower_norm', None)          # None: automatic (ORP_TOWER_GN_FUSE=0 switches it off, A/B timing)
         if fuse is None:
-            fuse = os.environ.get('ORP_TOWER_GN_FUSE', '1') == '1'
+            fuse = switches.TOWER_GN_FUSE
         fuse = bool(fuse) and all(conv_split_gn_ok(a.conv, b.conv, a.norm, b.norm, cur[0]) for a, b in zip(self.cls_convs, self.reg_convs))
         if fuse:
             # conv -> GroupNorm -> ReLU with the normalisation fused AROUND the convolution launches: statistics from the
@@ -338,10 +337,10 @@ class OrientedRepPointsHead(nn.Module):
         # with fp32 atomics (0.59 ms instead of 1.17 ms), which makes grad_input of THAT branch order-dependent in its last
         # bits.  `deterministic_backward = True` on the head (or ORP_DETERMINISTIC=1) keeps the fixed-order region pass for
         # both branches: bitwise reproducible gradients at the price of that half millisecond.
-        import os
+        from .. import switches
         det = getattr(self, 'deterministic_backward', None)
         if det is None:
-            det = os.environ.get('ORP_DETERMINISTIC', '0') == '1'
+            det = switches.DETERMINISTIC
         dcn_cls, dcn_pts = deform_conv_pair(cls_feats, pts_feats, offsets, a.weight, b.weight, a.stride, a.padding,
                                             a.dilation, sparse_grad=(False, not det))
         cls_outs = [self.reppoints_cls_out(torch.relu(c)) for c in dcn_cls]
@@ -359,15 +358,12 @@ class OrientedRepPointsHead(nn.Module):
         dcn_base_offset = self._base_offset_on(feats[0])
         fused = self._fused_towers_ok(feats)
         if fused:
-            import os
             # channels-last hand-over to the DeformConv pair launch (round 4): the last GroupNorm of each tower writes its
             # result transposed -- the classification tower ONLY so (nothing else reads it), the regression tower both ways
             # (the init branch's 3x3 convolution reads NCHW) -- which removes the pair launch's transposition kernel
-            # (one more read + write of both towers' outputs per image).  ORP_HEAD_NHWC=0: off (A/B timing).
+            # (one more read + write of both towers' outputs per image).
             a_, b_ = self.reppoints_cls_conv, self.reppoints_pts_refine_conv
-            hand = getattr(self, 'nhwc_handover', None)
-            if hand is None:
-                hand = os.environ.get('ORP_HEAD_NHWC', '1') == '1'
+            hand = getattr(self, 'nhwc_handover', True)         # (attribute: False switches the hand-over off, A/B timing)
             hand = bool(hand) and not getattr(self, 'fuse_output_convs', False) and a_.weight.size(1) % 256 == 0 and \
                 tuple(a_.weight.shape) == tuple(b_.weight.shape) and a_.stride == b_.stride and a_.padding == b_.padding and \
                 a_.dilation == b_.dilation and a_.groups == 1 and b_.groups == 1 and a_.deformable_groups == 1 and \
@@ -375,8 +371,8 @@ class OrientedRepPointsHead(nn.Module):
             from ..mmdet_ops.fused_norm import bias_act_multi, conv3x3_multi
             split = hand and self._split_towers_ok(feats)
             side = None
-            two = getattr(self, 'tower_streams', None)                # None: default on (ORP_TOWER_STREAMS=0: off, for A/B timing)
-            if not split and (two if two is not None else os.environ.get('ORP_TOWER_STREAMS', '1') == '1'):
+            two = getattr(self, 'tower_streams', None)                # None: default on (attribute False: off; PipelinedInference sets it)
+            if not split and (two if two is not None else True):
                 # the two towers are independent chains: the classification tower runs on a second stream (a fork / join in
                 # a captured graph), so that its small-level kernels fill the CUs the other tower's leave idle
                 cur = torch.cuda.current_stream(feats[0].device)

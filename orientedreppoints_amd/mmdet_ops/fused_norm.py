@@ -387,8 +387,7 @@ class Amax(object):
     __slots__ = ('bits', 'stride', 'count')
 
     def __new__(cls, bits, stride=0, count=1):
-        import os
-        if bits is None or os.environ.get('ORP_AMAX_HANDOVER', '1') != '1':      # (0: every consumer takes its own maximum; A/B aid)
+        if bits is None:
             return None
         return object.__new__(cls)
 
@@ -779,8 +778,8 @@ def conv_split_train_ok(convs, x, allow_bias=False):
     """the modules' convolutions can run as a conv_split_train node: split mode on (ORP_TRAIN_SPLIT=0 switches the training
     route off for A/B timing), no autocast, stride 1, fp32 nn.Conv2d of one shape that `orp_conv_split_multi` takes (bias-free
     unless the caller adds the bias itself), fp32 CUDA input"""
-    import os
-    if os.environ.get('ORP_TRAIN_SPLIT', '1') != '1' or _lib.lib().orp_dcn_get_split_mode() == 0 or torch.is_autocast_enabled():
+    from .. import switches
+    if not switches.TRAIN_SPLIT or _lib.lib().orp_dcn_get_split_mode() == 0 or torch.is_autocast_enabled():
         return False
     c0 = convs[0]
     for c in convs:
