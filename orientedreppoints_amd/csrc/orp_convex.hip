@@ -8,7 +8,8 @@
 //     copies of the fp32 inputs, so the float -> double widening on load is exact);
 //   * the gt quad is wave-uniform (scalar loads), grid.y splits the gt range so small N still fills the chip;
 //   * fp64 clipping scratch is a per-lane LDS column of 8 + 8 vertices instead of ~3 KB of private stack;
-//   * results are written straight to the [N, K] matrix on the caller's stream -- no host round trip.
+//   * results go through a [64][gts per workgroup] LDS tile and are written to the [N, K] matrix as row pieces (a lane storing
+//     one float at stride K touched a 128-byte line per float: 40 MB of writes for a 2.8 MB result) -- no host round trip.
 // Arithmetic (fp64 internals, eps 1e-8, signed triangle fan WITHOUT fabs on each term, convex_iou_kernel.cu:137)
 // follows the reference operation for operation: assignment decisions downstream compare these floats.
 #include <hip/hip_runtime.h>
@@ -24,7 +25,7 @@ using orp::Pt;
 
 constexpr int kThreads = 64;                  // one wave per workgroup: LDS per lane is what limits occupancy
 constexpr int kHullKeep = 12;                 // stored hull vertices (a 9-point hull has <= 9)
-constexpr int kMaxGtsPerBlock = 64;           // queue capacity = 64 lanes x this many gts
+constexpr int kMaxGtsPerBlock = 16;           // gts per workgroup: queue capacity = 64 lanes x this many, result tile 64 x this many
 
 // float-backed store that widens to double on access (exact)
 struct HullStoreF {
@@ -91,6 +92,7 @@ convex_iou_kernel(const float* __restrict__ pts, int n, const float* __restrict_
   // Resolved pairs are written at once; the others are queued and evaluated densely in phase B (one pair per lane,
   // hull and gt fetched by index), instead of one straggler lane holding 63 finished ones.
   __shared__ unsigned short s_queue[kThreads * kMaxGtsPerBlock];
+  __shared__ float s_out[kThreads][kMaxGtsPerBlock + 1];
   __shared__ int s_n1[kThreads];
   __shared__ double s_spred[kThreads];
   __shared__ int s_qcount;
@@ -114,7 +116,7 @@ convex_iou_kernel(const float* __restrict__ pts, int n, const float* __restrict_
     if (active && far) {
       const double inter0 = 0;
       const double uni0 = fabs(s_pred) + fabs(s_gt) - inter0;
-      out[(size_t)idx * k + j] = (float)(inter0 / uni0);
+      s_out[lane][j - j0] = (float)(inter0 / uni0);
     }
     const bool pend = active && !far;
     const unsigned long long pmask = __ballot(pend);
@@ -186,7 +188,15 @@ convex_iou_kernel(const float* __restrict__ pts, int n, const float* __restrict_
       a = b;
     }
     const double uni = fabs(hs) + fabs(s_gt) - inter;
-    out[(size_t)(blockIdx.x * kThreads + sl) * k + j] = (float)(inter / uni);
+    s_out[sl][j - j0] = (float)(inter / uni);
+  }
+  __syncthreads();
+  // the tile's rows, piece by piece: consecutive lanes write consecutive floats of a row
+  const int ng = j1 - j0;
+  const int rows = min(kThreads, n - blockIdx.x * kThreads);
+  for (int e = lane; e < rows * ng; e += kThreads) {
+    const int r = e / ng, c = e - r * ng;
+    out[(size_t)(blockIdx.x * kThreads + r) * k + j0 + c] = s_out[r][c];
   }
 }
 }  // namespace
@@ -196,12 +206,12 @@ int orp_convex_iou(const float* pts, int n, const float* gts, int k, float* out,
   if (n < 0 || k < 0 || ((n > 0 && k > 0) && (!pts || !gts || !out))) return ORP_EINVAL;
   if (n == 0 || k == 0) return ORP_OK;
   const int nb = (n + kThreads - 1) / kThreads;
-  // split the gt range until there are ~8 waves per SIMD worth of workgroups (or one gt per block)
-  int ysplit = 1;
-  while (nb * ysplit < 8192 && ysplit < k) ysplit *= 2;
-  int gpb = (k + ysplit - 1) / ysplit;
-  if (gpb > kMaxGtsPerBlock) gpb = kMaxGtsPerBlock;
-  ysplit = (k + gpb - 1) / gpb;
+  // gts per workgroup: every workgroup rebuilds the hulls of its 64 point sets, so as many gts as possible behind one build --
+  // while the launch still has ~2 000 workgroups (one wave each, LDS holds ~7 per CU) when the problem is large enough
+  int gpb = kMaxGtsPerBlock;
+  while (gpb > 1 && (long)nb * ((k + gpb - 1) / gpb) < 2048) gpb >>= 1;      // (1 280 / 4 096 measured no better: 21 824 x 64 in 387 / 341 us against 338)
+  if (gpb > k) gpb = k;
+  const int ysplit = (k + gpb - 1) / gpb;
   OrpProfScope prof(ORP_PROF_CONVEX_IOU, (hipStream_t)stream);
   hipLaunchKernelGGL(convex_iou_kernel, dim3(nb, ysplit), dim3(kThreads), 0, (hipStream_t)stream, pts, n, gts, k, gpb,
                      out);
