@@ -191,6 +191,310 @@ __global__ void __launch_bounds__(kVictimThreads) mask_probe_v0(int iters, int H
 #undef POST
 #define PRE ""
 #define POST ""
+__global__ void __launch_bounds__(kVictimThreads) mask_probe_v7(int iters, int H, int W, unsigned* __restrict__ bad_lane /* [64][4] */, float* __restrict__ sink,
+                                                       int mfma_burst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned seed = (blockIdx.x * kVictimThreads + threadIdx.x) * 2654435761u + 12345u;
+  const __bf16 one = (__bf16)1.f;
+  const bf8 a = bf8{one, one, one, one, one, one, one, one};
+  floatx16 acc = floatx16{0};
+  unsigned nbad[4] = {0, 0, 0, 0};
+  const int Hm1 = H - 1, Wm1 = W - 1;
+  for (int it = 0; it < iters; it++) {
+    // sample coordinates inside (-1, H) x (-1, W): mostly interior, some on every border
+    seed = seed * 1664525u + 1013904223u;
+    const float h_im = -0.999f + (float)(seed >> 8) * (1.f / 16777216.f) * ((float)H + 0.998f);
+    seed = seed * 1664525u + 1013904223u;
+    const float w_im = -0.999f + (float)(seed >> 8) * (1.f / 16777216.f) * ((float)W + 0.998f);
+    float wx, wy, wz, ww;
+    // v16 = h_im, v17 = w_im (a register pair for the packed instructions); the block is the compiler's own code for
+    // orp_dcn_split.hip's coefficient table (%bb.20 of dcn_fwd_split_kernel<1, 6, true, false>), registers as there
+    asm volatile(
+        "v_mov_b32 v16, %[him]\n\tv_mov_b32 v17, %[wim]\n\t"
+        "s_mov_b64 s[10:11], 0\n\ts_mov_b64 s[4:5], 0\n\ts_mov_b64 s[14:15], 0\n\t"
+        "v_floor_f32_e32 v2, v16\n\t"
+        "v_floor_f32_e32 v3, v17\n\t"
+        "v_cvt_i32_f32_e32 v6, v3\n\t"
+        "v_cvt_i32_f32_e32 v7, v2\n\t"
+        "v_cvt_f32_i32_e32 v3, v6\n\t"
+        "v_cvt_f32_i32_e32 v2, v7\n\t"
+        "v_or_b32_e32 v19, v7, v6\n\t"
+        "v_cmp_lt_i32_e64 s[6:7], -1, v7\n\t"
+        "v_cmp_gt_i32_e64 s[8:9], %[Wm1], v6\n\t"
+        "v_pk_add_f32 v[8:9], v[16:17], v[2:3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_cmp_lt_i32_e32 vcc, -1, v19\n\t"
+        "v_pk_add_f32 v[4:5], v[8:9], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+        "v_cmp_gt_i32_e64 s[10:11], %[Hm1], v7\n\t"
+        "v_mul_f32_e32 v2, v4, v5\n\t"
+        "v_cmp_lt_i32_e64 s[4:5], -1, v6\n\t"
+        "v_cndmask_b32_e32 v2, 0, v2, vcc\n\t"
+        "v_pk_mul_f32 v[20:21], v[8:9], v[4:5] op_sel:[0,1] op_sel_hi:[1,0]\n\tv_mov_b32_e32 v4, v20\n\tv_mov_b32_e32 v5, v21\n\t"
+        "s_and_b64 vcc, s[6:7], s[8:9]\n\t"
+        "v_cndmask_b32_e32 v3, 0, v5, vcc\n\t"
+        PRE "s_and_b64 vcc, s[10:11], s[4:5]\n\t" POST
+        "v_mul_f32_e32 v5, v8, v9\n\t"
+        "s_and_b64 s[12:13], s[10:11], s[8:9]\n\t"
+        "v_cndmask_b32_e32 v4, 0, v4, vcc\n\t"
+        "s_andn2_b64 vcc, exec, s[14:15]\n\t"
+        "v_cndmask_b32_e64 v5, 0, v5, s[12:13]\n\t"
+        "s_nop 4\n\t"
+        "v_mov_b32 %[wx], v2\n\tv_mov_b32 %[wy], v3\n\tv_mov_b32 %[wz], v4\n\tv_mov_b32 %[ww], v5\n\t"
+        : [wx] "=&v"(wx), [wy] "=&v"(wy), [wz] "=&v"(wz), [ww] "=&v"(ww)
+        : [him] "v"(h_im), [wim] "v"(w_im), [Hm1] "s"(Hm1), [Wm1] "s"(Wm1)
+        : "v20", "v21", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v16", "v17", "v19", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13",
+          "s14", "s15", "vcc");
+    // select-free evaluation of the same values: the borders as 0 / 1 factors (exact)
+    const float fh = floorf(h_im), fw = floorf(w_im);
+    const int h_low = (int)fh, w_low = (int)fw;
+    const float lh = h_im - fh, lw = w_im - fw, hh = 1.f - lh, hw = 1.f - lw;
+    const float t_ok = (float)min(h_low + 1, 1), b_ok = (float)min(Hm1 - h_low, 1);
+    const float l_ok = (float)min(w_low + 1, 1), r_ok = (float)min(Wm1 - w_low, 1);
+    const float ex = (hh * hw) * (t_ok * l_ok), ey = (hh * lw) * (t_ok * r_ok), ez = (lh * hw) * (b_ok * l_ok), ew = (lh * lw) * (b_ok * r_ok);
+    nbad[0] += (wx != ex); nbad[1] += (wy != ey); nbad[2] += (wz != ez); nbad[3] += (ww != ew);
+    // a burst of MFMAs now and then, out of step between the waves of a SIMD (the other workgroup of the CU is in its K loop
+    // while this one builds its table)
+    if (mfma_burst && ((it + wave * 7) & 15) == 0) {
+#pragma unroll
+      for (int u = 0; u < 12; u++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, acc, 0, 0, 0);
+    }
+  }
+  for (int k = 0; k < 4; k++) if (nbad[k]) atomicAdd(&bad_lane[lane * 4 + k], nbad[k]);
+  if (acc[0] == 12345.f) sink[0] = acc[1];
+}
+
+
+#undef PRE
+#undef POST
+#define PRE ""
+#define POST ""
+__global__ void __launch_bounds__(kVictimThreads) mask_probe_v8(int iters, int H, int W, unsigned* __restrict__ bad_lane /* [64][4] */, float* __restrict__ sink,
+                                                       int mfma_burst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned seed = (blockIdx.x * kVictimThreads + threadIdx.x) * 2654435761u + 12345u;
+  const __bf16 one = (__bf16)1.f;
+  const bf8 a = bf8{one, one, one, one, one, one, one, one};
+  floatx16 acc = floatx16{0};
+  unsigned nbad[4] = {0, 0, 0, 0};
+  const int Hm1 = H - 1, Wm1 = W - 1;
+  for (int it = 0; it < iters; it++) {
+    // sample coordinates inside (-1, H) x (-1, W): mostly interior, some on every border
+    seed = seed * 1664525u + 1013904223u;
+    const float h_im = -0.999f + (float)(seed >> 8) * (1.f / 16777216.f) * ((float)H + 0.998f);
+    seed = seed * 1664525u + 1013904223u;
+    const float w_im = -0.999f + (float)(seed >> 8) * (1.f / 16777216.f) * ((float)W + 0.998f);
+    float wx, wy, wz, ww;
+    // v16 = h_im, v17 = w_im (a register pair for the packed instructions); the block is the compiler's own code for
+    // orp_dcn_split.hip's coefficient table (%bb.20 of dcn_fwd_split_kernel<1, 6, true, false>), registers as there
+    asm volatile(
+        "v_mov_b32 v16, %[him]\n\tv_mov_b32 v17, %[wim]\n\t"
+        "s_mov_b64 s[10:11], 0\n\ts_mov_b64 s[4:5], 0\n\ts_mov_b64 s[14:15], 0\n\t"
+        "v_floor_f32_e32 v2, v16\n\t"
+        "v_floor_f32_e32 v3, v17\n\t"
+        "v_cvt_i32_f32_e32 v6, v3\n\t"
+        "v_cvt_i32_f32_e32 v7, v2\n\t"
+        "v_cvt_f32_i32_e32 v3, v6\n\t"
+        "v_cvt_f32_i32_e32 v2, v7\n\t"
+        "v_or_b32_e32 v19, v7, v6\n\t"
+        "v_cmp_lt_i32_e64 s[6:7], -1, v7\n\t"
+        "v_cmp_gt_i32_e64 s[8:9], %[Wm1], v6\n\t"
+        "v_pk_add_f32 v[8:9], v[16:17], v[2:3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_cmp_lt_i32_e32 vcc, -1, v19\n\t"
+        "v_pk_add_f32 v[4:5], v[8:9], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+        "v_cmp_gt_i32_e64 s[10:11], %[Hm1], v7\n\t"
+        "v_mul_f32_e32 v2, v4, v5\n\t"
+        "v_cmp_lt_i32_e64 s[4:5], -1, v6\n\t"
+        "v_cndmask_b32_e32 v2, 0, v2, vcc\n\t"
+        "s_nop 3\n\t" "v_pk_mul_f32 v[4:5], v[8:9], v[4:5] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+        "s_and_b64 vcc, s[6:7], s[8:9]\n\t"
+        "v_cndmask_b32_e32 v3, 0, v5, vcc\n\t"
+        PRE "s_and_b64 vcc, s[10:11], s[4:5]\n\t" POST
+        "v_mul_f32_e32 v5, v8, v9\n\t"
+        "s_and_b64 s[12:13], s[10:11], s[8:9]\n\t"
+        "v_cndmask_b32_e32 v4, 0, v4, vcc\n\t"
+        "s_andn2_b64 vcc, exec, s[14:15]\n\t"
+        "v_cndmask_b32_e64 v5, 0, v5, s[12:13]\n\t"
+        "s_nop 4\n\t"
+        "v_mov_b32 %[wx], v2\n\tv_mov_b32 %[wy], v3\n\tv_mov_b32 %[wz], v4\n\tv_mov_b32 %[ww], v5\n\t"
+        : [wx] "=&v"(wx), [wy] "=&v"(wy), [wz] "=&v"(wz), [ww] "=&v"(ww)
+        : [him] "v"(h_im), [wim] "v"(w_im), [Hm1] "s"(Hm1), [Wm1] "s"(Wm1)
+        : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v16", "v17", "v19", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13",
+          "s14", "s15", "vcc");
+    // select-free evaluation of the same values: the borders as 0 / 1 factors (exact)
+    const float fh = floorf(h_im), fw = floorf(w_im);
+    const int h_low = (int)fh, w_low = (int)fw;
+    const float lh = h_im - fh, lw = w_im - fw, hh = 1.f - lh, hw = 1.f - lw;
+    const float t_ok = (float)min(h_low + 1, 1), b_ok = (float)min(Hm1 - h_low, 1);
+    const float l_ok = (float)min(w_low + 1, 1), r_ok = (float)min(Wm1 - w_low, 1);
+    const float ex = (hh * hw) * (t_ok * l_ok), ey = (hh * lw) * (t_ok * r_ok), ez = (lh * hw) * (b_ok * l_ok), ew = (lh * lw) * (b_ok * r_ok);
+    nbad[0] += (wx != ex); nbad[1] += (wy != ey); nbad[2] += (wz != ez); nbad[3] += (ww != ew);
+    // a burst of MFMAs now and then, out of step between the waves of a SIMD (the other workgroup of the CU is in its K loop
+    // while this one builds its table)
+    if (mfma_burst && ((it + wave * 7) & 15) == 0) {
+#pragma unroll
+      for (int u = 0; u < 12; u++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, acc, 0, 0, 0);
+    }
+  }
+  for (int k = 0; k < 4; k++) if (nbad[k]) atomicAdd(&bad_lane[lane * 4 + k], nbad[k]);
+  if (acc[0] == 12345.f) sink[0] = acc[1];
+}
+
+
+#undef PRE
+#undef POST
+#define PRE ""
+#define POST ""
+__global__ void __launch_bounds__(kVictimThreads) mask_probe_v9(int iters, int H, int W, unsigned* __restrict__ bad_lane /* [64][4] */, float* __restrict__ sink,
+                                                       int mfma_burst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned seed = (blockIdx.x * kVictimThreads + threadIdx.x) * 2654435761u + 12345u;
+  const __bf16 one = (__bf16)1.f;
+  const bf8 a = bf8{one, one, one, one, one, one, one, one};
+  floatx16 acc = floatx16{0};
+  unsigned nbad[4] = {0, 0, 0, 0};
+  const int Hm1 = H - 1, Wm1 = W - 1;
+  for (int it = 0; it < iters; it++) {
+    // sample coordinates inside (-1, H) x (-1, W): mostly interior, some on every border
+    seed = seed * 1664525u + 1013904223u;
+    const float h_im = -0.999f + (float)(seed >> 8) * (1.f / 16777216.f) * ((float)H + 0.998f);
+    seed = seed * 1664525u + 1013904223u;
+    const float w_im = -0.999f + (float)(seed >> 8) * (1.f / 16777216.f) * ((float)W + 0.998f);
+    float wx, wy, wz, ww;
+    // v16 = h_im, v17 = w_im (a register pair for the packed instructions); the block is the compiler's own code for
+    // orp_dcn_split.hip's coefficient table (%bb.20 of dcn_fwd_split_kernel<1, 6, true, false>), registers as there
+    asm volatile(
+        "v_mov_b32 v16, %[him]\n\tv_mov_b32 v17, %[wim]\n\t"
+        "s_mov_b64 s[10:11], 0\n\ts_mov_b64 s[4:5], 0\n\ts_mov_b64 s[14:15], 0\n\t"
+        "v_floor_f32_e32 v2, v16\n\t"
+        "v_floor_f32_e32 v3, v17\n\t"
+        "v_cvt_i32_f32_e32 v6, v3\n\t"
+        "v_cvt_i32_f32_e32 v7, v2\n\t"
+        "v_cvt_f32_i32_e32 v3, v6\n\t"
+        "v_cvt_f32_i32_e32 v2, v7\n\t"
+        "v_or_b32_e32 v19, v7, v6\n\t"
+        "v_cmp_lt_i32_e64 s[6:7], -1, v7\n\t"
+        "v_cmp_gt_i32_e64 s[8:9], %[Wm1], v6\n\t"
+        "v_pk_add_f32 v[8:9], v[16:17], v[2:3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_cmp_lt_i32_e32 vcc, -1, v19\n\t"
+        "v_pk_add_f32 v[4:5], v[8:9], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+        "v_cmp_gt_i32_e64 s[10:11], %[Hm1], v7\n\t"
+        "v_mul_f32_e32 v2, v4, v5\n\t"
+        "v_cmp_lt_i32_e64 s[4:5], -1, v6\n\t"
+        "v_cndmask_b32_e32 v2, 0, v2, vcc\n\t"
+        "v_pk_mul_f32 v[4:5], v[8:9], v[4:5] op_sel:[0,1] op_sel_hi:[1,0]\n\t" "s_nop 3\n\t"
+        "s_and_b64 vcc, s[6:7], s[8:9]\n\t"
+        "v_cndmask_b32_e32 v3, 0, v5, vcc\n\t"
+        PRE "s_and_b64 vcc, s[10:11], s[4:5]\n\t" POST
+        "v_mul_f32_e32 v5, v8, v9\n\t"
+        "s_and_b64 s[12:13], s[10:11], s[8:9]\n\t"
+        "v_cndmask_b32_e32 v4, 0, v4, vcc\n\t"
+        "s_andn2_b64 vcc, exec, s[14:15]\n\t"
+        "v_cndmask_b32_e64 v5, 0, v5, s[12:13]\n\t"
+        "s_nop 4\n\t"
+        "v_mov_b32 %[wx], v2\n\tv_mov_b32 %[wy], v3\n\tv_mov_b32 %[wz], v4\n\tv_mov_b32 %[ww], v5\n\t"
+        : [wx] "=&v"(wx), [wy] "=&v"(wy), [wz] "=&v"(wz), [ww] "=&v"(ww)
+        : [him] "v"(h_im), [wim] "v"(w_im), [Hm1] "s"(Hm1), [Wm1] "s"(Wm1)
+        : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v16", "v17", "v19", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13",
+          "s14", "s15", "vcc");
+    // select-free evaluation of the same values: the borders as 0 / 1 factors (exact)
+    const float fh = floorf(h_im), fw = floorf(w_im);
+    const int h_low = (int)fh, w_low = (int)fw;
+    const float lh = h_im - fh, lw = w_im - fw, hh = 1.f - lh, hw = 1.f - lw;
+    const float t_ok = (float)min(h_low + 1, 1), b_ok = (float)min(Hm1 - h_low, 1);
+    const float l_ok = (float)min(w_low + 1, 1), r_ok = (float)min(Wm1 - w_low, 1);
+    const float ex = (hh * hw) * (t_ok * l_ok), ey = (hh * lw) * (t_ok * r_ok), ez = (lh * hw) * (b_ok * l_ok), ew = (lh * lw) * (b_ok * r_ok);
+    nbad[0] += (wx != ex); nbad[1] += (wy != ey); nbad[2] += (wz != ez); nbad[3] += (ww != ew);
+    // a burst of MFMAs now and then, out of step between the waves of a SIMD (the other workgroup of the CU is in its K loop
+    // while this one builds its table)
+    if (mfma_burst && ((it + wave * 7) & 15) == 0) {
+#pragma unroll
+      for (int u = 0; u < 12; u++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, acc, 0, 0, 0);
+    }
+  }
+  for (int k = 0; k < 4; k++) if (nbad[k]) atomicAdd(&bad_lane[lane * 4 + k], nbad[k]);
+  if (acc[0] == 12345.f) sink[0] = acc[1];
+}
+
+
+#undef PRE
+#undef POST
+#define PRE ""
+#define POST ""
+__global__ void __launch_bounds__(kVictimThreads) mask_probe_v10(int iters, int H, int W, unsigned* __restrict__ bad_lane /* [64][4] */, float* __restrict__ sink,
+                                                       int mfma_burst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned seed = (blockIdx.x * kVictimThreads + threadIdx.x) * 2654435761u + 12345u;
+  const __bf16 one = (__bf16)1.f;
+  const bf8 a = bf8{one, one, one, one, one, one, one, one};
+  floatx16 acc = floatx16{0};
+  unsigned nbad[4] = {0, 0, 0, 0};
+  const int Hm1 = H - 1, Wm1 = W - 1;
+  for (int it = 0; it < iters; it++) {
+    // sample coordinates inside (-1, H) x (-1, W): mostly interior, some on every border
+    seed = seed * 1664525u + 1013904223u;
+    const float h_im = -0.999f + (float)(seed >> 8) * (1.f / 16777216.f) * ((float)H + 0.998f);
+    seed = seed * 1664525u + 1013904223u;
+    const float w_im = -0.999f + (float)(seed >> 8) * (1.f / 16777216.f) * ((float)W + 0.998f);
+    float wx, wy, wz, ww;
+    // v16 = h_im, v17 = w_im (a register pair for the packed instructions); the block is the compiler's own code for
+    // orp_dcn_split.hip's coefficient table (%bb.20 of dcn_fwd_split_kernel<1, 6, true, false>), registers as there
+    asm volatile(
+        "v_mov_b32 v16, %[him]\n\tv_mov_b32 v17, %[wim]\n\t"
+        "s_mov_b64 s[10:11], 0\n\ts_mov_b64 s[4:5], 0\n\ts_mov_b64 s[14:15], 0\n\t"
+        "v_floor_f32_e32 v2, v16\n\t"
+        "v_floor_f32_e32 v3, v17\n\t"
+        "v_cvt_i32_f32_e32 v6, v3\n\t"
+        "v_cvt_i32_f32_e32 v7, v2\n\t"
+        "v_cvt_f32_i32_e32 v3, v6\n\t"
+        "v_cvt_f32_i32_e32 v2, v7\n\t"
+        "v_or_b32_e32 v19, v7, v6\n\t"
+        "v_cmp_lt_i32_e64 s[6:7], -1, v7\n\t"
+        "v_cmp_gt_i32_e64 s[8:9], %[Wm1], v6\n\t"
+        "v_pk_add_f32 v[8:9], v[16:17], v[2:3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_cmp_lt_i32_e32 vcc, -1, v19\n\t"
+        "v_pk_add_f32 v[4:5], v[8:9], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+        "v_cmp_gt_i32_e64 s[10:11], %[Hm1], v7\n\t"
+        "v_mul_f32_e32 v2, v4, v5\n\t"
+        "v_cmp_lt_i32_e64 s[4:5], -1, v6\n\t"
+        "v_cndmask_b32_e32 v2, 0, v2, vcc\n\t"
+        "v_mov_b32_e32 v20, v5\n\tv_mov_b32_e32 v21, v4\n\tv_pk_mul_f32 v[4:5], v[8:9], v[20:21]\n\t"
+        "s_and_b64 vcc, s[6:7], s[8:9]\n\t"
+        "v_cndmask_b32_e32 v3, 0, v5, vcc\n\t"
+        PRE "s_and_b64 vcc, s[10:11], s[4:5]\n\t" POST
+        "v_mul_f32_e32 v5, v8, v9\n\t"
+        "s_and_b64 s[12:13], s[10:11], s[8:9]\n\t"
+        "v_cndmask_b32_e32 v4, 0, v4, vcc\n\t"
+        "s_andn2_b64 vcc, exec, s[14:15]\n\t"
+        "v_cndmask_b32_e64 v5, 0, v5, s[12:13]\n\t"
+        "s_nop 4\n\t"
+        "v_mov_b32 %[wx], v2\n\tv_mov_b32 %[wy], v3\n\tv_mov_b32 %[wz], v4\n\tv_mov_b32 %[ww], v5\n\t"
+        : [wx] "=&v"(wx), [wy] "=&v"(wy), [wz] "=&v"(wz), [ww] "=&v"(ww)
+        : [him] "v"(h_im), [wim] "v"(w_im), [Hm1] "s"(Hm1), [Wm1] "s"(Wm1)
+        : "v20", "v21", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v16", "v17", "v19", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13",
+          "s14", "s15", "vcc");
+    // select-free evaluation of the same values: the borders as 0 / 1 factors (exact)
+    const float fh = floorf(h_im), fw = floorf(w_im);
+    const int h_low = (int)fh, w_low = (int)fw;
+    const float lh = h_im - fh, lw = w_im - fw, hh = 1.f - lh, hw = 1.f - lw;
+    const float t_ok = (float)min(h_low + 1, 1), b_ok = (float)min(Hm1 - h_low, 1);
+    const float l_ok = (float)min(w_low + 1, 1), r_ok = (float)min(Wm1 - w_low, 1);
+    const float ex = (hh * hw) * (t_ok * l_ok), ey = (hh * lw) * (t_ok * r_ok), ez = (lh * hw) * (b_ok * l_ok), ew = (lh * lw) * (b_ok * r_ok);
+    nbad[0] += (wx != ex); nbad[1] += (wy != ey); nbad[2] += (wz != ez); nbad[3] += (ww != ew);
+    // a burst of MFMAs now and then, out of step between the waves of a SIMD (the other workgroup of the CU is in its K loop
+    // while this one builds its table)
+    if (mfma_burst && ((it + wave * 7) & 15) == 0) {
+#pragma unroll
+      for (int u = 0; u < 12; u++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, acc, 0, 0, 0);
+    }
+  }
+  for (int k = 0; k < 4; k++) if (nbad[k]) atomicAdd(&bad_lane[lane * 4 + k], nbad[k]);
+  if (acc[0] == 12345.f) sink[0] = acc[1];
+}
+
+
+#undef PRE
+#undef POST
+#define PRE ""
+#define POST ""
 __global__ void __launch_bounds__(kVictimThreads) mask_probe_v6(int iters, int H, int W, unsigned* __restrict__ bad_lane /* [64][4] */, float* __restrict__ sink,
                                                        int mfma_burst) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -742,6 +1046,62 @@ void run(const char* name, const uint4* gB, int rounds, int lds_bytes, victim_fn
 }
 
 
+// ---- WHICH packed instructions are affected: one packed op on small integers (every result exact) per iteration, checked per half ----
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int OP>
+__global__ void __launch_bounds__(kVictimThreads) packed_victim(int iters, unsigned* __restrict__ bad /* [4 quarters][2 halves] */) {
+  const int lane = threadIdx.x & 63;
+  unsigned seed = (blockIdx.x * kVictimThreads + threadIdx.x) * 2654435761u + 777u;
+  unsigned nlo = 0, nhi = 0;
+  for (int it = 0; it < iters; it++) {
+    seed = seed * 1664525u + 1013904223u;
+    const int a0 = (seed >> 4) & 15, a1 = (seed >> 8) & 15, b0 = (seed >> 12) & 15, b1 = (seed >> 16) & 15, c0 = (seed >> 20) & 15, c1 = (seed >> 24) & 15;
+    if (OP < 3 || OP >= 6) {
+      f2v a = {(float)a0, (float)a1}, b = {(float)b0, (float)b1}, c = {(float)c0, (float)c1}, r;
+      if (OP == 0) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+      else if (OP == 6) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));   // lo = a.lo * b.hi, hi = a.hi * b.lo
+      else if (OP == 7) { r = b; asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(r) : "v"(a)); }                             // destination = second source
+      else if (OP == 8) { r = b; asm volatile("v_pk_mul_f32 %0, %1, %0 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(r) : "v"(a)); }
+      else if (OP == 1) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+      else asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+      asm volatile("s_nop 2");
+      const bool sw = OP == 6 || OP == 8;
+      const float e0 = sw ? (float)(a0 * b1) : (OP == 0 || OP == 7) ? (float)(a0 * b0) : OP == 1 ? (float)(a0 + b0) : (float)(a0 * b0 + c0);
+      const float e1 = sw ? (float)(a1 * b0) : (OP == 0 || OP == 7) ? (float)(a1 * b1) : OP == 1 ? (float)(a1 + b1) : (float)(a1 * b1 + c1);
+      nlo += r[0] != e0; nhi += r[1] != e1;
+    } else {
+      typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+      h2v a = {(_Float16)a0, (_Float16)a1}, b = {(_Float16)b0, (_Float16)b1}, c = {(_Float16)c0, (_Float16)c1}, r;
+      if (OP == 3) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+      else if (OP == 4) asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+      else asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+      asm volatile("s_nop 2");
+      const float e0 = OP == 3 ? (float)(a0 * b0) : OP == 4 ? (float)(a0 + b0) : (float)(a0 * b0 + c0);
+      const float e1 = OP == 3 ? (float)(a1 * b1) : OP == 4 ? (float)(a1 + b1) : (float)(a1 * b1 + c1);
+      nlo += (float)r[0] != e0; nhi += (float)r[1] != e1;
+    }
+  }
+  if (nlo) atomicAdd(&bad[(lane >> 4) * 2], nlo);
+  if (nhi) atomicAdd(&bad[(lane >> 4) * 2 + 1], nhi);
+}
+
+template <int OP>
+void run_packed(const char* name, const uint4* gB, int rounds, bool with_aggressor) {
+  unsigned* vbad; float* sink;
+  CHK(hipMalloc(&vbad, 64)); CHK(hipMalloc(&sink, 64)); CHK(hipMemset(vbad, 0, 64));
+  hipStream_t s[2]; CHK(hipStreamCreate(&s[0])); CHK(hipStreamCreate(&s[1]));
+  for (int r = 0; r < rounds; r++) {
+    if (with_aggressor) hipLaunchKernelGGL((aggressor2<0, false, true, false>), dim3(256 * 2), dim3(kThreads), 0, s[0], gB, 400, sink);
+    hipLaunchKernelGGL(packed_victim<OP>, dim3(512), dim3(kVictimThreads), 0, s[1], 4000, vbad);
+  }
+  CHK(hipGetLastError()); CHK(hipDeviceSynchronize());
+  unsigned h[8]; CHK(hipMemcpy(h, vbad, 32, hipMemcpyDeviceToHost));
+  printf("%-14s %s: %.1e results per half; wrong (low half | high half) by lane quarter: [%u | %u] [%u | %u] [%u | %u] [%u | %u]\n", name,
+         with_aggressor ? "next to bf16 MFMAs + accumulator reads" : "alone                                 ", (double)rounds * 512 * 512 * 4000,
+         h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  CHK(hipFree(vbad)); CHK(hipFree(sink)); CHK(hipStreamDestroy(s[0])); CHK(hipStreamDestroy(s[1]));
+}
+
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 200;
   uint4* gB; CHK(hipMalloc(&gB, sizeof(uint4) * 128));
@@ -785,6 +1145,21 @@ int main(int argc, char** argv) {
   run<3, true>("MFMAs + compiler-placed loads (SAFE)", gB, rounds, lds2, mask_probe_v6, "(v_pk_mul_f32 replaced by two v_mul_f32)");
   run2v<0, false, true, false>("bf16 32x32x16 MFMAs + a read of the accumulator per iteration, no loads", gB, rounds, mask_probe_v0, "as compiled");
   run2v<0, false, true, false>("bf16 32x32x16 MFMAs + a read of the accumulator per iteration, no loads", gB, rounds, mask_probe_v6, "without v_pk_mul_f32");
+  run2v<0, false, true, false>("same", gB, rounds, mask_probe_v7, "packed multiply into OTHER registers, then two v_mov");
+  run2v<0, false, true, false>("same", gB, rounds, mask_probe_v8, "s_nop 3 in front of the packed multiply");
+  run2v<0, false, true, false>("same", gB, rounds, mask_probe_v9, "s_nop 3 behind the packed multiply");
+  run2v<0, false, true, false>("same", gB, rounds, mask_probe_v10, "operands swapped by v_mov, packed multiply WITHOUT op_sel");
+  printf("== which packed instructions are affected\n");
+  run_packed<0>("v_pk_mul_f32", gB, rounds / 4, false);
+  run_packed<0>("v_pk_mul_f32", gB, rounds / 4, true);
+  run_packed<1>("v_pk_add_f32", gB, rounds / 4, true);
+  run_packed<2>("v_pk_fma_f32", gB, rounds / 4, true);
+  run_packed<6>("pk_mul op_sel", gB, rounds / 4, true);
+  run_packed<7>("pk_mul inplace", gB, rounds / 4, true);
+  run_packed<8>("pk_mul both", gB, rounds / 4, true);
+  run_packed<3>("v_pk_mul_f16", gB, rounds / 4, true);
+  run_packed<4>("v_pk_add_f16", gB, rounds / 4, true);
+  run_packed<5>("v_pk_fma_f16", gB, rounds / 4, true);
   CHK(hipFree(gB));
   return 0;
 }
