@@ -310,7 +310,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   if (F16) {
     unsigned am = P.amax[conv * P.amax_stride];
     if (P.amax_count > 1) {                                                   // (block-uniform) the producer left one bound per (tensor, image, group)
-      __shared__ unsigned red[kThreadsS / 64];
+      unsigned* red = reinterpret_cast<unsigned*>(sCw);                         // (the table is built after this; no static LDS in front of the dynamic region)
       unsigned m_ = 0u;
       for (int i = tid; i < P.amax_count; i += kThreadsS) m_ = max(m_, P.amax[conv * P.amax_stride + i]);
 #pragma unroll
@@ -320,6 +320,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       am = red[0];
 #pragma unroll
       for (int i = 1; i < kThreadsS / 64; i++) am = max(am, red[i]);
+      __syncthreads();                                                          // (before the table build overwrites the scratch)
     }
     int k = am == 0u ? 0 : 14 - ((int)((am >> 23) & 0xffu) - 127);
     k = k < -100 ? -100 : k > 100 ? 100 : k;
