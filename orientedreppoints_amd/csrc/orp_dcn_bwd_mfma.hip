@@ -54,6 +54,9 @@
 #ifndef ORP_BWD_WDIST
 #define ORP_BWD_WDIST 3      // kernel A: weight fragments fetched this many chunks ahead (ring of WDIST + 1 slots; 1, 3 or 7)
 #endif
+#ifndef ORP_BWD_WDIST16
+#define ORP_BWD_WDIST16 3    // ... of the fp16-pieces contraction (a chunk is 3 MFMAs = 96 cycles there; the other waves of the SIMD cover the rest)
+#endif
 #ifndef ORP_BWD_LANEPOS
 #define ORP_BWD_LANEPOS 1    // kernel A, dense path: accumulator as D[channel][position] (lane = position) and the in-lane derivative sums; 0 = the round-3 lane = channel epilogue
 #endif
@@ -64,11 +67,14 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));     // one operand of v_mfma_f32_32x32x16_f16: 8 k-values
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int CH = 256;          // Cin = Cout on this path
 constexpr int MAXL = 8;
 constexpr int MAXT = 9;
 constexpr int ASTR = CH + 4;     // kernel A: grad_out tile row stride (conflict-free ds_read_b128 of the permuted K order)
+constexpr int ASTRH = CH + 8;    // kernel A, fp16 pieces: row stride of a plane in halves (132 dwords: conflict-free ds_read_b128 over 16 rows)
 constexpr int RS = CH + 32;      // kernel B: row stride with RS % 64 == 32 (two half-waves read rows k, k+1 conflict-free)
 constexpr int kThreads = 512;
 
@@ -90,6 +96,12 @@ struct BwdParams {
   int nlev, B;
   int kh, kw, sh, sw, ph, pw, dh, dw;
   const float* wT;     // [tap][o/4][c][4]
+  // kernel A on the 16-bit matrix pipe (round 5): W as two fp16 planes [plane][tap][o/16][o%16/8][c][8] of w * wscale[0] (a power
+  // of two), go_amax[0] = bits of max |grad_out| over the launch (transpose_set_kernel); nullptr: the exact-fp32 contraction
+  const uint16_t* wT16;
+  size_t w16_plane;    // elements per plane
+  const float* wscale;
+  const unsigned* go_amax;
   float* partial;      // [nsplit][tap][o][c]
   int nsplit, total_chunks;
   const int* active;   // [total_chunks] chunk indices with a non-zero grad_out row, ascending; active[total_chunks] = count
@@ -115,6 +127,7 @@ struct TransposeSet {
   int chunk0[2 * MAXL];          // >= 0: tensor i is a grad_out [256][HoWo]; flags[chunk0 + (b*S + s) / 32] = 1 where non-zero
   int n;
   int* flags;
+  unsigned* amax;                // (or nullptr) [1] max |v| over the grad_out tensors as float bits, raised with atomicMax (zeroed by the caller)
 };
 __global__ void transpose_set_kernel(const TransposeSet T) {
   __shared__ float tile[32][33];
@@ -140,9 +153,11 @@ __global__ void transpose_set_kernel(const TransposeSet T) {
   }
   __syncthreads();
   const int c0 = T.chunk0[i];
+  unsigned vmax = 0u;
   for (int k = ty; k < 32; k += 8) {
     const int s = s0 + k, r = r0 + tx;
     const float v = tile[tx][k];
+    vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
     if (s < S && r < R) {
       const size_t at = plane + (size_t)s * R + r;
       if (T.out_code == 0) reinterpret_cast<float*>(T.out[i])[at] = v;
@@ -154,6 +169,11 @@ __global__ void transpose_set_kernel(const TransposeSet T) {
       const bool mine = (threadIdx.x & 32) ? (nz >> 32) != 0 : (nz & 0xffffffffull) != 0;
       if (mine && tx == 0 && s < S) T.flags[c0 + (int)(((long)blockIdx.y * S + s) >> 5)] = 1;
     }
+  }
+  if (c0 >= 0 && T.amax) {                                          // (block-uniform) range of grad_out for the fp16-pieces contraction
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, o, 64));
+    if ((threadIdx.x & 63) == 0 && vmax > __atomic_load_n(T.amax, __ATOMIC_RELAXED)) atomicMax(T.amax, vmax);
   }
 }
 
@@ -187,6 +207,42 @@ __global__ void pack_wT_kernel(const float* __restrict__ w, int taps, float* __r
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int q = i & 3, c = (i >> 2) % CH, og = ((i >> 2) / CH) % (CH / 4), tap = (i >> 2) / (CH * (CH / 4));
     wT[i] = w[((size_t)(og * 4 + q) * CH + c) * taps + tap];
+  }
+}
+
+// max |w| as float bits (out zeroed by the caller)
+__global__ void __launch_bounds__(256) absmax_w_kernel(const float* __restrict__ w, int n, unsigned* __restrict__ out) {
+  unsigned m = 0u;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, __float_as_uint(w[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, m);
+}
+// the power of two that puts a tensor's largest magnitude (float bits `am`) into [2^14, 2^15): fp16 pieces then neither overflow
+// nor lose their low piece to the subnormal range (same rule as csrc/orp_dcn_split.hip)
+__device__ __forceinline__ float range_scale(unsigned am) {
+  int k = am == 0u ? 0 : 14 - ((int)((am >> 23) & 0xffu) - 127);
+  k = k < -100 ? -100 : k > 100 ? 100 : k;
+  return __uint_as_float((unsigned)(127 + k) << 23);
+}
+// w [o][c][tap] -> two fp16 planes [pl][tap][o/16][kh][c][8] of w * 2^k (hi = nearest fp16, lo = the residual: exact in fp32, then rounded):
+// lane (c, kh) of kernel A reads the 8 k-values (output channels) of its MFMA operand as one 16-byte load
+__global__ void pack_wT16_kernel(const float* __restrict__ w, int taps, const unsigned* __restrict__ amax, uint16_t* __restrict__ planes,
+                                 float* __restrict__ wscale) {
+  const float sc = range_scale(*amax);
+  if (blockIdx.x == 0 && threadIdx.x == 0) wscale[0] = sc;
+  const int total = CH * CH * taps;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int e = i & 7, c = (i >> 3) % CH;
+    int r = (i >> 3) / CH;
+    const int khh = r & 1; r >>= 1;
+    const int ob = r % (CH / 16), tap = r / (CH / 16);
+    const int o = ob * 16 + khh * 8 + e;
+    const float v = w[((size_t)o * CH + c) * taps + tap] * sc;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    planes[i] = __builtin_bit_cast(uint16_t, hi);
+    planes[total + i] = __builtin_bit_cast(uint16_t, lo);
   }
 }
 
@@ -255,14 +311,22 @@ __device__ inline float half_wave_sum(float v) {
 // loads issued one group of four rows ahead of their use (1 203 - 1 215 vs 1 217 - 1 219 us: nothing; +40 VGPRs).  PMC:
 // ~1 400 non-MFMA VALU instructions per wave and tap next to 128 MFMAs -- the per-row address / select / DPP work of the
 // epilogue, replicated over the 64 lanes, is what the matrix pipe waits for.
-template <int MT, bool STORE_G>
+// Round 5, F16: the contraction on the 16-bit matrix pipe, as the forward's (csrc/orp_dcn_split.hip): grad_out and W each as TWO fp16
+// pieces after an exact power-of-two range scaling (|v - (hi + lo)| <= 2^-22 |v|), products lo*hi, hi*lo into a side accumulator and
+// hi*hi into the main one, fp32 accumulation, scaled back once per tap.  48 MFMAs of 32 cycles per tap and wave instead of 128 of 64.
+template <int MT>
+constexpr size_t input_tile_bytes() {
+  return sizeof(float) * 32 * MT * ASTR > (size_t)2 * 2 * 32 * MT * ASTRH ? sizeof(float) * 32 * MT * ASTR : (size_t)2 * 2 * 32 * MT * ASTRH;
+}
+template <int MT, bool STORE_G, bool F16>
 __global__ void __launch_bounds__(kThreads)
 dcn_bwd_input_kernel(const BwdParams P) {
   constexpr int BM2 = 32 * MT;
   static_assert(MT == 1, "the active-chunk list is in units of 32 positions");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* sG = reinterpret_cast<float*>(smem);                       // [BM2][ASTR] grad_out rows
-  int4* sCi = reinterpret_cast<int4*>(sG + BM2 * ASTR);             // [BM2 * taps]
+  float* sG = reinterpret_cast<float*>(smem);                       // [BM2][ASTR] grad_out rows  (F16: two planes [BM2][ASTRH] of halves)
+  uint16_t* sGh = reinterpret_cast<uint16_t*>(smem);
+  int4* sCi = reinterpret_cast<int4*>(smem + input_tile_bytes<MT>());   // [BM2 * taps]
   float4* sCl = reinterpret_cast<float4*>(sCi + BM2 * MAXT);        // [BM2 * taps] (lh, lw, modulation, -)
   float* sGO = reinterpret_cast<float*>(sCl + BM2 * MAXT);          // [8 waves][BM2][taps][3] grad_offset (+ grad_mask) partials
   int* sNZ = reinterpret_cast<int*>(sGO + 8 * BM2 * MAXT * 3);      // [BM2] row has a non-zero grad_out value
@@ -294,10 +358,23 @@ dcn_bwd_input_kernel(const BwdParams P) {
     sCi[e] = ix; sCl[e] = make_float4(fr.x, fr.y, mm, 0.f);
   }
   for (int e = tid; e < 8 * BM2 * MAXT * 3; e += kThreads) sGO[e] = 0.f;
+  float sx = 1.f, osc = 1.f;                                        // F16: grad_out scale 2^k, accumulator scale 1 / (sx * wscale)
+  if (F16) { sx = range_scale(P.go_amax[0]); osc = 1.f / (sx * P.wscale[0]); }
   for (int r = wave; r < BM2; r += 8) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p0 + r < npos) v = *reinterpret_cast<const float4*>(L.go + (size_t)(p0 + r) * CH + lane * 4);
-    *reinterpret_cast<float4*>(sG + (size_t)r * ASTR + lane * 4) = v;
+    if (F16) {
+      const float sv[4] = {v.x * sx, v.y * sx, v.z * sx, v.w * sx};   // exact (power of two)
+      _Float16 h[4], l[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { h[i] = (_Float16)sv[i]; l[i] = (_Float16)(sv[i] - (float)h[i]); }
+      const h2 h01 = {h[0], h[1]}, h23 = {h[2], h[3]}, l01 = {l[0], l[1]}, l23 = {l[2], l[3]};
+      uint16_t* dst = sGh + (size_t)r * ASTRH + lane * 4;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+      *reinterpret_cast<uint2*>(dst + BM2 * ASTRH) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+    } else {
+      *reinterpret_cast<float4*>(sG + (size_t)r * ASTR + lane * 4) = v;
+    }
     const unsigned long long nz = __ballot((v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f));
     if (lane == 0) sNZ[r] = nz != 0;
   }
@@ -306,22 +383,28 @@ dcn_bwd_input_kernel(const BwdParams P) {
   const int mrow = lane & 31, kh = lane >> 5;
   const int c = wave * 32 + mrow;                                   // this lane's input channel
   auto load_bq = [&](int tap, int j, float4 (&r)[2]) {
+    if (F16) {                                                       // r[0] / r[1] = the lane's 8 k-values of the hi / lo plane
+      const uint16_t* base = P.wT16 + ((((size_t)tap * (CH / 16) + j) * 2 + kh) * CH + c) * 8;
+      r[0] = *reinterpret_cast<const float4*>(base);
+      r[1] = *reinterpret_cast<const float4*>(base + P.w16_plane);
+      return;
+    }
     const float* base = P.wT + (((size_t)tap * (CH / 4) + j * 4 + kh) * CH + c) * 4;
     r[0] = *reinterpret_cast<const float4*>(base);
     r[1] = *reinterpret_cast<const float4*>(base + (size_t)2 * CH * 4);
   };
   // the weight fragments of chunk (tap, j) are fetched WD chunks ahead of their use: one chunk is 8 MFMAs = 512 cycles
   // of matrix work per wave, an L2 hit takes longer than that (measured: 1 221 vs 1 245 us at WD = 3 vs 1; 7 costs occupancy)
-  constexpr int WD = ORP_BWD_WDIST;
+  constexpr int WD = F16 ? ORP_BWD_WDIST16 : ORP_BWD_WDIST;
   float4 bqr[WD + 1][2];
 #pragma unroll
   for (int d = 0; d < WD; d++) load_bq(d / (CH / 16), d % (CH / 16), bqr[d]);
 
 #pragma unroll 1
   for (int tap = 0; tap < taps; tap++) {
-    floatx16 acc[MT];
+    floatx16 acc[MT], side[MT];                                     // (side: F16 only -- the small partial products)
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) acc[mt] = floatx16{0};
+    for (int mt = 0; mt < MT; mt++) { acc[mt] = floatx16{0}; side[mt] = floatx16{0}; }
 #if ORP_BWD_SPLITACC
     floatx16 acc_odd[MT];
 #pragma unroll
@@ -338,6 +421,25 @@ dcn_bwd_input_kernel(const BwdParams P) {
         float4 (&bn)[2] = bqr[(j + WD) % (WD + 1)];
         if (jn < CH / 16) load_bq(tap, jn, bn);
         else if (tap + 1 < taps) load_bq(tap + 1, jn - CH / 16, bn);
+      }
+      if (F16) {
+        const uint16_t* ar = sGh + (size_t)mrow * ASTRH + j * 16 + 8 * kh;
+        const h8 w_hi = __builtin_bit_cast(h8, bq[0]), w_lo = __builtin_bit_cast(h8, bq[1]);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+          const h8 g_hi = *reinterpret_cast<const h8*>(ar + (size_t)mt * 32 * ASTRH);
+          const h8 g_lo = *reinterpret_cast<const h8*>(ar + (size_t)mt * 32 * ASTRH + BM2 * ASTRH);
+          if (STORE_G && ORP_BWD_LANEPOS) {                            // D[channel][position]: lane = position
+            side[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_lo, g_hi, side[mt], 0, 0, 0);
+            side[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_hi, g_lo, side[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w_hi, g_hi, acc[mt], 0, 0, 0);
+          } else {                                                     // D[position][channel]: lane = channel
+            side[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(g_hi, w_lo, side[mt], 0, 0, 0);
+            side[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(g_lo, w_hi, side[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(g_hi, w_hi, acc[mt], 0, 0, 0);
+          }
+        }
+        continue;
       }
       const float* arow = sG + (size_t)mrow * ASTR + j * 16 + 4 * kh;
 #pragma unroll
@@ -367,6 +469,10 @@ dcn_bwd_input_kernel(const BwdParams P) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) acc[mt] += acc_odd[mt];
 #endif
+    if (F16) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) acc[mt] = (acc[mt] + side[mt]) * osc;
+    }
     // ---- consume G_t: scatter into grad_input, coordinate derivatives into the tile's grad_offset ---------------
     if (STORE_G && ORP_BWD_LANEPOS) {
       // Dense gradients, round 4: the accumulator holds D[channel][position] -- lane = position m (lane & 31), register r =
@@ -512,8 +618,7 @@ dcn_bwd_input_kernel(const BwdParams P) {
 
 template <int MT>
 size_t input_smem() {
-  return sizeof(float) * (size_t)32 * MT * ASTR + (sizeof(int4) + sizeof(float4) + 8 * 3 * sizeof(float)) * 32 * MT * MAXT +
-         sizeof(int) * 32 * MT;
+  return input_tile_bytes<MT>() + (sizeof(int4) + sizeof(float4) + 8 * 3 * sizeof(float)) * 32 * MT * MAXT + sizeof(int) * 32 * MT;
 }
 
 // ---- kernel A2: grad_input without atomics ------------------------------------------------------------------------------
@@ -881,7 +986,7 @@ int device_cus() {
 
 struct Plan {
   size_t x_off[MAXL], go_off[MAXL], gx_off[MAXL];
-  size_t gx_begin, gx_bytes, wT_off, partial_off, flags_off, list_off, total;
+  size_t gx_begin, gx_bytes, wT_off, partial_off, flags_off, scale_off, list_off, total;
   size_t G_off, keys_in_off, keys_out_off, vals_in_off, vals_out_off, rcount_off, desc_off, cub_off, cub_bytes;
   int Ho[MAXL], Wo[MAXL], reg0[MAXL], RH[MAXL], RW[MAXL];
   int total_chunks, nsplit, nregions, key_bits;
@@ -909,6 +1014,7 @@ int make_plan(const orp_dcn_bwd_level* lv, int nlevels, int batch, int kh, int k
   pl.nsplit = ns;
   pl.partial_off = cur; cur += align256(sizeof(float) * (size_t)ns * kh * kw * CH * CH);
   pl.flags_off = cur; cur += align256(sizeof(int) * (size_t)pl.total_chunks);
+  pl.scale_off = cur; cur += 256;       // [0] max |grad_out| bits, [1] max |W| bits, [2] the weights' scale (zeroed together with the flags)
   pl.list_off = cur; cur += align256(sizeof(int) * ((size_t)pl.total_chunks + 1));
   // kernel A2: regions, the G rows, the (region, sample) slots and the radix sort's scratch
   pl.nregions = 0;
@@ -1029,11 +1135,20 @@ int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float*
   for (int i = ti; i < 2 * MAXL; i++) { TI.in[i] = TI.in[0]; TI.out[i] = TI.out[0]; TI.R[i] = TI.S[i] = 0; TI.chunk0[i] = -1; }
   for (int i = nlevels; i < 2 * MAXL; i++) { TO.in[i] = TO.in[0]; TO.out[i] = TO.out[0]; TO.R[i] = TO.S[i] = 0; TO.chunk0[i] = -1; }
   TI.flags = flags; TO.flags = flags;
+  // the contraction of kernel A: 1 (default) = fp16 pieces on the 16-bit matrix pipe, 0 = exact fp32 (v_mfma_f32_32x32x2_f32)
+  static const int split_mode = getenv("ORP_DCN_BWD_SPLIT") ? atoi(getenv("ORP_DCN_BWD_SPLIT")) : 1;
+  const bool f16 = split_mode != 0 && need_input_grads;
+  unsigned* scale_words = reinterpret_cast<unsigned*>(ws + pl.scale_off);
+  TI.amax = f16 ? scale_words : nullptr; TO.amax = nullptr;
+  P.wT16 = reinterpret_cast<const uint16_t*>(ws + pl.wT_off);      // (the fp32 layout and the two fp16 planes have the same size)
+  P.w16_plane = (size_t)CH * CH * taps;
+  P.wscale = reinterpret_cast<const float*>(scale_words + 2);
+  P.go_amax = scale_words;
   TI.in_code = io_dtype; TI.out_code = 0;                   // x / grad_out arrive in the I/O type, the workspace is fp32
   TO.in_code = 0; TO.out_code = io_dtype;                   // grad_input leaves in the I/O type
 
   OrpProfScope prof(ORP_PROF_DCN_BWD, st);
-  hipError_t e = orp::fill_async(flags, 0, sizeof(int) * (size_t)pl.total_chunks, st);
+  hipError_t e = orp::fill_async(flags, 0, pl.scale_off + 256 - pl.flags_off, st);      // flags + range words
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(transpose_set_kernel, dim3(tin, batch), dim3(256), 0, st, TI);
   hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, st, flags, pl.total_chunks, const_cast<int*>(P.active));
@@ -1043,7 +1158,13 @@ int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float*
   if (need_input_grads) {
     static const int force = getenv("ORP_DCN_BWD_ATOMIC") ? atoi(getenv("ORP_DCN_BWD_ATOMIC")) : -1;   // dev aid: 1 / 0 force a path
     const bool use_atomics = force >= 0 ? force != 0 : (need_input_grads & ORP_DCN_BWD_SPARSE) != 0;
-    hipLaunchKernelGGL(pack_wT_kernel, dim3(1024), dim3(256), 0, st, weight, taps, const_cast<float*>(P.wT));
+    if (f16) {
+      hipLaunchKernelGGL(absmax_w_kernel, dim3(256), dim3(256), 0, st, weight, CH * CH * taps, scale_words + 1);
+      hipLaunchKernelGGL(pack_wT16_kernel, dim3(1024), dim3(256), 0, st, weight, taps, scale_words + 1, const_cast<uint16_t*>(P.wT16),
+                         reinterpret_cast<float*>(scale_words + 2));
+    } else {
+      hipLaunchKernelGGL(pack_wT_kernel, dim3(1024), dim3(256), 0, st, weight, taps, const_cast<float*>(P.wT));
+    }
     const int per = (tiles + 7) >> 3;
     P.flags = flags;
     P.nregions = pl.nregions;
@@ -1064,10 +1185,13 @@ int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float*
         }
       }
       struct T1 { int unused; };
-      e = orp::set_max_dynamic_lds_once<T1>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT, false>), input_smem<MT>());
+      struct T1h { int unused; };
+      e = f16 ? orp::set_max_dynamic_lds_once<T1h>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT, false, true>), input_smem<MT>())
+              : orp::set_max_dynamic_lds_once<T1>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT, false, false>), input_smem<MT>());
       if (e != hipSuccess) return (int)e;
       OrpProfScope prof_in(ORP_PROF_DCN_BWD_INPUT, st);
-      hipLaunchKernelGGL((dcn_bwd_input_kernel<MT, false>), dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
+      if (f16) hipLaunchKernelGGL((dcn_bwd_input_kernel<MT, false, true>), dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
+      else hipLaunchKernelGGL((dcn_bwd_input_kernel<MT, false, false>), dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
     } else {
       P.G = reinterpret_cast<float*>(ws + pl.G_off);
       // (region, sample) slots -> stable sort by region: every region's list in ascending sample order
@@ -1082,12 +1206,15 @@ int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float*
       hipLaunchKernelGGL(region_bounds_kernel, dim3((unsigned)((pl.nslots + 255) / 256)), dim3(256), 0, st,
                          reinterpret_cast<const unsigned*>(ws + pl.keys_out_off), pl.nslots, pl.nregions, P.rcount);
       struct T2 { int unused; };
-      e = orp::set_max_dynamic_lds_once<T2>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT, true>), input_smem<MT>());
+      struct T2h { int unused; };
+      e = f16 ? orp::set_max_dynamic_lds_once<T2h>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT, true, true>), input_smem<MT>())
+              : orp::set_max_dynamic_lds_once<T2>(reinterpret_cast<const void*>(&dcn_bwd_input_kernel<MT, true, false>), input_smem<MT>());
       if (e != hipSuccess) return (int)e;
       orp_prof_end(ORP_PROF_DCN_BWD_SCATTER, st);            // (paused around the GEMM kernel, which has its own slot)
       {
         OrpProfScope prof_in(ORP_PROF_DCN_BWD_INPUT, st);
-        hipLaunchKernelGGL((dcn_bwd_input_kernel<MT, true>), dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
+        if (f16) hipLaunchKernelGGL((dcn_bwd_input_kernel<MT, true, true>), dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
+        else hipLaunchKernelGGL((dcn_bwd_input_kernel<MT, true, false>), dim3(per * 8), dim3(kThreads), input_smem<MT>(), st, P);
       }
       orp_prof_begin(ORP_PROF_DCN_BWD_SCATTER, st);
       struct T3 { int unused; };
