@@ -73,6 +73,9 @@
 #ifndef ORP_DCNS_CC
 #define ORP_DCNS_CC 0                // dev aid: number of trailing chunks that carry the combine (0: the rule in the kernel)
 #endif
+#ifndef ORP_DCNS_AHEAD2
+#define ORP_DCNS_AHEAD2 1            // PLAIN instantiation: the rows of phase p + 2 are gathered during phase p (two register sets, the loop unrolled by two phases)
+#endif
 #ifndef ORP_DCNS_INTERLEAVE
 #define ORP_DCNS_INTERLEAVE 4        // VALU instructions of the combine pinned behind every MFMA of the chunk that carries it (0: scheduler's choice)
 #endif
@@ -513,11 +516,23 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   // body are UNCONDITIONAL (the final iteration re-fetches the last phase's rows and weights and drops them), so that the
   // compiler's s_waitcnt vmcnt counts are exact -- with the loads under `if (next_phase)` it has to assume the shortest
   // path and made the first MFMA of every phase wait for this phase's own gathers
-  int tap_n = 0, cb_n = 0;
-  auto advance = [&](int phase) {
-    if (phase + 1 < nphase) { if (++cb_n == ncb) { cb_n = 0; tap_n++; } }
+  // PLAIN (a row group is one float4 per lane): the gathers run TWO phases ahead -- the rows of phase p + 2 go out at the start of
+  // phase p into the register set phase p - 1 emptied, and are split into the other LDS buffer during phase p + 1.  With one phase of
+  // lead the first row group was consumed one chunk (~300 cycles of this wave's matrix work) after its loads went out and the wave sat
+  // in s_waitcnt: the timing variants without gathers / without their consumer both ran 40 us of 218 faster (profiles/r05_anatomy.log).
+  constexpr bool AHEAD2 = PLAIN && F16 && ORP_DCNS_AHEAD2;          // (the three-plane modes have no registers left at tile height 3)
+  int tap_n = 0, cb_n = 0, tap_n2 = 0, cb_n2 = 0;                             // phase + 1, phase + 2 (clamped to the last phase)
+  auto step = [&](int& t, int& c, int ph) {
+    if (ph + 1 < nphase) { if (++c == ncb) { c = 0; t++; } }
   };
-  advance(0);
+  step(tap_n, cb_n, 0);
+  tap_n2 = tap_n; cb_n2 = cb_n;
+  step(tap_n2, cb_n2, 1);
+  float4 gA[MT][4], gB[AHEAD2 ? MT : 1][4];
+  if (AHEAD2) {
+#pragma unroll
+    for (int r = 0; r < MT; r++) gather_issue(tap_n, cb_n, r, gA[r]);         // the rows of phase 1
+  }
   auto load_a = [&](const uint16_t* abase, int j, bf8 (&a)[MT][3]) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
@@ -526,8 +541,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
         if (!(ORP_DCNS_DBG & 16)) a[mt][pl] = *reinterpret_cast<const bf8*>(abase + (size_t)pl * PLANE + (size_t)mt * 32 * ASTRS + j * 16);
   };
 
-#pragma unroll 1
-  for (int phase = 0; phase < nphase; phase++) {
+  auto phase_body = [&](int phase, float4 (&g)[MT][4], float4 (&gf)[AHEAD2 ? MT : 1][4]) __attribute__((always_inline)) {
     const int cur = phase & 1;
 #if ORP_DCNS_TRACE >= 2
     if (P.dbg && !PLAIN) {   // hash of every row of the buffer this phase reads, as the readers see it (16 threads per row)
@@ -543,10 +557,14 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       }
     }
 #endif
-    // (1) the gathers of the next phase's rows go out first: a whole phase of matrix work to land
-    float4 g[MT][4];
+    // (1) the gathers of the next phase's rows go out first: a whole phase of matrix work to land  (AHEAD2: of the phase after it)
+    if (AHEAD2) {
 #pragma unroll
-    for (int r = 0; r < MT; r++) gather_issue(tap_n, cb_n, r, g[r]);
+      for (int r = 0; r < MT; r++) gather_issue(tap_n2, cb_n2, r, gf[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < MT; r++) gather_issue(tap_n, cb_n, r, g[r]);
+    }
     // (the scheduler would otherwise SINK these loads down to their use to save registers -- measured in the ISA: the
     //  gathers ended up between the last MFMAs with s_waitcnt vmcnt(0) right behind them; the barriers pin the pipeline)
     __builtin_amdgcn_sched_barrier(0);
@@ -608,8 +626,19 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
 #if ORP_DCNS_REFILL_LAG
     if (!(ORP_DCNS_DBG & 2)) load_b(tap_n, cb_n, NCH - 1, bq[NCH - 1]);
 #endif
-    advance(phase + 1);
+    step(tap_n, cb_n, phase + 1);
+    step(tap_n2, cb_n2, phase + 2);
     if (!(ORP_DCNS_DBG & 32)) __syncthreads();
+  };
+  if constexpr (AHEAD2) {
+#pragma unroll 1
+    for (int phase = 0; phase < nphase; phase += 2) {
+      phase_body(phase, gA, gB);                                               // splits gA (rows of phase + 1), fills gB (phase + 2)
+      if (phase + 1 < nphase) phase_body(phase + 1, gB, gA);
+    }
+  } else {
+#pragma unroll 1
+    for (int phase = 0; phase < nphase; phase++) phase_body(phase, gA, gB);
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------------------
