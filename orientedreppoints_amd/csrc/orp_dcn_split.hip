@@ -76,6 +76,9 @@
 #ifndef ORP_DCNS_AHEAD2
 #define ORP_DCNS_AHEAD2 1            // PLAIN instantiation: the rows of phase p + 2 are gathered during phase p (two register sets, the loop unrolled by two phases)
 #endif
+#ifndef ORP_DCNS_EARLYBAR
+#define ORP_DCNS_EARLYBAR 0          // with AHEAD2: the phase's barrier in front of the LAST chunk's MFMAs, the next phase's first A fragments read behind it (measured: 200.4 - 202.5 vs 202.1 - 206.8 us, within the noise: off)
+#endif
 #ifndef ORP_DCNS_INTERLEAVE
 #define ORP_DCNS_INTERLEAVE 4        // VALU instructions of the combine pinned behind every MFMA of the chunk that carries it (0: scheduler's choice)
 #endif
@@ -219,8 +222,16 @@ __device__ __forceinline__ unsigned pack_hi16(float a, float b) {
 __device__ __forceinline__ constexpr int prod_a(int t) { const int tab[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}; return tab[t]; }
 __device__ __forceinline__ constexpr int prod_b(int t) { const int tab[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}; return tab[t]; }
 // F16 (two fp16 pieces, 0 = hi, 1 = lo): lo * hi, hi * lo, hi * hi
+#ifndef ORP_DCNS_PROD_ORDER16
+#define ORP_DCNS_PROD_ORDER16 0      // 1: lo*hi, hi*hi, hi*lo -- with SIDE the two chains (side, main) alternate; the bits do not change (each chain keeps its own order)
+#endif
+#if ORP_DCNS_PROD_ORDER16
+__device__ __forceinline__ constexpr int prod_a16(int t) { const int tab[3] = {1, 0, 0}; return tab[t]; }
+__device__ __forceinline__ constexpr int prod_b16(int t) { const int tab[3] = {0, 0, 1}; return tab[t]; }
+#else
 __device__ __forceinline__ constexpr int prod_a16(int t) { const int tab[3] = {1, 0, 0}; return tab[t]; }
 __device__ __forceinline__ constexpr int prod_b16(int t) { const int tab[3] = {0, 1, 0}; return tab[t]; }
+#endif
 
 // SIDE: the small partial products (everything but hi * hi) go to a second accumulator set that is added once in the
 // epilogue -- the main chain then rounds once per 16 channels at the output's magnitude instead of 3 (6, 9) times, and the
@@ -230,7 +241,7 @@ struct Products {
   static __device__ __forceinline__ void run(floatx16 (&acc)[MT], floatx16 (&side)[SIDE ? MT : 1], const bf8 (&a)[MT][3],
                                              const bf8 (&b)[3]) {
     constexpr int pa = F16 ? prod_a16(T) : prod_a(T), pb = F16 ? prod_b16(T) : prod_b(T);
-    constexpr bool to_side = SIDE && T != TEND - 1;
+    constexpr bool to_side = SIDE && !(pa == 0 && pb == 0);          // everything but hi * hi
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
       if (ORP_DCNS_DBG & 4) { acc[mt][0] += (float)a[mt][pa][0] * (float)b[pb][0]; continue; }
@@ -541,6 +552,20 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
         if (!(ORP_DCNS_DBG & 16)) a[mt][pl] = *reinterpret_cast<const bf8*>(abase + (size_t)pl * PLANE + (size_t)mt * 32 * ASTRS + j * 16);
   };
 
+  // EARLYBAR (with AHEAD2: the rows are already in registers when the phase starts): the row groups are split into the other buffer
+  // in the FIRST chunks, the phase's one barrier sits in front of the last chunk's MFMAs, and the first A fragments of the next phase
+  // are read right behind it -- under the last chunk's matrix work instead of in front of the next phase's first MFMA.  Safe: at the
+  // barrier every wave has completed its reads of this phase's buffer (the last chunk's fragments are in registers) and its writes of
+  // the other one; nobody writes this phase's buffer before the next phase's first chunk.
+  constexpr bool EARLYBAR = AHEAD2 && ORP_DCNS_EARLYBAR && !(ORP_DCNS_DBG & 16);
+  bf8 a[2][MT][3];
+  if (EARLYBAR) {
+    const uint16_t* ab0 = sA + (size_t)mrow * ASTRS + 8 * kg;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++) a[0][mt][pl] = *reinterpret_cast<const bf8*>(ab0 + (size_t)pl * PLANE + (size_t)mt * 32 * ASTRS);
+  }
   auto phase_body = [&](int phase, float4 (&g)[MT][4], float4 (&gf)[AHEAD2 ? MT : 1][4]) __attribute__((always_inline)) {
     const int cur = phase & 1;
 #if ORP_DCNS_TRACE >= 2
@@ -571,7 +596,6 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     const uint16_t* abase = sA + (size_t)cur * NPL * PLANE + (size_t)mrow * ASTRS + 8 * kg;
     // (2) the phase: the A fragments of chunk j + 1 are read from LDS BEFORE the MFMAs of chunk j are issued (a second
     //     register set), the weight registers of chunk j are refilled for the next phase right after use
-    bf8 a[2][MT][3];
     if (ORP_DCNS_DBG & 16) {
 #pragma unroll
       for (int i = 0; i < 2; i++)
@@ -580,7 +604,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
 #pragma unroll
           for (int pl = 0; pl < 3; pl++) a[i][mt][pl] = bq[(i + mt + pl) & 3][pl];
     }
-    load_a(abase, 0, a[0]);
+    if (!EARLYBAR) load_a(abase, 0, a[0]);
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
       if (j + 1 < NCH) load_a(abase, j + 1, a[(j + 1) & 1]);
@@ -592,11 +616,17 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       //     The row groups ride in the LAST CC chunks, one each (CC = MT).  (All of them in the last chunk, so that the
       //     gathers have three chunks to land instead of one, measured no faster with fp16 pieces: 211 vs 200 us.)
       constexpr int CC = (ORP_DCNS_CC > 0) ? (ORP_DCNS_CC < MT ? ORP_DCNS_CC : MT) : MT;
-      const bool with_combine = ORP_DCNS_COMBINE_IN_LAST && j >= NCH - CC;
+      const bool with_combine = ORP_DCNS_COMBINE_IN_LAST && (EARLYBAR ? j < CC : j >= NCH - CC);
+      const int jc = EARLYBAR ? j : j - (NCH - CC);
       if (with_combine) {
 #pragma unroll
         for (int r = 0; r < MT; r++)
-          if (r * CC / MT == j - (NCH - CC)) combine_store(tap_n, cb_n, r, g[r], cur ^ 1);
+          if (r * CC / MT == jc) combine_store(tap_n, cb_n, r, g[r], cur ^ 1);
+      }
+      if (EARLYBAR && j == NCH - 1) {
+        if (!(ORP_DCNS_DBG & 32)) __syncthreads();
+        load_a(sA + (size_t)(cur ^ 1) * NPL * PLANE + (size_t)mrow * ASTRS + 8 * kg, 0, a[0]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       Products<F16 ? 0 : 9 - NPROD, F16 ? 3 : 9, MT, OUT_NCHW, SIDE, F16>::run(acc, side, a[j & 1], bq[j]);
 #if ORP_DCNS_FENCE
@@ -628,7 +658,7 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
 #endif
     step(tap_n, cb_n, phase + 1);
     step(tap_n2, cb_n2, phase + 2);
-    if (!(ORP_DCNS_DBG & 32)) __syncthreads();
+    if (!EARLYBAR && !(ORP_DCNS_DBG & 32)) __syncthreads();
   };
   if constexpr (AHEAD2) {
 #pragma unroll 1
