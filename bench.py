@@ -478,8 +478,9 @@ def train_probe(dev, model_name='r50', steps=10, warmup=4, gts=64):
             'steps': steps, 'warmup': warmup, 'ms_per_step': round(elapsed / steps * 1e3, 3),
             'images_per_s': round(batch * steps / elapsed, 2), 'loss': round(float(log_vars['loss']), 4),
             'dcn_forward_mode': int(L.orp_dcn_get_split_mode()), 'hip_events': ev,
-            'note': 'hot-path kernels are ~10 % of this step; ~30 ms is the library\'s convolution_backward (backbone / towers), '
-                    'outside the hot path'}
+            'note': 'the HIP-event slots above (this library\'s DeformConv, tower / FPN convolution and convex kernels) are about a '
+                    'quarter of the step; roughly half of it is the library\'s forward / backward convolutions of the backbone '
+                    '(stock PyTorch-ROCm by design), the rest losses, assigners, optimizer and normalisation passes'}
 
 
 def quick_config(dev, model_name, batch, size, steps=10, warmup=3, depth=4):
