@@ -947,6 +947,43 @@ def test_dcn_backward_input_without_atomics_is_bitwise_reproducible(dev, oracle)
         assert _rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4
 
 
+def test_dcn_backward_fp16_pieces_range_scaling(dev, oracle):
+    """The backward's grad_input / grad_offset contraction carries grad_out and W as two fp16 pieces after a power-of-two range
+    scaling taken from max |grad_out| and max |W| of the CALL (csrc/orp_dcn_bwd_mfma.hip, round 5).  The result must not depend on
+    the magnitudes: gradients scaled by 2^-60 / 2^40 and weights by 2^20 / 2^-30 give the correspondingly scaled results BIT FOR BIT
+    on the fixed-order route (powers of two commute with every rounding of the path) and to 1e-4 on the atomic route, and an
+    all-zero gradient gives exact zeros (range word 0: scale 1)."""
+    from orientedreppoints_amd.mmdet_ops import deform_conv_backward as bw
+    shapes = [(9, 11), (4, 5)]
+    cases = [_dcn_case(90 + i, 2, 256, h, w, 256, std_off=2.5) for i, (h, w) in enumerate(shapes)]
+    w = cases[0][2]
+    gos = [np.random.RandomState(95 + i).normal(size=(2, 256, h, ww)).astype(np.float32) for i, (h, ww) in enumerate(shapes)]
+
+    def run(gscale, wscale, sparse=False):
+        gis, goffs, _ = bw.backward_mfma([_t(c[0], dev) for c in cases], [_t(c[1], dev) for c in cases], _t(w * np.float32(wscale), dev),
+                                         [_t(g * np.float32(gscale), dev) for g in gos], (1, 1), (1, 1), (1, 1), need_weight=False,
+                                         sparse_grad=sparse)
+        return [g.cpu().numpy() for g in gis], [g.cpu().numpy() for g in goffs]
+    base_i, base_o = run(1.0, 1.0)
+    for c, g, gi, goff in zip(cases, gos, base_i, base_o):
+        wi, woff, _ = oracle.dcn_backward(c[0], c[1], w, g)
+        assert _rel_err(gi, wi) <= 1e-4 and _rel_err(goff, woff) <= 1e-4
+    for gscale, wscale in ((2.0 ** -60, 2.0 ** 20), (2.0 ** 40, 2.0 ** -30)):
+        for sparse in (False, True):
+            gi2, go2 = run(gscale, wscale, sparse)
+            k = np.float32(gscale) * np.float32(wscale)
+            for a, b in zip(gi2 + go2, base_i + base_o):
+                if sparse:
+                    assert _rel_err(a, b * k) <= 1e-4              # (atomics: another summation order)
+                else:
+                    assert np.array_equal(a, b * k), "a power-of-two scaling of grad_out / W changed the result's bits"
+    # an all-zero gradient: range word 0 -> scale 1, exact zeros, no NaN
+    gis, goffs, _ = bw.backward_mfma([_t(c[0], dev) for c in cases], [_t(c[1], dev) for c in cases], _t(w, dev),
+                                     [torch.zeros_like(_t(g, dev)) for g in gos], (1, 1), (1, 1), (1, 1), need_weight=False)
+    for t in gis + goffs:
+        assert not t.cpu().numpy().any()
+
+
 def test_dcn_v2_backward_on_mfma_path_vs_oracle(dev, oracle):
     """modulated_deform_conv backward at the head's 256 -> 256 channels through orp_dcn_backward_multi_ex (the modulation
     scalar rides in the sample weights of both MFMA GEMMs; grad_mask = G . sampled value) against oracle.dcn_v2_backward =
