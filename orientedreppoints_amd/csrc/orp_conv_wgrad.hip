@@ -21,11 +21,15 @@
 // Partial tiles per (slice, tap) go to the workspace and are summed in slice order by a second launch: deterministic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/orp_hip.h"
 #include "orp_prof.hpp"
 #include "orp_launch.hpp"
 
+#ifndef ORP_WG_ALIGNED
+#define ORP_WG_ALIGNED 1  // X rows: aligned 16-byte loads + one neighbour element instead of 4-byte-aligned 16-byte loads of the shifted octet
+#endif
 #ifndef ORP_WG_DBG
 #define ORP_WG_DBG 0      // dev aid (timing only, wrong results): 1 = no fetches after the first, 2 = no MFMA, 4 = no conversion / LDS writes
 #endif
@@ -62,6 +66,12 @@ struct WParams {
 struct Item { float v[8]; };
 struct __attribute__((packed, aligned(4))) F4u { float v[4]; };     // a 16-byte load at 4-byte alignment
 
+// FAST (chosen by the host when every level has W % 8 == 0, H * W % 32 == 0 and the taps' column shifts are -1 / 0 / +1 -- every
+// BASELINE shape): all fetches are branch-free (a fixed number of loads per item, so the compiler's s_waitcnt vmcnt counts are exact)
+// and the software pipeline is one step deeper: the two items a 16-position chunk has just converted are re-armed with the rows of
+// the step after next RIGHT THERE, behind the chunk's MFMAs -- a whole step for the loads to land.  In the general form the rows of
+// step t + 2 are requested at the end of step t and converted at the start of step t + 1: one barrier of latency hiding.
+template <bool FAST>
 __global__ void __launch_bounds__(kThreadsW)
 conv_wgrad_split_kernel(const WParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -118,10 +128,34 @@ conv_wgrad_split_kernel(const WParams P) {
         // the shifted run: eight consecutive floats of the same input row whenever the octet neither wraps nor touches the
         // border (two 16-byte loads, 4-byte aligned); else position by position (row starts / ends, map borders, the tail)
         const int hs0 = h0 + sh_h, ws0 = w0 + sh_w;
-        if (p0 + 8 <= HW && w0 + 8 <= L.W && hs0 >= 0 && hs0 < L.H && ws0 >= 0 && ws0 + 8 <= L.W) {
-          const F4u a = *reinterpret_cast<const F4u*>(row + hs0 * L.W + ws0), c = *reinterpret_cast<const F4u*>(row + hs0 * L.W + ws0 + 4);
+        const bool inrow = p0 + 8 <= HW && w0 + 8 <= L.W;              // the octet lies inside one image row
+        if (inrow && (hs0 < 0 || hs0 >= L.H)) {                         // ... of a row above / below the map: zeros, no loads
 #pragma unroll
-          for (int e = 0; e < 4; e++) { it[u].v[e] = a.v[e]; it[u].v[4 + e] = c.v[e]; }
+          for (int e = 0; e < 8; e++) it[u].v[e] = 0.f;
+        } else if (ORP_WG_ALIGNED && inrow && (L.W & 3) == 0 && sh_w >= -1 && sh_w <= 1) {
+          // 16-byte ALIGNED loads of the unshifted octet plus the one neighbour the tap's column shift brings in (zero at the row's
+          // end); the shift itself is a renaming under a workgroup-uniform condition
+          const float* src = row + hs0 * L.W + w0;
+          const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
+          float nb = 0.f;
+          if (sh_w < 0) { if (w0 > 0) nb = src[-1]; }
+          else if (sh_w > 0) { if (w0 + 8 < L.W) nb = src[8]; }
+          const float t[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+          for (int e = 0; e < 8; e++)
+            it[u].v[e] = sh_w == 0 ? t[e] : sh_w < 0 ? (e > 0 ? t[e > 0 ? e - 1 : 0] : nb) : (e < 7 ? t[e < 7 ? e + 1 : 7] : nb);
+        } else if (inrow && ws0 >= -1 && ws0 + 8 <= L.W + 1) {
+          // inside the row, or hanging over its left / right end by ONE position (the +-1 column shift of a 3 x 3 tap -- half
+          // of all steps have such octets, and a wave runs the position-by-position path below as soon as one lane needs it):
+          // the eight floats from the clamped start, moved by one lane-private select per element, zero at the border
+          const int wsc = min(max(ws0, 0), L.W - 8), d = wsc - ws0;     // d = +1: left end, -1: right end, 0: inside
+          const F4u a = *reinterpret_cast<const F4u*>(row + hs0 * L.W + wsc), c = *reinterpret_cast<const F4u*>(row + hs0 * L.W + wsc + 4);
+          const float t[8] = {a.v[0], a.v[1], a.v[2], a.v[3], c.v[0], c.v[1], c.v[2], c.v[3]};
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const float lft = e > 0 ? t[e > 0 ? e - 1 : 0] : 0.f, rgt = e < 7 ? t[e < 7 ? e + 1 : 7] : 0.f;
+            it[u].v[e] = d == 0 ? t[e] : d > 0 ? lft : rgt;
+          }
         } else {
           int h = h0, w = w0;
 #pragma unroll
@@ -131,6 +165,42 @@ conv_wgrad_split_kernel(const WParams P) {
             it[u].v[e] = ok ? row[hs * L.W + ws] : 0.f;
             if (++w == L.W) { w = 0; h++; }
           }
+        }
+      }
+    }
+  };
+  auto fetch_fast = [&](int chunk, Item (&it)[4], int u0, int u1) {
+    int l = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.nlev; i++) if (chunk >= P.lv[i].chunk0) l = i;
+    const WLevel& L = P.lv[l];
+    const int id = chunk - L.chunk0;
+    const int b = id / L.cpi, p0 = (id - b * L.cpi) * KS + q * 8;
+    const int HW = L.H * L.W;
+    const int h0 = p0 / L.W, w0 = p0 - h0 * L.W;             // (w0 + 8 <= W: W is a multiple of 8)
+#pragma unroll
+    for (int u = u0; u < u1; u++) {
+      const int r = (tid >> 2) + 128 * u;
+      const bool is_x = r >= CH;
+      const float* row = (is_x ? L.x : L.g) + ((size_t)b * CH + (r & (CH - 1))) * HW;
+      if (!is_x) {
+        const float4 a = *reinterpret_cast<const float4*>(row + p0), c = *reinterpret_cast<const float4*>(row + p0 + 4);
+        it[u].v[0] = a.x; it[u].v[1] = a.y; it[u].v[2] = a.z; it[u].v[3] = a.w;
+        it[u].v[4] = c.x; it[u].v[5] = c.y; it[u].v[6] = c.z; it[u].v[7] = c.w;
+      } else {
+        // the aligned octet of the (clamped) shifted row and the one neighbour element the column shift brings in; validity as selects
+        const int hs0 = h0 + sh_h;
+        const bool rv = hs0 >= 0 && hs0 < L.H;
+        const float* src = row + min(max(hs0, 0), L.H - 1) * L.W + w0;
+        const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
+        const bool nv = sh_w < 0 ? w0 > 0 : w0 + 8 < L.W;
+        const float nl = src[sh_w < 0 ? (nv ? -1 : 0) : (nv ? 8 : 7)];
+        const float nb = nv ? nl : 0.f;
+        const float t[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float v = sh_w == 0 ? t[e] : sh_w < 0 ? (e > 0 ? t[e > 0 ? e - 1 : 0] : nb) : (e < 7 ? t[e < 7 ? e + 1 : 7] : nb);
+          it[u].v[e] = rv ? v : 0.f;
         }
       }
     }
@@ -168,9 +238,10 @@ conv_wgrad_split_kernel(const WParams P) {
     // earlier, in registers) are converted and written to the other buffer in the shadow of the MFMAs (one MFMA : four VALU),
     // then the rows of step t + 2 are requested; ONE barrier per step
     Item it[4];
-    fetch(c_begin, it, 0, 4);
+    if (FAST) fetch_fast(c_begin, it, 0, 4); else fetch(c_begin, it, 0, 4);
     stash(it, 0, 0, 4);
-    if (c_begin + 1 < c_end) fetch(c_begin + 1, it, 0, 4);
+    if (FAST) fetch_fast(min(c_begin + 1, c_end - 1), it, 0, 4);
+    else if (c_begin + 1 < c_end) fetch(c_begin + 1, it, 0, 4);
     __syncthreads();
 #pragma unroll 1
     for (int chunk = c_begin; chunk < c_end; chunk++) {
@@ -195,6 +266,8 @@ conv_wgrad_split_kernel(const WParams P) {
         // (Converting first and re-arming the registers with the step after next right away -- a whole step for the loads to
         //  land instead of a barrier -- measured slower: 281 us against 257.)
         if (more && !(ORP_WG_DBG & 4)) stash(it, cur ^ 1, 2 * j, 2 * j + 2);
+        // FAST: the two items just converted take the rows of the step after next (past the end: the last step again, dropped)
+        if (FAST && !(ORP_WG_DBG & 1)) fetch_fast(min(chunk + 2, c_end - 1), it, 2 * j, 2 * j + 2);
         // smallest products first; eight independent accumulators between two MFMAs into the same one
 #pragma unroll
         for (int pr = 0; pr < 3; pr++)
@@ -211,7 +284,7 @@ conv_wgrad_split_kernel(const WParams P) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (more2 && !(ORP_WG_DBG & 1)) fetch(chunk + 2, it, 0, 4);           // lands during the next step
+      if (!FAST && more2 && !(ORP_WG_DBG & 1)) fetch(chunk + 2, it, 0, 4);  // lands during the next step
       __syncthreads();
     }
   }
@@ -336,12 +409,21 @@ int orp_conv_wgrad_split(const orp_wgrad_level* levels_host, int nlevels, int ba
   const size_t smem = sizeof(_Float16) * 2 * 4 * CH * RS;     // two buffers of 80 KB: all of a CU's LDS
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel),
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (ae != hipSuccess) return (int)ae;
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_wgrad_split_kernel, dim3(P.nsplit, kh * kw), dim3(kThreadsW), smem, st, P);
+  // the branch-free, deeper-pipelined form where every octet is a piece of one image row and a tap moves it by at most one column
+  static const int fast_env = getenv("ORP_WGRAD_FAST") ? atoi(getenv("ORP_WGRAD_FAST")) : 1;   // 0: dev aid (A/B timing)
+  bool fast = fast_env != 0;
+  for (int i = 0; i < nlevels; i++)
+    fast = fast && (levels_host[i].width % 8 == 0) && ((long)levels_host[i].height * levels_host[i].width % KS == 0);
+  for (int kj = 0; kj < kw; kj++) fast = fast && (kj * dil_w - pad_w >= -1) && (kj * dil_w - pad_w <= 1);
+  if (fast) hipLaunchKernelGGL(conv_wgrad_split_kernel<true>, dim3(P.nsplit, kh * kw), dim3(kThreadsW), smem, st, P);
+  else hipLaunchKernelGGL(conv_wgrad_split_kernel<false>, dim3(P.nsplit, kh * kw), dim3(kThreadsW), smem, st, P);
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(kh * kw * CH * CH / 256), dim3(256), 0, st, P.partial, P.nsplit, kh * kw, grad_weight);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;

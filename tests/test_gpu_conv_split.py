@@ -406,9 +406,11 @@ def test_conv_weight_gradient_kernel_vs_float64(dev):
     import conftest
     from orientedreppoints_amd.mmdet_ops.fused_norm import conv_split_train, conv_wgrad_split
     torch.manual_seed(29)
-    shapes = [(20, 24), (7, 9), (3, 3), (1, 2)]
+    # (W = 24 / 8: octets that hang over a row end by one position; 9, 3, 2: wrapping octets; the second set -- every W a multiple of
+    #  8, every H * W of 32 -- takes the branch-free, deeper-pipelined instantiation for the 3 x 3 and 1 x 1 kernels)
+    shape_sets = ([(20, 24), (7, 9), (3, 3), (1, 2), (16, 8)], [(16, 8), (8, 16), (4, 8), (32, 32)])
     worst = 0.0
-    for B in (1, 2):
+    for B, shapes in ((1, shape_sets[0]), (2, shape_sets[0]), (1, shape_sets[1]), (2, shape_sets[1])):
         for k, pad, dil in ((3, 1, 1), (3, 2, 2), (1, 0, 1)):
             xs = [torch.randn(B, 256, h, w, device=dev) * (1.0 + i) for i, (h, w) in enumerate(shapes)]
             gs = [torch.randn(B, 256, h, w, device=dev) * 0.01 * (1.0 + i) for i, (h, w) in enumerate(shapes)]
@@ -422,9 +424,10 @@ def test_conv_weight_gradient_kernel_vs_float64(dev):
             ax = torch.tensor([max(float(x.abs().max()) for x in xs) * 3.0], device=dev).view(torch.int32)   # a loose bound
             ag = torch.tensor([max(float(g.abs().max()) for g in gs)], device=dev).view(torch.int32)
             assert _rel(conv_wgrad_split(xs, gs, (256, 256, k, k), (pad, pad), (dil, dil), ax, ag), want) <= 1e-5
-    conftest.REPORT.append("convolution weight gradient (256 -> 256, 4 levels), max |err| / max |grad| vs float64: %.2e" % worst)
+    conftest.REPORT.append("convolution weight gradient (256 -> 256, 4 - 5 levels, both instantiations), max |err| / max |grad| vs float64: %.2e" % worst)
     # through the autograd node: two 256-channel layers on their own inputs (pair layout)
     convs = [nn.Conv2d(256, 256, 3, padding=1, bias=False).to(dev) for _ in range(2)]
+    shapes = shape_sets[0]
     xa = [torch.randn(2, 256, h, w, device=dev).requires_grad_(True) for h, w in shapes[:3]]
     xb = [torch.randn(2, 256, h, w, device=dev).requires_grad_(True) for h, w in shapes[:3]]
     outs = conv_split_train(xa + xb, [convs[0]] * 3 + [convs[1]] * 3)
