@@ -30,6 +30,9 @@
 #ifndef ORP_WG_ALIGNED
 #define ORP_WG_ALIGNED 1  // X rows: aligned 16-byte loads + one neighbour element instead of 4-byte-aligned 16-byte loads of the shifted octet
 #endif
+#ifndef ORP_WG_PAIRS
+#define ORP_WG_PAIRS 1    // the X fragments of a chunk in two pairs of column blocks, the second pair's LDS reads under the first pair's MFMAs
+#endif
 #ifndef ORP_WG_DBG
 #define ORP_WG_DBG 0      // dev aid (timing only, wrong results): 1 = no fetches after the first, 2 = no MFMA, 4 = no conversion / LDS writes
 #endif
@@ -248,6 +251,57 @@ conv_wgrad_split_kernel(const WParams P) {
       const int cur = (chunk - c_begin) & 1;
       const bool more = chunk + 1 < c_end, more2 = chunk + 2 < c_end;
       const _Float16* sB = sT + (size_t)cur * BUF;
+#if ORP_WG_PAIRS
+      // The X fragments in two PAIRS of column blocks: the second pair's LDS reads fly under the first pair's twelve MFMAs, and the first
+      // pair of the step's second chunk under the second pair's (its registers are free by then; the G fragments follow when theirs
+      // are).  Exposed LDS reads per step and wave: 12 KB instead of 24 -- all eight waves read at once, 1 536 cycles of the CU's LDS
+      // per step against 3 072 of matrix work.  Per accumulator the order of the three products is unchanged: the same bits.
+      h8 ga[2][2], xb[4][2];
+      auto ld_ga = [&](int j) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int pl = 0; pl < 2; pl++)
+            ga[a][pl] = *reinterpret_cast<const h8*>(sB + (size_t)pl * PL + (size_t)(wo * 64 + a * 32 + m) * RS + j * 16 + kg * 8);
+      };
+      auto ld_xb = [&](int j, int c0) {
+#pragma unroll
+        for (int c = c0; c < c0 + 2; c++)
+#pragma unroll
+          for (int pl = 0; pl < 2; pl++)
+            xb[c][pl] = *reinterpret_cast<const h8*>(sB + (size_t)(2 + pl) * PL + (size_t)(wc * 128 + c * 32 + m) * RS + j * 16 + kg * 8);
+      };
+      auto mfma_pair = [&](int c0) {
+#pragma unroll
+        for (int pr = 0; pr < 3; pr++)
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int c = c0; c < c0 + 2; c++)
+              if (ORP_WG_DBG & 2) acc[a][c][0] += (float)ga[a][pr == 0 ? 1 : 0][0] * (float)xb[c][pr == 1 ? 1 : 0][0];
+              else acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[a][pr == 0 ? 1 : 0], xb[c][pr == 1 ? 1 : 0], acc[a][c], 0, 0, 0);
+      };
+      ld_ga(0); ld_xb(0, 0);
+#pragma unroll
+      for (int j = 0; j < KS / 16; j++) {
+        ld_xb(j, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !(ORP_WG_DBG & 4)) stash(it, cur ^ 1, 2 * j, 2 * j + 2);
+        if (FAST && !(ORP_WG_DBG & 1)) fetch_fast(min(chunk + 2, c_end - 1), it, 2 * j, 2 * j + 2);
+        mfma_pair(0);
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < KS / 16) ld_xb(j + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < KS / 16) ld_ga(j + 1);
+      }
+#else
 #pragma unroll
       for (int j = 0; j < KS / 16; j++) {
         h8 ga[2][2], xb[4][2];
@@ -284,6 +338,7 @@ conv_wgrad_split_kernel(const WParams P) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
       if (!FAST && more2 && !(ORP_WG_DBG & 1)) fetch(chunk + 2, it, 0, 4);  // lands during the next step
       __syncthreads();
     }
