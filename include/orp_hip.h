@@ -144,11 +144,14 @@ int orp_dcn_fast_path_ok(int c_in, int c_out, int kh, int kw, int groups, int de
  * (Cin % 64 == 0) by the weights split exactly into three bf16 planes [3][kh*kw][Cin/16][2][Cout][8]. */
 size_t orp_dcn_packed_weight_floats(int c_out, int c_in, int kh, int kw);
 int orp_dcn_pack_weight(const float* weight, int c_out, int c_in, int kh, int kw, float* packed, void* stream);
-/* The contraction of the fp32 forward entry points below (same tensors, same fp32 accumulation) can be issued on the bf16
- * matrix pipe with every fp32 operand split EXACTLY into three bf16 pieces (csrc/orp_dcn_split.hip): mode 0 = off (exact
- * fp32 MFMA), 9 = all nine partial products of the pieces (no representation error), 6 = without the three below 2^-24 of
- * the product (the default); -1 = back to the environment's choice (ORP_DCN_SPLIT = 0 | 1 (= 6) | 6 | 9; unset = 6).  Process-wide;
- * takes effect for Cin % 64 == 0, Cout % 64 == 0 (the reference has one arithmetic: deform_conv_cuda.cpp:222-237). */
+/* The contraction of the fp32 forward entry points below (same tensors, same fp32 accumulation) is issued on the 16-bit matrix
+ * pipe (csrc/orp_dcn_split.hip): mode 3 (the default since round 5) = every fp32 operand as TWO fp16 pieces after an exact
+ * power-of-two range scaling, three partial products; 6 / 9 = every operand split EXACTLY into three bf16 pieces, six partial
+ * products (without the three below 2^-24 of the product) / all nine (no representation error); 0 = off (exact fp32 MFMA);
+ * -1 = back to the environment's choice (ORP_DCN_SPLIT = 0 | 3 | 6 | 9, 1 = 6; unset = 3).  Process-wide; takes effect for
+ * Cin % 64 == 0, Cout % 64 == 0; a launch without a known input range (DCNv2 modulation) runs mode 3 as mode 6.  Every mode's
+ * error against the fp64-accumulated oracle is at or below the exact-fp32 kernel's own (tests/test_gpu_dcn_split.py); the
+ * reference has one arithmetic: deform_conv_cuda.cpp:222-237. */
 int orp_dcn_set_split_mode(int mode);
 int orp_dcn_get_split_mode(void);
 /* (includes 25 MB of scratch for launches of more tiles than CUs: those split every layer's (tile, tap) steps evenly over
@@ -247,7 +250,9 @@ int orp_dcn_backward_multi(const orp_dcn_bwd_level* levels_host, int nlevels, in
  *     grad_weight's columns, grad_input's scatter and grad_offset; grad_masks_host[i] receives d loss / d mask
  *     (= G . sampled value, summed over the channels in a fixed order);
  *   io_dtype 0 / 1 / 2 = input, grad_output and grad_input are fp32 / fp16 / bf16 (converted inside the layout passes the
- *     call runs anyway); offsets, masks, weight and the remaining gradients stay fp32, the arithmetic is fp32 MFMA. */
+ *     call runs anyway); offsets, masks, weight and the remaining gradients stay fp32; fp32 accumulation -- grad_weight on fp32
+ *     MFMAs, the grad_input / grad_offset contraction on two fp16 pieces per operand like the forward's mode 3 (environment
+ *     ORP_DCN_BWD_SPLIT=0: fp32 MFMAs). */
 int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float* const* masks_host,
                               float* const* grad_masks_host, int io_dtype, int nlevels, int batch, int c_in, int c_out,
                               const float* weight, float* grad_weight, int need_input_grads, int kh, int kw, int stride_h,
