@@ -42,3 +42,27 @@ def test_bench_single_rank_dry_and_world_size_mismatch():
     # the hot path has no CPU fallback
     r = _run(['--device', 'cpu', '--steps', '1'])
     assert r.returncode != 0
+
+
+def test_bench_quotes_counters_only_from_the_running_build(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from committed rocprofv3 --pmc passes (profiles/<round>_pmc.json); bench.load_pmc must hand them out
+    only when the file was collected on the library build that runs now (`orp_version` carries a hash of the kernel sources), and say
+    why not otherwise -- stale counters are never reported."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    from orientedreppoints_amd import _lib
+    have = _lib.lib().orp_version().decode()
+    good = tmp_path / "good_pmc.json"
+    good.write_text(json.dumps({"_build": {"orp_version": have}, "dcn_fwd_split": {"hbm_bytes_per_launch": 1.0}}))
+    stale = tmp_path / "stale_pmc.json"
+    stale.write_text(json.dumps({"_build": {"orp_version": "orp_hip gfx950 abi1 000000000000"}, "dcn_fwd_split": {"hbm_bytes_per_launch": 1.0}}))
+    monkeypatch.setattr(bench, "PMC_FILE", os.path.relpath(str(good), bench.ROOT))
+    pmc, note = bench.load_pmc()
+    assert pmc.get("dcn_fwd_split", {}).get("hbm_bytes_per_launch") == 1.0 and "this build" in note
+    monkeypatch.setattr(bench, "PMC_FILE", os.path.relpath(str(stale), bench.ROOT))
+    pmc, note = bench.load_pmc()
+    assert pmc == {} and "traffic not reported" in note
+    monkeypatch.setattr(bench, "PMC_FILE", "profiles/does_not_exist_pmc.json")
+    pmc, note = bench.load_pmc()
+    assert pmc == {} and "not present" in note
