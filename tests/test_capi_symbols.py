@@ -67,3 +67,42 @@ def test_device_code_has_no_packed_fp32_instructions():
             packed += len(re.findall(r"\bv_pk_(?:mul|add|fma)_f32\b", asm))
         assert mfma > 1000                                  # (the disassembly really is this library's kernels)
         assert packed == 0, "%d packed fp32 instructions in the device code" % packed
+
+
+def test_default_hot_kernels_keep_their_registers():
+    """Code-object metadata of the shipped library: the instantiations the default configuration launches at the BASELINE shapes --
+    the split kernel in the fp16-pieces arithmetic (DeformConv and convolution form, every tile height), the DeformConv backward's
+    kernels, the tower weight gradient, the rotated-NMS mask kernel -- spill no vector registers, and the matrix kernels use no scratch memory.  (The
+    three-plane modes of the convolution form at tile height 3 are known to spill 2 - 4 registers: opt-in modes, not asserted.)"""
+    import shutil
+    import subprocess
+    import tempfile
+    from orientedreppoints_amd import build, _lib
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        import pytest
+        pytest.skip("llvm tools not found")
+    build.build_hip()
+    want = {  # substring of the mangled name -> at least this many kernels must match
+        "dcn_fwd_split_kernelILi1ELi3E": 4, "dcn_fwd_split_kernelILi2ELi3E": 4, "dcn_fwd_split_kernelILi3ELi3E": 4,
+        "dcn_bwd_input_kernel": 4, "dcn_bwd_weight_kernel": 1, "dcn_bwd_scatter_kernel": 1,
+        "conv_wgrad_split_kernel": 2, "nms_mask_loop_kernel": 2,
+    }
+    seen = {k: 0 for k in want}
+    with tempfile.TemporaryDirectory() as tmp:
+        so = os.path.join(tmp, "liborp_hip.so")
+        shutil.copy(_lib.LIB_PATH, so)
+        subprocess.run([objdump, "--offloading", so], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        for b in [f for f in os.listdir(tmp) if f.endswith("gfx950")]:
+            notes = subprocess.run([readelf, "--notes", os.path.join(tmp, b)], stdout=subprocess.PIPE, universal_newlines=True, check=True).stdout
+            for blk in notes.split("- .agpr_count")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+                for k in want:
+                    if k in name:
+                        seen[k] += 1
+                        spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
+                        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+                        # (the NMS kernel's generic polygon fallback indexes a small private array: scratch by design, not a spill)
+                        assert spill == 0 and (scratch == 0 or "nms_mask" in k), "%s: %d spilled VGPRs, %d bytes of scratch" % (name, spill, scratch)
+    for k, n in want.items():
+        assert seen[k] >= n, "expected >= %d kernels matching %s in the library, found %d" % (n, k, seen[k])
