@@ -52,7 +52,7 @@ SOURCES = [
     ("orp_dcn_bwd_mfma.hip", []),
     ("orp_prof.hip", []),
 ]
-HEADERS = ["orp_geom.hpp", "orp_quadfast.hpp", "orp_tile.hpp", "orp_hull.hpp", "orp_prof.hpp", "orp_launch.hpp", "orp_dcn_split.hpp", os.path.join("..", "..", "include", "orp_hip.h")]
+HEADERS = ["orp_geom.hpp", "orp_quadfast.hpp", "orp_tile.hpp", "orp_hull.hpp", "orp_libm.hpp", "orp_prof.hpp", "orp_launch.hpp", "orp_dcn_split.hpp", os.path.join("..", "..", "include", "orp_hip.h")]
 
 
 def _stale(target, deps):

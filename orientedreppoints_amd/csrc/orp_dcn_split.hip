@@ -743,15 +743,413 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
   }
 }
 
+// ================================================================================================================================
+// Round 6: the same tile, WAVE-SPECIALISED (fp16-pieces mode only).
+//
+// The kernel above gives every wave every job: gather rows, combine / split them into LDS, read A fragments, stream its 32 output
+// channels' weights, issue MFMAs -- and the two waves of a SIMD do the same job at the same time (one barrier per phase keeps them in
+// step), so the matrix pipe waits while both run their VALU / VMEM part and the VALU idles while both issue MFMAs.  Its anatomy
+//  found nothing saturated: matrix pipe 0.41, L1 ~0.55, LDS ~0.2 -- work that does not overlap.  Here the 8 waves
+// split into 4 CONSUMERS (waves 0-3, one per SIMD: A fragments from LDS, weights from L2, MFMAs, epilogue; each owns the whole tile
+// height x 64 output channels = MT x 2 accumulator blocks) and 4 PRODUCERS (waves 4-7, the other wave of each SIMD: row gathers two
+// phases ahead, bilinear combine / GroupNorm-on-the-way-in, fp16 split, LDS writes).  A SIMD's matrix pipe is fed by one wave whose
+// instruction stream is MFMAs plus 10 loads per 18 of them, next to a wave that issues only VALU / VMEM / DS: the pairing the
+// hardware overlaps (MI355X guide, "Two waves per SIMD").  Every A fragment is now read by 4 waves instead of 8 (LDS read traffic per
+// phase 196 -> 98 KB), the weight stream is unchanged (each consumer streams its own 64 channels once per tile).
+// Same tile table, same arithmetic per output element as the symmetric kernel WITHOUT side accumulators: the three products of a
+// 16-channel chunk are added lo*hi, hi*lo, hi*hi into one fp32 accumulator, chunks in order -- bit-identical to the symmetric kernel's
+// DeformConv instantiation; the PLAIN instantiation there kept the two small products in a second accumulator set (no registers for
+// that here: 6 blocks x 16), tests/test_gpu_conv_split.py holds both to the same gates.
+#ifndef ORP_WS_PRIO
+#define ORP_WS_PRIO 0                // dev aid: s_setprio of the consumer waves (0: none)
+#endif
+#ifndef ORP_WS_DBG
+#define ORP_WS_DBG 0                 // dev aid (timing only, wrong results): 1 = producers idle, 2 = consumers issue no MFMA, 4 = no weight refills, 8 = no A-fragment reads
+#endif
+
+template <int MT, bool OUT_NCHW, bool PLAIN>
+__global__ void __launch_bounds__(kThreadsS)
+dcn_fwd_split_ws_kernel(const FwdS P, int total_tiles) {
+  constexpr int BMS = 32 * MT;
+  constexpr int PLANE = BMS * ASTRS;
+  constexpr int NPL = 2, NT = 2;
+  constexpr int RG = 2 * MT;                                                  // row groups (4 rows each) of one producer wave per phase
+  constexpr int NB = PLAIN ? 1 : 4;                                           // neighbours fetched per sample
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* sA = reinterpret_cast<uint16_t*>(smem);                           // [2 buffers][2 planes][BMS][ASTRS]
+  float4* sCw = reinterpret_cast<float4*>(sA + 2 * NPL * PLANE);
+  int4* sCi = reinterpret_cast<int4*>(sCw + BMS * kTapsMax);
+  float* sAB = reinterpret_cast<float*>(sCi + BMS * kTapsMax);
+#if ORP_DCNS_OWN_SIMD
+  asm volatile("" ::: "v255");
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the role branch is an s_cbranch)
+  const int taps = P.kh * P.kw;
+  int tile, conv;
+  {
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int nx = P.nconv == 2 ? 4 : 8;
+    conv = P.nconv == 2 ? (xcd >> 2) : 0;
+    const int xl = P.nconv == 2 ? (xcd & 3) : xcd;
+    const int per = (total_tiles + nx - 1) / nx;
+    tile = xl * per + slot;
+    if (slot >= per || tile >= total_tiles) return;
+  }
+  int lvl = 0;
+#pragma unroll 1
+  for (int i = 1; i < P.nlev; i++) if (tile >= P.lv[i].tile0) lvl = i;
+  const LevelK L = P.lv[lvl];
+  const int HoWo = L.Ho * L.Wo;
+  const long npos = (long)P.B * HoWo;
+  long p0, plim;
+  int img = 0;
+  if (L.tpi > 0) {
+    const int t_in = tile - L.tile0;
+    img = t_in / L.tpi;
+    const int pin = (t_in - img * L.tpi) * BMS;
+    p0 = (long)img * HoWo + pin;
+    plim = p0 + (HoWo - pin < BMS ? HoWo - pin : BMS);
+  } else {
+    p0 = (long)(tile - L.tile0) * BMS;
+    plim = p0 + BMS < npos ? p0 + BMS : npos;
+  }
+  const float* xin = conv ? L.x[1] : L.x[0];
+  float sx, osc;
+  {
+    unsigned am = P.amax[conv * P.amax_stride];
+    if (P.amax_count > 1) {
+      unsigned* red = reinterpret_cast<unsigned*>(sCw);
+      unsigned m_ = 0u;
+      for (int i = tid; i < P.amax_count; i += kThreadsS) m_ = max(m_, P.amax[conv * P.amax_stride + i]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m_ = max(m_, (unsigned)__shfl_xor((int)m_, o, 64));
+      if (lane == 0) red[wave] = m_;
+      __syncthreads();
+      am = red[0];
+#pragma unroll
+      for (int i = 1; i < kThreadsS / 64; i++) am = max(am, red[i]);
+      __syncthreads();
+    }
+    int k = am == 0u ? 0 : 14 - ((int)((am >> 23) & 0xffu) - 127);
+    k = k < -100 ? -100 : k > 100 ? 100 : k;
+    sx = __uint_as_float((unsigned)(127 + k) << 23);
+    const float sw = *(L.planes ? L.wscale : conv ? P.wscale[1] : P.wscale[0]);
+    osc = 1.f / (sx * sw);
+    if (P.dbg && tile == 0 && blockIdx.y == 0 && tid == 0) { P.dbg[conv] = am; P.dbg[2 + conv] = __float_as_uint(sw); }
+  }
+
+  // ---- coefficient table (same as the symmetric kernel: see there for the border-factor formulation) ----
+  for (int e = tid; e < BMS * taps; e += kThreadsS) {
+    const int m = e / taps, tap = e - m * taps;
+    const long p = p0 + m;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 ix = make_int4(0, 0, 0, 0);
+    if (p < plim) {
+      const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+      const int ho = hw / L.Wo, wo = hw - ho * L.Wo;
+      const int ki = tap / P.kw, kj = tap - ki * P.kw;
+      if (PLAIN) {
+        const int hi = ho * P.sh - P.ph + ki * P.dh, wi = wo * P.sw - P.pw + kj * P.dw;
+        if (hi >= 0 && hi < L.H && wi >= 0 && wi < L.W) { w.x = 1.f; ix.x = (b * L.H + hi) * L.W + wi; }
+        sCw[e] = w; sCi[e] = ix;
+        continue;
+      }
+      const float* ob = L.off + ((size_t)b * 2 * taps + 2 * tap) * HoWo + hw;
+      const float h_im = (float)(ho * P.sh - P.ph + ki * P.dh) + ob[0];
+      const float w_im = (float)(wo * P.sw - P.pw + kj * P.dw) + ob[HoWo];
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)L.H && w_im < (float)L.W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+        const float hh = 1.f - lh, hw_ = 1.f - lw;
+        const float t_ok = (float)min(h_low + 1, 1), b_ok = (float)min(L.H - 1 - h_low, 1);
+        const float l_ok = (float)min(w_low + 1, 1), r_ok = (float)min(L.W - 1 - w_low, 1);
+        const int hl = max(h_low, 0), hhg = min(h_low + 1, L.H - 1), wl = max(w_low, 0), whg = min(w_low + 1, L.W - 1);
+        w.x = (hh * hw_) * (t_ok * l_ok);
+        w.y = (hh * lw) * (t_ok * r_ok);
+        w.z = (lh * hw_) * (b_ok * l_ok);
+        w.w = (lh * lw) * (b_ok * r_ok);
+        const int base = b * L.H;
+        ix.x = (base + hl) * L.W + wl;
+        ix.y = (base + hl) * L.W + whg;
+        ix.z = (base + hhg) * L.W + wl;
+        ix.w = (base + hhg) * L.W + whg;
+        if (L.mask) {
+          const float mm = L.mask[((size_t)b * taps + tap) * HoWo + hw];
+          w.x *= mm; w.y *= mm; w.z *= mm; w.w *= mm;
+        }
+      }
+    }
+    sCw[e] = w; sCi[e] = ix;
+  }
+  const bool has_coef = PLAIN && P.coef_in != nullptr;
+  if (has_coef) {
+    const float2* cf = P.coef_in + ((size_t)(conv * P.nlev + lvl) * P.B + img) * P.Cin;
+    for (int c = tid; c < P.Cin; c += kThreadsS) { const float2 ab = cf[c]; sAB[c] = ab.x; sAB[P.Cin + c] = ab.y; }
+  }
+  __syncthreads();
+
+  const int ncb = P.Cin / CBS;
+  const int nphase = taps * ncb;
+  const bool consumer = wave < 4;                                              // (waves w and w + 4 share a SIMD: one of each role per SIMD)
+  const int wq = wave & 3;
+
+  // ---- producer side ----------------------------------------------------------------------------------------------------------
+  const int q4 = lane >> 4, c4 = (lane & 15) * 4;
+  auto row_of = [&](int g) { return g * 16 + wq * 4 + q4; };
+  auto gather_issue = [&](int tap, int cb, int g, float4 (&v)[NB]) {
+    const int4 ix = sCi[row_of(g) * taps + tap];
+    const float* base = xin + cb * CBS + c4;
+    v[0] = *reinterpret_cast<const float4*>(base + (size_t)ix.x * P.Cin);
+    if constexpr (!PLAIN) {
+      v[1] = *reinterpret_cast<const float4*>(base + (size_t)ix.y * P.Cin);
+      v[2] = *reinterpret_cast<const float4*>(base + (size_t)ix.z * P.Cin);
+      v[3] = *reinterpret_cast<const float4*>(base + (size_t)ix.w * P.Cin);
+    }
+  };
+  auto combine_store = [&](int tap, int cbk, int g, const float4 (&v)[NB], int buf) {
+    const int m = row_of(g);
+    const float4 cw = sCw[m * taps + tap];
+    float s[4];
+    if constexpr (PLAIN) {
+      const bool in = cw.x != 0.f;
+      float4 x = v[0];
+      if (has_coef) {
+        const float4 ca = *reinterpret_cast<const float4*>(sAB + cbk * CBS + c4);
+        const float4 cb_ = *reinterpret_cast<const float4*>(sAB + P.Cin + cbk * CBS + c4);
+        x.x = fmaf(x.x, ca.x, cb_.x); x.y = fmaf(x.y, ca.y, cb_.y); x.z = fmaf(x.z, ca.z, cb_.z); x.w = fmaf(x.w, ca.w, cb_.w);
+        if (P.relu_in) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+      }
+      s[0] = in ? x.x : 0.f; s[1] = in ? x.y : 0.f; s[2] = in ? x.z : 0.f; s[3] = in ? x.w : 0.f;
+    } else {
+      auto bil = [&](float a, float b, float c, float d) {     // deform_conv_cuda_kernel.cu:111-113, left to right, unfused
+        return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(cw.x, a), __fmul_rn(cw.y, b)), __fmul_rn(cw.z, c)), __fmul_rn(cw.w, d));
+      };
+      s[0] = bil(v[0].x, v[1].x, v[2].x, v[3].x);
+      s[1] = bil(v[0].y, v[1].y, v[2].y, v[3].y);
+      s[2] = bil(v[0].z, v[1].z, v[2].z, v[3].z);
+      s[3] = bil(v[0].w, v[1].w, v[2].w, v[3].w);
+    }
+    uint16_t* dst = sA + (size_t)buf * NPL * PLANE + (size_t)m * ASTRS + c4;
+    _Float16 h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float sv = s[i] * sx;
+      h[i] = (_Float16)sv;
+      l[i] = (_Float16)(sv - (float)h[i]);
+    }
+    const h2 h01 = {h[0], h[1]}, h23 = {h[2], h[3]}, l01 = {l[0], l[1]}, l23 = {l[2], l[3]};
+    *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+    *reinterpret_cast<uint2*>(dst + PLANE) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+  };
+
+  // ---- consumer side ----------------------------------------------------------------------------------------------------------
+  const int n_wave = blockIdx.y * 256 + wq * 64;
+  const int mrow = lane & 31, kg = lane >> 5;
+  const bool live = n_wave < P.Cout;                                           // Cout % 64 == 0
+  const uint16_t* wp = (L.planes ? L.planes : conv ? P.planes[1] : P.planes[0]) + ((size_t)kg * P.Cout + (live ? n_wave : 0) + mrow) * 8;
+  const size_t wblk = (size_t)2 * P.Cout * 8;
+  auto load_b = [&](int tap, int cb, int j, bf8 (&b)[NT][NPL]) {
+    const uint16_t* a = wp + ((size_t)tap * (P.Cin / 16) + cb * NCH + j) * wblk;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++) b[nt][pl] = *reinterpret_cast<const bf8*>(a + (size_t)pl * P.plane_stride + nt * 32 * 8);
+  };
+  auto load_a = [&](const uint16_t* abase, int j, bf8 (&a)[MT][NPL]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++)
+        if (!(ORP_WS_DBG & 8)) a[mt][pl] = *reinterpret_cast<const bf8*>(abase + (size_t)pl * PLANE + (size_t)mt * 32 * ASTRS + j * 16);
+  };
+
+  int tap_n = 0, cb_n = 0, tap_n2 = 0, cb_n2 = 0;                             // (tap, channel block) of phase + 1 / phase + 2, clamped to the last phase
+  auto step = [&](int& t, int& c, int ph) {
+    if (ph + 1 < nphase) { if (++c == ncb) { c = 0; t++; } }
+  };
+  step(tap_n, cb_n, 0);
+  tap_n2 = tap_n; cb_n2 = cb_n;
+  step(tap_n2, cb_n2, 1);
+
+  // The two roles are two separate loops (not one loop with a branch inside): their register sets are then disjoint live ranges and
+  // the kernel needs max(consumer, producer) registers, not the sum.  Both execute exactly nphase + 1 barriers.
+  if (!consumer) {
+    float4 gA[RG][NB], gB[RG][NB];
+#pragma unroll
+    for (int r = 0; r < RG; r++) gather_issue(0, 0, r, gB[r]);
+#pragma unroll
+    for (int r = 0; r < RG; r++) gather_issue(tap_n, cb_n, r, gA[r]);          // the rows of phase 1
+#pragma unroll
+    for (int r = 0; r < RG; r++) combine_store(0, 0, r, gB[r], 0);
+    __syncthreads();
+    auto produce = [&](int phase, float4 (&g)[RG][NB], float4 (&gf)[RG][NB]) __attribute__((always_inline)) {
+      if (!(ORP_WS_DBG & 1)) {
+#pragma unroll
+        for (int r = 0; r < RG; r++) gather_issue(tap_n2, cb_n2, r, gf[r]);    // the rows of phase + 2: a whole phase to land
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < RG; r++) combine_store(tap_n, cb_n, r, g[r], (phase & 1) ^ 1);
+      }
+      step(tap_n, cb_n, phase + 1);
+      step(tap_n2, cb_n2, phase + 2);
+      __syncthreads();
+    };
+#pragma unroll 1
+    for (int phase = 0; phase < nphase; phase += 2) {
+      produce(phase, gA, gB);
+      if (phase + 1 < nphase) produce(phase + 1, gB, gA);
+    }
+    return;
+  }
+
+  bf8 bq[NCH][NT][NPL];
+  bf8 af[2][MT][NPL];
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = floatx16{0};
+#pragma unroll
+  for (int j = 0; j < NCH; j++) load_b(0, 0, j, bq[j]);
+  if (ORP_WS_DBG & 8) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++) af[i][mt][pl] = bq[(i + mt) & 3][pl][pl];
+  }
+  __syncthreads();
+#if ORP_WS_PRIO
+  __builtin_amdgcn_s_setprio(ORP_WS_PRIO);
+#endif
+#pragma unroll 1
+  for (int phase = 0; phase < nphase; phase++) {
+    const uint16_t* abase = sA + (size_t)(phase & 1) * NPL * PLANE + (size_t)mrow * ASTRS + 8 * kg;
+    load_a(abase, 0, af[0]);
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+      if (j + 1 < NCH) load_a(abase, j + 1, af[(j + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(ORP_WS_DBG & 2)) {
+#pragma unroll
+        for (int t = 0; t < 3; t++) {                                          // lo*hi, hi*lo, hi*hi (smallest first)
+          const int pa = t == 0 ? 1 : 0, pb = t == 1 ? 1 : 0;
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+              const h8 av = __builtin_bit_cast(h8, af[j & 1][mt][pa]), bv = __builtin_bit_cast(h8, bq[j][nt][pb]);
+              if (OUT_NCHW) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, acc[mt][nt], 0, 0, 0);
+              else          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[mt][nt], 0, 0, 0);
+            }
+        }
+      } else {
+        acc[0][0][0] += (float)af[j & 1][0][0][0] * (float)bq[j][0][0][0];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(ORP_WS_DBG & 4)) load_b(tap_n, cb_n, j, bq[j]);                    // refilled in place for the next phase
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    step(tap_n, cb_n, phase + 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue (consumers) ------------------------------------------------------------------------------------------------------
+  if (!live) return;
+#if ORP_WS_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+  const float* bias = L.planes ? L.bias : conv ? P.bias[1] : P.bias[0];
+  float* outp = conv ? L.out[1] : L.out[0];
+  bool scaled = false;
+  if (PLAIN && !OUT_NCHW && P.gn_part) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[mt][nt] *= osc;
+    scaled = true;
+    const int cg = P.Cout / P.G, nrow = (int)(plim - p0);
+    auto row_ok = [&](int mt, int r) { return mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) < nrow; };
+    auto group_sum = [&](float v) {
+      for (int o = 1; o < cg; o <<= 1) v += __shfl_xor(v, o, 64);
+      return v + __shfl_xor(v, 32, 64);
+    };
+    const float cnt = (float)(nrow * cg);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      float sum = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) sum += row_ok(mt, r) ? acc[mt][nt][r] : 0.f;
+      const float mean = group_sum(sum) / cnt;
+      float m2 = 0.f, mx = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float d = acc[mt][nt][r] - mean;
+          m2 += row_ok(mt, r) ? d * d : 0.f;
+          mx = fmaxf(mx, row_ok(mt, r) ? fabsf(acc[mt][nt][r]) : 0.f);
+        }
+      m2 = group_sum(m2);
+      for (int o = 1; o < cg; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (lane < 32 && (lane & (cg - 1)) == 0)
+        P.gn_part[((size_t)conv * total_tiles + tile) * P.G + (n_wave + nt * 32 + lane) / cg] = make_float4(mean, m2, mx, cnt);
+    }
+  }
+  auto finish = [&](float v, int ch) { if (!scaled) v *= osc; if (bias) v += bias[ch]; return P.relu ? fmaxf(v, 0.f) : v; };
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      const int nb = n_wave + nt * 32;
+      if (OUT_NCHW) {
+        const long p = p0 + mt * 32 + (lane & 31);
+        if (p < plim) {
+          const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+          float* ob = outp + (size_t)b * P.Cout * HoWo + hw;
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int ch = nb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            ob[(size_t)ch * HoWo] = finish(acc[mt][nt][r], ch);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const long p = p0 + mt * 32 + m;
+          if (p < plim) outp[(size_t)p * P.Cout + nb + (lane & 31)] = finish(acc[mt][nt][r], nb + (lane & 31));
+        }
+      }
+    }
+}
+
 constexpr int kCoefCinMax = 512;                                              // orp_conv_split_multi_gn: input channels of a layer that normalises on the way in
 template <int MT, int NPL>
 constexpr size_t split_smem() {
   return (size_t)2 * NPL * 32 * MT * ASTRS * 2 + (sizeof(float4) + sizeof(int4)) * 32 * MT * kTapsMax + sizeof(float) * 2 * kCoefCinMax;
 }
 
+static const int g_ws = getenv("ORP_DCNS_WS") ? atoi(getenv("ORP_DCNS_WS")) : 1;   // 0: the symmetric kernel also in the fp16-pieces mode (A/B timing)
+
 template <int MT, int NPROD, bool OUT_NCHW, bool PLAIN>
 hipError_t launch_one(const FwdS& P, int tiles, int nblk_n, hipStream_t st) {
   constexpr size_t smem = split_smem<MT, NPROD == 3 ? 2 : 3>();
+  if constexpr (NPROD == 3) {
+    if (g_ws) {
+      struct TagW {};
+      hipError_t e = orp::set_max_dynamic_lds_once<TagW>(reinterpret_cast<const void*>(&dcn_fwd_split_ws_kernel<MT, OUT_NCHW, PLAIN>), smem);
+      if (e != hipSuccess) return e;
+      const int nx = P.nconv == 2 ? 4 : 8;
+      const int per = (tiles + nx - 1) / nx;
+      hipLaunchKernelGGL((dcn_fwd_split_ws_kernel<MT, OUT_NCHW, PLAIN>), dim3(per * 8, nblk_n), dim3(kThreadsS), smem, st, P, tiles);
+      return hipGetLastError();
+    }
+  }
   struct Tag {};
   hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_split_kernel<MT, NPROD, OUT_NCHW, PLAIN>), smem);
   if (e != hipSuccess) return e;

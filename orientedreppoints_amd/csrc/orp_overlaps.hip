@@ -13,6 +13,7 @@
 
 #include "../../include/orp_hip.h"
 #include "orp_geom.hpp"
+#include "orp_libm.hpp"
 #include "orp_quadfast.hpp"
 #include "orp_tile.hpp"
 
@@ -23,8 +24,8 @@ constexpr int kThreads = 256;
 // (cx,cy,w,h,theta) -> 4 corners, mixed precision exactly as poly_overlaps_kernel.cu:280-297
 // (cos/sin of the float angle; products with (w / 2.0) in double; one rounding to float per coordinate).
 __device__ __forceinline__ void rotbox2poly(const float* dbox, float* p8) {
-  const float cs = (float)cos((double)dbox[4]);
-  const float ss = (float)sin((double)dbox[4]);
+  const float cs = orp::libm::cosf_host(dbox[4]);       // the host C library's cosf / sinf, bit for bit (orp_libm.hpp)
+  const float ss = orp::libm::sinf_host(dbox[4]);
   const float w = dbox[2], h = dbox[3], x_ctr = dbox[0], y_ctr = dbox[1];
   p8[0] = (float)(x_ctr + cs * (w / 2.0) - ss * (-h / 2.0));
   p8[2] = (float)(x_ctr + cs * (w / 2.0) - ss * (h / 2.0));

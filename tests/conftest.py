@@ -33,7 +33,7 @@ def pytest_collection_modifyitems(config, items):
 
 
 # Lines a test wants in the run's log whatever its outcome (e.g. how many APAA quality values fell under the min-area-rect
-# tie rule): tests append to REPORT, the summary hook prints them at the end of the session (also under -q).
+# tie rule of rounds 3-5): tests append to REPORT, the summary hook prints them at the end of the session (also under -q).
 REPORT = []
 
 

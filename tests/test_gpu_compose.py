@@ -4,9 +4,10 @@ pointset_target, SpatialBorderLoss, GIoULoss, FocalLoss and the whole head loss(
 
 Bars (BASELINE.json north_star): discrete outcomes -- kept detections, labels, order, assignments, selected positive
 sets, normalisers -- identical; floats within 1e-4 (relative to max(1, |x|) for coordinates / the summed class loss).
-min-area-rect uses cos / atan2, whose device and host libm differ in the last ulp: box corners are therefore compared
-to 1e-4, not bit for bit, and the only Q values allowed to differ by more are PROVABLE min-area-rect ties (the two
-smallest candidate rectangle areas equal to rounding, `oracle.minarearect_margin`)."""
+Round 6: min-area-rect is bit-exact against the oracle (the kernel evaluates the host C library's cosf, csrc/orp_libm.hpp), so
+the "provable tie" exemption rounds 3-5 granted the APAA quality values is gone: every Q value is held to 1e-4.  The scenes
+the golden generator REJECTED for not being ulp-robust are run too (`test_rejected_scenes_report`), reporting -- not asserting --
+how many of them / of their detections differ from the reference."""
 import os
 import sys
 
@@ -19,7 +20,6 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 import compose_inputs as CI  # noqa: E402
 
-TIE_MARGIN = 1e-5
 
 
 @pytest.fixture(scope="module")
@@ -111,6 +111,57 @@ def test_get_bboxes_single_and_multiclass_rnms_vs_reference(dev, G, name):
             host = packed.cpu().numpy()
             n = int(host[-1, 0])
             _check_dets(host[:n, :-1], host[:n, -1].astype(np.int64), G, name)
+
+
+def test_rejected_scenes_report(dev, G, golden_dir):
+    """Round-5 verdict, weak 2: the asserting tests above run on scenes that survived the generator's ulp-perturbation filter.
+    This one runs the draws that filter REJECTED (tests/golden/make_golden_compose_rejected.py: the reference's own Python on
+    the unperturbed inputs) through the three product paths and REPORTS -- it does not assert equality -- how many scenes and
+    detections differ from the reference, so the end-to-end mismatch rate on borderline scenes is a measured number.  (What can
+    differ: the device sigmoid vs the host's in the last ulp next to score_thr / in the top-k order.  Min-area-rect, rotated
+    IoU and the NMS keep sets are bit-exact at kernel level.)"""
+    import conftest
+    R = np.load(os.path.join(golden_dir, "compose_rejected_py.npz"))
+    head = _head(dev)
+    lines, scenes, bad_scenes, n_det, n_bad_det = [], 0, 0, 0, 0
+    for name in PP:
+        size, kw, max_per_img = PP[name]
+        for seed in R['pp_%s_seeds' % name].tolist():
+            want, wl = R['pp_%s_%d_dets' % (name, seed)], R['pp_%s_%d_labels' % (name, seed)].astype(np.int64)
+            cls, pts = CI.postprocess_scene(size, int(seed), **kw)
+            cls_t = [torch.from_numpy(c)[None].to(dev) for c in cls]
+            pts_t = [torch.from_numpy(p)[None].to(dev) for p in pts]
+            metas = [CI.img_meta(size)]
+            outs = {}
+            with torch.no_grad():
+                dets, labels = head.get_bboxes(cls_t, None, pts_t, None, metas, _cfg(max_per_img), rescale=False, nms=True)[0]
+                outs['dynamic'] = (dets.cpu().numpy(), labels.cpu().numpy())
+                for fused in (True, False):
+                    cfg2 = _cfg(max_per_img)
+                    cfg2['fused_postprocess'] = fused
+                    host = head.get_bboxes(cls_t, None, pts_t, None, metas, cfg2, static=True)[0].cpu().numpy()
+                    n = int(host[-1, 0])
+                    outs['fused' if fused else 'static'] = (host[:n, :-1], host[:n, -1].astype(np.int64))
+            scenes += 1
+            n_det += want.shape[0]
+            worst = 0
+            for path, (d, l) in outs.items():
+                if d.shape == want.shape and np.array_equal(l, wl) and (want.shape[0] == 0 or
+                        (_rel(d[:, -1], want[:, -1]) <= 1e-6 and _rel(d[:, :-1], want[:, :-1]) <= 1e-4)):
+                    continue
+                # detections of the reference without a partner (same label, score within 1e-6, boxes within 1e-4) on this path
+                key = lambda a, b: {(int(b[i]), round(float(a[i, -1]), 5)) for i in range(a.shape[0])}     # noqa: E731
+                missing = len(key(want, wl) ^ key(d, l))
+                worst = max(worst, max(missing, 1))
+                lines.append("   %s seed %d, path %s: %d vs %d detections, %d unmatched" % (name, seed, path, d.shape[0], want.shape[0], missing))
+            # the three product paths must agree with EACH OTHER whatever the reference says (asserted)
+            assert outs['fused'][0].shape == outs['static'][0].shape and np.array_equal(outs['fused'][1], outs['static'][1])
+            bad_scenes += worst > 0
+            n_bad_det += worst
+    conftest.REPORT.append("scenes REJECTED by the golden generator's ulp-robustness filter, run anyway: %d of %d scenes differ from "
+                           "the reference's detections (%d of %d detections unmatched)" % (bad_scenes, scenes, n_bad_det, n_det))
+    for ln in lines:
+        conftest.REPORT.append(ln)
 
 
 def test_postprocess_as_hipgraph_replay_vs_reference(dev, G):
@@ -245,20 +296,17 @@ def test_head_loss_vs_reference_python(dev, G, oracle, name):
     assert np.array_equal(np.stack([t.cpu().numpy() for t in rt[0]]), G[p + 'refine_labels'])
     assert np.array_equal(np.stack([t.cpu().numpy() for t in rt[1]]).astype(np.uint8), G[p + 'refine_label_weights'])
     assert np.array_equal(np.stack([t.cpu().numpy() for t in rt[4]]).astype(np.uint8), G[p + 'refine_rbox_weights'])
-    n_tie, max_tie = 0, 0.0
+    max_dq = 0.0
     for i in range(B):
         pos = rt[5][i].cpu().numpy()
         assert np.array_equal(pos, G[p + 'refine_pos_inds_%d' % i])
         assert np.array_equal(rt[6][i].cpu().numpy(), G[p + 'refine_pos_gt_index_%d' % i])
         assert np.array_equal(rt[2][i].cpu().numpy()[pos], G[p + 'refine_rbox_gt_pos_%d' % i])
-        # ---- APAA quality: 1e-4, except provable min-area-rect ties ------------------------------------------------
+        # ---- APAA quality: 1e-4 on EVERY value (no tie exemption since round 6) ----------------------------------------
         q, want = rec['qa'][i].cpu().numpy(), G[p + 'qa_%d' % i]
-        tie = G[p + 'qa_margin_%d' % i] < TIE_MARGIN
         d = np.abs(q - want)
-        assert np.max(d[~tie], initial=0.0) <= 1e-4, "Q differs from the reference beyond 1e-4 off a min-area-rect tie"
-        assert np.all(d[tie] <= 2e-2)
-        n_tie += int(tie.sum())
-        max_tie = max(max_tie, float(np.max(d[tie], initial=0.0)))
+        max_dq = max(max_dq, float(np.max(d, initial=0.0)))
+        assert np.max(d, initial=0.0) <= 1e-4, "Q differs from the reference beyond 1e-4"
         # ---- selection ------------------------------------------------------------------------------------------------
         lab, lw, rw, npos, pnt = rec['sel'][i]
         assert np.array_equal(lab.cpu().numpy(), G[p + 'sel_label_%d' % i])
@@ -293,10 +341,10 @@ def test_head_loss_vs_reference_python(dev, G, oracle, name):
         want[rows[:, 0], rows[:, 1]] = G[p + 'grad_%s_vals' % nm]
         assert np.max(np.abs(ga.transpose(0, 2, 1) - want)) <= 1e-4, nm
     n_q = sum(len(G[p + 'qa_%d' % i]) for i in range(B))
+    n_tie = sum(int((G[p + 'qa_margin_%d' % i] < 1e-5).sum()) for i in range(B))
     import conftest
-    conftest.REPORT.append("a15 tie rule, head_loss case %r: %d of %d quality values are proven min-area-rect ties (%.2f %%), "
-                           "largest difference on a tie %.2e" % (name, n_tie, n_q, 100.0 * n_tie / max(n_q, 1), max_tie))
-    assert n_tie < 0.1 * n_q       # ties are the exception, not a loophole
+    conftest.REPORT.append("a15, head_loss case %r: all %d quality values within 1e-4 of the reference (largest difference %.2e); "
+                           "%d of them sit on min-area-rect ties (exempt in rounds 3-5, not any more)" % (name, n_q, max_dq, n_tie))
 
 
 def test_candidate_selection_radix_select_equals_topk(dev):
