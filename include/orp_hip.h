@@ -128,6 +128,12 @@ int orp_sigmoid_focal_loss_forward(const float* logits, const int64_t* targets, 
                                    float gamma, float alpha, float* losses, void* stream);
 int orp_sigmoid_focal_loss_backward(const float* logits, const int64_t* targets, const float* d_losses, int num,
                                     int classes, float gamma, float alpha, float* d_logits, void* stream);
+/* scalar_t = double of the reference's dispatch (sigmoid_focal_loss_cuda.cu:121,160): double tensors, the expressions' single-precision
+ * expf / logf / powf calls kept as the template instantiates them. */
+int orp_sigmoid_focal_loss_forward_f64(const double* logits, const int64_t* targets, int num, int classes,
+                                       float gamma, float alpha, double* losses, void* stream);
+int orp_sigmoid_focal_loss_backward_f64(const double* logits, const int64_t* targets, const double* d_losses, int num,
+                                        int classes, float gamma, float alpha, double* d_logits, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Deformable convolution forward (DCNv1 / DCNv2).
@@ -276,6 +282,17 @@ int orp_dcn_col2im(const float* grad_columns, const float* input, const float* o
                    int c_in, int height, int width, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
                    int dil_h, int dil_w, int deformable_groups, float* grad_input, float* grad_offset, float* grad_mask,
                    void* stream);
+/* The same two kernels for DOUBLE tensors -- the `double` branch of the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF
+ * (deform_conv_cuda_kernel.cu:259,353,451,720,777,838): DeformConvFunction / ModulatedDeformConvFunction with float64 tensors run the
+ * reference's own column formulation (deform_conv_cuda.cpp:152-488) in double -- these sampling kernels around the library's double
+ * GEMMs -- instead of being narrowed to fp32 (rounds 1-5). */
+int orp_dcn_im2col_f64(const double* input, const double* offset, const double* mask, int batch, int c_in, int height,
+                       int width, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                       int deformable_groups, double* columns, void* stream);
+int orp_dcn_col2im_f64(const double* grad_columns, const double* input, const double* offset, const double* mask, int batch,
+                       int c_in, int height, int width, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                       int dil_h, int dil_w, int deformable_groups, double* grad_input, double* grad_offset, double* grad_mask,
+                       void* stream);
 /* channel-parallel variant for deformable_groups = 1: grad_columns_t [B*Ho*Wo, kh*kw, Cin] (position-major, from
  * grad_out(NHWC) . W[Cout, kh*kw*Cin]), input / grad_input NHWC (grad_input zeroed by the caller), offsets NCHW. */
 int orp_dcn_col2im_nhwc(const float* grad_columns_t, const float* input_nhwc, const float* offset, int batch, int c_in,

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "orp_chamfer2d_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "orp_sigmoid_focal_loss_forward": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     "orp_sigmoid_focal_loss_backward": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    "orp_sigmoid_focal_loss_forward_f64": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    "orp_sigmoid_focal_loss_backward_f64": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     "orp_point_assign_workspace_bytes": (_sz, [_i]),
     "orp_point_assign": (_i, [_vp, _i, _vp, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "orp_max_iou_assign_workspace_bytes": (_sz, [_i]),
@@ -74,6 +76,8 @@ _SIGNATURES = {
     "orp_dcn_forward_multi_h": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),
     "orp_dcn_im2col": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp]),
     "orp_dcn_col2im": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp, _vp]),
+    "orp_dcn_im2col_f64": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp, _vp]),
+    "orp_dcn_col2im_f64": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp, _vp, _vp]),
     "orp_dcn_col2im_nhwc": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp, _vp, _vp]),
     "orp_dcn_forward_direct": (_i, [_vp] * 6 + [_i] * 15 + [_vp]),
     "orp_dcn_backward_mfma_ok": (_i, [_i] * 6),

@@ -20,9 +20,15 @@ namespace {
 
 struct Geo { int B, C, H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, dg; };
 
+// T = float | double: the reference instantiates these kernels for both (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+// deform_conv_cuda_kernel.cu:259,353,451); for T = float every expression below is the fp32 expression of rounds 1-5
+__device__ __forceinline__ float floor_t(float v) { return floorf(v); }
+__device__ __forceinline__ double floor_t(double v) { return floor(v); }
+
 // col[(c*taps + t)][b][ho][wo] = (mask *) bilinear(x[b,c], ...)      one thread per (c, b, p), loops taps
-__global__ void dcn_im2col_kernel(const float* __restrict__ x, const float* __restrict__ off,
-                                  const float* __restrict__ mask, Geo g, float* __restrict__ col) {
+template <typename T>
+__global__ void dcn_im2col_kernel(const T* __restrict__ x, const T* __restrict__ off,
+                                  const T* __restrict__ mask, Geo g, T* __restrict__ col) {
   const int taps = g.kh * g.kw, P = g.Ho * g.Wo, cpdg = g.C / g.dg;
   const long total = (long)g.C * g.B * P;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -31,21 +37,21 @@ __global__ void dcn_im2col_kernel(const float* __restrict__ x, const float* __re
     const int c = (int)(idx / ((long)P * g.B));
     const int ho = p / g.Wo, wo = p - ho * g.Wo;
     const int dgi = c / cpdg;
-    const float* xp = x + ((size_t)b * g.C + c) * g.H * g.W;
-    const float* op = off + ((size_t)b * g.dg + dgi) * 2 * taps * P + p;
-    const float* mp = mask ? mask + ((size_t)b * g.dg + dgi) * taps * P + p : nullptr;
+    const T* xp = x + ((size_t)b * g.C + c) * g.H * g.W;
+    const T* op = off + ((size_t)b * g.dg + dgi) * 2 * taps * P + p;
+    const T* mp = mask ? mask + ((size_t)b * g.dg + dgi) * taps * P + p : nullptr;
     for (int t = 0; t < taps; t++) {
       const int ki = t / g.kw, kj = t - ki * g.kw;
-      const float h_im = (float)(ho * g.sh - g.ph + ki * g.dh) + op[(size_t)(2 * t) * P];
-      const float w_im = (float)(wo * g.sw - g.pw + kj * g.dw) + op[(size_t)(2 * t + 1) * P];
-      float val = 0.f;
-      if (h_im > -1.f && w_im > -1.f && h_im < (float)g.H && w_im < (float)g.W) {
-        const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hh = hl + 1, wh = wl + 1;
-        const float lh = h_im - hl, lw = w_im - wl, uh = 1.f - lh, uw = 1.f - lw;
-        const float v1 = (hl >= 0 && wl >= 0) ? xp[hl * g.W + wl] : 0.f;
-        const float v2 = (hl >= 0 && wh <= g.W - 1) ? xp[hl * g.W + wh] : 0.f;
-        const float v3 = (hh <= g.H - 1 && wl >= 0) ? xp[hh * g.W + wl] : 0.f;
-        const float v4 = (hh <= g.H - 1 && wh <= g.W - 1) ? xp[hh * g.W + wh] : 0.f;
+      const T h_im = (T)(ho * g.sh - g.ph + ki * g.dh) + op[(size_t)(2 * t) * P];
+      const T w_im = (T)(wo * g.sw - g.pw + kj * g.dw) + op[(size_t)(2 * t + 1) * P];
+      T val = 0;
+      if (h_im > (T)-1 && w_im > (T)-1 && h_im < (T)g.H && w_im < (T)g.W) {
+        const int hl = (int)floor_t(h_im), wl = (int)floor_t(w_im), hh = hl + 1, wh = wl + 1;
+        const T lh = h_im - hl, lw = w_im - wl, uh = (T)1 - lh, uw = (T)1 - lw;
+        const T v1 = (hl >= 0 && wl >= 0) ? xp[hl * g.W + wl] : (T)0;
+        const T v2 = (hl >= 0 && wh <= g.W - 1) ? xp[hl * g.W + wh] : (T)0;
+        const T v3 = (hh <= g.H - 1 && wl >= 0) ? xp[hh * g.W + wl] : (T)0;
+        const T v4 = (hh <= g.H - 1 && wh <= g.W - 1) ? xp[hh * g.W + wh] : (T)0;
         val = uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4;
       }
       if (mp) val *= mp[(size_t)t * P];
@@ -55,10 +61,11 @@ __global__ void dcn_im2col_kernel(const float* __restrict__ x, const float* __re
 }
 
 // one thread per (b, deformable group, tap, position): loops the group's channels
-__global__ void dcn_col2im_kernel(const float* __restrict__ gcol, const float* __restrict__ x,
-                                  const float* __restrict__ off, const float* __restrict__ mask, Geo g,
-                                  float* __restrict__ grad_x, float* __restrict__ grad_off,
-                                  float* __restrict__ grad_mask) {
+template <typename T>
+__global__ void dcn_col2im_kernel(const T* __restrict__ gcol, const T* __restrict__ x,
+                                  const T* __restrict__ off, const T* __restrict__ mask, Geo g,
+                                  T* __restrict__ grad_x, T* __restrict__ grad_off,
+                                  T* __restrict__ grad_mask) {
   const int taps = g.kh * g.kw, P = g.Ho * g.Wo, cpdg = g.C / g.dg;
   const long total = (long)g.B * g.dg * taps * P;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -69,25 +76,25 @@ __global__ void dcn_col2im_kernel(const float* __restrict__ gcol, const float* _
     const int ho = p / g.Wo, wo = p - ho * g.Wo;
     const int ki = t / g.kw, kj = t - ki * g.kw;
     const size_t obase = (((size_t)b * g.dg + dgi) * 2 * taps) * P + p;
-    const float h_im = (float)(ho * g.sh - g.ph + ki * g.dh) + off[obase + (size_t)(2 * t) * P];
-    const float w_im = (float)(wo * g.sw - g.pw + kj * g.dw) + off[obase + (size_t)(2 * t + 1) * P];
-    const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)g.H && w_im < (float)g.W;
-    const float m = mask ? mask[(((size_t)b * g.dg + dgi) * taps + t) * P + p] : 1.f;
-    float acc_h = 0.f, acc_w = 0.f, acc_m = 0.f;
+    const T h_im = (T)(ho * g.sh - g.ph + ki * g.dh) + off[obase + (size_t)(2 * t) * P];
+    const T w_im = (T)(wo * g.sw - g.pw + kj * g.dw) + off[obase + (size_t)(2 * t + 1) * P];
+    const bool inside = h_im > (T)-1 && w_im > (T)-1 && h_im < (T)g.H && w_im < (T)g.W;
+    const T m = mask ? mask[(((size_t)b * g.dg + dgi) * taps + t) * P + p] : (T)1;
+    T acc_h = 0, acc_w = 0, acc_m = 0;
     if (inside) {
-      const int hl = (int)floorf(h_im), wl = (int)floorf(w_im), hh = hl + 1, wh = wl + 1;
-      const float lh = h_im - hl, lw = w_im - wl, uh = 1.f - lh, uw = 1.f - lw;
+      const int hl = (int)floor_t(h_im), wl = (int)floor_t(w_im), hh = hl + 1, wh = wl + 1;
+      const T lh = h_im - hl, lw = w_im - wl, uh = (T)1 - lh, uw = (T)1 - lw;
       const bool t_ok = hl >= 0, b_ok = hh <= g.H - 1, l_ok = wl >= 0, r_ok = wh <= g.W - 1;
       for (int cc = 0; cc < cpdg; cc++) {
         const int c = dgi * cpdg + cc;
-        const float top = gcol[(((size_t)c * taps + t) * g.B + b) * P + p];
-        const float* xp = x + ((size_t)b * g.C + c) * g.H * g.W;
-        float* gp = grad_x + ((size_t)b * g.C + c) * g.H * g.W;
-        const float v1 = (t_ok && l_ok) ? xp[hl * g.W + wl] : 0.f;
-        const float v2 = (t_ok && r_ok) ? xp[hl * g.W + wh] : 0.f;
-        const float v3 = (b_ok && l_ok) ? xp[hh * g.W + wl] : 0.f;
-        const float v4 = (b_ok && r_ok) ? xp[hh * g.W + wh] : 0.f;
-        const float tm = top * m;
+        const T top = gcol[(((size_t)c * taps + t) * g.B + b) * P + p];
+        const T* xp = x + ((size_t)b * g.C + c) * g.H * g.W;
+        T* gp = grad_x + ((size_t)b * g.C + c) * g.H * g.W;
+        const T v1 = (t_ok && l_ok) ? xp[hl * g.W + wl] : (T)0;
+        const T v2 = (t_ok && r_ok) ? xp[hl * g.W + wh] : (T)0;
+        const T v3 = (b_ok && l_ok) ? xp[hh * g.W + wl] : (T)0;
+        const T v4 = (b_ok && r_ok) ? xp[hh * g.W + wh] : (T)0;
+        const T tm = top * m;
         if (t_ok && l_ok) atomicAdd(gp + hl * g.W + wl, uh * uw * tm);
         if (t_ok && r_ok) atomicAdd(gp + hl * g.W + wh, uh * lw * tm);
         if (b_ok && l_ok) atomicAdd(gp + hh * g.W + wl, lh * uw * tm);
@@ -167,21 +174,50 @@ inline int fill(Geo& g, int B, int C, int H, int W, int kh, int kw, int sh, int 
   return (g.Ho > 0 && g.Wo > 0) ? ORP_OK : ORP_EINVAL;
 }
 inline int blocks_for(long total) { long b = (total + 255) / 256; if (b > 256L * 64) b = 256L * 64; return (int)(b < 1 ? 1 : b); }
+
+template <typename T>
+int im2col_any(const T* input, const T* offset, const T* mask, int batch, int c_in, int height, int width, int kh, int kw,
+               int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int deformable_groups, T* columns, void* stream) {
+  Geo g;
+  if (!input || !offset || !columns) return ORP_EINVAL;
+  int rc = fill(g, batch, c_in, height, width, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, deformable_groups);
+  if (rc != ORP_OK) return rc;
+  OrpProfScope prof(ORP_PROF_DCN_BWD, (hipStream_t)stream);
+  hipLaunchKernelGGL(dcn_im2col_kernel<T>, dim3(blocks_for((long)c_in * batch * g.Ho * g.Wo)), dim3(256), 0,
+                     (hipStream_t)stream, input, offset, mask, g, columns);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
+template <typename T>
+int col2im_any(const T* grad_columns, const T* input, const T* offset, const T* mask, int batch, int c_in, int height, int width,
+               int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int deformable_groups,
+               T* grad_input, T* grad_offset, T* grad_mask, void* stream) {
+  Geo g;
+  if (!grad_columns || !input || !offset || !grad_input || !grad_offset) return ORP_EINVAL;
+  if ((mask == nullptr) != (grad_mask == nullptr)) return ORP_EINVAL;
+  int rc = fill(g, batch, c_in, height, width, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, deformable_groups);
+  if (rc != ORP_OK) return rc;
+  OrpProfScope prof(ORP_PROF_DCN_BWD, (hipStream_t)stream);
+  hipLaunchKernelGGL(dcn_col2im_kernel<T>, dim3(blocks_for((long)batch * deformable_groups * kh * kw * g.Ho * g.Wo)),
+                     dim3(256), 0, (hipStream_t)stream, grad_columns, input, offset, mask, g, grad_input, grad_offset,
+                     grad_mask);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ORP_OK : (int)e;
+}
 }  // namespace
 
 extern "C" {
 int orp_dcn_im2col(const float* input, const float* offset, const float* mask, int batch, int c_in, int height,
                    int width, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                    int deformable_groups, float* columns, void* stream) {
-  Geo g;
-  if (!input || !offset || !columns) return ORP_EINVAL;
-  int rc = fill(g, batch, c_in, height, width, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, deformable_groups);
-  if (rc != ORP_OK) return rc;
-  OrpProfScope prof(ORP_PROF_DCN_BWD, (hipStream_t)stream);
-  hipLaunchKernelGGL(dcn_im2col_kernel, dim3(blocks_for((long)c_in * batch * g.Ho * g.Wo)), dim3(256), 0,
-                     (hipStream_t)stream, input, offset, mask, g, columns);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? ORP_OK : (int)e;
+  return im2col_any<float>(input, offset, mask, batch, c_in, height, width, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
+                           deformable_groups, columns, stream);
+}
+int orp_dcn_im2col_f64(const double* input, const double* offset, const double* mask, int batch, int c_in, int height,
+                       int width, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                       int deformable_groups, double* columns, void* stream) {
+  return im2col_any<double>(input, offset, mask, batch, c_in, height, width, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
+                            deformable_groups, columns, stream);
 }
 
 // grad_input must be ZEROED by the caller (it is accumulated with atomics); grad_offset / grad_mask are overwritten.
@@ -189,17 +225,15 @@ int orp_dcn_col2im(const float* grad_columns, const float* input, const float* o
                    int c_in, int height, int width, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
                    int dil_h, int dil_w, int deformable_groups, float* grad_input, float* grad_offset, float* grad_mask,
                    void* stream) {
-  Geo g;
-  if (!grad_columns || !input || !offset || !grad_input || !grad_offset) return ORP_EINVAL;
-  if ((mask == nullptr) != (grad_mask == nullptr)) return ORP_EINVAL;
-  int rc = fill(g, batch, c_in, height, width, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, deformable_groups);
-  if (rc != ORP_OK) return rc;
-  OrpProfScope prof(ORP_PROF_DCN_BWD, (hipStream_t)stream);
-  hipLaunchKernelGGL(dcn_col2im_kernel, dim3(blocks_for((long)batch * deformable_groups * kh * kw * g.Ho * g.Wo)),
-                     dim3(256), 0, (hipStream_t)stream, grad_columns, input, offset, mask, g, grad_input, grad_offset,
-                     grad_mask);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? ORP_OK : (int)e;
+  return col2im_any<float>(grad_columns, input, offset, mask, batch, c_in, height, width, kh, kw, stride_h, stride_w, pad_h, pad_w,
+                           dil_h, dil_w, deformable_groups, grad_input, grad_offset, grad_mask, stream);
+}
+int orp_dcn_col2im_f64(const double* grad_columns, const double* input, const double* offset, const double* mask, int batch,
+                       int c_in, int height, int width, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                       int dil_h, int dil_w, int deformable_groups, double* grad_input, double* grad_offset, double* grad_mask,
+                       void* stream) {
+  return col2im_any<double>(grad_columns, input, offset, mask, batch, c_in, height, width, kh, kw, stride_h, stride_w, pad_h, pad_w,
+                            dil_h, dil_w, deformable_groups, grad_input, grad_offset, grad_mask, stream);
 }
 
 // Channel-parallel variant (deformable_groups = 1): grad_columns_t [B*Ho*Wo, kh*kw, C] (position-major), input and

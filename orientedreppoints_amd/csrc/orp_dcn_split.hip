@@ -744,27 +744,43 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
 }
 
 // ================================================================================================================================
-// Round 6: the same tile, WAVE-SPECIALISED (fp16-pieces mode only).
+// Round 6: the same tile, WAVE-SPECIALISED (fp16-pieces mode only; ORP_DCNS_WS=1 -- built, measured, NOT the default).
 //
 // The kernel above gives every wave every job: gather rows, combine / split them into LDS, read A fragments, stream its 32 output
-// channels' weights, issue MFMAs -- and the two waves of a SIMD do the same job at the same time (one barrier per phase keeps them in
-// step), so the matrix pipe waits while both run their VALU / VMEM part and the VALU idles while both issue MFMAs.  Its anatomy
-//  found nothing saturated: matrix pipe 0.41, L1 ~0.55, LDS ~0.2 -- work that does not overlap.  Here the 8 waves
-// split into 4 CONSUMERS (waves 0-3, one per SIMD: A fragments from LDS, weights from L2, MFMAs, epilogue; each owns the whole tile
-// height x 64 output channels = MT x 2 accumulator blocks) and 4 PRODUCERS (waves 4-7, the other wave of each SIMD: row gathers two
-// phases ahead, bilinear combine / GroupNorm-on-the-way-in, fp16 split, LDS writes).  A SIMD's matrix pipe is fed by one wave whose
-// instruction stream is MFMAs plus 10 loads per 18 of them, next to a wave that issues only VALU / VMEM / DS: the pairing the
-// hardware overlaps (MI355X guide, "Two waves per SIMD").  Every A fragment is now read by 4 waves instead of 8 (LDS read traffic per
-// phase 196 -> 98 KB), the weight stream is unchanged (each consumer streams its own 64 channels once per tile).
-// Same tile table, same arithmetic per output element as the symmetric kernel WITHOUT side accumulators: the three products of a
-// 16-channel chunk are added lo*hi, hi*lo, hi*hi into one fp32 accumulator, chunks in order -- bit-identical to the symmetric kernel's
-// DeformConv instantiation; the PLAIN instantiation there kept the two small products in a second accumulator set (no registers for
-// that here: 6 blocks x 16), tests/test_gpu_conv_split.py holds both to the same gates.
+// channels' weights, issue MFMAs -- and the two waves of a SIMD do the same job at the same time.  Here the 8 waves split into 4
+// CONSUMERS (waves 0-3, one per SIMD: A fragments from LDS, weights from L2, MFMAs, epilogue; each owns the whole tile height x 64
+// output channels = MT x 2 accumulator blocks) and 4 PRODUCERS (waves 4-7, the other wave of each SIMD: row gathers two phases
+// ahead, bilinear combine / GroupNorm-on-the-way-in, fp16 split, LDS writes).  Every A fragment is read by 4 waves instead of 8 (LDS
+// read traffic per phase 196 -> 98 KB), the weight stream is unchanged.  The two roles are two separate loops, so the kernel needs
+// max(consumer, producer) registers; A fragments and weights are refilled in place behind the MFMAs that read them.
+//
+// What the measurements say (profiles/r06_ws_anatomy.log; pair launches at 1024^2, us incl. the range pre-pass and the host's launch
+// gap, symmetric kernel 242 DeformConv / 185 convolution):
+//   * as first written 315 / 232: the producers' VALU starves beside the consumers' MFMAs (issue arbitration is priority, then age).
+//     s_setprio 3 on the producers: 244 / 175.  The DeformConv launch gains nothing -- its producers (349 VALU + 24 row fetches per
+//     wave and phase) take as long as a phase's 72 MFMAs --, the convolution gains 5 %.
+//   * consumers alone 178 / 166, consumers without weight refills 158 / 148, consumers issuing nothing but MFMAs 156 / 146: the tile
+//     structure's floor (2 tiles per CU, 2 592 MFMAs per SIMD and tile at the ~1.4 GHz the part sustains under dense MFMAs, plus
+//     prologue / epilogue) is ~146 us -- the symmetric kernel's 180 us of the bench is within 20 % of it.
+//   * L2: 93 % hits, 132 cycles average read latency, 11 TB/s of 34 (profiles/r06_l2_counters.log): not the bound.
+// Why it is not the default: the convolution instantiation of the symmetric kernel keeps the two small partial products in a second
+// accumulator set (SIDE); a consumer would need 2 x 96 accumulator registers + fragments > 256 (the attempt spills inside the MFMA
+// loop), and without SIDE the error against float64 is 1.28e-6 where tests/test_gpu_conv_split.py admits 1.20e-6 (1.5 x the library's
+// own).  The DeformConv instantiation is bit-identical to the symmetric kernel's (same products, same order, no SIDE there).
 #ifndef ORP_WS_PRIO
 #define ORP_WS_PRIO 0                // dev aid: s_setprio of the consumer waves (0: none)
 #endif
+#ifndef ORP_WS_SIDE
+#define ORP_WS_SIDE 0                // PLAIN: second accumulator set for the small partial products
+#endif
+#ifndef ORP_WS_PPRIO
+#define ORP_WS_PPRIO 3               // s_setprio of the producer waves: without it their VALU starves beside the consumers' MFMAs (pair launch 314 us, with it 243)
+#endif
+#ifndef ORP_WS_ROT
+#define ORP_WS_ROT 0
+#endif
 #ifndef ORP_WS_DBG
-#define ORP_WS_DBG 0                 // dev aid (timing only, wrong results): 1 = producers idle, 2 = consumers issue no MFMA, 4 = no weight refills, 8 = no A-fragment reads
+#define ORP_WS_DBG 0                 // dev aid (timing only, wrong results): 1 = producers idle, 2 = consumers issue no MFMA, 4 = no weight refills, 8 = no A-fragment reads, 16 = producers: no gathers, 32 = producers: gathers only (no combine / split / LDS write)
 #endif
 
 template <int MT, bool OUT_NCHW, bool PLAIN>
@@ -890,6 +906,14 @@ dcn_fwd_split_ws_kernel(const FwdS P, int total_tiles) {
 
   const int ncb = P.Cin / CBS;
   const int nphase = taps * ncb;
+#if ORP_WS_ROT
+  // dev aid (hypothesis test): the workgroups walk the channel blocks in rotated orders, so that at any moment the CUs of an XCD read
+  // different 256-byte columns of the 1 KB input rows (L2 channel = address bits above the 256-byte piece?)
+  const int rot = (tile * ORP_WS_ROT) % ncb;
+  auto phys = [&](int cb) { const int c = cb + rot; return c >= ncb ? c - ncb : c; };
+#else
+  auto phys = [&](int cb) { return cb; };
+#endif
   const bool consumer = wave < 4;                                              // (waves w and w + 4 share a SIMD: one of each role per SIMD)
   const int wq = wave & 3;
 
@@ -898,7 +922,7 @@ dcn_fwd_split_ws_kernel(const FwdS P, int total_tiles) {
   auto row_of = [&](int g) { return g * 16 + wq * 4 + q4; };
   auto gather_issue = [&](int tap, int cb, int g, float4 (&v)[NB]) {
     const int4 ix = sCi[row_of(g) * taps + tap];
-    const float* base = xin + cb * CBS + c4;
+    const float* base = xin + phys(cb) * CBS + c4;
     v[0] = *reinterpret_cast<const float4*>(base + (size_t)ix.x * P.Cin);
     if constexpr (!PLAIN) {
       v[1] = *reinterpret_cast<const float4*>(base + (size_t)ix.y * P.Cin);
@@ -914,8 +938,8 @@ dcn_fwd_split_ws_kernel(const FwdS P, int total_tiles) {
       const bool in = cw.x != 0.f;
       float4 x = v[0];
       if (has_coef) {
-        const float4 ca = *reinterpret_cast<const float4*>(sAB + cbk * CBS + c4);
-        const float4 cb_ = *reinterpret_cast<const float4*>(sAB + P.Cin + cbk * CBS + c4);
+        const float4 ca = *reinterpret_cast<const float4*>(sAB + phys(cbk) * CBS + c4);
+        const float4 cb_ = *reinterpret_cast<const float4*>(sAB + P.Cin + phys(cbk) * CBS + c4);
         x.x = fmaf(x.x, ca.x, cb_.x); x.y = fmaf(x.y, ca.y, cb_.y); x.z = fmaf(x.z, ca.z, cb_.z); x.w = fmaf(x.w, ca.w, cb_.w);
         if (P.relu_in) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
       }
@@ -949,7 +973,7 @@ dcn_fwd_split_ws_kernel(const FwdS P, int total_tiles) {
   const uint16_t* wp = (L.planes ? L.planes : conv ? P.planes[1] : P.planes[0]) + ((size_t)kg * P.Cout + (live ? n_wave : 0) + mrow) * 8;
   const size_t wblk = (size_t)2 * P.Cout * 8;
   auto load_b = [&](int tap, int cb, int j, bf8 (&b)[NT][NPL]) {
-    const uint16_t* a = wp + ((size_t)tap * (P.Cin / 16) + cb * NCH + j) * wblk;
+    const uint16_t* a = wp + ((size_t)tap * (P.Cin / 16) + phys(cb) * NCH + j) * wblk;
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
 #pragma unroll
@@ -982,13 +1006,23 @@ dcn_fwd_split_ws_kernel(const FwdS P, int total_tiles) {
 #pragma unroll
     for (int r = 0; r < RG; r++) combine_store(0, 0, r, gB[r], 0);
     __syncthreads();
+#if ORP_WS_PPRIO
+    __builtin_amdgcn_s_setprio(ORP_WS_PPRIO);
+#endif
     auto produce = [&](int phase, float4 (&g)[RG][NB], float4 (&gf)[RG][NB]) __attribute__((always_inline)) {
       if (!(ORP_WS_DBG & 1)) {
+        if (!(ORP_WS_DBG & 16)) {
 #pragma unroll
-        for (int r = 0; r < RG; r++) gather_issue(tap_n2, cb_n2, r, gf[r]);    // the rows of phase + 2: a whole phase to land
+          for (int r = 0; r < RG; r++) gather_issue(tap_n2, cb_n2, r, gf[r]);  // the rows of phase + 2: a whole phase to land
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if (!(ORP_WS_DBG & 32)) {
 #pragma unroll
-        for (int r = 0; r < RG; r++) combine_store(tap_n, cb_n, r, g[r], (phase & 1) ^ 1);
+          for (int r = 0; r < RG; r++) combine_store(tap_n, cb_n, r, g[r], (phase & 1) ^ 1);
+        } else {
+#pragma unroll
+          for (int r = 0; r < RG; r++) asm volatile("" :: "v"(g[r][0].x), "v"(g[r][NB - 1].w));
+        }
       }
       step(tap_n, cb_n, phase + 1);
       step(tap_n2, cb_n2, phase + 2);
@@ -1002,57 +1036,84 @@ dcn_fwd_split_ws_kernel(const FwdS P, int total_tiles) {
     return;
   }
 
-  bf8 bq[NCH][NT][NPL];
-  bf8 af[2][MT][NPL];
-  floatx16 acc[MT][NT];
+  // Register plan of a consumer (256 per lane): accumulators MT x NT x 16 = 96; PLAIN: a second set for the two small partial
+  // products (SIDE, as in the symmetric kernel: the main chain then rounds once per 16 channels at the output's magnitude instead of
+  // three times -- the accuracy gate of tests/test_gpu_conv_split.py) = 192.  What is left holds ONE set of A fragments (24) and a weight
+  // ring of BR chunks (16 each).  Both are refilled IN PLACE right behind the MFMAs that read them (an issued MFMA has read its A / B
+  // operands: tests/checks/mfma_war.hip): a chunk's MFMAs run tile row by tile row (mt outer), the A fragments of row mt are re-read
+  // for the next chunk as soon as its 6 MFMAs are out -- 12 MFMAs = 384 cycles before their next use --, the weights of chunk j are
+  // replaced by those of chunk j + BR behind the chunk's last MFMA.
+  constexpr bool SIDE = PLAIN && ORP_WS_SIDE;
+  constexpr int BR = SIDE ? 2 : NCH;                                           // weight ring depth in chunks
+  bf8 bq[BR][NT][NPL];
+  bf8 af[MT][NPL];
+  floatx16 acc[MT][NT], side[SIDE ? MT : 1][SIDE ? NT : 1];
 #pragma unroll
   for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = floatx16{0};
+    for (int nt = 0; nt < NT; nt++) { acc[mt][nt] = floatx16{0}; if (SIDE) side[SIDE ? mt : 0][SIDE ? nt : 0] = floatx16{0}; }
 #pragma unroll
-  for (int j = 0; j < NCH; j++) load_b(0, 0, j, bq[j]);
-  if (ORP_WS_DBG & 8) {
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int pl = 0; pl < NPL; pl++) af[i][mt][pl] = bq[(i + mt) & 3][pl][pl];
-  }
+  for (int j = 0; j < BR; j++) load_b(0, 0, j, bq[j]);
   __syncthreads();
 #if ORP_WS_PRIO
   __builtin_amdgcn_s_setprio(ORP_WS_PRIO);
 #endif
+  int tap_c = 0, cb_c = 0;                                                     // (tap, channel block) of the current phase
+  auto load_a_row = [&](const uint16_t* abase, int j, int mt) {
+#pragma unroll
+    for (int pl = 0; pl < NPL; pl++)
+      if (!(ORP_WS_DBG & 8)) af[mt][pl] = *reinterpret_cast<const bf8*>(abase + (size_t)pl * PLANE + (size_t)mt * 32 * ASTRS + j * 16);
+  };
+  if (ORP_WS_DBG & 8) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++) af[mt][pl] = bq[mt & (BR - 1)][pl][pl];
+  }
 #pragma unroll 1
   for (int phase = 0; phase < nphase; phase++) {
     const uint16_t* abase = sA + (size_t)(phase & 1) * NPL * PLANE + (size_t)mrow * ASTRS + 8 * kg;
-    load_a(abase, 0, af[0]);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) load_a_row(abase, 0, mt);
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
-      if (j + 1 < NCH) load_a(abase, j + 1, af[(j + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(ORP_WS_DBG & 2)) {
 #pragma unroll
-        for (int t = 0; t < 3; t++) {                                          // lo*hi, hi*lo, hi*hi (smallest first)
-          const int pa = t == 0 ? 1 : 0, pb = t == 1 ? 1 : 0;
+      for (int mt = 0; mt < MT; mt++) {
+        if (!(ORP_WS_DBG & 2)) {
 #pragma unroll
-          for (int nt = 0; nt < NT; nt++)
+          for (int t = 0; t < 3; t++) {                                        // lo*hi, hi*lo, hi*hi (smallest first)
+            const int pa = t == 0 ? 1 : 0, pb = t == 1 ? 1 : 0;
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-              const h8 av = __builtin_bit_cast(h8, af[j & 1][mt][pa]), bv = __builtin_bit_cast(h8, bq[j][nt][pb]);
-              if (OUT_NCHW) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, acc[mt][nt], 0, 0, 0);
-              else          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; nt++) {
+              floatx16& d = (SIDE && t < 2) ? side[SIDE ? mt : 0][SIDE ? nt : 0] : acc[mt][nt];
+              const h8 av = __builtin_bit_cast(h8, af[mt][pa]), bv = __builtin_bit_cast(h8, bq[j % BR][nt][pb]);
+              if (OUT_NCHW) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, d, 0, 0, 0);
+              else          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, d, 0, 0, 0);
             }
+          }
+        } else {
+          acc[0][0][0] += (float)af[mt][0][0] * (float)bq[j % BR][0][0][0];
         }
-      } else {
-        acc[0][0][0] += (float)af[j & 1][0][0][0] * (float)bq[j][0][0][0];
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < NCH) load_a_row(abase, j + 1, mt);                          // in place, for the next chunk
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!(ORP_WS_DBG & 4)) {                                                 // the ring slot of chunk j takes chunk j + BR (of the next phase when past this one's end)
+        if (j + BR < NCH) load_b(tap_c, cb_c, j + BR, bq[j % BR]);
+        else              load_b(tap_n, cb_n, j + BR - NCH, bq[j % BR]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (!(ORP_WS_DBG & 4)) load_b(tap_n, cb_n, j, bq[j]);                    // refilled in place for the next phase
-      __builtin_amdgcn_sched_barrier(0);
     }
+    tap_c = tap_n; cb_c = cb_n;
     step(tap_n, cb_n, phase + 1);
     __syncthreads();
+  }
+  if (SIDE) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[mt][nt] += side[SIDE ? mt : 0][SIDE ? nt : 0];
   }
 
   // ---- epilogue (consumers) ------------------------------------------------------------------------------------------------------
@@ -1134,7 +1195,7 @@ constexpr size_t split_smem() {
   return (size_t)2 * NPL * 32 * MT * ASTRS * 2 + (sizeof(float4) + sizeof(int4)) * 32 * MT * kTapsMax + sizeof(float) * 2 * kCoefCinMax;
 }
 
-static const int g_ws = getenv("ORP_DCNS_WS") ? atoi(getenv("ORP_DCNS_WS")) : 1;   // 0: the symmetric kernel also in the fp16-pieces mode (A/B timing)
+static const int g_ws = getenv("ORP_DCNS_WS") ? atoi(getenv("ORP_DCNS_WS")) : 0;   // 1: the wave-specialised kernel in the fp16-pieces mode (measured, not the default: see its header)
 
 template <int MT, int NPROD, bool OUT_NCHW, bool PLAIN>
 hipError_t launch_one(const FwdS& P, int tiles, int nblk_n, hipStream_t st) {

@@ -152,6 +152,55 @@ __global__ void focal_bwd_kernel(const float* __restrict__ logits, const int64_t
 }
 
 
+// scalar_t = double (AT_DISPATCH_FLOATING_TYPES, sigmoid_focal_loss_cuda.cu:121,160): the reference's templated expressions keep
+// their SINGLE-precision transcendental calls (expf / logf / powf take a float argument and return a float) inside double
+// arithmetic; restated with every implicit conversion written out
+__global__ void focal_fwd_kernel_f64(const double* __restrict__ logits, const int64_t* __restrict__ targets, long total,
+                                     int classes, float gamma, float alpha, double* __restrict__ losses) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / classes), d = (int)(i % classes);
+    const int t = (int)targets[n];
+    const double c1 = (t == (d + 1));
+    const double c2 = (t >= 0 & t != (d + 1));
+    const double zn = (1.0 - alpha);
+    const double zp = alpha;
+    const double x = logits[i];
+    const double p = 1. / (1. + (double)expf((float)-x));
+    const double term1 = (double)powf((float)(1. - p), gamma) * (double)logf((float)fmax(p, (double)FLT_MIN));
+    const double term2 = (double)powf((float)p, gamma) *
+                         (-1. * x * (x >= 0) - (double)logf((float)(1. + (double)expf((float)(x - 2. * x * (x >= 0))))));
+    double l = 0.0;
+    l += -c1 * term1 * zp;
+    l += -c2 * term2 * zn;
+    losses[i] = l;
+  }
+}
+
+__global__ void focal_bwd_kernel_f64(const double* __restrict__ logits, const int64_t* __restrict__ targets,
+                                     const double* __restrict__ d_losses, long total, int classes, float gamma, float alpha,
+                                     double* __restrict__ d_logits) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / classes), d = (int)(i % classes);
+    const int t = (int)targets[n];
+    const double c1 = (t == (d + 1));
+    const double c2 = (t >= 0 & t != (d + 1));
+    const double zn = (1.0 - alpha);
+    const double zp = alpha;
+    const double x = logits[i];
+    const double p = 1. / (1. + (double)expf((float)-x));
+    const double term1 = (double)powf((float)(1. - p), gamma) * (1. - p - (p * gamma * (double)logf((float)fmax(p, (double)FLT_MIN))));
+    const double term2 = (double)powf((float)p, gamma) *
+                         ((-1. * x * (x >= 0) - (double)logf((float)(1. + (double)expf((float)(x - 2. * x * (x >= 0)))))) *
+                              (1. - p) * gamma -
+                          p);
+    double g = 0.0;
+    g += -c1 * term1 * zp;
+    g += -c2 * term2 * zn;
+    d_logits[i] = g * d_losses[i];
+  }
+}
+
+
 // ---- segment losses ---------------------------------------------------------------------------------------------------
 // border: per row (a positive point set and its gt quad), over the points OUTSIDE the quad (pointsJf == 0; rows with
 // weight <= 0 do not count): sum of 0.2 * |p - centre|, their number, and d(0.2 |p - c|)/dp for the backward pass.
@@ -321,6 +370,26 @@ int orp_sigmoid_focal_loss_backward(const float* logits, const int64_t* targets,
   if (!logits || !targets || !d_losses || !d_logits) return ORP_EINVAL;
   const long total = (long)num * classes;
   hipLaunchKernelGGL(focal_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, logits, targets,
+                     d_losses, total, classes, gamma, alpha, d_logits);
+  return done();
+}
+int orp_sigmoid_focal_loss_forward_f64(const double* logits, const int64_t* targets, int num, int classes, float gamma,
+                                       float alpha, double* losses, void* stream) {
+  if (num < 0 || classes < 0) return ORP_EINVAL;
+  if (num == 0 || classes == 0) return ORP_OK;
+  if (!logits || !targets || !losses) return ORP_EINVAL;
+  const long total = (long)num * classes;
+  hipLaunchKernelGGL(focal_fwd_kernel_f64, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, logits, targets,
+                     total, classes, gamma, alpha, losses);
+  return done();
+}
+int orp_sigmoid_focal_loss_backward_f64(const double* logits, const int64_t* targets, const double* d_losses, int num,
+                                        int classes, float gamma, float alpha, double* d_logits, void* stream) {
+  if (num < 0 || classes < 0) return ORP_EINVAL;
+  if (num == 0 || classes == 0) return ORP_OK;
+  if (!logits || !targets || !d_losses || !d_logits) return ORP_EINVAL;
+  const long total = (long)num * classes;
+  hipLaunchKernelGGL(focal_bwd_kernel_f64, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, logits, targets,
                      d_losses, total, classes, gamma, alpha, d_logits);
   return done();
 }

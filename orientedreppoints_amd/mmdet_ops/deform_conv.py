@@ -404,7 +404,12 @@ class DeformConvFunction(Function):
             raise NotImplementedError
         cur_im2col_step = min(ctx.im2col_step, input.shape[0])
         assert (input.shape[0] % cur_im2col_step) == 0, 'im2col step must divide batchsize'
-        if fast_path_ok(weight, groups, deformable_groups):
+        from . import deform_conv_backward as bw
+        if bw.is_f64(input, offset, weight):
+            # the `double` branch of AT_DISPATCH_FLOATING_TYPES_AND_HALF (deform_conv_cuda_kernel.cu:259): computed in double
+            out = bw.forward_columns(input, offset, None, weight, None, ctx.stride, ctx.padding, ctx.dilation, groups,
+                                     deformable_groups)
+        elif fast_path_ok(weight, groups, deformable_groups):
             out = deform_conv_forward_multi([input], [offset], weight, ctx.stride, ctx.padding, ctx.dilation,
                                             cache_pack=not ctx.needs_input_grad[2])[0]
         else:
@@ -459,7 +464,11 @@ class ModulatedDeformConvFunction(Function):
             raise NotImplementedError
         if weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad:
             ctx.save_for_backward(input, offset, mask, weight, bias if bias is not None else input.new_empty(1))
-        if fast_path_ok(weight, groups, deformable_groups):
+        from . import deform_conv_backward as bw
+        if bw.is_f64(input, offset, mask, weight):
+            out = bw.forward_columns(input, offset, mask, weight, bias, _pair(stride), _pair(padding), _pair(dilation), groups,
+                                     deformable_groups)
+        elif fast_path_ok(weight, groups, deformable_groups):
             # DCNv2 on the MFMA implicit GEMM: the modulation scalar is folded into the bilinear weights of the tile
             out = deform_conv_forward_multi([input], [offset], weight, stride, padding, dilation, masks=[mask],
                                             bias=bias, cache_pack=not ctx.needs_input_grad[3])[0]

@@ -96,9 +96,10 @@ def _geo(input, weight, stride, padding, dilation):
 
 def _im2col(input, offset, mask, weight, stride, padding, dilation, dg):
     B, C, H, W, kh, kw, Ho, Wo = _geo(input, weight, stride, padding, dilation)
-    col = torch.empty((C * kh * kw, B * Ho * Wo), dtype=torch.float32, device=input.device)
+    col = torch.empty((C * kh * kw, B * Ho * Wo), dtype=input.dtype, device=input.device)
+    fn = _lib.lib().orp_dcn_im2col_f64 if input.dtype == torch.float64 else _lib.lib().orp_dcn_im2col
     with torch.cuda.device(input.device):
-        rc = _lib.lib().orp_dcn_im2col(_lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), B, C, H, W, kh, kw, stride[0],
+        rc = fn(_lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), B, C, H, W, kh, kw, stride[0],
                                        stride[1], padding[0], padding[1], dilation[0], dilation[1], dg, _lib.ptr(col),
                                        _lib.stream_of(input))
     _lib.check(rc, "orp_dcn_im2col")
@@ -118,8 +119,9 @@ def _col2im(gcol, input, offset, mask, weight, stride, padding, dilation, dg):
     grad_input = torch.zeros_like(input)
     grad_offset = torch.empty_like(offset)
     grad_mask = torch.empty_like(mask) if mask is not None else None
+    fn = _lib.lib().orp_dcn_col2im_f64 if input.dtype == torch.float64 else _lib.lib().orp_dcn_col2im
     with torch.cuda.device(input.device):
-        rc = _lib.lib().orp_dcn_col2im(_lib.ptr(gcol), _lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), B, C, H, W, kh,
+        rc = fn(_lib.ptr(gcol), _lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), B, C, H, W, kh,
                                        kw, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], dg,
                                        _lib.ptr(grad_input), _lib.ptr(grad_offset), _lib.ptr(grad_mask),
                                        _lib.stream_of(input))
@@ -127,8 +129,28 @@ def _col2im(gcol, input, offset, mask, weight, stride, padding, dilation, dg):
     return grad_input, grad_offset, grad_mask
 
 
+def is_f64(*ts):
+    """float64 tensors take the `double` branch of the reference's dispatch: the column formulation in double."""
+    return any(t is not None and t.dtype == torch.float64 for t in ts)
+
+
 def _prep(*ts):
-    return [t.detach().float().contiguous() if t is not None else None for t in ts]
+    dt = torch.float64 if is_f64(*ts) else torch.float32
+    return [t.detach().to(dt).contiguous() if t is not None else None for t in ts]
+
+
+def forward_columns(input, offset, mask, weight, bias, stride, padding, dilation, groups, deformable_groups):
+    """The reference's own forward formulation (deform_conv_cuda.cpp:152-260, 490-567): columns = deformable_im2col (x mask),
+    out = W . columns per group (+ bias) -- used for float64 tensors (sampling kernel here, double GEMM from the library)."""
+    x, off, m, w, b = _prep(input, offset, mask, weight, bias)
+    B, C, H, W, kh, kw, Ho, Wo = _geo(x, w, stride, padding, dilation)
+    Cout = w.size(0)
+    col = _im2col(x, off, m, w, stride, padding, dilation, deformable_groups)
+    out = torch.bmm(w.reshape(groups, Cout // groups, -1), col.reshape(groups, -1, B * Ho * Wo))
+    out = out.reshape(Cout, B, Ho, Wo).permute(1, 0, 2, 3).contiguous()
+    if b is not None:
+        out += b[None, :, None, None]
+    return out
 
 
 def _backward_input_nhwc(input, offset, weight, grad_output, stride, padding, dilation):
@@ -151,6 +173,12 @@ def _backward_input_nhwc(input, offset, weight, grad_output, stride, padding, di
 
 
 def backward_input(input, offset, weight, grad_output, stride, padding, dilation, groups, deformable_groups):
+    if is_f64(input, offset, weight, grad_output):
+        dt, dto = input.dtype, offset.dtype
+        x, off, w, go = _prep(input, offset, weight, grad_output)
+        gcol = _grad_columns(w, go, groups)
+        gi, goff, _ = _col2im(gcol, x, off, None, w, stride, padding, dilation, deformable_groups)
+        return gi.to(dt), goff.to(dto)
     if mfma_ok(weight, groups, deformable_groups):
         gi, go, _ = backward_mfma([input], [offset], weight, [grad_output], stride, padding, dilation, True, False)
         return gi[0], go[0]
@@ -165,7 +193,7 @@ def backward_input(input, offset, weight, grad_output, stride, padding, dilation
 
 
 def backward_parameters(input, offset, weight, grad_output, stride, padding, dilation, groups, deformable_groups):
-    if mfma_ok(weight, groups, deformable_groups):
+    if not is_f64(input, offset, weight, grad_output) and mfma_ok(weight, groups, deformable_groups):
         return backward_mfma([input], [offset], weight, [grad_output], stride, padding, dilation, False, True)[2]
     dt = weight.dtype
     input, offset, weight, grad_output = _prep(input, offset, weight, grad_output)
@@ -182,7 +210,7 @@ def _grad_weight(col, weight, grad_output, groups):
 
 def modulated_backward(input, offset, mask, weight, grad_output, stride, padding, dilation, groups, deformable_groups,
                        with_bias):
-    if mfma_ok(weight, groups, deformable_groups):
+    if not is_f64(input, offset, mask, weight, grad_output) and mfma_ok(weight, groups, deformable_groups):
         # DCNv2 on the MFMA implicit GEMMs (orp_dcn_backward_multi_ex): the modulation rides in the sample weights
         gis, gos, gw, gms = backward_mfma([input], [offset], weight, [grad_output], stride, padding, dilation, True, True,
                                           masks=[mask])
@@ -195,7 +223,7 @@ def modulated_backward(input, offset, mask, weight, grad_output, stride, padding
     col = _im2col(input, offset, mask, weight, stride, padding, dilation, deformable_groups)
     gw = _grad_weight(col, weight, grad_output, groups)
     gb = grad_output.sum(dim=(0, 2, 3)) if with_bias else None
-    if dt != torch.float32:
+    if dt != input.dtype:
         gi, go, gm, gw = gi.to(dt), go.to(dt), gm.to(dt), gw.to(dt)
         gb = gb.to(dt) if gb is not None else None
     return gi, go, gm, gw, gb

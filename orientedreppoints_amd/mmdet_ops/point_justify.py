@@ -15,8 +15,17 @@ def pointsJf(points, polygons, output):
     if points.size(1) != 2:
         print("wrong points size")
         return 0
-    if points.dtype != torch.float32 or polygons.dtype != torch.float32 or output.dtype != torch.float32:
-        raise TypeError("pointsJf: float32 tensors only")
+    dts = {points.dtype, polygons.dtype, output.dtype}
+    if dts == {torch.float64}:
+        # scalar_t = double of AT_DISPATCH_FLOATING_TYPES (points_justify_kernel.cu:107): the kernel copies every coordinate into a
+        # `struct point { float x, y; }` (:20-23, 36-50) and tests in float -- so the double instantiation IS the float arithmetic on
+        # the rounded coordinates, its 0 / 1 flags stored as double.  Same here, bit for bit.
+        out32 = torch.empty(output.shape, dtype=torch.float32, device=output.device)
+        r = pointsJf(points.float(), polygons.float(), out32)
+        output.copy_(out32)
+        return r
+    if dts != {torch.float32}:
+        raise TypeError("pointsJf: float32 (or all-float64) tensors only")
     rows, cols = points.size(0), polygons.size(0)
     with torch.cuda.device(points.device):
         rc = _lib.lib().orp_points_justify(_lib.ptr(points), rows, _lib.ptr(polygons), cols, _lib.ptr(output),

@@ -16,15 +16,15 @@ class _FocalExt(object):
         assert logits.dim() == 2, "logits should be NxClass"
         x = logits.contiguous()
         t = targets.contiguous()
-        if x.dtype != torch.float32:
-            raise TypeError("sigmoid_focal_loss: float32 logits only")
+        if x.dtype not in (torch.float32, torch.float64):        # AT_DISPATCH_FLOATING_TYPES (sigmoid_focal_loss_cuda.cu:121)
+            raise TypeError("sigmoid_focal_loss: float32 / float64 logits only")
         if t.dtype != torch.long:
             t = t.long()
         losses = torch.empty_like(x)
+        fn = _lib.lib().orp_sigmoid_focal_loss_forward if x.dtype == torch.float32 else _lib.lib().orp_sigmoid_focal_loss_forward_f64
         with torch.cuda.device(x.device):
-            rc = _lib.lib().orp_sigmoid_focal_loss_forward(_lib.ptr(x), _lib.ptr(t), x.size(0), x.size(1),
-                                                           float(gamma), float(alpha), _lib.ptr(losses),
-                                                           _lib.stream_of(x))
+            rc = fn(_lib.ptr(x), _lib.ptr(t), x.size(0), x.size(1), float(gamma), float(alpha), _lib.ptr(losses),
+                    _lib.stream_of(x))
         _lib.check(rc, "orp_sigmoid_focal_loss_forward")
         return losses
 
@@ -37,12 +37,14 @@ class _FocalExt(object):
         t = targets.contiguous()
         if t.dtype != torch.long:
             t = t.long()
-        g = d_losses.contiguous()
+        if x.dtype not in (torch.float32, torch.float64):
+            raise TypeError("sigmoid_focal_loss: float32 / float64 logits only")
+        g = d_losses.to(x.dtype).contiguous()
         d_logits = torch.zeros_like(x)
+        fn = _lib.lib().orp_sigmoid_focal_loss_backward if x.dtype == torch.float32 else _lib.lib().orp_sigmoid_focal_loss_backward_f64
         with torch.cuda.device(x.device):
-            rc = _lib.lib().orp_sigmoid_focal_loss_backward(_lib.ptr(x), _lib.ptr(t), _lib.ptr(g), x.size(0),
-                                                            x.size(1), float(gamma), float(alpha),
-                                                            _lib.ptr(d_logits), _lib.stream_of(x))
+            rc = fn(_lib.ptr(x), _lib.ptr(t), _lib.ptr(g), x.size(0), x.size(1), float(gamma), float(alpha),
+                    _lib.ptr(d_logits), _lib.stream_of(x))
         _lib.check(rc, "orp_sigmoid_focal_loss_backward")
         return d_logits
 

@@ -188,3 +188,37 @@ def test_one_outlier_channel_inside_a_tensor(dev, oracle, split, log2_ratio):
     conftest.REPORT.append("DeformConv, one input channel 2^%d x the others, error of the output channels that do not read it / their own "
                            "scale: exact-fp32 %.2e, 9 products %.2e, 6 products %.2e, two fp16 pieces %.2e"
                            % (log2_ratio, errs[0], errs[9], errs[6], errs[3]))
+
+
+def test_wave_specialised_kernel_as_a_switch():
+    """ORP_DCNS_WS=1 (csrc/orp_dcn_split.hip, round 6: 4 consumer + 4 producer waves per tile; measured, not the default): the
+    DeformConv tests of this file and the convolution-vs-float64 test pass on it in a fresh process.  Its DeformConv instantiation
+    is bit-identical to the default kernel's (same products, same order); the convolution instantiation has no side accumulators
+    and is held to 1e-5 here (the default kernel's tighter gate, 1.5 x the library's own error, is why it is not the default)."""
+    import subprocess
+    env = dict(os.environ, ORP_DCNS_WS="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                          os.path.join(here, "test_gpu_dcn_split.py"), "-k", "forward_vs_oracle or pair_launch or modulated or pieces_are_exact",
+                          os.path.join(here, "test_gpu_conv_split.py") + "::test_conv_split_vs_oracle_and_float64",
+                          os.path.join(here, "test_gpu_conv_split.py") + "::test_tower_layers_with_groupnorm_fused_around_the_convolutions"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:]
+
+
+def test_wave_specialised_deformconv_is_bitwise_the_default_kernel(dev):
+    """Both kernels in two fresh processes on the same seeded head-shaped pair launch: identical bits."""
+    import subprocess
+    code = ("import torch,hashlib,sys;sys.path.insert(0,%r);from orientedreppoints_amd.mmdet_ops import deform_conv_forward_pair as f;"
+            "torch.manual_seed(5);d=torch.device('cuda:0');s=[(40,40),(20,20),(7,9)];"
+            "a=[torch.randn(2,256,h,w,device=d) for h,w in s];b=[torch.randn(2,256,h,w,device=d) for h,w in s];"
+            "o=[torch.randn(2,18,h,w,device=d)*2 for h,w in s];w1=torch.randn(256,256,3,3,device=d)*.02;w2=torch.randn(256,256,3,3,device=d)*.02;"
+            "pa,pb=f(a,b,o,w1,w2,1,1,1,relu=True);print('HASH',hashlib.sha1(b''.join(t.cpu().numpy().tobytes() for t in pa+pb)).hexdigest())"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    hashes = []
+    for ws in ("0", "1"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ORP_DCNS_WS=ws, ORP_DCN_SPLIT="3"), stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:]
+        hashes.append([ln for ln in out.stdout.splitlines() if ln.startswith("HASH")][0])
+    assert hashes[0] == hashes[1]

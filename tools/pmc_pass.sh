@@ -2,7 +2,7 @@
 # usage: tools/pmc_pass.sh <outdir-under-gpurun_out> <which> "<counters>"   (one rocprofv3 --pmc pass, kernel-trace only)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $3 --output-format csv -d $R/gpurun_out/$1 -- python $R/tools/run_hot_kernels.py $2 5 > $R/gpurun_out/$1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc $3 --output-format csv -d $R/gpurun_out/$1 -- python $R/tools/run_hot_kernels.py $2 5 > $R/gpurun_out/$1.log 2>&1
 cd $R
 python - "$1" <<'PY'
 import csv, glob, sys, collections
