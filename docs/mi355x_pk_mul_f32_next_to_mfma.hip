@@ -3,18 +3,20 @@
 // Aggressor (stream 0): v_mfma_f32_32x32x16_bf16 chains + one VALU read of the accumulators per 12 MFMAs, no memory traffic.
 // Victim (stream 1): hipcc's own code for four bilinear weights with border masks (floor, 1 - frac as v_pk_add_f32, the cross
 // products as ONE v_pk_mul_f32 v[4:5], v[8:9], v[4:5] op_sel:[0,1] op_sel_hi:[1,0]), checked against scalar arithmetic.
-// Variant 0 = as compiled; 1 = the packed multiply as two v_mul_f32; 2 = s_nop 3 in front of the packed multiply.
-// Seen on ROCm 7.2.0: variant 0 ~5e6 wrong w.z per 5e10, all in lanes 48..63; variant 1: 0; variant 2: ~3e4; victim alone: 0.
+// Variants: as compiled; the packed multiply as two v_mul_f32; s_nop 0 / 1 / 3 / 7 in front of the packed multiply (the failure is
+// timing dependent: which variant fails moves with code placement -- in the long program tests/checks/mfma_refill_victim.hip it is the
+// as-compiled one, 5e6 wrong per 5e10; here (ROCm 7.2.0, two leases) s_nop 3: 3e3 .. 4e5 wrong per 5e10, ALL w.z in lanes 48..63).
+// The scalar form never fails; no variant fails without the aggressor.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
-__global__ void __launch_bounds__(512) aggressor(int iters, float* sink) {
-  const __bf16 v = (__bf16)(float)((threadIdx.x & 31) % 5 + 1);
-  const bf8 a = {v, v, v, v, v, v, v, v};
+__global__ void __launch_bounds__(512) aggressor(const uint4* __restrict__ gB, int iters, float* sink) {
+  const bf8 a = __builtin_bit_cast(bf8, gB[threadIdx.x & 63]);        // bf16 splat of (lane % 32) % 5 + 1
   floatx16 acc0 = floatx16{0}, acc1 = floatx16{0};
   float keep = 0.f;
   for (int it = 0; it < iters; it++) {
@@ -29,9 +31,14 @@ __global__ void __launch_bounds__(512) aggressor(int iters, float* sink) {
 #define PK0 "v_pk_mul_f32 v[4:5], v[8:9], v[4:5] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
 #define PK1 "v_mul_f32_e32 v19, v8, v5\n\tv_mul_f32_e32 v5, v9, v4\n\tv_mov_b32_e32 v4, v19\n\t"
 #define PK2 "s_nop 3\n\t" PK0
+#define PK3 "s_nop 0\n\t" PK0
+#define PK4 "s_nop 1\n\t" PK0
+#define PK5 "s_nop 7\n\t" PK0
 #define VICTIM(NAME, PK)                                                                                                          \
-  __global__ void __launch_bounds__(512) NAME(int iters, int Hm1, int Wm1, unsigned* __restrict__ bad /* [64 lanes][4 weights] */) { \
+  __global__ void __launch_bounds__(512) NAME(int iters, int Hm1, int Wm1, unsigned* __restrict__ bad /* [64 lanes][4 weights] */, \
+                                              float* __restrict__ sink, int mfma_burst /* 0: never taken */) {                      \
     unsigned seed = (blockIdx.x * 512 + threadIdx.x) * 2654435761u + 12345u, nbad[4] = {0, 0, 0, 0};                               \
+    const __bf16 one = (__bf16)1.f; const bf8 a1 = {one, one, one, one, one, one, one, one}; floatx16 acc = floatx16{0};            \
     for (int it = 0; it < iters; it++) {                                                                                          \
       seed = seed * 1664525u + 1013904223u;                                                                                       \
       const float h_im = -0.999f + (float)(seed >> 8) * (1.f / 16777216.f) * ((float)(Hm1 + 1) + 0.998f);                         \
@@ -58,20 +65,29 @@ __global__ void __launch_bounds__(512) aggressor(int iters, float* sink) {
       const float t = (float)min(hl + 1, 1), b = (float)min(Hm1 - hl, 1), l = (float)min(wl + 1, 1), r = (float)min(Wm1 - wl, 1); \
       nbad[0] += wx != (hh * hw) * (t * l); nbad[1] += wy != (hh * lw) * (t * r);                                                 \
       nbad[2] += wz != (lh * hw) * (b * l); nbad[3] += ww != (lh * lw) * (b * r);                                                 \
+      if (mfma_burst && ((it + (threadIdx.x >> 6) * 7) & 15) == 0)                                                                \
+        for (int u = 0; u < 12; u++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, a1, acc, 0, 0, 0);                          \
     }                                                                                                                             \
     for (int k = 0; k < 4; k++) if (nbad[k]) atomicAdd(&bad[(threadIdx.x & 63) * 4 + k], nbad[k]);                                \
+    if (acc[0] == 12345.f) sink[0] = acc[1];                                                                                      \
   }
 VICTIM(victim_as_compiled, PK0)
 VICTIM(victim_two_v_mul, PK1)
 VICTIM(victim_s_nop_3, PK2)
+VICTIM(victim_s_nop_0, PK3)
+VICTIM(victim_s_nop_1, PK4)
+VICTIM(victim_s_nop_7, PK5)
 
-static void run(const char* name, void (*victim)(int, int, int, unsigned*), int launches, bool with_aggressor) {
-  unsigned* bad; float* sink; hipStream_t s[2];
-  CHK(hipMalloc(&bad, 1024)); CHK(hipMalloc(&sink, 64)); CHK(hipMemset(bad, 0, 1024));
+static void run(const char* name, void (*victim)(int, int, int, unsigned*, float*, int), int launches, bool with_aggressor) {
+  unsigned* bad; float* sink; uint4* gB; hipStream_t s[2];
+  CHK(hipMalloc(&bad, 1024)); CHK(hipMalloc(&sink, 64)); CHK(hipMemset(bad, 0, 1024)); CHK(hipMalloc(&gB, 1024));
+  unsigned short hb[512];
+  for (int l = 0; l < 64; l++) { const float v = (float)((l & 31) % 5 + 1); unsigned u; memcpy(&u, &v, 4); for (int e = 0; e < 8; e++) hb[l * 8 + e] = (unsigned short)(u >> 16); }
+  CHK(hipMemcpy(gB, hb, 1024, hipMemcpyHostToDevice));
   CHK(hipStreamCreate(&s[0])); CHK(hipStreamCreate(&s[1]));
   for (int r = 0; r < launches; r++) {
-    if (with_aggressor) hipLaunchKernelGGL(aggressor, dim3(512), dim3(512), 0, s[0], 400, sink);
-    hipLaunchKernelGGL(victim, dim3(512), dim3(512), 0, s[1], 2000, 31, 31, bad);
+    if (with_aggressor) hipLaunchKernelGGL(aggressor, dim3(512), dim3(512), 0, s[0], gB, 400, sink);
+    hipLaunchKernelGGL(victim, dim3(512), dim3(512), 0, s[1], 2000, 31, 31, bad, sink, 0);
   }
   CHK(hipGetLastError()); CHK(hipDeviceSynchronize());
   unsigned h[256]; CHK(hipMemcpy(h, bad, 1024, hipMemcpyDeviceToHost));
@@ -86,5 +102,9 @@ int main(int argc, char** argv) {
   run("as_compiled", victim_as_compiled, n, true);
   run("two_v_mul_f32", victim_two_v_mul, n, true);
   run("s_nop_3_in_front", victim_s_nop_3, n, true);
+  run("s_nop_0_in_front", victim_s_nop_0, n, true);
+  run("s_nop_1_in_front", victim_s_nop_1, n, true);
+  run("s_nop_7_in_front", victim_s_nop_7, n, true);
+  run("s_nop_3_in_front", victim_s_nop_3, n, false);
   return 0;
 }

@@ -19,6 +19,15 @@
 namespace {
 
 typedef unsigned long long u64;
+// Total order of the quality values in the FINAL ranking of orp_apaa_select (both formulations below use it, so a gt with more
+// than kSelCap positives and one with fewer cannot rank a NaN differently -- round-5 advisor): the float order for ordinary values
+// (+0 == -0), NaN above everything (where torch.sort, which the reference ranks with, puts it).
+__device__ __forceinline__ unsigned apaa_rank_key(float v) {
+  if (v != v) return 0xffffffffu;
+  if (v == 0.f) v = 0.f;
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 constexpr int kThreads = 256;
 
 __device__ __forceinline__ u64 pack_key(float v, int idx) {
@@ -327,7 +336,8 @@ apaa_select_kernel(const float* __restrict__ q, const int64_t* __restrict__ pos_
         for (int b = 0; b < n; b++) {
           const u64 kb = c_key[b]; const int lb = c_lvl[b];
           const float qb = q[(int)(unsigned)(kb & 0xffffffffu)];
-          const bool before = (qb < qa) || (qb == qa && (lb < la || (lb == la && kb < ka)));
+          const unsigned ob = apaa_rank_key(qb), oa = apaa_rank_key(qa);
+          const bool before = (ob < oa) || (ob == oa && (lb < la || (lb == la && kb < ka)));
           pos += before ? 1 : 0;
         }
         const int topk = (int)ceil((double)n * top_ratio);
@@ -367,7 +377,7 @@ apaa_select_kernel(const float* __restrict__ q, const int64_t* __restrict__ pos_
       for (int a = 1; a < n; a++) {
         const float vq = cand_q[a]; const int vi = cand_i[a];
         int b = a - 1;
-        while (b >= 0 && cand_q[b] > vq) { cand_q[b + 1] = cand_q[b]; cand_i[b + 1] = cand_i[b]; b--; }
+        while (b >= 0 && apaa_rank_key(cand_q[b]) > apaa_rank_key(vq)) { cand_q[b + 1] = cand_q[b]; cand_i[b + 1] = cand_i[b]; b--; }
         cand_q[b + 1] = vq; cand_i[b + 1] = vi;
       }
       const int topk = (int)ceil((double)n * top_ratio);

@@ -13,6 +13,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "../../include/orp_hip.h"
 #include "orp_dcn_split.hpp"
 #include "orp_prof.hpp"
@@ -101,6 +103,29 @@ static int fill_args(orp_split::Args& A, const orp_conv_level* levels_host, int 
   return ORP_OK;
 }
 
+// The tile table of the launch that filled a `partials` buffer, kept on the host (keyed by the buffer; the last kGnPlans launches):
+// orp_conv_split_gn_finish merges the tiles by THAT table instead of rebuilding one from its own arguments -- a finish call whose
+// layer / level / image counts differ from the launch's would otherwise pick another tile height and merge the wrong slots unnoticed
+// (round-5 advisor).  Host calls of a capture happen in program order, so a captured graph is validated when it is captured.
+struct GnPlanRecord { const float* partials; orp_split::Plan plan; int nconv, nlev, batch, groups; };
+constexpr int kGnPlans = 32;
+static GnPlanRecord g_gn_plans[kGnPlans];
+static int g_gn_next = 0;
+static std::mutex g_gn_mutex;
+static void remember_gn_plan(const float* partials, const orp_split::Plan& pl, int nconv, int nlev, int batch, int groups) {
+  std::lock_guard<std::mutex> lock(g_gn_mutex);
+  int slot = -1;
+  for (int i = 0; i < kGnPlans; i++) if (g_gn_plans[i].partials == partials) slot = i;
+  if (slot < 0) { slot = g_gn_next; g_gn_next = (g_gn_next + 1) % kGnPlans; }
+  g_gn_plans[slot] = GnPlanRecord{partials, pl, nconv, nlev, batch, groups};
+}
+static bool recall_gn_plan(const float* partials, GnPlanRecord* out) {
+  std::lock_guard<std::mutex> lock(g_gn_mutex);
+  for (int i = 0; i < kGnPlans; i++)
+    if (g_gn_plans[i].partials == partials && partials) { *out = g_gn_plans[i]; return true; }
+  return false;
+}
+
 static int conv_split_impl(const orp_conv_level* levels_host, const float* const* weights_host, const float* const* biases_host,
                            int nlevels, int batch, int c_in, int c_out, const float* weight_a_packed, const float* weight_b_packed,
                            const float* bias_a, const float* bias_b, int relu, int kh, int kw, int stride_h, int stride_w,
@@ -150,12 +175,14 @@ static int conv_split_impl(const orp_conv_level* levels_host, const float* const
     S.Wo = out_dim(lv.width, pad_w, dil_w, kw, stride_w);
     if (S.Ho <= 0 || S.Wo <= 0) return ORP_EINVAL;
   }
+  orp_split::Plan pl_gn;
   if (gn && gn->partials) {                                // room for [layer][tile][group] (mean, M2, max |y|, count)
-    const orp_split::Plan pl = orp_split::plan(A);
-    if (gn->partial_floats < (size_t)4 * nconv * pl.tiles * gn->groups) return ORP_EWORKSPACE;
+    pl_gn = orp_split::plan(A);
+    if (gn->partial_floats < (size_t)4 * nconv * pl_gn.tiles * gn->groups) return ORP_EWORKSPACE;
   }
   OrpProfScope prof(ORP_PROF_CONV_SPLIT, (hipStream_t)stream);
   const hipError_t e = orp_split::launch(A, (hipStream_t)stream);
+  if (e == hipSuccess && gn && gn->partials) remember_gn_plan(gn->partials, pl_gn, nconv, nlevels, batch, gn->groups);
   return e == hipSuccess ? ORP_OK : (int)e;
 }
 
@@ -291,11 +318,18 @@ int orp_conv_split_gn_finish(const orp_conv_level* levels_host, int nlevels, int
   if (!levels_host || nlevels <= 0 || nlevels > orp_split::kMaxLevels || batch <= 0 || batch > 65535 || nlayers < 1 || nlayers > 2 ||
       !gammas_host || !betas_host || !partials || !coef_out || groups <= 0 || channels % groups != 0 || channels / groups > 64)
     return ORP_EINVAL;
-  orp_split::Args A;                                        // the tile table of the launch that wrote the partials
-  const int rc = fill_args(A, levels_host, nlevels, batch, channels, channels, nlayers, 3, 3, 1, 1, 1, 1, 1, 1);
-  if (rc != ORP_OK) return rc;
-  A.per_image = 1;
-  const orp_split::Plan pl = orp_split::plan(A);
+  orp_split::Plan pl;                                       // the tile table of the launch that wrote the partials
+  GnPlanRecord rec;
+  if (recall_gn_plan(partials, &rec)) {
+    if (rec.nconv != nlayers || rec.nlev != nlevels || rec.batch != batch || rec.groups != groups) return ORP_EINVAL;
+    pl = rec.plan;
+  } else {                                                  // (a buffer this process never launched into: the table the arguments imply)
+    orp_split::Args A;
+    const int rc = fill_args(A, levels_host, nlevels, batch, channels, channels, nlayers, 3, 3, 1, 1, 1, 1, 1, 1);
+    if (rc != ORP_OK) return rc;
+    A.per_image = 1;
+    pl = orp_split::plan(A);
+  }
   GnFinish F;
   F.part = reinterpret_cast<const float4*>(partials); F.coef = reinterpret_cast<float2*>(coef_out); F.bound = bound_out;
   F.nlev = nlevels; F.tiles = pl.tiles; F.B = batch; F.C = channels; F.G = groups; F.eps = eps;

@@ -90,7 +90,10 @@ class ResNet(nn.Module):
             raise KeyError('invalid depth {} for resnet'.format(depth))
         assert gcb is None and gen_attention is None, 'context / attention blocks are not part of the DOTA configs'
         assert conv_cfg is None, 'the backbone convolutions are stock nn.Conv2d (dcn= selects the deformable conv2)'
-        self.dcn = dcn
+        # one private copy per model build: the blocks pop 'fallback_on_stride' from the dict they share (the reference's pop-once
+        # semantics, which decide the checkpoint's conv_offset key set) -- the CALLER's config object is left as it was, so a second
+        # backbone built from the same config sees the flag again (round-5 advisor)
+        self.dcn = dict(dcn) if dcn is not None else None
         self.stage_with_dcn = tuple(stage_with_dcn) if stage_with_dcn is not None else (False,) * num_stages
         if dcn is not None:
             assert len(self.stage_with_dcn) == num_stages

@@ -435,18 +435,13 @@ class DeformConvFunction(Function):
 
     @staticmethod
     def _output_size(input, weight, padding, dilation, stride):
-        channels = weight.size(0)
-        output_size = (input.size(0), channels)
-        for d in range(input.dim() - 2):
-            in_size = input.size(d + 2)
-            pad = padding[d]
-            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
-            stride_ = stride[d]
-            output_size += ((in_size + (2 * pad) - kernel) // stride_ + 1, )
-        if not all(map(lambda s: s > 0, output_size)):
-            raise ValueError('convolution input is too small (output would be {})'.format(
-                'x'.join(map(str, output_size))))
-        return output_size
+        """(B, Cout, Ho, Wo) of the convolution; a non-positive extent is the reference's 'input is too small' error."""
+        spatial = tuple((input.size(ax + 2) + 2 * padding[ax] - (dilation[ax] * (weight.size(ax + 2) - 1) + 1)) // stride[ax] + 1
+                        for ax in range(input.dim() - 2))
+        shape = (input.size(0), weight.size(0)) + spatial
+        if min(shape) <= 0:
+            raise ValueError('convolution input is too small (output would be {})'.format('x'.join(str(v) for v in shape)))
+        return shape
 
 
 class ModulatedDeformConvFunction(Function):
@@ -557,36 +552,41 @@ deform_conv = DeformConvFunction.apply
 modulated_deform_conv = ModulatedDeformConvFunction.apply
 
 
+def _fan_in_uniform_(weight, in_channels, kernel_size):
+    """U(-1/sqrt(fan_in), 1/sqrt(fan_in)) with fan_in = Cin * kh * kw (what both reference modules initialise with)."""
+    bound = 1.0 / math.sqrt(in_channels * kernel_size[0] * kernel_size[1])
+    weight.data.uniform_(-bound, bound)
+
+
+def _adopt_legacy_offset_keys(state_dict, prefix, local_metadata):
+    """Checkpoints written before module version 2 store the offset convolution as `<name>_offset.{weight,bias}`; move them
+    to `<name>.conv_offset.*` unless the new key is already there."""
+    if local_metadata.get('version', None) not in (None, 1):
+        return
+    for leaf in ('weight', 'bias'):
+        old, new = prefix[:-1] + '_offset.' + leaf, prefix + 'conv_offset.' + leaf
+        if new not in state_dict and old in state_dict:
+            state_dict[new] = state_dict.pop(old)
+
+
 class DeformConv(nn.Module):
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
                  deformable_groups=1, bias=False):
         super(DeformConv, self).__init__()
         assert not bias
-        assert in_channels % groups == 0, \
-            'in_channels {} cannot be divisible by groups {}'.format(in_channels, groups)
-        assert out_channels % groups == 0, \
-            'out_channels {} cannot be divisible by groups {}'.format(out_channels, groups)
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.kernel_size = _pair(kernel_size)
-        self.stride = _pair(stride)
-        self.padding = _pair(padding)
-        self.dilation = _pair(dilation)
-        self.groups = groups
-        self.deformable_groups = deformable_groups
-        # enable compatibility with nn.Conv2d
-        self.transposed = False
-        self.output_padding = _single(0)
-        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
+        for name, ch in (('in_channels', in_channels), ('out_channels', out_channels)):
+            assert ch % groups == 0, '{} {} cannot be divisible by groups {}'.format(name, ch, groups)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.transposed, self.output_padding = False, _single(0)             # the attributes nn.Conv2d consumers look for
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
         self.reset_parameters()
 
     def reset_parameters(self):
-        n = self.in_channels
-        for k in self.kernel_size:
-            n *= k
-        stdv = 1. / math.sqrt(n)
-        self.weight.data.uniform_(-stdv, stdv)
+        _fan_in_uniform_(self.weight, self.in_channels, self.kernel_size)
 
     def forward(self, x, offset):
         # inputs smaller than the kernel are padded, as the reference does (deform_conv.py:239-255)
@@ -613,33 +613,27 @@ class DeformConv(nn.Module):
 
 
 class DeformConvPack(DeformConv):
+    """DeformConv that predicts its own offsets with a zero-initialised convolution of the same geometry."""
     _version = 2
 
     def __init__(self, *args, **kwargs):
         super(DeformConvPack, self).__init__(*args, **kwargs)
-        self.conv_offset = nn.Conv2d(
-            self.in_channels, self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
-            kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
+        taps = self.kernel_size[0] * self.kernel_size[1]
+        self.conv_offset = nn.Conv2d(self.in_channels, 2 * taps * self.deformable_groups, kernel_size=self.kernel_size,
+                                     stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
         self.init_offset()
 
     def init_offset(self):
-        self.conv_offset.weight.data.zero_()
-        self.conv_offset.bias.data.zero_()
+        for t in (self.conv_offset.weight, self.conv_offset.bias):
+            t.data.zero_()
 
     def forward(self, x):
-        offset = self.conv_offset(x)
-        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+        return deform_conv(x, self.conv_offset(x), self.weight, self.stride, self.padding, self.dilation, self.groups,
                            self.deformable_groups)
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                               error_msgs):
-        version = local_metadata.get('version', None)
-        if version is None or version < 2:
-            # early checkpoints name the offset conv `<name>_offset`
-            if (prefix + 'conv_offset.weight' not in state_dict and prefix[:-1] + '_offset.weight' in state_dict):
-                state_dict[prefix + 'conv_offset.weight'] = state_dict.pop(prefix[:-1] + '_offset.weight')
-            if (prefix + 'conv_offset.bias' not in state_dict and prefix[:-1] + '_offset.bias' in state_dict):
-                state_dict[prefix + 'conv_offset.bias'] = state_dict.pop(prefix[:-1] + '_offset.bias')
+        _adopt_legacy_offset_keys(state_dict, prefix, local_metadata)
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                                       error_msgs)
 
@@ -649,30 +643,18 @@ class ModulatedDeformConv(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
                  deformable_groups=1, bias=True):
         super(ModulatedDeformConv, self).__init__()
-        self.in_channels = in_channels
-        self.out_channels = out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size = _pair(kernel_size)
-        self.stride = stride
-        self.padding = padding
-        self.dilation = dilation
-        self.groups = groups
-        self.deformable_groups = deformable_groups
+        self.stride, self.padding, self.dilation = stride, padding, dilation  # (kept as given, like the reference: ints or pairs)
+        self.groups, self.deformable_groups = groups, deformable_groups
         self.with_bias = bias
-        self.transposed = False
-        self.output_padding = _single(0)
+        self.transposed, self.output_padding = False, _single(0)
         self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
-        if bias:
-            self.bias = nn.Parameter(torch.Tensor(out_channels))
-        else:
-            self.register_parameter('bias', None)
+        self.register_parameter('bias', nn.Parameter(torch.Tensor(out_channels)) if bias else None)
         self.reset_parameters()
 
     def reset_parameters(self):
-        n = self.in_channels
-        for k in self.kernel_size:
-            n *= k
-        stdv = 1. / math.sqrt(n)
-        self.weight.data.uniform_(-stdv, stdv)
+        _fan_in_uniform_(self.weight, self.in_channels, self.kernel_size)
         if self.bias is not None:
             self.bias.data.zero_()
 
@@ -682,34 +664,27 @@ class ModulatedDeformConv(nn.Module):
 
 
 class ModulatedDeformConvPack(ModulatedDeformConv):
+    """DCNv2 with its own predictor: one zero-initialised convolution emits 2 offset maps and 1 modulation logit per tap."""
     _version = 2
 
     def __init__(self, *args, **kwargs):
         super(ModulatedDeformConvPack, self).__init__(*args, **kwargs)
-        self.conv_offset = nn.Conv2d(
-            self.in_channels, self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
-            kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
+        taps = self.kernel_size[0] * self.kernel_size[1]
+        self.conv_offset = nn.Conv2d(self.in_channels, 3 * taps * self.deformable_groups, kernel_size=self.kernel_size,
+                                     stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
         self.init_offset()
 
     def init_offset(self):
-        self.conv_offset.weight.data.zero_()
-        self.conv_offset.bias.data.zero_()
+        for t in (self.conv_offset.weight, self.conv_offset.bias):
+            t.data.zero_()
 
     def forward(self, x):
-        out = self.conv_offset(x)
-        o1, o2, mask = torch.chunk(out, 3, dim=1)
-        offset = torch.cat((o1, o2), dim=1)
-        mask = torch.sigmoid(mask)
-        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
-                                     self.dilation, self.groups, self.deformable_groups)
+        dy, dx, logit = torch.chunk(self.conv_offset(x), 3, dim=1)
+        return modulated_deform_conv(x, torch.cat((dy, dx), dim=1), torch.sigmoid(logit), self.weight, self.bias, self.stride,
+                                     self.padding, self.dilation, self.groups, self.deformable_groups)
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                               error_msgs):
-        version = local_metadata.get('version', None)
-        if version is None or version < 2:
-            if (prefix + 'conv_offset.weight' not in state_dict and prefix[:-1] + '_offset.weight' in state_dict):
-                state_dict[prefix + 'conv_offset.weight'] = state_dict.pop(prefix[:-1] + '_offset.weight')
-            if (prefix + 'conv_offset.bias' not in state_dict and prefix[:-1] + '_offset.bias' in state_dict):
-                state_dict[prefix + 'conv_offset.bias'] = state_dict.pop(prefix[:-1] + '_offset.bias')
+        _adopt_legacy_offset_keys(state_dict, prefix, local_metadata)
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                                       error_msgs)

@@ -4,7 +4,7 @@
     weights go through ONE `v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (hipcc's own code for that expression) next to an aggressor
     kernel that issues dense bf16 MFMAs and reads its accumulators.  The test builds it with hipcc AT TEST TIME, runs it for a few
     seconds and REPORTS -- it does not assert -- the wrong-result counts of the three variants (as compiled / the multiply as two
-    v_mul_f32 / s_nop 3 in front), so that every GPU-suite log says whether a fresh MI355X reproduces the finding.
+    v_mul_f32 / s_nop 0, 1, 3, 7 in front; with and without the aggressor), so that every GPU-suite log says whether a fresh MI355X reproduces the finding.
 (2) The consequence the product cares about: captured-graph replays of the WHOLE inference step at 1024^2, four graphs in flight on
     their own streams (stock MIOpen / rocBLAS / ATen kernels -- which do contain packed fp32 -- running beside this library's MFMA
     loops), compared with the eager step stage by stage and bit by bit, backbone stages included (tests/checks/graph_bitwise.py).
@@ -32,14 +32,17 @@ def test_packed_fp32_next_to_mfma_reproducer_reports(tmp_path):
     out = subprocess.run([exe, "40"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=120)
     assert out.returncode == 0, out.stdout
     rows = re.findall(r"RESULT (\S+)\s+(\S+)\s+evaluations (\S+) wrong (\d+) wrong_wz_lanes_48_63 (\d+)", out.stdout)
-    assert len(rows) == 4, out.stdout
+    assert len(rows) == 8, out.stdout
     for name, where, n, wrong, q3 in rows:
         conftest.REPORT.append("packed-fp32 hardware probe (docs/mi355x_pk_mul_f32_next_to_mfma.hip) on this box: victim %-16s %-12s: "
                                "%s wrong of %s evaluations (%s of them w.z in lanes 48..63)" % (name, where, wrong, n, q3))
     got = {(n, w): int(x) for n, w, _, x, _ in rows}
+    conftest.REPORT.append("   -> wrong results of exact arithmetic next to MFMAs on this box: %d (packed forms), %d (scalar form); alone: %d"
+                           % (sum(v for (n, w), v in got.items() if w == "next_to_mfma" and n != "two_v_mul_f32"),
+                              got[("two_v_mul_f32", "next_to_mfma")], sum(v for (n, w), v in got.items() if w == "alone")))
     # the only thing asserted: the scalar form of the same arithmetic -- what this library is compiled to -- is exact
     assert got[("two_v_mul_f32", "next_to_mfma")] == 0
-    assert got[("as_compiled", "alone")] == 0
+    assert got[("as_compiled", "alone")] == 0 and got[("s_nop_3_in_front", "alone")] == 0
 
 
 def test_four_graphs_in_flight_at_1024_are_bitwise_the_eager_step_stage_by_stage():
