@@ -79,6 +79,9 @@
 #ifndef ORP_DCNS_EARLYBAR
 #define ORP_DCNS_EARLYBAR 0          // with AHEAD2: the phase's barrier in front of the LAST chunk's MFMAs, the next phase's first A fragments read behind it (measured: 200.4 - 202.5 vs 202.1 - 206.8 us, within the noise: off)
 #endif
+#ifndef ORP_DCNS_PRIO
+#define ORP_DCNS_PRIO 0             // dev aid: bit 0 = s_setprio 2 while the phase's gathers are issued, bit 1 = while a chunk carries the combine
+#endif
 #ifndef ORP_DCNS_INTERLEAVE
 #define ORP_DCNS_INTERLEAVE 4        // VALU instructions of the combine pinned behind every MFMA of the chunk that carries it (0: scheduler's choice)
 #endif
@@ -583,6 +586,9 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     }
 #endif
     // (1) the gathers of the next phase's rows go out first: a whole phase of matrix work to land  (AHEAD2: of the phase after it)
+#if ORP_DCNS_PRIO & 1
+    __builtin_amdgcn_s_setprio(2);
+#endif
     if (AHEAD2) {
 #pragma unroll
       for (int r = 0; r < MT; r++) gather_issue(tap_n2, cb_n2, r, gf[r]);
@@ -593,6 +599,9 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
     // (the scheduler would otherwise SINK these loads down to their use to save registers -- measured in the ISA: the
     //  gathers ended up between the last MFMAs with s_waitcnt vmcnt(0) right behind them; the barriers pin the pipeline)
     __builtin_amdgcn_sched_barrier(0);
+#if ORP_DCNS_PRIO & 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const uint16_t* abase = sA + (size_t)cur * NPL * PLANE + (size_t)mrow * ASTRS + 8 * kg;
     // (2) the phase: the A fragments of chunk j + 1 are read from LDS BEFORE the MFMAs of chunk j are issued (a second
     //     register set), the weight registers of chunk j are refilled for the next phase right after use
@@ -618,6 +627,10 @@ dcn_fwd_split_kernel(const FwdS P, int total_tiles) {
       constexpr int CC = (ORP_DCNS_CC > 0) ? (ORP_DCNS_CC < MT ? ORP_DCNS_CC : MT) : MT;
       const bool with_combine = ORP_DCNS_COMBINE_IN_LAST && (EARLYBAR ? j < CC : j >= NCH - CC);
       const int jc = EARLYBAR ? j : j - (NCH - CC);
+#if ORP_DCNS_PRIO & 2
+      if (with_combine) __builtin_amdgcn_s_setprio(2);                          // dev aid: the chunks that carry the combine issue ahead of the SIMD's other wave
+      else __builtin_amdgcn_s_setprio(0);
+#endif
       if (with_combine) {
 #pragma unroll
         for (int r = 0; r < MT; r++)

@@ -72,7 +72,10 @@ __device__ __forceinline__ int unpack_sign(int packed, int k) {
 //   B3  one lane per pair: the values are summed in the reference's order (row edge outer, column edge inner -- the
 //       run is in ascending term order), then `sink`.
 // Chunks of kChunkPairs pairs; kChunkPairs * 16 term slots.
-constexpr int kChunkPairs = 256;
+#ifndef ORP_CHUNK_PAIRS
+#define ORP_CHUNK_PAIRS 256
+#endif
+constexpr int kChunkPairs = ORP_CHUNK_PAIRS;   // (a power of two <= kDrainThreads; 128 halves the term queue's 16 KB of LDS)
 constexpr int kTermCap = kChunkPairs * 16;
 constexpr int kDrainThreads = 256;          // workgroup size of the callers
 constexpr int kTermGeneric = 1 << 30;       // queue entry flag: skip the tree

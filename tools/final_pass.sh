@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's measurement set at HEAD (run on the GPU box through gpurun; everything lands in gpurun_out/, the summaries are
 # then folded into profiles/<tag>_* locally -- see the tail of this file).  usage: tools/final_pass.sh <tag>
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out
@@ -37,6 +37,9 @@ ORP_DCN_SPLIT=3 python tests/checks/time_dcn_pair.py >> $O/${TAG}_dcn_pair.log 2
 ORP_DCN_SPLIT=6 python tests/checks/time_dcn_pair.py >> $O/${TAG}_dcn_pair.log 2>&1
 ORP_DCN_SPLIT=9 python tests/checks/time_dcn_pair.py >> $O/${TAG}_dcn_pair.log 2>&1
 python tests/checks/time_towers.py > $O/${TAG}_towers.log 2>&1
+(python tests/checks/time_ws.py; ORP_DCNS_WS=1 python tests/checks/time_ws.py) 2>&1 | grep '^\[' > $O/${TAG}_ws_vs_symmetric.log
+python tests/checks/time_minarearect.py 2>&1 | grep sets > $O/${TAG}_minarearect.log
+(hipcc --offload-arch=gfx950 -O3 -o /tmp/pk_repro docs/mi355x_pk_mul_f32_next_to_mfma.hip 2>/dev/null && timeout 200 /tmp/pk_repro 100) > $O/${TAG}_pk_mul_reproducer.log 2>&1
 python tests/checks/time_wgrad.py > $O/${TAG}_wgrad.log 2>&1
 ORP_DCN_SPLIT=6 python bench.py --steps 100 --no-cpu-baseline > $O/${TAG}_bench_mode6.json 2>/dev/null
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/${TAG}_prof_bench -- python $R/bench.py --steps 30 --no-cpu-baseline --pipeline 1 > $R/$O/${TAG}_prof_bench.log 2>&1)

@@ -4,7 +4,7 @@
 #   reverse   ORP_TEST_ORDER=reverse (tests/conftest.py): no test may depend on allocator / cache state of an earlier one
 #   perfile   every test file alone in a fresh process
 # usage: tools/gpu_suite.sh <tag>     e.g. r03
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out
 mkdir -p $OUT
 python -c "import orientedreppoints_amd._lib as L; print('orp_version', L.lib().orp_version().decode())" > $OUT/${TAG}_gputest_forward.log 2>&1
