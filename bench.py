@@ -697,6 +697,9 @@ def main_train(args):
         gt_bboxes=[torch.from_numpy(S.gen_polys(args.gts, 40 + i + 7 * rank, wh=(16, 120))[:, :8]
                                     .astype(np.float32) * (sz / 1024.0)).to(dev) for i in range(batch)],
         gt_labels=[torch.randint(1, 16, (args.gts,), generator=g).to(dev) for _ in range(batch)]) for sz in sizes]
+    backbone_graphed = False
+    if args.graph_backbone and amp_dtype is None and len(sizes) == 1 and args.model in ('r50', 'r101'):
+        backbone_graphed = D.graph_backbone(model, datas[0]['img'])
     count = [0]
 
     def step():
@@ -753,6 +756,7 @@ def main_train(args):
                    'imgs_per_gpu': batch, 'gts_per_image': args.gts,
                    'parallelism': 'dp%d (image-parallel, bucketed gradient all-reduce overlapped with backward)' % world},
         'loss': round(float(log_vars['loss']), 4),
+        'backbone_graphed': backbone_graphed,
         'hip_events_ms_per_step': {k: (round(v[0] / args.steps, 3) if v[1] else None) for k, v in prof.items()},
     }
     print(json.dumps(out))
@@ -790,6 +794,10 @@ def main():
                     help="test (default): the headline inference step; train: one SGD iteration of BASELINE configs[2] "
                          "(2 img/GPU, APAA on), gradients all-reduced over RCCL for N > 1")
     ap.add_argument('--gts', type=int, default=64, help='--mode train: ground-truth polygons per image')
+    ap.add_argument('--graph-backbone', type=int, default=0,
+                    help='--mode train, f32, one patch size: 1 = the backbone forward + backward replayed as two hipGraphs '
+                         '(dist_utils.graph_backbone).  Measured round 6: 31.2 ms per step against 29.7 eager -- the step is not '
+                         'bound by the launch rate of the backbone -- so the default stays 0')
     ap.add_argument('--dtype', choices=('f32', 'fp16', 'bf16'), default='f32',
                     help='--mode train only: f32 (default, the reference\'s arithmetic) or torch.autocast in fp16 (with a '
                          'GradScaler) / bf16: library convolutions in half, hot-path operators on fp32-cast inputs')

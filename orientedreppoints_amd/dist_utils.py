@@ -275,3 +275,24 @@ def train_step(model, optimizer, data, hook, autocast_dtype=None):
     loss, log_vars = parse_losses(losses)
     hook.after_train_iter(model, optimizer, loss)
     return log_vars
+
+
+def graph_backbone(model, sample_img):
+    """Training with static patch shapes: capture the BACKBONE's forward and backward as two hipGraphs
+    (`torch.cuda.make_graphed_callables`) so that an iteration replays them instead of launching the backbone's several hundred
+    stock kernels from Python one by one -- the step is bound by the GPU, but the Python launch rate shows wherever the host has to
+    wait for a count (the loss's positives) and then catch up.  The backbone is stock PyTorch-ROCm (ResNet: library convolutions,
+    eval-mode BatchNorm, ReLU, max-pool), has no data-dependent control flow and no host-side caches; neck, head and loss stay eager
+    (their weight packs are keyed on the parameters' version counters, and the loss has data-dependent shapes).  The parameters keep
+    their identity: optimiser, gradient hooks and `state_dict` are unaffected.  Returns True when the backbone was captured.
+    Measured (round 6, configs[2], 2 x 1024^2): 31.2 ms per step against 29.7 eager -- same losses and weights after three steps
+    (tests/test_gpu_train_graph.py) but SLOWER: the replayed backward is one opaque node (no overlap with the head's backward on other
+    streams, static input / output copies), and the 2.3 ms between wall and kernel-busy time of the eager step are 1 361 kernel
+    boundaries at ~1.7 us each, not Python.  Off by default (`bench.py --graph-backbone 1`)."""
+    if not (torch.cuda.is_available() and sample_img.is_cuda):
+        return False
+    was_training = model.backbone.training
+    model.backbone = torch.cuda.make_graphed_callables(model.backbone, (sample_img.detach().clone(),))
+    model.backbone.train(was_training)
+    return True
+
