@@ -90,11 +90,11 @@ int orp_box_iou_rotated_host(const float* boxes1, int n, const float* boxes2, in
  * ------------------------------------------------------------------------------------------------------- */
 int orp_minarearect(const float* pts, int m, float* out, void* stream);
 int orp_minarearect_decode(const float* pts, int m, const float* centers, const float* scales, float* out, void* stream);
-/* Self-check of the single-precision cosine / sine the geometry kernels evaluate (csrc/orp_libm.hpp: the host C library's
- * cosf / sinf algorithm, so that minareabbox's `cos(unique_angles[i])`, minarearect_kernel.cu:117-120, and RotBox2Poly's
- * `cos(dbox[4])`, poly_overlaps_kernel.cu:281-282, give the bits the reference compiled for the host gives):
- * out[i] = which ? sinf(x[i]) : cosf(x[i]) on the device.  Tests only. */
-int orp_libm_eval(const float* x, long n, int which, float* out, void* stream);
+/* Self-check of the single-precision elementary functions the kernels evaluate with the HOST C library's algorithms (csrc/orp_libm.hpp),
+ * so that minareabbox's `cos(unique_angles[i])` (minarearect_kernel.cu:117-120), RotBox2Poly's `cos(dbox[4])` (poly_overlaps_kernel.cu:
+ * 281-282) and the focal loss's expf / logf / powf (sigmoid_focal_loss_cuda.cu:36-57) give the bits the reference compiled for the host
+ * gives: out[i] = cosf (which 0) | sinf (1) | expf (2) | logf (3) of x[i], or powf(x[i], y[i]) (4; y may be NULL otherwise).  Tests only. */
+int orp_libm_eval(const float* x, const float* y, long n, int which, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * convex_iou: IoU(hull(9 points), gt quad) for all pairs, fp64 internals.

@@ -34,7 +34,7 @@ _SIGNATURES = {
     "orp_box_iou_rotated_host": (_i, [_vp, _i, _vp, _i, _vp]),
     "orp_minarearect": (_i, [_vp, _i, _vp, _vp]),
     "orp_minarearect_decode": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
-    "orp_libm_eval": (_i, [_vp, ctypes.c_long, _i, _vp, _vp]),
+    "orp_libm_eval": (_i, [_vp, _vp, ctypes.c_long, _i, _vp, _vp]),
     "orp_convex_iou": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "orp_convex_giou": (_i, [_vp, _vp, _i, _vp, _vp]),
     "orp_points_justify": (_i, [_vp, _i, _vp, _i, _vp, _vp]),

@@ -126,9 +126,11 @@ minarearect_kernel(const float* __restrict__ pts, int m, const float* __restrict
 }
 
 // self-check entry (tests only): the device build of orp_libm.hpp over an array
-__global__ void __launch_bounds__(256) libm_eval_kernel(const float* __restrict__ x, long n, int which, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) libm_eval_kernel(const float* __restrict__ x, const float* __restrict__ y, long n, int which,
+                                                        float* __restrict__ out) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-    out[i] = which ? orp::libm::sinf_host(x[i]) : orp::libm::cosf_host(x[i]);
+    out[i] = which == 0 ? orp::libm::cosf_host(x[i]) : which == 1 ? orp::libm::sinf_host(x[i])
+           : which == 2 ? orp::libm::expf_host(x[i]) : which == 3 ? orp::libm::logf_host(x[i]) : orp::libm::powf_host(x[i], y[i]);
 }
 }  // namespace
 
@@ -146,12 +148,12 @@ int orp_minarearect_decode(const float* pts, int m, const float* centers, const 
 int orp_minarearect(const float* pts, int m, float* out, void* stream) {
   return orp_minarearect_decode(pts, m, nullptr, nullptr, out, stream);
 }
-int orp_libm_eval(const float* x, long n, int which, float* out, void* stream) {
-  if (n < 0 || (n > 0 && (!x || !out)) || which < 0 || which > 1) return ORP_EINVAL;
+int orp_libm_eval(const float* x, const float* y, long n, int which, float* out, void* stream) {
+  if (n < 0 || (n > 0 && (!x || !out)) || which < 0 || which > 4 || (which == 4 && n > 0 && !y)) return ORP_EINVAL;
   if (n == 0) return ORP_OK;
   const long blocks = (n + 255) / 256;
   hipLaunchKernelGGL(libm_eval_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
-                     x, n, which, out);
+                     x, y, n, which, out);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ORP_OK : (int)e;
 }

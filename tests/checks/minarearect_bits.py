@@ -71,7 +71,7 @@ def libm_check(dev):
                 x = bits.view(np.float32)
                 xd = torch.from_numpy(x).to(dev)
                 out = torch.empty_like(xd)
-                rc = L.orp_libm_eval(_lib.ptr(xd), x.size, which, _lib.ptr(out), _lib.stream_of(xd))
+                rc = L.orp_libm_eval(_lib.ptr(xd), None, x.size, which, _lib.ptr(out), _lib.stream_of(xd))
                 assert rc == 0
                 got = out.cpu().numpy()
                 want = np.empty_like(x)

@@ -295,6 +295,49 @@ def test_minarearect_one_million_sets_bitwise(dev, oracle):
     assert total >= 1000000
 
 
+def test_device_exp_log_pow_are_the_host_librarys(dev):
+    """csrc/orp_libm.hpp on gfx950 against the C library of THIS host: expf / logf on 4 M floats drawn over the whole range (bit
+    patterns), powf on 4 M (x, y) pairs incl. the focal loss's (p in [0, 1], gamma) region.  Bitwise (NaN == NaN)."""
+    import ctypes
+    from orientedreppoints_amd import _lib
+    L = _lib.lib()
+    harness = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_harness", "liblibm_host.so")
+    if not os.path.exists(harness):
+        import subprocess
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC", "-o", harness,
+                               os.path.join(os.path.dirname(harness), "libm_host.cpp")])
+    libm = ctypes.CDLL("libm.so.6")
+    rng = np.random.RandomState(3)
+    bits = rng.randint(0, 2 ** 32, 4_000_000, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    xs = np.concatenate([x[:2_000_000], rng.uniform(-100, 100, 2_000_000).astype(np.float32)])
+    for which, fn in ((2, np.exp), (3, np.log)):
+        xd = _t(xs, dev)
+        out = torch.empty_like(xd)
+        assert L.orp_libm_eval(_lib.ptr(xd), None, xs.size, which, _lib.ptr(out), _lib.stream_of(xd)) == 0
+        H = ctypes.CDLL(harness)                                   # the g++ build of the same header == libm (tests/test_libm_host.py)
+        want = np.empty_like(xs)
+        H.host_libm_eval(xs.ctypes.data_as(ctypes.c_void_p), xs.size, which, want.ctypes.data_as(ctypes.c_void_p))
+        got = out.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32)[~np.isnan(want)], want.view(np.uint32)[~np.isnan(want)]) and np.all(np.isnan(got[np.isnan(want)]))
+        # and directly against libm on a sample
+        f = getattr(libm, "expf" if which == 2 else "logf"); f.restype = ctypes.c_float; f.argtypes = [ctypes.c_float]
+        idx = rng.randint(0, xs.size, 20000)
+        ref = np.array([f(float(v)) for v in xs[idx]], np.float32)
+        assert np.array_equal(got[idx].view(np.uint32)[~np.isnan(ref)], ref.view(np.uint32)[~np.isnan(ref)])
+    px = np.concatenate([rng.uniform(0, 1, 2_000_000), np.abs(x[:2_000_000])]).astype(np.float32)
+    py = np.concatenate([rng.choice([2.0, 1.5, 0.5, 3.0], 2_000_000), x[2_000_000:]]).astype(np.float32)
+    out = torch.empty(px.size, device=dev)
+    xd, yd = _t(px, dev), _t(py, dev)
+    assert L.orp_libm_eval(_lib.ptr(xd), _lib.ptr(yd), px.size, 4, _lib.ptr(out), _lib.stream_of(xd)) == 0
+    libm.powf.restype = ctypes.c_float; libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    idx = rng.randint(0, px.size, 40000)
+    ref = np.array([libm.powf(float(a), float(b)) for a, b in zip(px[idx], py[idx])], np.float32)
+    got = out.cpu().numpy()[idx]
+    ok = ~np.isnan(ref)
+    assert np.array_equal(got.view(np.uint32)[ok], ref.view(np.uint32)[ok]) and np.all(np.isnan(got[~ok]))
+
+
 def test_device_cos_sin_are_the_host_librarys(dev):
     """csrc/orp_libm.hpp on gfx950 against the C library of THIS host (glibc): every float in (-4, 4), both functions, bitwise.
     The g++ build of the same header is checked against libm over (-96, 96) by tests/test_libm_host.py."""
@@ -314,15 +357,15 @@ def test_device_cos_sin_are_the_host_librarys(dev):
             x = bits.view(np.float32)
             xd = _t(x, dev)
             out = torch.empty_like(xd)
-            assert L.orp_libm_eval(_lib.ptr(xd), x.size, which, _lib.ptr(out), _lib.stream_of(xd)) == 0
+            assert L.orp_libm_eval(_lib.ptr(xd), None, x.size, which, _lib.ptr(out), _lib.stream_of(xd)) == 0
             want = np.array([fn(float(v)) for v in x], np.float32)
             assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
         allbits = np.arange(0, hi, dtype=np.uint32)
         xd = _t(allbits.view(np.float32), dev)
         pos, negv = torch.empty_like(xd), torch.empty_like(xd)
-        assert L.orp_libm_eval(_lib.ptr(xd), allbits.size, which, _lib.ptr(pos), _lib.stream_of(xd)) == 0
+        assert L.orp_libm_eval(_lib.ptr(xd), None, allbits.size, which, _lib.ptr(pos), _lib.stream_of(xd)) == 0
         xn = -xd
-        assert L.orp_libm_eval(_lib.ptr(xn), allbits.size, which, _lib.ptr(negv), _lib.stream_of(xd)) == 0
+        assert L.orp_libm_eval(_lib.ptr(xn), None, allbits.size, which, _lib.ptr(negv), _lib.stream_of(xd)) == 0
         assert torch.equal(pos, -negv if which else negv)             # cos even, sin odd: exact symmetries of the algorithm
         dbl = (np.sin if which else np.cos)(allbits.view(np.float32).astype(np.float64))
         ulp = np.abs(pos.cpu().numpy().astype(np.float64) - dbl) / np.maximum(np.spacing(np.abs(dbl).astype(np.float32)), 1e-45)
@@ -414,13 +457,25 @@ def test_chamfer_and_focal(dev, oracle, golden_dir):
     ga, gb = oracle.chamfer_backward(c["a"], c["b"], w1.cpu().numpy(), w2.cpu().numpy(), c["idx1"], c["idx2"])
     assert np.allclose(a2.grad.cpu().numpy(), ga, rtol=1e-4, atol=1e-4)
     assert np.allclose(b2.grad.cpu().numpy(), gb, rtol=1e-4, atol=1e-4)
-    # focal: tolerance 1e-4 (exp/log/pow come from different libms)
+    # focal: BIT-EXACT since round 6 (expf / logf / powf are the host C library's algorithms, csrc/orp_libm.hpp; rounds 1-5: 1e-4,
+    # "exp/log/pow come from different libms"); the golden is the reference's kernel compiled for the host
     x = _t(c["logits"], dev).requires_grad_(True)
     t = torch.from_numpy(c["targets"]).to(dev)
     loss = sigmoid_focal_loss(x, t, 2.0, 0.25)
-    assert np.max(np.abs(loss.detach().cpu().numpy() - c["focal_fwd"])) <= 1e-4
+    assert np.array_equal(loss.detach().cpu().numpy(), c["focal_fwd"])
     loss.backward(_t(c["d_losses"], dev))
-    assert np.max(np.abs(x.grad.cpu().numpy() - c["focal_bwd"])) <= 1e-4
+    assert np.array_equal(x.grad.cpu().numpy(), c["focal_bwd"])
+    # ... and against the oracle on 200 000 logits over the whole range the head produces (incl. saturated ones), three gammas
+    rng = np.random.RandomState(5)
+    xl = rng.permutation(np.concatenate([rng.normal(0, 4, 150000), rng.uniform(-90, 90, 45000)])).astype(np.float32).reshape(-1, 15)
+    tl = rng.randint(0, 16, xl.shape[0]).astype(np.int64)
+    dl = rng.uniform(0.2, 2.0, xl.shape).astype(np.float32)
+    from orientedreppoints_amd.mmdet_ops.sigmoid_focal_loss import sigmoid_focal_loss_cuda as ext
+    for gamma, alpha in ((2.0, 0.25), (1.5, 0.5), (0.5, 0.75)):
+        got = ext.forward(_t(xl, dev), torch.from_numpy(tl).to(dev), 15, gamma, alpha).cpu().numpy()
+        assert np.array_equal(got, oracle.focal_forward(xl, tl, gamma, alpha), equal_nan=True)
+        gb_ = ext.backward(_t(xl, dev), torch.from_numpy(tl).to(dev), _t(dl, dev), 15, gamma, alpha).cpu().numpy()
+        assert np.array_equal(gb_, oracle.focal_backward(xl, tl, dl, gamma, alpha), equal_nan=True)
     with pytest.raises(RuntimeError):
         sigmoid_focal_loss(torch.zeros(2, 15), torch.zeros(2, dtype=torch.long), 2.0, 0.25)
 

@@ -45,6 +45,25 @@ def test_every_third_float_up_to_96_matches_the_c_library(harness, which):
     assert bad == 0, "first mismatch at %r" % first.value
 
 
+@pytest.mark.parametrize("which", [2, 3], ids=["expf", "logf"])
+def test_expf_logf_match_the_c_library_over_all_floats_strided(harness, which):
+    """Every 5th bit pattern of ALL floats, both signs (NaN payloads compare as NaN); developed against the full 2^32 sweep: 0
+    mismatches (docs/notebook/round6.md)."""
+    first = ctypes.c_float(0)
+    bad = harness.host_libm_mismatches(0, 0x7fffffff, 5, which, ctypes.byref(first))
+    assert bad == 0, "first mismatch at %r" % first.value
+
+
+def test_powf_matches_the_c_library(harness):
+    harness.host_powf_mismatches.restype = ctypes.c_long
+    harness.host_powf_mismatches.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int, ctypes.c_long,
+                                             ctypes.c_void_p]
+    ys = np.array([2.0, 1.5, 0.5, 3.0, 2.5, 1.0, 0.3, 5.0], np.float32)       # focal's gamma is 2; a few more exponents
+    first = (ctypes.c_float * 2)()
+    bad = harness.host_powf_mismatches(0, _bits(2.0), 41, ys.ctypes.data_as(ctypes.c_void_p), len(ys), 30_000_000, first)
+    assert bad == 0, "first mismatch at %r ^ %r" % (first[0], first[1])
+
+
 def test_c_library_cosf_is_not_correctly_rounded():
     """The reason the header exists: (float)cos((double)x) -- correctly rounded for practically every x -- is NOT what the C
     library's cosf returns; were it, the simpler form would do."""
