@@ -1433,11 +1433,14 @@ def test_box_iou_rotated(dev, oracle, golden_dir):
     from orientedreppoints_amd.mmdet_ops import box_iou_rotated
     g = _g(golden_dir, "box_iou_rotated.npz")
     got = box_iou_rotated(_t(g["a"], dev), _t(g["b"], dev)).cpu().numpy()
-    assert got.shape == g["iou"].shape and np.max(np.abs(got - g["iou"])) <= 1e-4
-    a = S.gen_rboxes(700, 31).astype(np.float32); b = S.gen_rboxes(300, 32).astype(np.float32)
-    b[:200, :2] = a[:200, :2] + 5
+    assert got.shape == g["iou"].shape and np.array_equal(got, g["iou"], equal_nan=True)
+    # BIT-EXACT (round 6: measured 0 of 2.16 M pairs differing from the reference compiled for the host, tests/checks/
+    # box_iou_rotated_bits.py; the test held 1e-4 before): the only library calls are double cos / sin rounded to float
+    a = S.gen_rboxes(900, 31).astype(np.float32); b = S.gen_rboxes(400, 32).astype(np.float32)
+    b[:300, :2] = a[:300, :2] + np.random.RandomState(1).uniform(-8, 8, (300, 2)).astype(np.float32)
     got = box_iou_rotated(_t(a, dev), _t(b, dev)).cpu().numpy()
-    assert np.max(np.abs(got - oracle.box_iou_rotated(a, b))) <= 1e-4
+    want = oracle.box_iou_rotated(a, b)
+    assert np.array_equal(got, want, equal_nan=True) and (want > 0).sum() > 3000
     assert box_iou_rotated(torch.zeros((0, 5), device=dev), _t(b, dev)).shape == (0, 300)
 
 
