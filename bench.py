@@ -85,7 +85,7 @@ def calibrate_head(model, img, target=TARGET_DETS):
             head.reppoints_cls_out.bias[c] += thr_logit - kth + 1e-4
 
 
-PMC_FILE = 'profiles/r05_pmc.json'
+PMC_FILE = 'profiles/r06_pmc.json'
 
 
 def load_pmc():
