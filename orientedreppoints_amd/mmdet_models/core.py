@@ -210,8 +210,9 @@ def fused_postprocess(cls_scores, points_preds, strides, cfg, num_points=9):
     widths = [int(c.size(2)) for c in cls_scores]
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     N = int(offs[-1])
-    logits = torch.cat([c.reshape(C, -1) for c in cls_scores], 1)                    # [C, N]
-    pts_all = torch.cat([p.reshape(2 * num_points, -1) for p in points_preds], 1).contiguous()   # [18, N]
+    # (fp32 from here on: the kernels below take float pointers -- a half / bfloat16 model's head outputs are widened once)
+    logits = torch.cat([c.reshape(C, -1) for c in cls_scores], 1).float()            # [C, N]
+    pts_all = torch.cat([p.reshape(2 * num_points, -1) for p in points_preds], 1).float().contiguous()   # [18, N]
     sig = logits.sigmoid()
     nms_pre = cfg.get('nms_pre', -1)
     if 0 < nms_pre <= 4096 and any(n_l > nms_pre for n_l in sizes) and len(sizes) <= 8 and max(sizes) <= 40960:

@@ -258,8 +258,10 @@ class OrientedRepPointsHead(nn.Module):
         from ..mmdet_ops.deform_conv import deform_conv_forward_pair, fast_path_ok
         same = (a.stride == b.stride and a.padding == b.padding and a.dilation == b.dilation and
                 a.weight.shape == b.weight.shape)
-        if same and cls_feats[0].is_cuda and fast_path_ok(a.weight, a.groups, a.deformable_groups) and \
-                fast_path_ok(b.weight, b.groups, b.deformable_groups):
+        # (fp32 tensors only: half / bfloat16 / double tensors go layer by layer through forward_multi, which picks the half kernel
+        #  -- the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF half branch -- or the double column formulation)
+        if same and cls_feats[0].is_cuda and cls_feats[0].dtype == torch.float32 and a.weight.dtype == torch.float32 and \
+                fast_path_ok(a.weight, a.groups, a.deformable_groups) and fast_path_ok(b.weight, b.groups, b.deformable_groups):
             return deform_conv_forward_pair(cls_feats, pts_feats, offsets, a.weight, b.weight, a.stride, a.padding,
                                             a.dilation, relu=True, out_channels_last=out_channels_last, amax=amax)
         assert out_channels_last is None
