@@ -354,11 +354,245 @@ dcn_fwd_half_kernel(const FwdH P, int total_tiles) {
   }
 }
 
+// ---- round 6: the same operator, wave-specialised ---------------------------------------------------------------------------------
+// The kernel above runs every tap as  gathers out -> 16 chunks of MFMAs -> barrier -> combine + LDS writes -> barrier: the matrix pipe
+// idles through the combine, and every one of the 8 waves reads the whole A tile (its own analysis, top of this file: "the next step is
+// a wave tile of 64 output channels").  Here, as in csrc/orp_dcn_split.hip's wave-specialised kernel: 4 CONSUMER waves (one per SIMD;
+// the whole tile height x 64 output channels each = MT x 2 accumulator blocks; A fragments from a DOUBLE-buffered LDS tile, weights L2
+// -> an in-place-refilled register ring of one phase) and 4 PRODUCER waves at s_setprio 3 (the rows of phase + 2 gathered during phase
+// p, packed bilinear combine, one 16-byte LDS write per row piece); phases of 128 input channels of one tap, ONE barrier per phase.
+// Same products in the same order per accumulator as the kernel above (one MFMA per 16 channels, channels ascending, taps outer):
+// bit-identical results.
+constexpr int CBW = 128;            // input channels per phase
+constexpr int ASTRW = CBW + 8;      // A row stride in elements (68 dwords: 16 rows x 4 dwords = all 64 banks per ds_read_b128 group)
+constexpr int NCHW8 = CBW / KCH;    // 8 MFMA steps per phase
+
+template <typename T, int MT, bool OUT_NCHW>
+__global__ void __launch_bounds__(kThreadsH)
+dcn_fwd_half_ws_kernel(const FwdH P, int total_tiles) {
+  typedef typename Elem<T>::v8 v8;
+  constexpr int BMH = 32 * MT;
+  constexpr int RG = 2 * MT;                                                 // row groups (4 rows each) of one producer wave per phase
+  constexpr int NT = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* sA = reinterpret_cast<T*>(smem);                                        // [2][BMH][ASTRW]
+  float4* sCw = reinterpret_cast<float4*>(sA + 2 * BMH * ASTRW);
+  int4* sCi = reinterpret_cast<int4*>(sCw + BMH * MAX_TAPS);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int taps = P.kh * P.kw;
+  int tile;
+  {
+    const int b = blockIdx.x, per = (total_tiles + 7) >> 3;
+    tile = (b & 7) * per + (b >> 3);
+    if (tile >= total_tiles) return;
+  }
+  int lvl = 0;
+#pragma unroll 1
+  for (int i = 1; i < P.nlev; i++) if (tile >= P.lv[i].tile0) lvl = i;
+  const LevelH L = P.lv[lvl];
+  const int HoWo = L.Ho * L.Wo;
+  const long npos = (long)P.B * HoWo;
+  const long p0 = (long)(tile - L.tile0) * BMH;
+  const int nb = blockIdx.y;
+  const T* xin = reinterpret_cast<const T*>(L.x);
+  const T* offp = reinterpret_cast<const T*>(L.off);
+  const T* maskp = reinterpret_cast<const T*>(L.mask);
+
+  // ---- bilinear coefficient table (as above) ----
+  for (int e = tid; e < BMH * taps; e += kThreadsH) {
+    const int m = e / taps, tap = e - m * taps;
+    const long p = p0 + m;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 ix = make_int4(0, 0, 0, 0);
+    if (p < npos) {
+      const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+      const int ho = hw / L.Wo, wo = hw - ho * L.Wo;
+      const int ki = tap / P.kw, kj = tap - ki * P.kw;
+      const T* ob = offp + ((size_t)b * 2 * taps + 2 * tap) * HoWo + hw;
+      const float off_h = Elem<T>::to_f(ob[0]), off_w = Elem<T>::to_f(ob[HoWo]);
+      const float h_im = (float)(ho * P.sh - P.ph + ki * P.dh) + off_h;
+      const float w_im = (float)(wo * P.sw - P.pw + kj * P.dw) + off_w;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)L.H && w_im < (float)L.W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+        const float hh = 1.f - lh, hw_ = 1.f - lw;
+        const bool t_ok = h_low >= 0, b_ok = h_high <= L.H - 1, l_ok = w_low >= 0, r_ok = w_high <= L.W - 1;
+        const int hl = t_ok ? h_low : 0, hhg = b_ok ? h_high : L.H - 1, wl = l_ok ? w_low : 0, whg = r_ok ? w_high : L.W - 1;
+        w.x = (t_ok && l_ok) ? hh * hw_ : 0.f;
+        w.y = (t_ok && r_ok) ? hh * lw : 0.f;
+        w.z = (b_ok && l_ok) ? lh * hw_ : 0.f;
+        w.w = (b_ok && r_ok) ? lh * lw : 0.f;
+        const int base = b * L.H;
+        ix.x = (base + hl) * L.W + wl;
+        ix.y = (base + hl) * L.W + whg;
+        ix.z = (base + hhg) * L.W + wl;
+        ix.w = (base + hhg) * L.W + whg;
+        if (maskp) {
+          const float mm = Elem<T>::to_f(maskp[((size_t)b * taps + tap) * HoWo + hw]);
+          w.x *= mm; w.y *= mm; w.z *= mm; w.w *= mm;
+        }
+      }
+    }
+    sCw[e] = w; sCi[e] = ix;
+  }
+  __syncthreads();
+
+  const int ncb = P.Cin / CBW;
+  const int nphase = taps * ncb;
+  const bool consumer = wave < 4;
+  const int wq = wave & 3;
+  int tap_n = 0, cb_n = 0, tap_n2 = 0, cb_n2 = 0;                             // (tap, channel block) of phase + 1 / + 2, clamped to the last
+  auto step = [&](int& t, int& c, int ph) {
+    if (ph + 1 < nphase) { if (++c == ncb) { c = 0; t++; } }
+  };
+  step(tap_n, cb_n, 0);
+  tap_n2 = tap_n; cb_n2 = cb_n;
+  step(tap_n2, cb_n2, 1);
+
+  if (!consumer) {
+    // one A row piece = 128 channels = 16 lanes x 8 elements (16 B): a wave fetches the same neighbour of FOUR rows per instruction
+    const int q4 = lane >> 4, l8 = (lane & 15) * 8;
+    auto row_of = [&](int g) { return g * 16 + wq * 4 + q4; };
+    auto gather_issue = [&](int tap, int cb, int g, uint4 (&v)[4]) {
+      const int4 ix = sCi[row_of(g) * taps + tap];
+      const T* base = xin + cb * CBW + l8;
+      v[0] = *reinterpret_cast<const uint4*>(base + (size_t)ix.x * P.Cin);
+      v[1] = *reinterpret_cast<const uint4*>(base + (size_t)ix.y * P.Cin);
+      v[2] = *reinterpret_cast<const uint4*>(base + (size_t)ix.z * P.Cin);
+      v[3] = *reinterpret_cast<const uint4*>(base + (size_t)ix.w * P.Cin);
+    };
+    auto combine_store = [&](int tap, int g, const uint4 (&v)[4], int buf) {
+      const int m = row_of(g);
+      *reinterpret_cast<uint4*>(sA + (size_t)buf * BMH * ASTRW + (size_t)m * ASTRW + l8) = Elem<T>::combine8(v, sCw[m * taps + tap]);
+    };
+    uint4 gA[RG][4], gB[RG][4];
+#pragma unroll
+    for (int r = 0; r < RG; r++) gather_issue(0, 0, r, gB[r]);
+#pragma unroll
+    for (int r = 0; r < RG; r++) gather_issue(tap_n, cb_n, r, gA[r]);         // the rows of phase 1
+#pragma unroll
+    for (int r = 0; r < RG; r++) combine_store(0, r, gB[r], 0);
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(3);                                           // (a VALU / VMEM wave starves beside an MFMA wave otherwise: docs/notebook/round6.md 2)
+    auto produce = [&](int phase, uint4 (&g)[RG][4], uint4 (&gf)[RG][4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < RG; r++) gather_issue(tap_n2, cb_n2, r, gf[r]);    // the rows of phase + 2: a whole phase to land
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < RG; r++) combine_store(tap_n, r, g[r], (phase & 1) ^ 1);
+      step(tap_n, cb_n, phase + 1);
+      step(tap_n2, cb_n2, phase + 2);
+      __syncthreads();
+    };
+#pragma unroll 1
+    for (int phase = 0; phase < nphase; phase += 2) {
+      produce(phase, gA, gB);
+      if (phase + 1 < nphase) produce(phase + 1, gB, gA);
+    }
+    return;
+  }
+
+  // ---- consumers ----
+  const int n_wave = nb * 256 + wq * 64;
+  const int mrow = lane & 31, kg = lane >> 5;
+  const bool live = n_wave < P.Cout;                                          // Cout % 64 == 0
+  const T* wp = reinterpret_cast<const T*>(P.wp);
+  auto load_b = [&](int tap, int cb, int j, v8 (&b)[NT]) {
+    const size_t blk = (size_t)tap * (P.Cin / 16) + cb * (CBW / 16) + j;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+      b[nt] = *reinterpret_cast<const v8*>(wp + ((blk * 2 + kg) * P.Cout + (live ? n_wave : 0) + nt * 32 + mrow) * 8);
+  };
+  v8 bq[NCHW8][NT];
+  v8 af[2][MT];
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = floatx16{0};
+#pragma unroll
+  for (int j = 0; j < NCHW8; j++) load_b(0, 0, j, bq[j]);
+  __syncthreads();
+#pragma unroll 1
+  for (int phase = 0; phase < nphase; phase++) {
+    const T* arow = sA + (size_t)(phase & 1) * BMH * ASTRW + (size_t)mrow * ASTRW + 8 * kg;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) af[0][mt] = *reinterpret_cast<const v8*>(arow + (size_t)mt * 32 * ASTRW);
+#pragma unroll
+    for (int j = 0; j < NCHW8; j++) {
+      if (j + 1 < NCHW8) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) af[(j + 1) & 1][mt] = *reinterpret_cast<const v8*>(arow + (size_t)mt * 32 * ASTRW + (j + 1) * KCH);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+          if (OUT_NCHW) acc[mt][nt] = Elem<T>::mfma(bq[j][nt], af[j & 1][mt], acc[mt][nt]);     // D[channel][position]
+          else          acc[mt][nt] = Elem<T>::mfma(af[j & 1][mt], bq[j][nt], acc[mt][nt]);     // D[position][channel]
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(tap_n, cb_n, j, bq[j]);                                          // refilled in place for the next phase
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    step(tap_n, cb_n, phase + 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  if (!live) return;
+  const T* biasp = reinterpret_cast<const T*>(P.bias);
+  T* outp = reinterpret_cast<T*>(L.out);
+  auto finish = [&](float v, int ch) { if (biasp) v += Elem<T>::to_f(biasp[ch]); return Elem<T>::from_f(P.relu ? fmaxf(v, 0.f) : v); };
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      const int nbase = n_wave + nt * 32;
+      if (OUT_NCHW) {
+        const long p = p0 + mt * 32 + (lane & 31);
+        if (p < npos) {
+          const int b = (int)(p / HoWo), hw = (int)(p - (long)b * HoWo);
+          T* ob = outp + (size_t)b * P.Cout * HoWo + hw;
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int ch = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            ob[(size_t)(nbase + ch) * HoWo] = finish(acc[mt][nt][r], nbase + ch);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const long p = p0 + mt * 32 + m;
+          if (p < npos) outp[(size_t)p * P.Cout + nbase + (lane & 31)] = finish(acc[mt][nt][r], nbase + (lane & 31));
+        }
+      }
+    }
+}
+
+template <int MT>
+size_t half_ws_smem() { return 2 * ((size_t)2 * 32 * MT * ASTRW) + (sizeof(float4) + sizeof(int4)) * 32 * MT * MAX_TAPS; }
+
+static const int g_half_ws = getenv("ORP_DCNH_WS") ? atoi(getenv("ORP_DCNH_WS")) : 1;   // 0: the symmetric kernel above (A/B timing)
+
 template <int MT>
 size_t half_smem() { return 2 * ((size_t)32 * MT * ASTRH) + (sizeof(float4) + sizeof(int4)) * 32 * MT * MAX_TAPS; }
 
 template <typename T, int MT, bool OUT_NCHW>
 hipError_t launch_half(const FwdH& P, int tiles, int nblk_n, hipStream_t st) {
+  if (g_half_ws && P.Cin % CBW == 0) {
+    const size_t smem_w = half_ws_smem<MT>();
+    struct TagW {};
+    hipError_t ew = orp::set_max_dynamic_lds_once<TagW>(reinterpret_cast<const void*>(&dcn_fwd_half_ws_kernel<T, MT, OUT_NCHW>), smem_w);
+    if (ew != hipSuccess) return ew;
+    const int per_w = (tiles + 7) >> 3;
+    hipLaunchKernelGGL((dcn_fwd_half_ws_kernel<T, MT, OUT_NCHW>), dim3(per_w * 8, nblk_n), dim3(kThreadsH), smem_w, st, P, tiles);
+    return hipGetLastError();
+  }
   const size_t smem = half_smem<MT>();
   struct Tag {};
   hipError_t e = orp::set_max_dynamic_lds_once<Tag>(reinterpret_cast<const void*>(&dcn_fwd_half_kernel<T, MT, OUT_NCHW>), smem);

@@ -222,3 +222,27 @@ def test_wave_specialised_deformconv_is_bitwise_the_default_kernel(dev):
         assert out.returncode == 0, out.stdout[-2000:]
         hashes.append([ln for ln in out.stdout.splitlines() if ln.startswith("HASH")][0])
     assert hashes[0] == hashes[1]
+
+
+def test_wave_specialised_half_kernel_is_bitwise_the_symmetric_one(dev):
+    """csrc/orp_dcn_half.hip, round 6: the fp16 / bf16 DeformConv forward on 4 consumer + 4 producer waves (the default) against the
+    symmetric kernel (ORP_DCNH_WS=0), two fresh processes, same seeded launch over three levels and two images: identical bits."""
+    import subprocess
+    code = ("import torch,hashlib,sys;sys.path.insert(0,%r);from orientedreppoints_amd.mmdet_ops import deform_conv_forward_multi as f;"
+            "d=torch.device('cuda:0');out=[]\n"
+            "for dt in (torch.float16, torch.bfloat16):\n"
+            "    torch.manual_seed(5);s=[(40,40),(20,20),(7,9)]\n"
+            "    x=[torch.randn(2,256,h,w,device=d).to(dt) for h,w in s];o=[(torch.randn(2,18,h,w,device=d)*2).to(dt) for h,w in s]\n"
+            "    w=(torch.randn(256,256,3,3,device=d)*.02).to(dt)\n"
+            "    for cl in (False, True):\n"
+            "        xs=[t.contiguous(memory_format=torch.channels_last) for t in x] if cl else x\n"
+            "        out+=[t.float().cpu().numpy().tobytes() for t in f(xs,o,w,1,1,1,relu=True)]\n"
+            "print('HASH',hashlib.sha1(b''.join(out)).hexdigest())"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    hashes = []
+    for ws in ("0", "1"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ORP_DCNH_WS=ws), stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:]
+        hashes.append([ln for ln in out.stdout.splitlines() if ln.startswith("HASH")][0])
+    assert hashes[0] == hashes[1]
