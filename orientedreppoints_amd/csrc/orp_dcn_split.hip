@@ -992,13 +992,6 @@ dcn_fwd_split_ws_kernel(const FwdS P, int total_tiles) {
 #pragma unroll
       for (int pl = 0; pl < NPL; pl++) b[nt][pl] = *reinterpret_cast<const bf8*>(a + (size_t)pl * P.plane_stride + nt * 32 * 8);
   };
-  auto load_a = [&](const uint16_t* abase, int j, bf8 (&a)[MT][NPL]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-      for (int pl = 0; pl < NPL; pl++)
-        if (!(ORP_WS_DBG & 8)) a[mt][pl] = *reinterpret_cast<const bf8*>(abase + (size_t)pl * PLANE + (size_t)mt * 32 * ASTRS + j * 16);
-  };
 
   int tap_n = 0, cb_n = 0, tap_n2 = 0, cb_n2 = 0;                             // (tap, channel block) of phase + 1 / phase + 2, clamped to the last phase
   auto step = [&](int& t, int& c, int ph) {
