@@ -102,8 +102,14 @@ class PipelinedInference(object):
     that leave most CUs idle) then overlaps the backbone of the next one, and the host never waits on the image it has
     just queued.  Every image still runs the complete step and produces the same detections as `GraphedInference`."""
 
-    def __init__(self, model, img, img_metas, depth=2, warmup=3):
+    def __init__(self, model, img, img_metas, depth=2, warmup=3, _allow_half=False):
         dev = img.device
+        if depth > 1 and not _allow_half and any(p.dtype != torch.float32 for p in model.parameters()):
+            # measured (round 6, tests/checks/half_pipeline_probe.py): a model.half() detector replays correctly from ONE captured graph,
+            # but with four of its graphs in flight the device stops making progress (the completion event of a replay never
+            # signals; either half-precision DeformConv kernel, ORP_DCNH_WS=0 / 1) -- refused here rather than hung there
+            raise ValueError("PipelinedInference: several graphs in flight are supported for float32 models only "
+                             "(use GraphedInference, or depth=1, for half / bfloat16 models)")
         self.model, self.metas, self.depth = model, list(img_metas), depth
         self.num_classes = model.bbox_head.num_classes
         # with several images in flight the two towers of ONE image need no second stream (measured: 225 vs 218 img/s)
