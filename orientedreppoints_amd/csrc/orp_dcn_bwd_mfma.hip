@@ -128,6 +128,7 @@ struct TransposeSet {
   int n;
   int* flags;
   unsigned* amax;                // (or nullptr) [1] max |v| over the grad_out tensors as float bits, raised with atomicMax (zeroed by the caller)
+  unsigned* amax_x;              // (or nullptr) the same over the tensors that are not a grad_out (the inputs x; kernel B on the 16-bit pipe)
 };
 __global__ void transpose_set_kernel(const TransposeSet T) {
   __shared__ float tile[32][33];
@@ -174,6 +175,11 @@ __global__ void transpose_set_kernel(const TransposeSet T) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, o, 64));
     if ((threadIdx.x & 63) == 0 && vmax > __atomic_load_n(T.amax, __ATOMIC_RELAXED)) atomicMax(T.amax, vmax);
+  }
+  if (c0 < 0 && T.amax_x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, o, 64));
+    if ((threadIdx.x & 63) == 0 && vmax > __atomic_load_n(T.amax_x, __ATOMIC_RELAXED)) atomicMax(T.amax_x, vmax);
   }
 }
 
@@ -970,6 +976,265 @@ dcn_bwd_weight_kernel(const BwdParams P) {
       }
 }
 
+// ---- kernel B on the 16-bit matrix pipe (round 6) ------------------------------------------------------------------------------
+// The same contraction, gW_t[o, c] = sum_p go[p, o] * col_t[p, c], in the fp16-pieces arithmetic of the forward (csrc/orp_dcn_split.hip)
+// and of the towers' weight gradient (csrc/orp_conv_wgrad.hip): both operands scaled by a power of two that puts the tensor's largest
+// magnitude into [2^14, 2^15), split into hi = fp16(v), lo = fp16(v - hi) (2^-22 relative), products lo*hi, hi*lo, hi*hi into one fp32
+// accumulator, smallest first.  The contraction runs over POSITIONS, so a lane's eight k-values of an MFMA operand are eight consecutive
+// positions of one channel, and LDS holds [piece][channel][32 positions] (80-byte rows: conflict-free 16-byte fragment reads).
+// Gathers: thread = a PAIR of channels (8-byte loads: a wave fetches half an NHWC row, 512 B, per request) and four positions of every
+// chunk.  A position's sampling corners and bilinear weights are wave-uniform: they come from a table a pre-pass leaves
+// (sample_table_kernel; 32 B per (position, tap), read with scalar loads; the row offsets are the SCALAR offsets of buffer loads, the
+// lane's channels the vector offset -- no per-lane 64-bit addresses); the four corner values are combined in the lane, split, and
+// written as 8-byte row pieces.  grad_out arrives ready-made: its two pieces are written once per call in the staging order
+// (pack_go16_kernel) instead of being split by every tap's workgroups.
+// Workgroup = (split, tap, half of the input channels): tile 256 (o) x 128 (c), 64 accumulator registers per wave; the corner values of
+// the chunk after next are requested one load behind every MFMA of the current chunk (two register sets that swap roles from chunk to
+// chunk), the next chunk's are combined and split between the MFMAs.  LDS is double buffered (2 x 60 KB); one barrier per chunk.
+// Measured (2 x 21 824 positions, dense gradient): weight kernel + reduction 542 us (exact fp32) -> 253 us.  Anatomy (ORP_BW16_DBG builds):
+// without the MFMAs 239 us, without the gathers 182 us -- the kernel sits on the gathers, and what limits them is the vector memory
+// unit's REQUEST rate, not latency and not bytes: with 4-byte loads per lane (thread = channel) 2.4 GB moved at ~27 B/clk per CU and the
+// same kernel took 300 us, whether 16 or 64 loads per thread were in flight and whether they were issued in a burst or spread between the
+// MFMAs (286 - 312 us); 8-byte loads: 253.  Next lever: 16-byte loads (thread = channel quad; a wave then spans two positions and the
+// row offsets become per-lane).
+// The exact-fp32 kernel above stays for DCNv2 (a modulated column has no known range) and behind ORP_DCN_BWD_SPLIT=0 / ORP_DCN_BWD_W16=0.
+struct __attribute__((aligned(32))) SampleTab { int ix[4]; float w[4]; };     // corner pixels (clamped; BYTE offsets of their NHWC rows) and weights x the range scale of x (0: outside)
+
+__global__ void __launch_bounds__(256) sample_table_kernel(const BwdParams P, const unsigned* __restrict__ amax_x, SampleTab* __restrict__ tab) {
+  const int taps = P.kh * P.kw;
+  const long per_tap = (long)P.total_chunks * 32;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per_tap * taps) return;
+  const int tap = (int)(i / per_tap);
+  const long e = i - (long)tap * per_tap;
+  const int chunk = (int)(e >> 5), m = (int)(e & 31);
+  int lvl = 0;
+  for (int k = 1; k < P.nlev; k++) if (chunk >= P.lv[k].chunk0) lvl = k;
+  const BLevel& L = P.lv[lvl];
+  const int HoWo = L.Ho * L.Wo;
+  const long p = (long)(chunk - L.chunk0) * 32 + m;
+  SampleTab t;
+  t.ix[0] = t.ix[1] = t.ix[2] = t.ix[3] = 0;
+  t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0.f;
+  if (p < (long)P.B * HoWo) {
+    int4 ix; float2 fr;
+    sample_point(P, L, p, tap, taps, HoWo, ix, fr);
+    const float sx = range_scale(*amax_x);                            // a power of two: scaling the weights scales the column exactly
+    const float lh = fr.x, lw = fr.y, uh = 1.f - lh, uw = 1.f - lw;
+    t.w[0] = ix.x >= 0 ? uh * uw * sx : 0.f; t.w[1] = ix.y >= 0 ? uh * lw * sx : 0.f;
+    t.w[2] = ix.z >= 0 ? lh * uw * sx : 0.f; t.w[3] = ix.w >= 0 ? lh * lw * sx : 0.f;
+    const int rb = CH * (int)sizeof(float);                           // (the host checked that every level's rows fit 2^31 bytes)
+    t.ix[0] = ix.x < 0 ? 0 : ix.x * rb; t.ix[1] = ix.y < 0 ? 0 : ix.y * rb; t.ix[2] = ix.z < 0 ? 0 : ix.z * rb; t.ix[3] = ix.w < 0 ? 0 : ix.w * rb;
+  }
+  tab[i] = t;
+}
+
+constexpr int RS16 = 40;                    // LDS row stride in halves (64 B of payload + 16 B)
+constexpr int CX16 = 128;                   // input channels (columns of gW) per workgroup
+constexpr int GPL16 = CH * RS16;            // halves per grad_out piece plane
+constexpr int XPL16 = CX16 * RS16;          // halves per column piece plane
+constexpr int BUF16 = 2 * GPL16 + 2 * XPL16;          // G hi | G lo | X hi | X lo
+constexpr size_t weight16_smem() { return sizeof(_Float16) * 2 * BUF16; }
+constexpr size_t kGo16ChunkHalves = (size_t)2 * 4 * CH * 8;       // grad_out planes of one chunk: [piece][octet][channel][8 positions]
+
+// grad_out (NHWC fp32 in the workspace) -> its two fp16 pieces, scaled, laid out as kernel B stages them: thread = (chunk, octet, channel)
+// reads eight positions of its channel (consecutive channels: coalesced) and writes 16 bytes per piece (consecutive channels: contiguous).
+// Rows past a level's end are zero.
+__global__ void __launch_bounds__(256) pack_go16_kernel(const BwdParams P, _Float16* __restrict__ planes) {
+  const int chunk = blockIdx.x >> 2, q = blockIdx.x & 3, c = threadIdx.x;
+  int lvl = 0;
+  for (int k = 1; k < P.nlev; k++) if (chunk >= P.lv[k].chunk0) lvl = k;
+  const BLevel& L = P.lv[lvl];
+  const long npos = (long)P.B * L.Ho * L.Wo;
+  const long p0 = (long)(chunk - L.chunk0) * 32 + q * 8;
+  const float sg = range_scale(*P.go_amax);
+  h8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const float v = (p0 + e < npos ? L.go[(size_t)(p0 + e) * CH + c] : 0.f) * sg;
+    hi[e] = (_Float16)v;
+    lo[e] = (_Float16)(v - (float)hi[e]);
+  }
+  _Float16* dst = planes + (size_t)chunk * kGo16ChunkHalves + ((size_t)q * CH + c) * 8;
+  *reinterpret_cast<h8*>(dst) = hi;
+  *reinterpret_cast<h8*>(dst + (size_t)4 * CH * 8) = lo;
+}
+
+#ifndef ORP_BW16_DBG
+#define ORP_BW16_DBG 0      // dev aid (timing only, wrong results): 1 = no gathers after the prologue, 2 = no MFMA, 4 = no combine / split / LDS writes
+#endif
+
+__global__ void __launch_bounds__(kThreads)
+dcn_bwd_weight16_kernel(const BwdParams P, const SampleTab* __restrict__ tab, const _Float16* __restrict__ go16,
+                        const unsigned* __restrict__ amax_x, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  _Float16* sT = reinterpret_cast<_Float16*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cz = blockIdx.z;                                          // which 128 input channels
+  const int cp = lane;                                                // this thread's two column rows: channels cz * 128 + 2 cp, + 1 ...
+  const int px = wave * 4;                                            // ... and its four positions of every chunk (8-byte loads: twice the bytes per request)
+  const int cg = tid & (CH - 1), hf = wave >> 2;                      // grad_out staging: channel cg, octets hf and hf + 2
+  const int taps = P.kh * P.kw, tap = blockIdx.y;
+  const int n_active = P.active[P.total_chunks];
+  const int per = (n_active + nsplit - 1) / nsplit;
+  const int c_begin = blockIdx.x * per;
+  const int c_end = (c_begin + per < n_active) ? c_begin + per : n_active;
+  const float sx = range_scale(*amax_x), sg = range_scale(*P.go_amax);
+  const SampleTab* tap_tab = tab + (size_t)tap * P.total_chunks * 32 + px;
+  const int c4 = (cz * CX16 + 2 * cp) * (int)sizeof(float);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(go16), 0, P.total_chunks * (int)(kGo16ChunkHalves * sizeof(_Float16)), 0x00020000);
+
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  struct Raw { f2 x[4][4]; };
+  struct GRaw { h8 v[2][2]; };
+  auto level_of = [&](int chunk) {
+    int lvl = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.nlev; i++) if (chunk >= P.lv[i].chunk0) lvl = i;
+    return lvl;
+  };
+  auto issue_half = [&](int ci, int half, Raw& r) {                   // 2 positions x 4 corners of this thread's channel pair: positions px + 2 half, + 1
+    const int chunk = P.active[ci];
+    const BLevel& L = P.lv[level_of(chunk)];
+    const SampleTab* t = tap_tab + (size_t)chunk * 32 + 2 * half;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.x), 0, P.B * L.H * L.W * CH * (int)sizeof(float), 0x00020000);
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) r.x[2 * half + e][k] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs, c4, t[e].ix[k], 0));
+  };
+  auto issue = [&](int ci, Raw& r) { issue_half(ci, 0, r); issue_half(ci, 1, r); };
+  // positions px + 2 half, + 1: [channel of the pair][piece] -> two halves each
+  auto convert = [&](int ci, int half, const Raw& r, h2 (&out)[2][2]) {
+    const SampleTab* t = tap_tab + (size_t)P.active[ci] * 32 + 2 * half;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const f2* x = r.x[2 * half + e];
+#pragma unroll
+      for (int cc = 0; cc < 2; cc++) {
+        const float sv = __builtin_fmaf(t[e].w[3], x[3][cc], __builtin_fmaf(t[e].w[2], x[2][cc], __builtin_fmaf(t[e].w[1], x[1][cc], t[e].w[0] * x[0][cc])));
+        const _Float16 hi = (_Float16)sv;
+        out[cc][0][e] = hi;
+        out[cc][1][e] = (_Float16)(sv - (float)hi);                   // the residual is exact in fp32
+      }
+    }
+  };
+  auto put_x = [&](int buf, const h2 (&a)[2][2], const h2 (&b)[2][2]) {      // a: positions px, px + 1; b: px + 2, px + 3
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+      for (int pl = 0; pl < 2; pl++) {
+        h4 v; v[0] = a[cc][pl][0]; v[1] = a[cc][pl][1]; v[2] = b[cc][pl][0]; v[3] = b[cc][pl][1];
+        *reinterpret_cast<h4*>(sT + (size_t)buf * BUF16 + (size_t)2 * GPL16 + (size_t)pl * XPL16 + (size_t)(2 * cp + cc) * RS16 + px) = v;
+      }
+  };
+  auto get_g = [&](int ci, GRaw& g) {                                 // octets hf, hf + 2 of grad_out, both pieces
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int so = P.active[ci] * (int)(kGo16ChunkHalves * sizeof(_Float16)) + (hf + 2 * u) * CH * 16;
+      g.v[u][0] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs_g, cg * 16, so, 0));
+      g.v[u][1] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs_g, cg * 16, so + 4 * CH * 16, 0));
+    }
+  };
+  auto put_g = [&](int buf, const GRaw& g) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      _Float16* dst = sT + (size_t)buf * BUF16 + (size_t)cg * RS16 + (hf + 2 * u) * 8;
+      *reinterpret_cast<h8*>(dst) = g.v[u][0];
+      *reinterpret_cast<h8*>(dst + GPL16) = g.v[u][1];
+    }
+  };
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int q = 0; q < 2; q++) acc[a][q] = floatx16{0};
+  const int m = lane & 31, kg = lane >> 5;
+  const int wo = wave >> 1, wc = wave & 1;                            // o rows [64 wo, +64), c columns [64 wc, +64) of the workgroup's 128
+
+  if (c_begin < c_end) {
+    Raw r1, r2;
+    {                                                                 // the first chunk, unpipelined
+      h2 cv[2][2][2];
+      GRaw g;
+      issue(c_begin, r1); get_g(c_begin, g);
+      convert(c_begin, 0, r1, cv[0]); convert(c_begin, 1, r1, cv[1]);
+      put_x(0, cv[0], cv[1]);
+      put_g(0, g);
+    }
+    issue(min(c_begin + 1, c_end - 1), r1);                           // the second chunk's corners are in flight when the loop starts
+    __syncthreads();
+    // one chunk: MFMAs out of buffer `cur`; `ra` holds the next chunk's corner values (requested a chunk ago), `rb` receives those of
+    // the chunk after next.  The two register sets swap roles from chunk to chunk (the loop below is unrolled by two): a copy would
+    // wait for the loads it copies.
+    auto step = [&](int ci, int cur, Raw& ra, Raw& rb) {
+      const bool more = ci + 1 < c_end;
+      const int nx = min(ci + 1, c_end - 1), nx2 = min(ci + 2, c_end - 1);
+      const _Float16* sB = sT + (size_t)cur * BUF16;
+      GRaw g;
+      h2 cv[2][2][2];
+      __builtin_amdgcn_sched_barrier(0);
+      get_g(nx, g);                                                   // (first: the memory counter retires in order, and these are written to LDS first)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {                                   // the chunk's two 16-position k-steps
+        h8 ga[2][2], xb[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int pl = 0; pl < 2; pl++)
+            ga[a][pl] = *reinterpret_cast<const h8*>(sB + (size_t)pl * GPL16 + (size_t)(wo * 64 + a * 32 + m) * RS16 + j * 16 + kg * 8);
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int pl = 0; pl < 2; pl++)
+            xb[q][pl] = *reinterpret_cast<const h8*>(sB + (size_t)2 * GPL16 + (size_t)pl * XPL16 + (size_t)(wc * 64 + q * 32 + m) * RS16 + j * 16 + kg * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        // two chunks ahead: 16 of the 32 corner loads per k-step, a load or two behind every MFMA (issued in one burst they hold every
+        // wave of the workgroup at the vector memory unit's door at the same time, with the matrix pipe idle behind them)
+        if (!(ORP_BW16_DBG & 1)) issue_half(nx2, j, rb);
+        // the next chunk's corner values: half an octet per k-step, between the MFMAs
+        if (!(ORP_BW16_DBG & 4)) convert(nx, j, ra, cv[j]);
+        // smallest products first; four independent accumulators between two MFMAs into the same one
+#pragma unroll
+        for (int pr = 0; pr < 3; pr++)
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+              if (ORP_BW16_DBG & 2) acc[a][q][0] += (float)ga[a][pr == 0 ? 1 : 0][0] * (float)xb[q][pr == 1 ? 1 : 0][0];
+              else acc[a][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[a][pr == 0 ? 1 : 0], xb[q][pr == 1 ? 1 : 0], acc[a][q], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more && !(ORP_BW16_DBG & 4)) { put_x(cur ^ 1, cv[0], cv[1]); put_g(cur ^ 1, g); }
+      __syncthreads();
+    };
+    int ci = c_begin;
+#pragma unroll 1
+    for (; ci + 1 < c_end; ci += 2) { step(ci, 0, r1, r2); step(ci + 1, 1, r2, r1); }
+    if (ci < c_end) step(ci, 0, r1, r2);
+  }
+
+  const float osc = 1.f / (sx * sg);
+  float* outp = P.partial + ((size_t)blockIdx.x * taps + tap) * CH * CH;
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int o = wo * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        outp[(size_t)o * CH + cz * CX16 + wc * 64 + q * 32 + m] = acc[a][q][r] * osc;
+      }
+}
+
 constexpr size_t weight_smem() { return sizeof(float) * 2 * 32 * RS + (sizeof(float4) + sizeof(int4) + sizeof(long)) * 64; }
 
 int device_cus() {
@@ -1138,8 +1403,13 @@ int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float*
   // the contraction of kernel A: 1 (default) = fp16 pieces on the 16-bit matrix pipe, 0 = exact fp32 (v_mfma_f32_32x32x2_f32)
   static const int split_mode = getenv("ORP_DCN_BWD_SPLIT") ? atoi(getenv("ORP_DCN_BWD_SPLIT")) : 1;
   const bool f16 = split_mode != 0 && need_input_grads;
-  unsigned* scale_words = reinterpret_cast<unsigned*>(ws + pl.scale_off);
-  TI.amax = f16 ? scale_words : nullptr; TO.amax = nullptr;
+  // ... of kernel B: 1 (default) = fp16 pieces as well (DCNv1: the sampled columns are bounded by max |x|), 0 / DCNv2 = exact fp32
+  static const int w16_env = getenv("ORP_DCN_BWD_W16") ? atoi(getenv("ORP_DCN_BWD_W16")) : 1;        // dev aid (A/B timing)
+  bool w16 = split_mode != 0 && w16_env != 0 && grad_weight && !masks_host && taps >= 2 && (long)pl.total_chunks * 32768 < (1L << 31);
+  for (int i = 0; i < nlevels; i++) w16 = w16 && (long)batch * levels_host[i].height * levels_host[i].width * CH * 4 < (1L << 31);   // 32-bit buffer offsets
+  unsigned* scale_words = reinterpret_cast<unsigned*>(ws + pl.scale_off);    // [0] max |grad_out|, [1] max |W|, [2] the weights' scale, [3] max |x|
+  TI.amax = (f16 || w16) ? scale_words : nullptr; TO.amax = nullptr;
+  TI.amax_x = w16 ? scale_words + 3 : nullptr; TO.amax_x = nullptr;
   P.wT16 = reinterpret_cast<const uint16_t*>(ws + pl.wT_off);      // (the fp32 layout and the two fp16 planes have the same size)
   P.w16_plane = (size_t)CH * CH * taps;
   P.wscale = reinterpret_cast<const float*>(scale_words + 2);
@@ -1238,10 +1508,26 @@ int orp_dcn_backward_multi_ex(const orp_dcn_bwd_level* levels_host, const float*
     e = orp::set_max_dynamic_lds_once<TW>(reinterpret_cast<const void*>(&dcn_bwd_weight_kernel), weight_smem());
     if (e != hipSuccess) return (int)e;
     OrpProfScope prof_w(ORP_PROF_DCN_BWD_WEIGHT, st);
-    hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(pl.nsplit, taps), dim3(kThreads), weight_smem(), st, P);
+    int ns_w = pl.nsplit;
+    if (w16) {
+      struct TW16 { int unused; };
+      e = orp::set_max_dynamic_lds_once<TW16>(reinterpret_cast<const void*>(&dcn_bwd_weight16_kernel), weight16_smem());
+      if (e != hipSuccess) return (int)e;
+      // the sampling table lives where kernel A left the G rows for A2 (both are done with them by now, in stream order)
+      // and the two fp16 pieces of grad_out behind it (taps >= 2: both fit into the G rows' space)
+      SampleTab* tab = reinterpret_cast<SampleTab*>(ws + pl.G_off);
+      const long nsamp = (long)pl.total_chunks * 32 * taps;
+      _Float16* go16 = reinterpret_cast<_Float16*>(ws + pl.G_off + align256(sizeof(SampleTab) * (size_t)nsamp));
+      ns_w = pl.nsplit >= 2 ? pl.nsplit / 2 : 1;                       // two workgroups (column halves) per (split, tap)
+      hipLaunchKernelGGL(sample_table_kernel, dim3((unsigned)((nsamp + 255) / 256)), dim3(256), 0, st, P, scale_words + 3, tab);
+      hipLaunchKernelGGL(pack_go16_kernel, dim3((unsigned)pl.total_chunks * 4), dim3(256), 0, st, P, go16);
+      hipLaunchKernelGGL(dcn_bwd_weight16_kernel, dim3(ns_w, taps, CH / CX16), dim3(kThreads), weight16_smem(), st, P, tab, go16, scale_words + 3, ns_w);
+    } else {
+      hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(pl.nsplit, taps), dim3(kThreads), weight_smem(), st, P);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(reduce_partial_kernel, dim3(1024), dim3(256), 0, st, P.partial, pl.nsplit, taps, grad_weight);
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3(1024), dim3(256), 0, st, P.partial, ns_w, taps, grad_weight);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }

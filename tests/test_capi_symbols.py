@@ -85,7 +85,7 @@ def test_default_hot_kernels_keep_their_registers():
     build.build_hip()
     want = {  # substring of the mangled name -> at least this many kernels must match
         "dcn_fwd_split_kernelILi1ELi3E": 4, "dcn_fwd_split_kernelILi2ELi3E": 4, "dcn_fwd_split_kernelILi3ELi3E": 4,
-        "dcn_bwd_input_kernel": 4, "dcn_bwd_weight_kernel": 1, "dcn_bwd_scatter_kernel": 1,
+        "dcn_bwd_input_kernel": 4, "dcn_bwd_weight_kernel": 1, "dcn_bwd_weight16_kernel": 1, "dcn_bwd_scatter_kernel": 1,
         "conv_wgrad_split_kernel": 2, "nms_mask_loop_kernel": 2,
     }
     seen = {k: 0 for k in want}

@@ -1131,6 +1131,54 @@ def test_dcn_backward_fp16_pieces_range_scaling(dev, oracle):
         assert not t.cpu().numpy().any()
 
 
+def test_dcn_backward_weight_gradient_on_the_16bit_pipe(dev, oracle):
+    """grad_weight of orp_dcn_backward_multi runs on the 16-bit matrix pipe since round 6 (dcn_bwd_weight16_kernel: sampled columns and
+    grad_out as two fp16 pieces after power-of-two range scalings taken from max |x| and max |grad_out| of the CALL).  Against the
+    exact-fp32 MFMA kernel of the same library (ORP_DCN_BWD_W16=0, in a subprocess) the difference stays at the pieces' 2^-22 level;
+    magnitudes do not matter (inputs scaled by 2^30 / 2^-40, gradients by 2^-50 / 2^25: the same bits, scaled); an all-zero gradient
+    gives exact zeros; the weight-only call returns the bits of the combined call; a level whose last chunk is partial and a
+    single-position level are in the launch."""
+    import os, subprocess, sys, tempfile
+    from orientedreppoints_amd.mmdet_ops import deform_conv_backward as bw
+    shapes = [(9, 11), (4, 5), (1, 1)]
+    cases = [_dcn_case(190 + i, 2, 256, h, w, 256, std_off=2.5) for i, (h, w) in enumerate(shapes)]
+    w = cases[0][2]
+    gos = [np.random.RandomState(195 + i).normal(size=(2, 256, h, ww)).astype(np.float32) for i, (h, ww) in enumerate(shapes)]
+
+    def run(xscale=1.0, gscale=1.0, need_input=True, zero=False):
+        out = bw.backward_mfma([_t(c[0] * np.float32(xscale), dev) for c in cases], [_t(c[1], dev) for c in cases], _t(w, dev),
+                               [_t(g * np.float32(0.0 if zero else gscale), dev) for g in gos], (1, 1), (1, 1), (1, 1), need_input=need_input)
+        return out[2].cpu().numpy()
+    base = run()
+    want = np.zeros_like(w)
+    for c, g in zip(cases, gos):
+        want += oracle.dcn_backward(c[0], c[1], w, g)[2]
+    assert _rel_err(base, want) <= 1e-4
+    assert np.array_equal(run(need_input=False), base), "the weight-only call and the combined call differ"
+    for xs, gs in ((2.0 ** 30, 2.0 ** -50), (2.0 ** -40, 2.0 ** 25)):
+        got = run(xs, gs)
+        assert np.array_equal(got, base * (np.float32(xs) * np.float32(gs))), "a power-of-two scaling of x / grad_out changed grad_weight's bits"
+    assert not run(zero=True).any()
+    # the exact-fp32 kernel of the same build, same inputs
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), w=w, **{"x%d" % i: c[0] for i, c in enumerate(cases)}, **{"o%d" % i: c[1] for i, c in enumerate(cases)},
+                 **{"g%d" % i: g for i, g in enumerate(gos)})
+        code = ("import numpy as np, torch, sys; sys.path.insert(0, %r)\n"
+                "from orientedreppoints_amd.mmdet_ops import deform_conv_backward as bw\n"
+                "d = np.load(%r); dev = torch.device('cuda:0'); t = lambda a: torch.from_numpy(a).to(dev)\n"
+                "n = %d\n"
+                "gw = bw.backward_mfma([t(d['x%%d' %% i]) for i in range(n)], [t(d['o%%d' %% i]) for i in range(n)], t(d['w']),\n"
+                "                      [t(d['g%%d' %% i]) for i in range(n)], (1, 1), (1, 1), (1, 1))[2]\n"
+                "np.save(%r, gw.cpu().numpy())\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(tmp, "in.npz"),
+                                                        len(cases), os.path.join(tmp, "gw.npy"))
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ORP_DCN_BWD_W16="0"), stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:]
+        exact = np.load(os.path.join(tmp, "gw.npy"))
+    assert not np.array_equal(exact, base), "ORP_DCN_BWD_W16=0 did not switch kernels"
+    assert _rel_err(base, exact) <= 4e-6
+
+
 def test_dcn_v2_backward_on_mfma_path_vs_oracle(dev, oracle):
     """modulated_deform_conv backward at the head's 256 -> 256 channels through orp_dcn_backward_multi_ex (the modulation
     scalar rides in the sample weights of both MFMA GEMMs; grad_mask = G . sampled value) against oracle.dcn_v2_backward =
