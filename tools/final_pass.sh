@@ -23,6 +23,7 @@ python bench.py --gpus 2 --device cpu --dry --mode train 2>/dev/null | grep "^{"
 # every result compared, >= 10 000 launches per configuration (tile heights 1 and 3, one and two images, 3 and 6 products, the
 # DeformConv and the convolution instantiation), next to a GEMM stream and a second stream of the same kernel
 SOAK_N=10000 timeout 900 python tests/checks/soak_split_full.py > $O/${TAG}_soak.log 2>&1
+SOAK_N=1000 timeout 600 python tests/checks/soak_dcn_wgrad16.py > $O/${TAG}_soak_dcn_wgrad16.log 2>&1
 (cd tests/checks && timeout 200 ./mfma_refill_victim 100) > $O/${TAG}_mfma_refill_victim.log 2>&1
 AGGR=none,gemm,conv_big,conv_small,dcn_small N=300 timeout 200 python tests/checks/victim_probe.py > $O/${TAG}_victim_probe.log 2>&1
 SIZE=256 BATCH=2 DEPTH=3 ITERS=2000 MODE=3 SPLIT=auto timeout 300 python tests/checks/graph_bitwise.py > $O/${TAG}_graph_bitwise_mode3.log 2>&1
