@@ -349,6 +349,13 @@ class OrientedRepPointsHead(nn.Module):
         refines = [self.reppoints_pts_refine_out(torch.relu(p)) + init.detach() for p, init in zip(dcn_pts, inits)]
         return cls_outs, inits, refines, list(feats)
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle of a head that has run with its towers on two streams: the stream object is per process (and cannot be
+        # pickled); the copy creates its own on first use
+        state = self.__dict__.copy()
+        state['_side_stream'] = None
+        return state
+
     def forward(self, feats):
         if torch.is_grad_enabled():
             from ..mmdet_ops.deform_conv import pair_autograd_ok

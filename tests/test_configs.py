@@ -97,3 +97,23 @@ def test_pipelined_inference_refuses_half_models_loudly():
     metas = [dict(img_shape=(64, 64, 3), pad_shape=(64, 64, 3), scale_factor=1.0, flip=False)]
     with pytest.raises(ValueError, match="float32 models only"):
         PipelinedInference(model, img, metas, depth=4)
+
+
+def test_detector_with_a_side_stream_can_be_deep_copied_and_pickled():
+    """A head that has run its two towers on two streams (ORP_DCN_SPLIT=0, or training) holds a torch.cuda.Stream; copy.deepcopy(model)
+    failed with "cannot pickle 'Stream' object" (round 6: found by running the GPU suite under ORP_DCN_SPLIT=0).  The stream is per
+    process: copies and pickles drop it and create their own on first use."""
+    import copy, io
+    import torch
+    from orientedreppoints_amd import dota_configs
+    from orientedreppoints_amd.mmdet_models import ConfigDict, build_detector
+    model = build_detector(ConfigDict(dota_configs.r50_model), train_cfg=None, test_cfg=ConfigDict(dota_configs.test_cfg)).eval()
+
+    class NotPicklable(object):                              # what a Stream looks like to copy / pickle
+        def __reduce_ex__(self, protocol):
+            raise TypeError("cannot pickle 'Stream' object")
+    model.bbox_head._side_stream = NotPicklable()
+    twin = copy.deepcopy(model)
+    assert twin.bbox_head._side_stream is None and isinstance(model.bbox_head._side_stream, NotPicklable)
+    assert set(twin.state_dict().keys()) == set(model.state_dict().keys())
+    torch.save(model, io.BytesIO())

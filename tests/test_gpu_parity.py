@@ -1140,6 +1140,8 @@ def test_dcn_backward_weight_gradient_on_the_16bit_pipe(dev, oracle):
     single-position level are in the launch."""
     import os, subprocess, sys, tempfile
     from orientedreppoints_amd.mmdet_ops import deform_conv_backward as bw
+    if os.environ.get("ORP_DCN_BWD_W16", "1") == "0" or os.environ.get("ORP_DCN_BWD_SPLIT", "1") == "0":
+        pytest.skip("the 16-bit weight-gradient kernel is switched off in this environment")
     shapes = [(9, 11), (4, 5), (1, 1)]
     cases = [_dcn_case(190 + i, 2, 256, h, w, 256, std_off=2.5) for i, (h, w) in enumerate(shapes)]
     w = cases[0][2]
