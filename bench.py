@@ -837,7 +837,7 @@ def main():
     # the eager loop (kernel timings, roofline) runs the launch sequence of the throughput mode's graphs: one stream, no
     # tower fork -- the fork belongs to the one-image-at-a-time replay below
     model.bbox_head.tower_streams = False
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup)):                    # (--warmup 0: one untimed step still, the reference result of the checks below)
         res = step()
     ndet = int(sum(sum(len(c) for c in r) for r in res))
     # the step is meant to be bitwise reproducible (fixed-order sums in every HIP kernel; the library convolutions the
@@ -892,7 +892,7 @@ def main():
         try:
             from orientedreppoints_amd.mmdet_models import GraphedInference
             gi = GraphedInference(model, img, metas)
-            for _ in range(args.warmup):
+            for _ in range(max(1, args.warmup)):
                 gres = gi(img)
             ngraph = int(sum(sum(len(c) for c in r) for r in gres))
             if abs(ngraph - ndet) > count_slack:
