@@ -483,10 +483,14 @@ def train_probe(dev, model_name='r50', steps=10, warmup=4, gts=64):
                     '(stock PyTorch-ROCm by design), the rest losses, assigners, optimizer and normalisation passes'}
 
 
-def quick_config(dev, model_name, batch, size, steps=10, warmup=3, depth=4):
+def quick_config(dev, model_name, batch, size, steps=10, warmup=3, depth=4, half=None):
     """A compact line for another BASELINE configuration at its per-GPU load (rank 0, N = 1, after the headline loops): the same
     measurement as the headline -- captured graphs, `depth` in flight for `value`, one at a time for `value_serial` -- with fewer
-    steps; every replay's detections are compared with the eager step's."""
+    steps; every replay's detections are compared with the eager step's.  half = torch.float16 / torch.bfloat16: the whole detector
+    (weights and activations) in that type -- the DeformConvs on `orp_dcn_forward_half`, the post-processing on fp32 copies of the head's
+    outputs (the reference dispatches its operators over float AND half: deform_conv_cuda_kernel.cu:259).  The library's half-precision
+    solvers are not reproducible and its deterministic ones stall the device with four graphs in flight (docs/notebook/round6.md 8), so a
+    half configuration is measured in the default library mode and says so in `replays_identical_to_eager`."""
     import copy
     from orientedreppoints_amd.mmdet_models import GraphedInference, PipelinedInference
     torch.manual_seed(0)
@@ -495,12 +499,16 @@ def quick_config(dev, model_name, batch, size, steps=10, warmup=3, depth=4):
     img = torch.randn(batch, 3, size, size, generator=g).to(dev)
     metas = [dict(img_shape=(size, size, 3), pad_shape=(size, size, 3), scale_factor=1.0, flip=False) for _ in range(batch)]
     calibrate_head(model, img[:1])
+    if half is not None:
+        model, img = model.to(half), img.to(half)
     det_flag = torch.backends.cudnn.deterministic
+    if half is not None and det_flag:
+        raise RuntimeError('half configuration skipped: torch.backends.cudnn.deterministic is set')
     try:
         with torch.no_grad():
             ref = model.simple_test_batch(img, metas)
             same_ = lambda ra, rb: all(a.shape == b.shape and np.array_equal(a, b) for r, q in zip(ra, rb) for a, b in zip(r, q))   # noqa: E731
-            if not all(same_(ref, model.simple_test_batch(img, metas)) for _ in range(2)):
+            if half is None and not all(same_(ref, model.simple_test_batch(img, metas)) for _ in range(2)):
                 torch.backends.cudnn.deterministic = True       # (1536^2: the library's default solvers accumulate with atomics)
                 ref = model.simple_test_batch(img, metas)
         gi = GraphedInference(model, img, metas)
@@ -523,12 +531,30 @@ def quick_config(dev, model_name, batch, size, steps=10, warmup=3, depth=4):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
         assert n == steps
-        return dict(workload='%s FPN inference, %dx%d, bs=%d/GPU' % (MODEL_LABEL[model_name], size, size, batch), value=batch / ms * 1e3,
+        return dict(workload='%s FPN inference, %dx%d, bs=%d/GPU%s' % (MODEL_LABEL[model_name], size, size, batch,
+                                                                        '' if half is None else ', model.to(%s)' % str(half).split('.')[-1]),
+                    value=batch / ms * 1e3,
                     value_serial=batch / serial_ms * 1e3, unit='images/s', ms_per_step=ms, graph_replay_ms=serial_ms, steps=steps,
                     images_in_flight=depth, detections=int(sum(sum(len(c) for c in r) for r in ref)),
                     replays_identical_to_eager=bool(identical), library_deterministic_mode=bool(torch.backends.cudnn.deterministic))
     finally:
         torch.backends.cudnn.deterministic = det_flag
+
+
+def half_config_in_a_subprocess(depth, timeout=180):
+    """The fp16-model line of `other_configs`, measured by a CHILD process under a timeout: a configuration one library flag away from a
+    device stall (see quick_config) must not be able to take the headline line with it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--half-config', '1', '--pipeline', str(depth)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=timeout,
+                           env={k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')})
+    except subprocess.TimeoutExpired:
+        return 'failed: no result within %d s (child killed)' % timeout
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    if r.returncode != 0 or not lines:
+        return 'failed: %s' % ((r.stderr or r.stdout)[-200:],)
+    return json.loads(lines[-1])
 
 
 def _free_port():
@@ -779,6 +805,7 @@ def main():
                     help='launcher / rank / timing plumbing only, stand-in step (the CPU test of the N > 1 path)')
     ap.add_argument('--batch', type=int, default=1, help='images per GPU per step (config 1: 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--half-config', type=int, default=0, help=argparse.SUPPRESS)     # internal: the fp16-model line, run by a child process
     ap.add_argument('--train-probe', type=int, default=1,
                     help='1 (default): the line also carries `train` = 10 SGD iterations of BASELINE configs[2] at its per-GPU load '
                          '(rank 0, N = 1, after the timed inference loops)')
@@ -811,6 +838,11 @@ def main():
         TRAIN_SIZES = size_list
     if args.device == 'cpu' and not args.dry:
         raise SystemExit('bench.py: the hot path has no CPU fallback; --device cpu is only valid with --dry')
+    if args.half_config:                                  # child of half_config_in_a_subprocess: one compact line, nothing else
+        assert torch.cuda.is_available()
+        _lib.lib()
+        print(json.dumps(quick_config(torch.device('cuda', 0), 'r50', 1, 1024, depth=max(args.pipeline, 1), half=torch.float16)))
+        return
     maybe_spawn(args)                                     # --gpus N by hand -> N ranks (no-op under a launcher)
     if args.dry:
         return main_dry(args)
@@ -1175,6 +1207,10 @@ def main():
             train = train_probe(dev)
         except Exception as e:   # noqa: BLE001
             train = 'failed: %s' % (str(e)[:200],)
+    if other is not None:
+        # last, and in a child process under a timeout (every measurement of this line is done by now): the whole detector in fp16
+        torch.cuda.synchronize()
+        other['fp16 model'] = half_config_in_a_subprocess(max(args.pipeline, 1))
     out = {
         'metric': 'images/sec (%dx%d DOTA, %s FPN)' % (IMG, IMG, MODEL_LABEL[args.model]), 'value': value,
         'value_serial': value_serial, 'unit': 'images/s', 'n_gpus': world,

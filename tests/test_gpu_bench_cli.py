@@ -26,3 +26,15 @@ def test_bench_line_with_zero_warmup_and_two_steps():
     assert j['replays_identical_to_eager'] is True
     rf = j['roofline']
     assert rf['bound'] == 'mfma' and 0.05 < rf['frac'] < 1.0 and rf['peak'] == 2500.0 and rf['launches'] >= 2
+
+
+def test_fp16_model_line_from_the_child_process():
+    """`other_configs['fp16 model']` is measured by `bench.py --half-config 1` in a child process under a timeout (a half-precision model is
+    one library flag away from a device stall, docs/notebook/round6.md 8): the child prints one compact line."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--half-config', '1', '--pipeline', '2'], cwd=ROOT, env=env, timeout=300,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert 'float16' in j['workload'] and j['images_in_flight'] == 2 and j['value'] > 50 and j['detections'] > 100
+    assert j['library_deterministic_mode'] is False
